@@ -1,0 +1,267 @@
+// Fused attention  O = softmax(Q K^T * scale) V  for gfx950 — one kernel: QK^T, online softmax, PV on MFMA.
+//
+// Orientation ("swapped QK^T"): each wave computes S^T = K Q^T with mfma(A = K fragment, B = Q^T fragment), so a
+// lane owns ONE query column (lane & 15) and its 16 accumulator registers per 64-key tile are keys.  Row max / row
+// sum are therefore in-lane reductions plus two cross-lane xor steps (16, 32), and the P^T accumulators are
+// already laid out as the B operand of the second product O^T = V^T P^T (no LDS round trip for P).  V is staged
+// row-major [key][dv] (coalesced from HBM) and consumed column-wise with ds_read_b64_tr_b16.
+//
+// Block = 4 waves; each wave owns QF x 16 queries (QF = 2 -> 128 queries per block), K/V tiles of KVT keys are
+// shared by the 4 waves through LDS; the next tile's global loads are in flight behind the current tile's MFMAs.
+#include "common.h"
+#include "../../include/edgestyle_hip.h"
+
+namespace {
+
+template <typename T, int KS /* QK k-steps of 32: DPAD = 32*KS */, int DF /* dv fragments of 16 */, int QF, int KVT>
+__global__ __launch_bounds__(256) void attention_kernel(const es_attn_desc p) {
+  constexpr int DPAD = 32 * KS;
+  constexpr int DVP = 16 * DF;
+  constexpr int KROW = DPAD * 2 + 16;   // bytes per K row in LDS (+16 B pad)
+  constexpr int VROW = DVP * 2 + 16;
+  constexpr int KF = KVT / 16;          // key fragments per tile
+  constexpr int KCH = DPAD / 8;         // 16-byte chunks per K row
+  constexpr int VCH = DVP / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ks_ = smem;
+  char* vs_ = smem + KVT * KROW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, n = blockIdx.z;
+  const int q0 = blockIdx.x * (64 * QF) + wave * (16 * QF);
+  const int d = p.d;
+  const int dch = d / 8;                // valid 16-byte chunks per row
+
+  const T* Q = (const T*)p.q + (size_t)n * p.bsq + (size_t)h * d;
+  const T* K = (const T*)p.k + (size_t)n * p.bsk + (size_t)h * d;
+  const T* V = (const T*)p.v + (size_t)n * p.bsv + (size_t)h * d;
+  T* O = (T*)p.o + (size_t)n * p.bso + (size_t)h * d;
+
+  // Q^T fragments (B operand): lane holds Q[query = col][32*ks + 8*g .. +7]
+  typename Traits<T>::vec8 qf[QF][KS];
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    int qi = q0 + f * 16 + col;
+    qi = qi < p.Sq ? qi : p.Sq - 1;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int ch = 4 * s + g;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ch < dch) v = *(const u32x4*)(Q + (size_t)qi * p.ldq + ch * 8);
+      qf[f][s] = as_vec8<T>(v);
+    }
+  }
+
+  // zero the K pad chunks once (they multiply the zero Q pad; must not be NaN garbage)
+  for (int i = tid; i < KVT * KCH; i += 256) {
+    const int r = i / KCH, c = i - r * KCH;
+    if (c >= dch) *(u32x4*)(ks_ + r * KROW + c * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+  for (int i = tid; i < KVT * VCH; i += 256) {
+    const int r = i / VCH, c = i - r * VCH;
+    if (c >= dch) *(u32x4*)(vs_ + r * VROW + c * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+
+  // staging: chunks of the K/V tile handled by this thread
+  constexpr int KPT = (KVT * KCH + 255) / 256;   // K chunks per thread (upper bound)
+  constexpr int VPT = (KVT * VCH + 255) / 256;
+  u32x4 kr[KPT], vr[VPT];
+  const int nch = KVT * dch;                     // valid chunks per tile (same for K and V)
+  auto load_kv = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int idx = tid + i * 256;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (idx < nch) {
+        const int r = idx / dch, c = idx - r * dch;
+        if (kv0 + r < p.Skv) v = *(const u32x4*)(K + (size_t)(kv0 + r) * p.ldk + c * 8);
+      }
+      kr[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int idx = tid + i * 256;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (idx < nch) {
+        const int r = idx / dch, c = idx - r * dch;
+        if (kv0 + r < p.Skv) v = *(const u32x4*)(V + (size_t)(kv0 + r) * p.ldv + c * 8);
+      }
+      vr[i] = v;
+    }
+  };
+  auto store_kv = [&]() {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < nch) {
+        const int r = idx / dch, c = idx - r * dch;
+        *(u32x4*)(ks_ + r * KROW + c * 16) = kr[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < nch) {
+        const int r = idx / dch, c = idx - r * dch;
+        *(u32x4*)(vs_ + r * VROW + c * 16) = vr[i];
+      }
+    }
+  };
+
+  f32x4 o[QF][DF];
+  float mrun[QF], lrun[QF];
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    mrun[f] = -1e30f; lrun[f] = 0.f;
+#pragma unroll
+    for (int j = 0; j < DF; ++j) o[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float sl2 = p.scale * 1.4426950408889634f;
+
+  load_kv(0);
+  for (int kv0 = 0; kv0 < p.Skv; kv0 += KVT) {
+    __syncthreads();               // previous tile fully consumed (and pad zeroing visible on first pass)
+    store_kv();
+    __syncthreads();
+    if (kv0 + KVT < p.Skv) load_kv(kv0 + KVT);
+
+    // ---- S^T = K Q^T ----
+    f32x4 s[QF][KF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f)
+#pragma unroll
+      for (int kf = 0; kf < KF; ++kf) s[f][kf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ksx = 0; ksx < KS; ++ksx) {
+#pragma unroll
+      for (int kf = 0; kf < KF; ++kf) {
+        const auto ka = as_vec8<T>(*(const u32x4*)(ks_ + (kf * 16 + col) * KROW + (4 * ksx + g) * 16));
+#pragma unroll
+        for (int f = 0; f < QF; ++f) s[f][kf] = mfma16(ka, qf[f][ksx], s[f][kf]);
+      }
+    }
+    // ---- online softmax (per query = per lane column) ----
+    typename Traits<T>::vec8 pb[QF][KF / 2];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+      float mx = -1e30f;
+#pragma unroll
+      for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kv0 + kf * 16 + g * 4 + r;
+          float v = s[f][kf][r] * sl2;
+          v = key < p.Skv ? v : -1e30f;
+          s[f][kf][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(mrun[f], mx);
+      const float alpha = exp2f(mrun[f] - mnew);
+      mrun[f] = mnew;
+      float rs = 0.f;
+#pragma unroll
+      for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = exp2f(s[f][kf][r] - mnew);
+          s[f][kf][r] = e;
+          rs += e;
+        }
+      rs += __shfl_xor(rs, 16, 64);
+      rs += __shfl_xor(rs, 32, 64);
+      lrun[f] = lrun[f] * alpha + rs;
+#pragma unroll
+      for (int j = 0; j < DF; ++j) o[f][j] *= alpha;
+      // P^T as B operand: k index 8g+j <-> key 32*sx + 16*(j>>2) + 4g + (j&3)
+#pragma unroll
+      for (int sx = 0; sx < KF / 2; ++sx) {
+        typename Traits<T>::vec8 b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = from_f32<T>(s[f][2 * sx + (j >> 2)][j & 3]);
+        pb[f][sx] = b;
+      }
+    }
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int sx = 0; sx < KF / 2; ++sx) {
+#pragma unroll
+      for (int j = 0; j < DF; ++j) {
+        // lane 4q+pp of each 16-lane group supplies row q, columns 4pp..4pp+3 of its 4x16 block
+        const int q = col >> 2, pp = col & 3;
+        const char* base = vs_ + (32 * sx + 4 * g + q) * VROW + (j * 16 + 4 * pp) * 2;
+        const u32x2 lo = lds_read_tr16(base);
+        const u32x2 hi = lds_read_tr16(base + 16 * VROW);
+        const u32x4 av = {lo[0], lo[1], hi[0], hi[1]};
+        const auto va = as_vec8<T>(av);
+#pragma unroll
+        for (int f = 0; f < QF; ++f) o[f][j] = mfma16(va, pb[f][sx], o[f][j]);
+      }
+    }
+  }
+
+  // ---- epilogue: O[query][dv] = O^T / l ----
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    const int qi = q0 + f * 16 + col;
+    const float inv = 1.0f / lrun[f];
+    if (qi < p.Sq) {
+#pragma unroll
+      for (int j = 0; j < DF; ++j) {
+        const int dv = j * 16 + g * 4;
+        if (dv < d) {     // d % 8 == 0 so a quad is entirely valid or entirely pad
+          typename Traits<T>::vec4 pk;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pk[r] = from_f32<T>(o[f][j][r] * inv);
+          *(typename Traits<T>::vec4*)(O + (size_t)qi * p.ldo + dv) = pk;
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int KS, int DF, int QF, int KVT>
+int launch_attn(const es_attn_desc& d, hipStream_t st) {
+  constexpr int lds = KVT * (32 * KS * 2 + 16) + KVT * (16 * DF * 2 + 16);
+  auto kfn = attention_kernel<T, KS, DF, QF, KVT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  dim3 grid((d.Sq + 64 * QF - 1) / (64 * QF), d.heads, d.N);
+  hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, d);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <typename T>
+int dispatch(const es_attn_desc& d, hipStream_t st) {
+  switch (d.d) {
+    case 8: case 16: return launch_attn<T, 1, 1, 2, 64>(d, st);
+    case 24: case 32: return launch_attn<T, 1, 2, 2, 64>(d, st);
+    case 40: case 48: return launch_attn<T, 2, 3, 2, 64>(d, st);
+    case 64: return launch_attn<T, 2, 4, 2, 64>(d, st);
+    case 80: return launch_attn<T, 3, 5, 2, 64>(d, st);
+    case 128: return launch_attn<T, 4, 8, 2, 64>(d, st);
+    case 160: return launch_attn<T, 5, 10, 2, 64>(d, st);
+    case 512: return launch_attn<T, 16, 32, 1, 32>(d, st);
+    default: return -3;
+  }
+}
+
+}  // namespace
+
+extern "C" void es_set_error(const char* msg);
+
+extern "C" int es_attention(const es_attn_desc* d, void* stream) {
+  if (!d->q || !d->k || !d->v || !d->o) { es_set_error("es_attention: null pointer"); return -1; }
+  if (d->d % 8 || d->ldq % 8 || d->ldk % 8 || d->ldv % 8 || d->ldo % 4) { es_set_error("es_attention: d and strides must be multiples of 8"); return -1; }
+  if (d->Sq < 1 || d->Skv < 1 || d->N < 1 || d->heads < 1) { es_set_error("es_attention: empty problem"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  int rc = d->dtype == ES_F16 ? dispatch<f16>(*d, st) : dispatch<bf16>(*d, st);
+  if (rc == -3) es_set_error("es_attention: unsupported head_dim (8,16,24,32,40,48,64,80,128,160,512)");
+  else if (rc) es_set_error("es_attention: launch failed");
+  return rc;
+}

@@ -1,0 +1,63 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels of the EdgeStyle hot path.
+// Wave = 64 lanes, MFMA 16x16x32 f16/bf16, fp32 accumulate everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __fp16 h16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#define ES_DEVICE __device__ __forceinline__
+
+template <typename T> struct Traits;
+template <> struct Traits<f16> {
+  typedef f16x8 vec8;
+  typedef f16x4 vec4;
+};
+template <> struct Traits<bf16> {
+  typedef bf16x8 vec8;
+  typedef bf16x4 vec4;
+};
+
+ES_DEVICE f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+ES_DEVICE f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+ES_DEVICE float to_f32(f16 x) { return (float)x; }
+ES_DEVICE float to_f32(bf16 x) { return (float)x; }
+template <typename T> ES_DEVICE T from_f32(float x) { return (T)x; }
+
+ES_DEVICE float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// exact (erf) GELU, as torch.nn.functional.gelu default used by diffusers GEGLU
+ES_DEVICE float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// transposed LDS read: 16-lane group reads a 4x16 block of 16-bit elements, lane i gets column i (4 rows)
+ES_DEVICE u32x2 lds_read_tr16(const void* lds_ptr) {
+  h16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h16x4*)lds_ptr);
+  return __builtin_bit_cast(u32x2, v);
+}
+
+template <typename T> ES_DEVICE typename Traits<T>::vec8 as_vec8(u32x4 v) {
+  return __builtin_bit_cast(typename Traits<T>::vec8, v);
+}
+
+ES_DEVICE float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+ES_DEVICE float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+#define ES_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : -2)

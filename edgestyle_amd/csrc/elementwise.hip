@@ -1,0 +1,204 @@
+// Small streaming kernels of the EdgeStyle hot path (gfx950): timestep sinusoid, CFG + DDIM step,
+// NCHW<->NHWC boundary conversion, elementwise add, VAE latent sampling, device step counter.
+#include "common.h"
+#include "../../include/edgestyle_hip.h"
+#include <string.h>
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+template <typename T>
+__global__ void timestep_kernel(const float* __restrict__ t, T* __restrict__ out, int N, int dim) {
+  // diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin], f_i = exp(-ln(1e4) i/half)
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * half) return;
+  const int n = i / half, k = i - n * half;
+  const float f = expf(-9.210340371976184f * (float)k / (float)half);
+  const float a = t[n] * f;
+  out[(size_t)n * dim + k] = from_f32<T>(cosf(a));
+  out[(size_t)n * dim + half + k] = from_f32<T>(sinf(a));
+}
+
+template <typename T>
+__global__ void cfg_ddim_kernel(const T* __restrict__ noise, float* __restrict__ lat, T* __restrict__ model_in,
+                                const float* __restrict__ coef, const int* __restrict__ step_idx, float gs, int B,
+                                int HW, int L, int Ls, int cfg) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)B * HW * L;
+  if (i >= total) return;
+  const long long mi = (i / L) * Ls + (i % L);         // model_in is channel-padded to Ls
+  const long long mtotal = (long long)B * HW * Ls;
+  const float* c = coef + (size_t)(*step_idx) * 4;
+  float eps;
+  if (cfg) {
+    const float eu = to_f32(noise[i]), ec = to_f32(noise[total + i]);
+    eps = eu + gs * (ec - eu);
+  } else {
+    eps = to_f32(noise[i]);
+  }
+  const float x = lat[i];
+  const float x0 = (x - c[1] * eps) / c[0];
+  const float xn = c[2] * x0 + c[3] * eps;
+  lat[i] = xn;
+  const T xt = from_f32<T>(xn);
+  model_in[mi] = xt;
+  if (cfg) model_in[mtotal + mi] = xt;
+}
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int N, int C, int HW,
+                                    int Cpad) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)N * HW * Cpad;
+  if (i >= total) return;
+  const int c = (int)(i % Cpad);
+  const long long np = i / Cpad;
+  const int px = (int)(np % HW);
+  const int n = (int)(np / HW);
+  out[i] = c < C ? from_f32<T>(in[((size_t)n * C + c) * HW + px]) : from_f32<T>(0.f);
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, int N, int C, int HW,
+                                    int Cs, float scale, float shift, int clamp01) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)N * C * HW;
+  if (i >= total) return;
+  const int px = (int)(i % HW);
+  const long long nc = i / HW;
+  const int c = (int)(nc % C);
+  const int n = (int)(nc / C);
+  float v = to_f32(in[((size_t)n * HW + px) * Cs + c]) * scale + shift;
+  if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+  out[i] = v;
+}
+
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long long n8) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8;
+       i += (long long)gridDim.x * blockDim.x) {
+    const auto va = as_vec8<T>(((const u32x4*)a)[i]);
+    const auto vb = as_vec8<T>(((const u32x4*)b)[i]);
+    typename Traits<T>::vec8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = from_f32<T>(to_f32(va[e]) + to_f32(vb[e]));
+    ((typename Traits<T>::vec8*)y)[i] = r;
+  }
+}
+
+template <typename T>
+__global__ void vae_sample_kernel(const T* __restrict__ mom, const float* __restrict__ noise, T* __restrict__ z,
+                                  int N, int HW, int L, int Lpad, float scaling) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)N * HW * Lpad;
+  if (i >= total) return;
+  const int c = (int)(i % Lpad);
+  const long long np = i / Lpad;
+  const int px = (int)(np % HW);
+  const int n = (int)(np / HW);
+  float v = 0.f;
+  if (c < L) {
+    const float mean = to_f32(mom[np * (2 * L) + c]);
+    float logvar = to_f32(mom[np * (2 * L) + L + c]);
+    logvar = fminf(fmaxf(logvar, -30.f), 20.f);
+    v = (mean + expf(0.5f * logvar) * noise[((size_t)n * L + c) * HW + px]) * scaling;
+  }
+  z[i] = from_f32<T>(v);
+}
+
+__global__ void incr_kernel(int* ctr) { *ctr += 1; }
+
+inline unsigned nblk(long long n, int b = 256) { return (unsigned)((n + b - 1) / b); }
+
+}  // namespace
+
+extern "C" void es_set_error(const char* msg) {
+  strncpy(g_err, msg, sizeof(g_err) - 1);
+  g_err[sizeof(g_err) - 1] = 0;
+}
+extern "C" const char* es_last_error(void) { return g_err; }
+extern "C" int es_abi_version(void) { return ES_ABI_VERSION; }
+
+#define ES_RET(name)                                              \
+  do {                                                            \
+    if (hipGetLastError() != hipSuccess) {                        \
+      es_set_error(name ": launch failed");                       \
+      return -2;                                                  \
+    }                                                             \
+    return 0;                                                     \
+  } while (0)
+
+extern "C" int es_timestep_embedding(const float* t, void* out, int N, int dim, int dtype, void* stream) {
+  if (!t || !out || dim % 2 || N < 1) { es_set_error("es_timestep_embedding: bad arguments"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)N * (dim / 2);
+  if (dtype == ES_F16) hipLaunchKernelGGL(timestep_kernel<f16>, dim3(nblk(n)), dim3(256), 0, st, t, (f16*)out, N, dim);
+  else hipLaunchKernelGGL(timestep_kernel<bf16>, dim3(nblk(n)), dim3(256), 0, st, t, (bf16*)out, N, dim);
+  ES_RET("es_timestep_embedding");
+}
+
+extern "C" int es_cfg_ddim_step(const void* noise, float* latents, void* model_in, const float* coef,
+                                const int32_t* step_idx, float guidance_scale, int B, int HW, int L, int Lstride,
+                                int cfg, int dtype, void* stream) {
+  if (!noise || !latents || !model_in || !coef || !step_idx || B < 1 || HW < 1 || L < 1 || Lstride < L) {
+    es_set_error("es_cfg_ddim_step: bad arguments"); return -1;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)B * HW * L;
+  if (dtype == ES_F16)
+    hipLaunchKernelGGL(cfg_ddim_kernel<f16>, dim3(nblk(n)), dim3(256), 0, st, (const f16*)noise, latents,
+                       (f16*)model_in, coef, step_idx, guidance_scale, B, HW, L, Lstride, cfg);
+  else
+    hipLaunchKernelGGL(cfg_ddim_kernel<bf16>, dim3(nblk(n)), dim3(256), 0, st, (const bf16*)noise, latents,
+                       (bf16*)model_in, coef, step_idx, guidance_scale, B, HW, L, Lstride, cfg);
+  ES_RET("es_cfg_ddim_step");
+}
+
+extern "C" int es_nchw_f32_to_nhwc(const float* in, void* out, int N, int C, int HW, int Cpad, int dtype,
+                                   void* stream) {
+  if (!in || !out || Cpad < C || N < 1) { es_set_error("es_nchw_f32_to_nhwc: bad arguments"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)N * HW * Cpad;
+  if (dtype == ES_F16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16>, dim3(nblk(n)), dim3(256), 0, st, in, (f16*)out, N, C, HW, Cpad);
+  else hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16>, dim3(nblk(n)), dim3(256), 0, st, in, (bf16*)out, N, C, HW, Cpad);
+  ES_RET("es_nchw_f32_to_nhwc");
+}
+
+extern "C" int es_nhwc_to_nchw_f32(const void* in, float* out, int N, int C, int HW, int Cstride, float scale,
+                                   float shift, int clamp01, int dtype, void* stream) {
+  if (!in || !out || Cstride < C || N < 1) { es_set_error("es_nhwc_to_nchw_f32: bad arguments"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)N * C * HW;
+  if (dtype == ES_F16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<f16>, dim3(nblk(n)), dim3(256), 0, st, (const f16*)in, out, N, C, HW, Cstride, scale, shift, clamp01);
+  else hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16>, dim3(nblk(n)), dim3(256), 0, st, (const bf16*)in, out, N, C, HW, Cstride, scale, shift, clamp01);
+  ES_RET("es_nhwc_to_nchw_f32");
+}
+
+extern "C" int es_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream) {
+  if (!a || !b || !y || n < 8 || n % 8) { es_set_error("es_add: n must be a positive multiple of 8"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  const long long n8 = n / 8;
+  unsigned blocks = nblk(n8);
+  if (blocks > 2048) blocks = 2048;
+  if (dtype == ES_F16) hipLaunchKernelGGL(add_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const f16*)a, (const f16*)b, (f16*)y, n8);
+  else hipLaunchKernelGGL(add_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (bf16*)y, n8);
+  ES_RET("es_add");
+}
+
+extern "C" int es_vae_sample(const void* moments, const float* noise_nchw, void* z, int N, int HW, int L, int Lpad,
+                             float scaling, int dtype, void* stream) {
+  if (!moments || !noise_nchw || !z || Lpad < L || N < 1) { es_set_error("es_vae_sample: bad arguments"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)N * HW * Lpad;
+  if (dtype == ES_F16) hipLaunchKernelGGL(vae_sample_kernel<f16>, dim3(nblk(n)), dim3(256), 0, st, (const f16*)moments, noise_nchw, (f16*)z, N, HW, L, Lpad, scaling);
+  else hipLaunchKernelGGL(vae_sample_kernel<bf16>, dim3(nblk(n)), dim3(256), 0, st, (const bf16*)moments, noise_nchw, (bf16*)z, N, HW, L, Lpad, scaling);
+  ES_RET("es_vae_sample");
+}
+
+extern "C" int es_incr(int32_t* ctr, void* stream) {
+  if (!ctr) { es_set_error("es_incr: null pointer"); return -1; }
+  hipLaunchKernelGGL(incr_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ctr);
+  ES_RET("es_incr");
+}

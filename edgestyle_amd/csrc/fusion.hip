@@ -1,0 +1,187 @@
+// EdgeStyle fusion block for gfx950: interleave_tensors (model/edgestyle_multicontrolnet.py:479-501) +
+// ControlNetBlock (model/edgestyle_multicontrolnet.py:23-63) with the interleaved [N,6C,H,W] tensor never
+// materialised.  With the reference's channel interleave k = c*6 + net and its grouped 1x1 convs, output channel c
+// depends only on the SAME channel c of the six nets:
+//   z_p = w1[c,p,0]*r[2p] + w1[c,p,1]*r[2p+1] + b1[c,p]                      p = 0..2   (first_conv, groups=3C)
+//   y_p = silu( LN1(z)[c,p,h,w] )      LN1 over all (3C,H,W) of a sample, affine planes [3C,H,W]
+//   u   = sum_p w2[c,p]*y_p + b2[c]                                          (second_conv, groups=C)
+//   v   = silu( LN2(u)[c,h,w] )        LN2 over (C,H,W), affine planes [C,H,W]
+//   out = w3[c]*v + b3[c]                                                    (third_conv, depthwise)
+// HBM-bound: three streaming passes (stats of z; y,u + stats of u; output), 16-byte loads along C from the six
+// NHWC residual tensors in place, fp32 statistics, deterministic two-level reductions (no global atomics).
+#include "common.h"
+#include "../../include/edgestyle_hip.h"
+
+namespace {
+
+constexpr int FU_MAX_CHUNK = 64;
+
+ES_DEVICE float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+template <typename T>
+ES_DEVICE void load_z(const es_fusion_desc& p, int n, size_t off, int c, float z[3][8]) {
+  // off = pix*C + c  (element offset inside one sample of one net)
+  float r[6][8];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const auto v = as_vec8<T>(*(const u32x4*)((const T*)p.res[k] + (size_t)n * p.res_bs[k] + off));
+    float sc = p.res_scale[k];
+    if (p.res_scale_dev) sc *= p.res_scale_dev[k];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[k][e] = to_f32(v[e]) * sc;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const float* w = p.w1 + ((size_t)(c + e) * 3 + q) * 2;
+      z[q][e] = w[0] * r[2 * q][e] + w[1] * r[2 * q + 1][e] + p.b1[(c + e) * 3 + q];
+    }
+}
+
+ES_DEVICE void reduce_partials(const float* part, int nchunk, float cnt, float eps, float& mean, float& rstd) {
+  float s = 0.f, ss = 0.f;
+  for (int k = 0; k < nchunk; ++k) { s += part[k * 2]; ss += part[k * 2 + 1]; }
+  mean = s / cnt;
+  float var = ss / cnt - mean * mean;
+  var = var < 0.f ? 0.f : var;
+  rstd = rsqrtf(var + eps);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fusion_pass_a(const es_fusion_desc p) {
+  __shared__ float red[4];
+  const int n = blockIdx.y;
+  const int CH8 = p.C / 8;
+  const long long items = (long long)p.HW * CH8;
+  float s = 0.f, ss = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % CH8) * 8;
+    float z[3][8];
+    load_z<T>(p, n, (size_t)i * 8, c, z);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s += z[q][e]; ss += z[q][e] * z[q][e]; }
+  }
+  s = block_sum(s, red);
+  ss = block_sum(ss, red);
+  if (threadIdx.x == 0) {
+    float* o = p.scratch + (((size_t)n * 2 + 0) * FU_MAX_CHUNK + blockIdx.x) * 2;
+    o[0] = s; o[1] = ss;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fusion_pass_b(const es_fusion_desc p, const int nchunk) {
+  __shared__ float red[4];
+  const int n = blockIdx.y;
+  const int CH8 = p.C / 8;
+  const long long items = (long long)p.HW * CH8;
+  float mean1, rstd1;
+  reduce_partials(p.scratch + ((size_t)n * 2 + 0) * FU_MAX_CHUNK * 2, nchunk, 3.f * (float)p.C * (float)p.HW,
+                  p.eps, mean1, rstd1);
+  float s = 0.f, ss = 0.f;
+  T* U = (T*)p.u + (size_t)n * p.HW * p.C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % CH8) * 8;
+    float z[3][8];
+    load_z<T>(p, n, (size_t)i * 8, c, z);
+    // affine planes: [(pix*C + c)*3 + q], 24 contiguous values for this thread
+    const T* g1 = (const T*)p.g1 + (size_t)i * 24;
+    const T* be1 = (const T*)p.be1 + (size_t)i * 24;
+    float gv[24], bv[24];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const auto a = as_vec8<T>(*(const u32x4*)(g1 + k * 8));
+      const auto b = as_vec8<T>(*(const u32x4*)(be1 + k * 8));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { gv[k * 8 + e] = to_f32(a[e]); bv[k * 8 + e] = to_f32(b[e]); }
+    }
+    typename Traits<T>::vec8 uo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float u = p.b2[c + e];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const float y = silu_f((z[q][e] - mean1) * rstd1 * gv[e * 3 + q] + bv[e * 3 + q]);
+        u += p.w2[(c + e) * 3 + q] * y;
+      }
+      uo[e] = from_f32<T>(u);
+      const float ur = to_f32(uo[e]);      // statistics of the value pass C will actually read
+      s += ur; ss += ur * ur;
+    }
+    *(typename Traits<T>::vec8*)(U + (size_t)i * 8) = uo;
+  }
+  s = block_sum(s, red);
+  ss = block_sum(ss, red);
+  if (threadIdx.x == 0) {
+    float* o = p.scratch + (((size_t)n * 2 + 1) * FU_MAX_CHUNK + blockIdx.x) * 2;
+    o[0] = s; o[1] = ss;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fusion_pass_c(const es_fusion_desc p, const int nchunk) {
+  const int n = blockIdx.y;
+  const int CH8 = p.C / 8;
+  const long long items = (long long)p.HW * CH8;
+  float mean2, rstd2;
+  reduce_partials(p.scratch + ((size_t)n * 2 + 1) * FU_MAX_CHUNK * 2, nchunk, (float)p.C * (float)p.HW, p.eps,
+                  mean2, rstd2);
+  const T* U = (const T*)p.u + (size_t)n * p.HW * p.C;
+  T* O = (T*)p.out + (size_t)n * p.HW * p.C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % CH8) * 8;
+    const auto u = as_vec8<T>(*(const u32x4*)(U + (size_t)i * 8));
+    const auto g = as_vec8<T>(*(const u32x4*)((const T*)p.g2 + (size_t)i * 8));
+    const auto b = as_vec8<T>(*(const u32x4*)((const T*)p.be2 + (size_t)i * 8));
+    typename Traits<T>::vec8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = silu_f((to_f32(u[e]) - mean2) * rstd2 * to_f32(g[e]) + to_f32(b[e]));
+      r[e] = from_f32<T>(p.w3[c + e] * v + p.b3[c + e]);
+    }
+    *(typename Traits<T>::vec8*)(O + (size_t)i * 8) = r;
+  }
+}
+
+template <typename T>
+int launch_fusion(const es_fusion_desc& d, hipStream_t st) {
+  const long long items = (long long)d.HW * (d.C / 8);
+  int nchunk = (int)(items / 1024);
+  if (nchunk < 1) nchunk = 1;
+  if (nchunk > FU_MAX_CHUNK) nchunk = FU_MAX_CHUNK;
+  dim3 grid(nchunk, d.N);
+  hipLaunchKernelGGL(fusion_pass_a<T>, grid, dim3(256), 0, st, d);
+  hipLaunchKernelGGL(fusion_pass_b<T>, grid, dim3(256), 0, st, d, nchunk);
+  int cb = (int)((items + 255) / 256);
+  if (cb > 512) cb = 512;
+  hipLaunchKernelGGL(fusion_pass_c<T>, dim3(cb, d.N), dim3(256), 0, st, d, nchunk);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace
+
+extern "C" void es_set_error(const char* msg);
+
+extern "C" size_t es_fusion_scratch_bytes(int N) { return (size_t)N * 2 * FU_MAX_CHUNK * 2 * sizeof(float); }
+
+extern "C" int es_fusion_block(const es_fusion_desc* d, void* stream) {
+  for (int i = 0; i < 6; ++i)
+    if (!d->res[i]) { es_set_error("es_fusion_block: null residual pointer"); return -1; }
+  if (!d->w1 || !d->b1 || !d->g1 || !d->be1 || !d->w2 || !d->b2 || !d->g2 || !d->be2 || !d->w3 || !d->b3 ||
+      !d->scratch || !d->u || !d->out) { es_set_error("es_fusion_block: null pointer"); return -1; }
+  if (d->C % 8 || d->N < 1 || d->HW < 1) { es_set_error("es_fusion_block: C must be a multiple of 8"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  int rc = d->dtype == ES_F16 ? launch_fusion<f16>(*d, st) : launch_fusion<bf16>(*d, st);
+  if (rc) es_set_error("es_fusion_block: launch failed");
+  return rc;
+}

@@ -1,0 +1,245 @@
+// GroupNorm(+SiLU) over NHWC and LayerNorm over [M, C] for gfx950 — HBM-bound wavefront-reduction kernels.
+//
+// GroupNorm: two launches, both with 16-byte vector loads along the contiguous channel dim.
+//   1. gn_stats_kernel: grid (nchunk, N).  A block walks its pixel range once; each thread keeps 8 per-channel
+//      (sum, sumsq) pairs for its fixed 16-byte channel chunk, then folds them into 32 per-group LDS
+//      accumulators -> fp32 partials [N][nchunk][G][2] (deterministic: no global atomics).
+//   2. gn_apply_kernel: grid (blocks, N).  Prologue reduces the partials to mean / rstd and builds per-channel
+//      scale/shift tables in LDS (gamma*rstd, beta-mean*gamma*rstd), so the streaming loop is one FMA (+SiLU) per
+//      element with no integer division.  Two sources (UNet skip concat) are read in place and written as one
+//      concatenated, normalised tensor.
+// LayerNorm: one wave per row, values held in registers, exact two-pass mean/variance via wave shuffles.
+#include "common.h"
+#include "../../include/edgestyle_hip.h"
+
+namespace {
+
+constexpr int GN_MAX_CHUNK = 32;
+constexpr int GN_MAX_GROUPS = 64;
+
+ES_DEVICE int gn_pixels_per_block(int HW) {
+  int ppb = HW / GN_MAX_CHUNK;
+  return ppb < 16 ? 16 : ppb;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const es_gn_desc p) {
+  __shared__ float gs[GN_MAX_GROUPS * 2];
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int C = p.C1 + p.C2, CH8 = C / 8, cpg = C / p.groups;
+  const int ppb = gn_pixels_per_block(p.HW);
+  const int p0 = chunk * ppb;
+  const int p1 = min(p0 + ppb, p.HW);
+  for (int i = threadIdx.x; i < p.groups * 2; i += 256) gs[i] = 0.f;
+  __syncthreads();
+  const int lanes_used = (256 / CH8) * CH8;          // threads that own a (pixel-slot, chunk)
+  if (CH8 <= 256) {
+    if ((int)threadIdx.x < lanes_used) {
+      const int q = threadIdx.x % CH8, ps = threadIdx.x / CH8, pstride = 256 / CH8;
+      const int c = q * 8;
+      const bool second = c >= p.C1;
+      const T* src = second ? (const T*)p.x2 : (const T*)p.x;
+      const int cs = second ? p.C2 : p.C1, cc = second ? c - p.C1 : c;
+      float s[8], ss[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+      for (int px = p0 + ps; px < p1; px += pstride) {
+        const auto v = as_vec8<T>(*(const u32x4*)(src + ((size_t)n * p.HW + px) * cs + cc));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = to_f32(v[e]); s[e] += f; ss[e] += f * f; }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int gi = (c + e) / cpg;
+        atomicAdd(&gs[gi * 2], s[e]);
+        atomicAdd(&gs[gi * 2 + 1], ss[e]);
+      }
+    }
+  } else {
+    // wide tensors (C > 2048): each thread strides over chunks
+    for (int q = threadIdx.x; q < CH8; q += 256) {
+      const int c = q * 8;
+      const bool second = c >= p.C1;
+      const T* src = second ? (const T*)p.x2 : (const T*)p.x;
+      const int cs = second ? p.C2 : p.C1, cc = second ? c - p.C1 : c;
+      float s[8], ss[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+      for (int px = p0; px < p1; ++px) {
+        const auto v = as_vec8<T>(*(const u32x4*)(src + ((size_t)n * p.HW + px) * cs + cc));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = to_f32(v[e]); s[e] += f; ss[e] += f * f; }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int gi = (c + e) / cpg;
+        atomicAdd(&gs[gi * 2], s[e]);
+        atomicAdd(&gs[gi * 2 + 1], ss[e]);
+      }
+    }
+  }
+  __syncthreads();
+  const int nchunk = gridDim.x;
+  for (int i = threadIdx.x; i < p.groups * 2; i += 256)
+    p.partials[((size_t)n * nchunk + chunk) * p.groups * 2 + i] = gs[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const es_gn_desc p, const int nchunk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n = blockIdx.y;
+  const int C = p.C1 + p.C2, CH8 = C / 8, cpg = C / p.groups;
+  float* scale = (float*)smem;         // [C]
+  float* shift = scale + C;            // [C]
+  float* gstat = shift + C;            // [groups*2] mean, rstd
+  for (int gi = threadIdx.x; gi < p.groups; gi += 256) {
+    float s = 0.f, ss = 0.f;
+    for (int k = 0; k < nchunk; ++k) {
+      const float* pp = p.partials + ((size_t)n * nchunk + k) * p.groups * 2 + gi * 2;
+      s += pp[0]; ss += pp[1];
+    }
+    const float cnt = (float)cpg * (float)p.HW;
+    const float mean = s / cnt;
+    float var = ss / cnt - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    gstat[gi * 2] = mean;
+    gstat[gi * 2 + 1] = rsqrtf(var + p.eps);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int gi = c / cpg;
+    const float sc = p.gamma[c] * gstat[gi * 2 + 1];
+    scale[c] = sc;
+    shift[c] = p.beta[c] - gstat[gi * 2] * sc;
+  }
+  __syncthreads();
+  const long long total = (long long)p.HW * CH8;
+  T* out = (T*)p.out + (size_t)n * p.HW * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int px = (int)(i / CH8);
+    const int c = (int)(i - (long long)px * CH8) * 8;
+    const bool second = c >= p.C1;
+    const T* src = second ? (const T*)p.x2 : (const T*)p.x;
+    const int cs = second ? p.C2 : p.C1, cc = second ? c - p.C1 : c;
+    const auto v = as_vec8<T>(*(const u32x4*)(src + ((size_t)n * p.HW + px) * cs + cc));
+    typename Traits<T>::vec8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = to_f32(v[e]) * scale[c + e] + shift[c + e];
+      if (p.silu) f = silu_f(f);
+      r[e] = from_f32<T>(f);
+    }
+    *(typename Traits<T>::vec8*)(out + (size_t)px * C + c) = r;
+  }
+}
+
+template <typename T, int VPL /* 16-byte chunks per lane */>
+__global__ __launch_bounds__(256) void layer_norm_kernel(const T* __restrict__ x, T* __restrict__ out,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int CH8 = C / 8;
+  const T* xr = x + (size_t)row * C;
+  typename Traits<T>::vec8 v[VPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int q = lane + 64 * i;
+    if (q < CH8) {
+      v[i] = as_vec8<T>(*(const u32x4*)(xr + q * 8));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += to_f32(v[i][e]);
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int q = lane + 64 * i;
+    if (q < CH8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float dlt = to_f32(v[i][e]) - mean; ss += dlt * dlt; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+  T* orow = out + (size_t)row * C;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int q = lane + 64 * i;
+    if (q < CH8) {
+      typename Traits<T>::vec8 r;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        r[e] = from_f32<T>((to_f32(v[i][e]) - mean) * rstd * gamma[q * 8 + e] + beta[q * 8 + e]);
+      *(typename Traits<T>::vec8*)(orow + q * 8) = r;
+    }
+  }
+}
+
+template <typename T>
+int launch_gn(const es_gn_desc& d, hipStream_t st) {
+  const int C = d.C1 + d.C2;
+  int ppb = d.HW / GN_MAX_CHUNK;
+  if (ppb < 16) ppb = 16;
+  const int nchunk = (d.HW + ppb - 1) / ppb;
+  hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(nchunk, d.N), dim3(256), 0, st, d);
+  const long long total = (long long)d.HW * (C / 8);
+  int blocks = (int)((total + 256 * 4 - 1) / (256 * 4));
+  if (blocks < 1) blocks = 1;
+  if (blocks > 1024) blocks = 1024;
+  const size_t lds = (size_t)(2 * C + 2 * d.groups) * sizeof(float);
+  hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(blocks, d.N), dim3(256), lds, st, d, nchunk);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <typename T>
+int launch_ln(const void* x, void* out, const float* gamma, const float* beta, int M, int C, float eps,
+              hipStream_t st) {
+  const int CH8 = C / 8;
+  const int vpl = (CH8 + 63) / 64;
+  dim3 grid((M + 3) / 4);
+#define ES_LN(V) hipLaunchKernelGGL((layer_norm_kernel<T, V>), grid, dim3(256), 0, st, (const T*)x, (T*)out, gamma, beta, M, C, eps)
+  if (vpl <= 1) ES_LN(1);
+  else if (vpl <= 2) ES_LN(2);
+  else if (vpl <= 3) ES_LN(3);
+  else if (vpl <= 4) ES_LN(4);
+  else if (vpl <= 8) ES_LN(8);
+  else return -3;
+#undef ES_LN
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace
+
+extern "C" void es_set_error(const char* msg);
+
+extern "C" size_t es_group_norm_partials_bytes(int N, int groups) {
+  return (size_t)N * GN_MAX_CHUNK * groups * 2 * sizeof(float);
+}
+
+extern "C" int es_group_norm(const es_gn_desc* d, void* stream) {
+  const int C = d->C1 + d->C2;
+  if (!d->x || !d->out || !d->gamma || !d->beta || !d->partials) { es_set_error("es_group_norm: null pointer"); return -1; }
+  if (d->C1 % 8 || d->C2 % 8 || (d->C2 && !d->x2)) { es_set_error("es_group_norm: channels must be multiples of 8"); return -1; }
+  if (d->groups < 1 || d->groups > GN_MAX_GROUPS || C % d->groups) { es_set_error("es_group_norm: bad group count"); return -1; }
+  if (C > 8192) { es_set_error("es_group_norm: C too large for the LDS tables"); return -1; }
+  if (d->N < 1 || d->HW < 1) { es_set_error("es_group_norm: empty problem"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  int rc = d->dtype == ES_F16 ? launch_gn<f16>(*d, st) : launch_gn<bf16>(*d, st);
+  if (rc) es_set_error("es_group_norm: launch failed");
+  return rc;
+}
+
+extern "C" int es_layer_norm(const void* x, void* out, const float* gamma, const float* beta, int M, int C,
+                             float eps, int dtype, void* stream) {
+  if (!x || !out || !gamma || !beta) { es_set_error("es_layer_norm: null pointer"); return -1; }
+  if (C % 8 || M < 1) { es_set_error("es_layer_norm: C must be a multiple of 8"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  int rc = dtype == ES_F16 ? launch_ln<f16>(x, out, gamma, beta, M, C, eps, st)
+                           : launch_ln<bf16>(x, out, gamma, beta, M, C, eps, st);
+  if (rc == -3) es_set_error("es_layer_norm: C > 4096 unsupported");
+  else if (rc) es_set_error("es_layer_norm: launch failed");
+  return rc;
+}

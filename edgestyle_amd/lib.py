@@ -1,0 +1,113 @@
+"""ctypes binding of libedgestyle_hip.so (the C ABI declared in include/edgestyle_hip.h).
+
+The product path has NO fallback: if the shared library is missing or an entry point fails, this raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libedgestyle_hip.so")
+
+ES_F16, ES_BF16 = 0, 1
+ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x2", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("temb", C.c_void_p),
+        ("residual", C.c_void_p), ("out_scale_dev", C.c_void_p), ("out", C.c_void_p), ("workspace", C.c_void_p),
+        ("N", C.c_int32), ("Hsrc", C.c_int32), ("Wsrc", C.c_int32), ("C1", C.c_int32), ("C2", C.c_int32),
+        ("Hout", C.c_int32), ("Wout", C.c_int32), ("Cout", C.c_int32),
+        ("rows_padded", C.c_int32), ("Kpad", C.c_int32),
+        ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("upsample", C.c_int32), ("temb_stride", C.c_int32), ("act", C.c_int32), ("splitk", C.c_int32),
+        ("bn", C.c_int32), ("dtype", C.c_int32), ("out_scale", C.c_float),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p),
+        ("N", C.c_int32), ("heads", C.c_int32), ("Sq", C.c_int32), ("Skv", C.c_int32), ("d", C.c_int32),
+        ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32),
+        ("bsq", C.c_int64), ("bsk", C.c_int64), ("bsv", C.c_int64), ("bso", C.c_int64),
+        ("scale", C.c_float), ("dtype", C.c_int32),
+    ]
+
+
+class GnDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x2", C.c_void_p), ("out", C.c_void_p),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p), ("partials", C.c_void_p),
+        ("N", C.c_int32), ("HW", C.c_int32), ("C1", C.c_int32), ("C2", C.c_int32), ("groups", C.c_int32),
+        ("eps", C.c_float), ("silu", C.c_int32), ("dtype", C.c_int32),
+    ]
+
+
+class FusionDesc(C.Structure):
+    _fields_ = [
+        ("res", C.c_void_p * 6), ("res_bs", C.c_int64 * 6),
+        ("w1", C.c_void_p), ("b1", C.c_void_p), ("g1", C.c_void_p), ("be1", C.c_void_p),
+        ("w2", C.c_void_p), ("b2", C.c_void_p), ("g2", C.c_void_p), ("be2", C.c_void_p),
+        ("w3", C.c_void_p), ("b3", C.c_void_p),
+        ("scratch", C.c_void_p), ("u", C.c_void_p), ("out", C.c_void_p),
+        ("res_scale_dev", C.c_void_p),
+        ("res_scale", C.c_float * 6),
+        ("N", C.c_int32), ("HW", C.c_int32), ("C", C.c_int32),
+        ("eps", C.c_float), ("dtype", C.c_int32),
+    ]
+
+
+# every symbol include/edgestyle_hip.h declares: (name, restype, argtypes)
+_P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
+SYMBOLS = {
+    "es_abi_version": (C.c_int, []),
+    "es_last_error": (C.c_char_p, []),
+    "es_conv_gemm": (C.c_int, [C.POINTER(GemmDesc), _P]),
+    "es_conv_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
+    "es_attention": (C.c_int, [C.POINTER(AttnDesc), _P]),
+    "es_group_norm": (C.c_int, [C.POINTER(GnDesc), _P]),
+    "es_group_norm_partials_bytes": (C.c_size_t, [_I, _I]),
+    "es_layer_norm": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _I, _P]),
+    "es_fusion_block": (C.c_int, [C.POINTER(FusionDesc), _P]),
+    "es_fusion_scratch_bytes": (C.c_size_t, [_I]),
+    "es_timestep_embedding": (C.c_int, [_P, _P, _I, _I, _I, _P]),
+    "es_cfg_ddim_step": (C.c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P]),
+    "es_nchw_f32_to_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "es_nhwc_to_nchw_f32": (C.c_int, [_P, _P, _I, _I, _I, _I, _F, _F, _I, _I, _P]),
+    "es_add": (C.c_int, [_P, _P, _P, _L, _I, _P]),
+    "es_vae_sample": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
+    "es_incr": (C.c_int, [_P, _P]),
+}
+
+_lib = None
+
+
+class EdgeStyleHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises EdgeStyleHipError — never falls back to another implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EdgeStyleHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)           # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.es_abi_version() != 1:
+        raise EdgeStyleHipError("libedgestyle_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().es_last_error()
+        raise EdgeStyleHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,351 @@
+"""Thin Python wrappers over the C ABI: torch only allocates device memory and supplies the current HIP stream.
+
+Internal activation layout is NHWC ([N,H,W,C], dtype fp16/bf16); every wrapper launches on
+`torch.cuda.current_stream()` so the calls can be captured into a hipGraph (`torch.cuda.graph`).
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import lib as L
+
+_DT = {torch.float16: L.ES_F16, torch.bfloat16: L.ES_BF16}
+BK = 64
+BM = 128
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise L.EdgeStyleHipError(f"unsupported dtype {t.dtype}: the HIP path computes in fp16 or bf16")
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# weight packing (host side, once at load)
+# ----------------------------------------------------------------------------------------------------------------
+@dataclass
+class PackedWeight:
+    w: torch.Tensor                 # [rows_padded, Kpad] dtype, K = (ky,kx,c) tap-major
+    bias: Optional[torch.Tensor]    # [rows_padded] fp32
+    cout: int                       # true GEMM N
+    cin: int                        # padded input channels (multiple of 8)
+    ksize: int
+    bn: int
+    geglu: bool = False
+
+    @property
+    def rows_padded(self):
+        return self.w.shape[0]
+
+    @property
+    def kpad(self):
+        return self.w.shape[1]
+
+
+def choose_bn(cout: int) -> int:
+    return 160 if (cout % 160 == 0 and cout % 128 != 0) else 128
+
+
+def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype, device, geglu: bool = False,
+                cin_pad: Optional[int] = None) -> PackedWeight:
+    """weight: [Cout, Cin, k, k] (conv) or [Cout, Cin] (linear), fp32 CPU -> packed device tensor.
+
+    GEGLU (ff.net.0.proj, out = 2*inner): rows are re-ordered in blocks of 32 = [16 hidden | 16 gate] so that
+    the GEMM epilogue finds hidden and gate of the same output column in adjacent MFMA fragments.
+    """
+    if weight.dim() == 2:
+        weight = weight[:, :, None, None]
+    cout, cin, k, _ = weight.shape
+    cp = cin_pad or ((cin + 7) // 8 * 8)
+    w = weight.float().permute(0, 2, 3, 1)                      # [Cout, k, k, Cin]
+    if cp != cin:
+        w = torch.nn.functional.pad(w, (0, cp - cin))
+    w = w.reshape(cout, k * k * cp)
+    b = None if bias is None else bias.float().clone()
+    if geglu:
+        inner = cout // 2
+        assert inner % 16 == 0
+        idx = torch.arange(cout)
+        blk, within = idx // 32, idx % 32
+        src = torch.where(within < 16, blk * 16 + within, inner + blk * 16 + (within - 16))
+        w = w[src]
+        if b is not None:
+            b = b[src]
+    bn = 128 if geglu else choose_bn(cout)
+    rows = (cout + bn - 1) // bn * bn
+    ktrue = w.shape[1]
+    kpad = (ktrue + BK - 1) // BK * BK
+    wp = torch.zeros(rows, kpad, dtype=torch.float32)
+    wp[:cout, :ktrue] = w
+    bp = None
+    if b is not None:
+        bp = torch.zeros(rows, dtype=torch.float32)
+        bp[:cout] = b
+        bp = bp.to(device)
+    return PackedWeight(wp.to(device=device, dtype=dtype), bp, cout, cp, k, bn, geglu)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# split-K workspace (grown outside graph capture by a warm-up pass)
+# ----------------------------------------------------------------------------------------------------------------
+_workspace = {}
+
+
+def _get_workspace(nbytes: int, device) -> torch.Tensor:
+    ws = _workspace.get(device)
+    if ws is None or ws.numel() * 4 < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise L.EdgeStyleHipError("split-K workspace too small during graph capture; run one eager warm-up first")
+        ws = torch.empty(max(nbytes // 4, 1 << 22), dtype=torch.float32, device=device)
+        _workspace[device] = ws
+    return ws
+
+
+def choose_splitk(M: int, rows_padded: int, bn: int, kpad: int) -> int:
+    tiles = ((M + BM - 1) // BM) * (rows_padded // bn)
+    nk = kpad // BK
+    if tiles >= 160 or nk < 8:
+        return 1
+    s = min(max(1, 320 // tiles), nk // 4, 32)
+    return max(1, s)
+
+
+def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Optional[int] = None,
+              upsample: bool = False, x2: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None,
+              residual: Optional[torch.Tensor] = None, act: int = L.ACT_NONE, out_scale: float = 1.0,
+              out_scale_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+              out_hw=None, splitk: Optional[int] = None) -> torch.Tensor:
+    """x: [N,H,W,C1] (+ x2 [N,H,W,C2]); returns [N,Hout,Wout,Cout] (Cout/2 for GEGLU)."""
+    N, H, W, C1 = x.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    if C1 + C2 != pw.cin:
+        raise L.EdgeStyleHipError(f"conv_gemm: input channels {C1}+{C2} != packed {pw.cin}")
+    k = pw.ksize
+    if pad is None:
+        pad = 1 if k == 3 else 0
+    Hin, Win = (H * 2, W * 2) if upsample else (H, W)
+    if out_hw is None:
+        Hout = (Hin + 2 * pad - k) // stride + 1
+        Wout = (Win + 2 * pad - k) // stride + 1
+    else:
+        Hout, Wout = out_hw
+    act_i = L.ACT_GEGLU if pw.geglu else act
+    cstore = pw.cout // 2 if pw.geglu else pw.cout
+    if out is None:
+        out = torch.empty((N, Hout, Wout, cstore), dtype=x.dtype, device=x.device)
+    M = N * Hout * Wout
+    if splitk is None:
+        splitk = 1 if pw.geglu else choose_splitk(M, pw.rows_padded, pw.bn, pw.kpad)
+    d = L.GemmDesc()
+    d.x, d.x2, d.w = x.data_ptr(), (x2.data_ptr() if x2 is not None else None), pw.w.data_ptr()
+    d.bias = pw.bias.data_ptr() if pw.bias is not None else None
+    d.temb = temb.data_ptr() if temb is not None else None
+    d.residual = residual.data_ptr() if residual is not None else None
+    d.out_scale_dev = out_scale_dev.data_ptr() if out_scale_dev is not None else None
+    d.out = out.data_ptr()
+    d.N, d.Hsrc, d.Wsrc, d.C1, d.C2 = N, H, W, C1, C2
+    d.Hout, d.Wout, d.Cout = Hout, Wout, pw.cout
+    d.rows_padded, d.Kpad = pw.rows_padded, pw.kpad
+    d.ksize, d.stride, d.pad = k, stride, pad
+    d.upsample = 1 if upsample else 0
+    d.temb_stride = temb.stride(0) if temb is not None else 0
+    d.act, d.splitk, d.bn, d.dtype, d.out_scale = act_i, splitk, pw.bn, _dt(x), out_scale
+    if splitk > 1:
+        ws = _get_workspace(splitk * M * pw.rows_padded * 4, x.device)
+        d.workspace = ws.data_ptr()
+    L.check(L.load().es_conv_gemm(C.byref(d), _stream()), "es_conv_gemm")
+    return out
+
+
+def linear(x: torch.Tensor, pw: PackedWeight, **kw) -> torch.Tensor:
+    """x: [..., K] -> [..., Cout]; runs the same implicit-GEMM kernel with a 1x1 'image' of M pixels."""
+    shp = x.shape
+    M = x.numel() // shp[-1]
+    out = kw.pop("out", None)
+    res = kw.pop("residual", None)
+    cstore = pw.cout // 2 if pw.geglu else pw.cout
+    y = conv_gemm(x.reshape(M, 1, 1, shp[-1]), pw,
+                  residual=None if res is None else res.reshape(M, 1, 1, cstore),
+                  out=None if out is None else out.reshape(M, 1, 1, cstore), **kw)
+    return y.reshape(*shp[:-1], cstore)
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: Optional[float] = None,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q: [N,Sq,heads*d] view (any row stride), k/v: [N,Skv,heads*d] views -> [N,Sq,heads*d] contiguous."""
+    N, Sq, Cq = q.shape
+    Skv = k.shape[1]
+    dh = Cq // heads
+    if out is None:
+        out = torch.empty((N, Sq, Cq), dtype=q.dtype, device=q.device)
+    for t in (q, k, v, out):
+        if t.stride(2) != 1:
+            raise L.EdgeStyleHipError("attention: innermost stride must be 1")
+    d = L.AttnDesc()
+    d.q, d.k, d.v, d.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    d.N, d.heads, d.Sq, d.Skv, d.d = N, heads, Sq, Skv, dh
+    d.ldq, d.ldk, d.ldv, d.ldo = q.stride(1), k.stride(1), v.stride(1), out.stride(1)
+    d.bsq, d.bsk, d.bsv, d.bso = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    d.scale = scale if scale is not None else 1.0 / math.sqrt(dh)
+    d.dtype = _dt(q)
+    L.check(L.load().es_attention(C.byref(d), _stream()), "es_attention")
+    return out
+
+
+_gn_partials = {}
+
+
+def group_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool,
+               x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x: [N,H,W,C1] (+x2 [N,H,W,C2]) -> normalised [N,H,W,C1+C2]."""
+    N, H, W, C1 = x.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    out = torch.empty((N, H, W, C1 + C2), dtype=x.dtype, device=x.device)
+    key = (x.device, N, groups)
+    part = _gn_partials.get(key)
+    if part is None:
+        part = torch.empty(L.load().es_group_norm_partials_bytes(N, groups) // 4, dtype=torch.float32, device=x.device)
+        _gn_partials[key] = part
+    d = L.GnDesc()
+    d.x, d.x2, d.out = x.data_ptr(), (x2.data_ptr() if x2 is not None else None), out.data_ptr()
+    d.gamma, d.beta, d.partials = gamma.data_ptr(), beta.data_ptr(), part.data_ptr()
+    d.N, d.HW, d.C1, d.C2, d.groups = N, H * W, C1, C2, groups
+    d.eps, d.silu, d.dtype = eps, 1 if silu else 0, _dt(x)
+    L.check(L.load().es_group_norm(C.byref(d), _stream()), "es_group_norm")
+    return out
+
+
+def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    out = torch.empty_like(x)
+    L.check(L.load().es_layer_norm(_ptr(x), _ptr(out), _ptr(gamma), _ptr(beta), M, Cc, eps, _dt(x), _stream()),
+            "es_layer_norm")
+    return out
+
+
+def timestep_embedding(t: torch.Tensor, dim: int, dtype) -> torch.Tensor:
+    """t: fp32 device [N] -> [N, dim]"""
+    N = t.numel()
+    out = torch.empty((N, dim), dtype=dtype, device=t.device)
+    L.check(L.load().es_timestep_embedding(_ptr(t), _ptr(out), N, dim, _DT[dtype], _stream()), "es_timestep_embedding")
+    return out
+
+
+def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if out is None:
+        out = torch.empty_like(a)
+    L.check(L.load().es_add(_ptr(a), _ptr(b), _ptr(out), a.numel(), _dt(a), _stream()), "es_add")
+    return out
+
+
+def nchw_to_nhwc(x: torch.Tensor, dtype, cpad: Optional[int] = None) -> torch.Tensor:
+    """fp32 NCHW (contiguous, device) -> NHWC dtype with channels zero-padded to cpad."""
+    N, Cc, H, W = x.shape
+    cp = cpad or Cc
+    x = x.contiguous().float()
+    out = torch.empty((N, H, W, cp), dtype=dtype, device=x.device)
+    L.check(L.load().es_nchw_f32_to_nhwc(_ptr(x), _ptr(out), N, Cc, H * W, cp, _DT[dtype], _stream()),
+            "es_nchw_f32_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor, channels: Optional[int] = None, scale: float = 1.0, shift: float = 0.0,
+                 clamp01: bool = False) -> torch.Tensor:
+    """NHWC dtype -> fp32 NCHW, optionally y = clamp(x*scale+shift, 0, 1) (image postprocess PL:570-572)."""
+    N, H, W, Cs = x.shape
+    Cc = channels or Cs
+    out = torch.empty((N, Cc, H, W), dtype=torch.float32, device=x.device)
+    L.check(L.load().es_nhwc_to_nchw_f32(_ptr(x), _ptr(out), N, Cc, H * W, Cs, scale, shift, 1 if clamp01 else 0,
+                                         _dt(x), _stream()), "es_nhwc_to_nchw_f32")
+    return out
+
+
+def vae_sample(moments: torch.Tensor, noise_nchw: torch.Tensor, latent: int, lpad: int, scaling: float):
+    N, H, W, _ = moments.shape
+    z = torch.empty((N, H, W, lpad), dtype=moments.dtype, device=moments.device)
+    L.check(L.load().es_vae_sample(_ptr(moments), _ptr(noise_nchw.contiguous().float()), _ptr(z), N, H * W, latent,
+                                   lpad, scaling, _dt(moments), _stream()), "es_vae_sample")
+    return z
+
+
+def cfg_ddim_step(noise: torch.Tensor, latents: torch.Tensor, model_in: torch.Tensor, coef: torch.Tensor,
+                  step_idx: torch.Tensor, guidance_scale: float, cfg: bool):
+    """noise [2B|B,H,W,L] dtype; latents fp32 [B,H,W,L] (in place); model_in [2B|B,H,W,Ls] dtype (rewritten)."""
+    B, H, W, Lc = latents.shape
+    L.check(L.load().es_cfg_ddim_step(_ptr(noise), _ptr(latents), _ptr(model_in), _ptr(coef), _ptr(step_idx),
+                                      guidance_scale, B, H * W, Lc, model_in.shape[3], 1 if cfg else 0, _dt(noise),
+                                      _stream()), "es_cfg_ddim_step")
+
+
+def incr(ctr: torch.Tensor):
+    L.check(L.load().es_incr(_ptr(ctr), _stream()), "es_incr")
+
+
+_fusion_scratch = {}
+
+
+def fusion_block(res, res_bs, params: dict, N: int, HW: int, Cc: int, scales, scales_dev=None,
+                 out: Optional[torch.Tensor] = None, eps: float = 1e-5) -> torch.Tensor:
+    """res: 6 tensors (or views) whose data_ptr() is sample 0 of net i; res_bs: 6 batch strides (elements)."""
+    t0 = res[0]
+    key = (t0.device, N)
+    sc = _fusion_scratch.get(key)
+    if sc is None:
+        sc = torch.empty(L.load().es_fusion_scratch_bytes(N) // 4, dtype=torch.float32, device=t0.device)
+        _fusion_scratch[key] = sc
+    u = torch.empty((N, HW, Cc), dtype=t0.dtype, device=t0.device)
+    if out is None:
+        out = torch.empty((N, HW, Cc), dtype=t0.dtype, device=t0.device)
+    d = L.FusionDesc()
+    for i in range(6):
+        d.res[i] = res[i].data_ptr()
+        d.res_bs[i] = res_bs[i]
+        d.res_scale[i] = float(scales[i])
+    d.res_scale_dev = scales_dev.data_ptr() if scales_dev is not None else None
+    for name in ("w1", "b1", "g1", "be1", "w2", "b2", "g2", "be2", "w3", "b3"):
+        setattr(d, name, params[name].data_ptr())
+    d.scratch, d.u, d.out = sc.data_ptr(), u.data_ptr(), out.data_ptr()
+    d.N, d.HW, d.C, d.eps, d.dtype = N, HW, Cc, eps, _dt(t0)
+    L.check(L.load().es_fusion_block(C.byref(d), _stream()), "es_fusion_block")
+    return out
+
+
+def pack_fusion_params(sd: dict, prefix: str, dtype, device) -> dict:
+    """Repack one ControlNetBlock (MC:23-53) pixel-major for es_fusion_block."""
+    w1 = sd[f"{prefix}.first_conv.weight"].float()            # [3C, 2, 1, 1], out channel j = 3c + p
+    c3 = w1.shape[0]
+    c = c3 // 3
+    g1 = sd[f"{prefix}.first_normalization.weight"].float()   # [3C, H, W]
+    hw = g1.shape[1] * g1.shape[2]
+
+    def plane3(t):   # [3C,H,W] -> [HW, C, 3]
+        return t.reshape(c, 3, hw).permute(2, 0, 1).contiguous()
+
+    def plane1(t):   # [C,H,W] -> [HW, C]
+        return t.reshape(c, hw).permute(1, 0).contiguous()
+
+    p = {
+        "w1": w1.reshape(c, 3, 2).contiguous(),
+        "b1": sd[f"{prefix}.first_conv.bias"].float().reshape(c, 3).contiguous(),
+        "g1": plane3(g1).to(dtype), "be1": plane3(sd[f"{prefix}.first_normalization.bias"].float()).to(dtype),
+        "w2": sd[f"{prefix}.second_conv.weight"].float().reshape(c, 3).contiguous(),
+        "b2": sd[f"{prefix}.second_conv.bias"].float().contiguous(),
+        "g2": plane1(sd[f"{prefix}.second_normalization.weight"].float()).to(dtype),
+        "be2": plane1(sd[f"{prefix}.second_normalization.bias"].float()).to(dtype),
+        "w3": sd[f"{prefix}.third_conv.weight"].float().reshape(c).contiguous(),
+        "b3": sd[f"{prefix}.third_conv.bias"].float().contiguous(),
+    }
+    return {k: v.to(device) for k, v in p.items()}

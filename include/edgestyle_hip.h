@@ -1,0 +1,144 @@
+/*
+ * edgestyle_hip.h — C ABI of libedgestyle_hip.so: the MI355X (gfx950) kernels behind EdgeStyle's
+ * multi-ControlNet SD1.5 denoising hot path.
+ *
+ * The reference (andrei-ace/EdgeStyle) has no FFI: every FLOP of this path is a PyTorch/cuDNN op launched by
+ * diffusers modules.  Each entry point below names the reference/diffusers op it replaces so a
+ * maintainer can bind it (ctypes stub shown in INTEGRATION.md).  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (a torch tensor's data_ptr()); it must outlive the
+ *     stream operation; nothing is allocated, freed or synchronised inside (hipGraph-capture safe);
+ *   - activations are NHWC ([N,H,W,C], C contiguous) in `dtype` (ES_F16 / ES_BF16); accumulation is fp32;
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous w.r.t. it;
+ *   - return 0 on success, <0 on error (es_last_error() gives the text); never throws across the boundary.
+ */
+#ifndef EDGESTYLE_HIP_H
+#define EDGESTYLE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ES_F16 = 0, ES_BF16 = 1 };
+enum { ES_ACT_NONE = 0, ES_ACT_SILU = 1, ES_ACT_GEGLU = 2 };
+
+#define ES_ABI_VERSION 1
+int es_abi_version(void);
+const char* es_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * es_conv_gemm — implicit-GEMM convolution / linear on MFMA (16x16x32 f16|bf16, fp32 accumulate).
+ * Replaces: torch conv2d 3x3 s1/s2 + 1x1 and nn.Linear as invoked by diffusers ResnetBlock2D.conv1/conv2,
+ * conv_shortcut, Downsample2D, Upsample2D (nearest-2x fused into the loader), Transformer2DModel.proj_in/out,
+ * Attention.to_q/k/v/to_out, GEGLU/FeedForward, TimestepEmbedding, ControlNet zero-convs
+ * (model/controllora.py:197-254) and the skip-concat `torch.cat([h, res], 1)` of the UNet up blocks (x2).
+ *   out[m, co] = act( sum_k A[m,k] * W[co,k] + bias[co] + temb[n(m), co] ) * out_scale (+ residual[m, co])
+ * with m = (n, oy, ox), k = (ky, kx, c) tap-major over the channel-concatenated sources (x | x2).
+ * W is pre-packed by es_pack_conv_weight layout rules: [rows_padded][Kpad] K-contiguous, dtype.
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x;          /* [N, Hsrc, Wsrc, C1] */
+  const void* x2;         /* optional second source [N, Hsrc, Wsrc, C2] (channel concat), or NULL */
+  const void* w;          /* packed weights [rows_padded][Kpad] */
+  const float* bias;      /* [rows_padded] fp32 or NULL */
+  const void* temb;       /* optional per-sample per-channel add, dtype, [N, temb_stride] (already offset) */
+  const void* residual;   /* optional [M, Cout_store] dtype, added after act*scale */
+  const float* out_scale_dev; /* optional device scalar multiplied into the result (conditioning_scale) */
+  void* out;              /* [N, Hout, Wout, Cout_store] dtype */
+  float* workspace;       /* split-K partials [splitk][M][rows_padded] fp32 (NULL if splitk == 1) */
+  int32_t N, Hsrc, Wsrc, C1, C2;
+  int32_t Hout, Wout, Cout;   /* Cout = true GEMM N (before GEGLU halving) */
+  int32_t rows_padded, Kpad;  /* packed weight geometry */
+  int32_t ksize, stride, pad; /* ksize 1|3 ; input coord = o*stride + k - pad */
+  int32_t upsample;           /* 1: sources are nearest-2x upsampled on the fly (Hin = 2*Hsrc) */
+  int32_t temb_stride;
+  int32_t act;                /* ES_ACT_* ; GEGLU halves the stored width (weights packed interleaved) */
+  int32_t splitk;
+  int32_t bn;                 /* N tile the weights were packed for: 128 or 160 */
+  int32_t dtype;
+  float out_scale;
+} es_gemm_desc;
+int es_conv_gemm(const es_gemm_desc* d, void* stream);
+size_t es_conv_gemm_workspace_bytes(const es_gemm_desc* d);
+
+/* Fused attention softmax(Q K^T * scale) V (flash-style, online softmax, MFMA).
+ * Replaces torch.nn.functional.scaled_dot_product_attention under diffusers Attention (attn1/attn2/VAE attn).
+ * Q [N,Sq,ldq], K [N,Skv,ldk], V [N,Skv,ldv], O [N,Sq,ldo]; head h lives at column h*d of every row. */
+typedef struct {
+  const void* q; const void* k; const void* v; void* o;
+  int32_t N, heads, Sq, Skv, d;
+  int32_t ldq, ldk, ldv, ldo;         /* row strides in elements */
+  int64_t bsq, bsk, bsv, bso;         /* batch strides in elements */
+  float scale;
+  int32_t dtype;
+} es_attn_desc;
+int es_attention(const es_attn_desc* d, void* stream);
+
+/* GroupNorm (+SiLU) over NHWC with optional channel-concat of two sources.
+ * Replaces torch group_norm + silu of ResnetBlock2D.norm1/norm2, conv_norm_out, Transformer2DModel.norm.
+ * partials: fp32 scratch [N][nchunk<=32][groups][2]. */
+typedef struct {
+  const void* x; const void* x2; void* out;
+  const float* gamma; const float* beta; float* partials;
+  int32_t N, HW, C1, C2, groups;
+  float eps;
+  int32_t silu, dtype;
+} es_gn_desc;
+int es_group_norm(const es_gn_desc* d, void* stream);
+size_t es_group_norm_partials_bytes(int N, int groups);
+
+/* LayerNorm over the last dim of [M, C] (BasicTransformerBlock.norm1/2/3), eps 1e-5. */
+int es_layer_norm(const void* x, void* out, const float* gamma, const float* beta, int M, int C, float eps,
+                  int dtype, void* stream);
+
+/* EdgeStyle fusion block: interleave (model/edgestyle_multicontrolnet.py:479-501) + ControlNetBlock
+ * (model/edgestyle_multicontrolnet.py:23-63) without materialising the interleaved tensor.
+ * res[i]: residual of net i, [N, HW, C] dtype (batch stride res_bs[i] elements so nets batched together can be
+ * addressed in place).  Params are repacked pixel-major: w1[C][3][2], b1[C][3], g1/be1[HW][C][3] (dtype),
+ * w2[C][3], b2[C], g2/be2[HW][C] (dtype), w3[C], b3[C] (fp32 unless noted).
+ * scratch: fp32 [N][2][nchunk<=64][2] partial sums; u: dtype [N,HW,C] intermediate; out: [N,HW,C] dtype. */
+typedef struct {
+  const void* res[6];
+  int64_t res_bs[6];
+  const float* w1; const float* b1; const void* g1; const void* be1;
+  const float* w2; const float* b2; const void* g2; const void* be2;
+  const float* w3; const float* b3;
+  float* scratch; void* u; void* out;
+  const float* res_scale_dev;  /* optional device float[6]: per-net conditioning_scale (CL:266-270), graph-updatable */
+  float res_scale[6];          /* per-net conditioning_scale applied to res[i] on load (multiplied with the above) */
+  int32_t N, HW, C;
+  float eps;
+  int32_t dtype;
+} es_fusion_desc;
+int es_fusion_block(const es_fusion_desc* d, void* stream);
+size_t es_fusion_scratch_bytes(int N);
+
+/* Sinusoidal timestep features (diffusers Timesteps(dim, flip_sin_to_cos=True, freq_shift=0); CL:150-155):
+ * out[n, :] = [cos(t_n f_i) | sin(t_n f_i)], dtype.  t: fp32 [N] device. */
+int es_timestep_embedding(const float* t, void* out, int N, int dim, int dtype, void* stream);
+
+/* CFG combine + DDIM(eta=0) step (model/edgestyle_pipeline.py:513-522):
+ *   eps = e_u + g (e_c - e_u);  x0 = (x - sqrt(1-a_t) eps)/sqrt(a_t);  x <- sqrt(a_prev) x0 + sqrt(1-a_prev) eps
+ * noise: [2B or B, HW, L] dtype NHWC (uncond first); latents fp32 [B,HW,L] in/out; model_in: dtype [2B or B,HW,Lstride]
+ * rewritten for the next step (CFG duplicate, PL:443-447).  coef: device fp32 table [steps][4] =
+ * {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)}, row selected by *step_idx (device int32). */
+int es_cfg_ddim_step(const void* noise, float* latents, void* model_in, const float* coef, const int32_t* step_idx,
+                     float guidance_scale, int B, int HW, int L, int Lstride, int cfg, int dtype, void* stream);
+
+/* Layout / dtype conversion at the drop-in boundary (callers hand NCHW fp32, TT:328-359). */
+int es_nchw_f32_to_nhwc(const float* in, void* out, int N, int C, int HW, int Cpad, int dtype, void* stream);
+int es_nhwc_to_nchw_f32(const void* in, float* out, int N, int C, int HW, int Cstride, float scale, float shift,
+                        int clamp01, int dtype, void* stream);
+/* y = a + b (elementwise, dtype), n elements (n % 8 == 0) */
+int es_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream);
+/* DiagonalGaussianDistribution.sample()*scaling_factor (CL:39-40): moments [N,HW,2L] -> z [N,HW,Lpad] */
+int es_vae_sample(const void* moments, const float* noise_nchw, void* z, int N, int HW, int L, int Lpad,
+                  float scaling, int dtype, void* stream);
+/* dst (int32 device) += 1  — advances the step counter inside a captured graph */
+int es_incr(int32_t* ctr, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

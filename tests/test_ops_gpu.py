@@ -1,0 +1,299 @@
+"""Per-kernel parity: every C-ABI entry point vs a plain PyTorch fp32 restatement of the same op (the primitives the
+oracle is made of), on seeded inputs.  Tolerances: fp16 storage + fp32 accumulate => rel err <= 2e-3 of the output
+scale per op."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def rel_err(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-6))
+
+
+def nhwc(x, dtype=torch.float16):
+    return x.permute(0, 2, 3, 1).contiguous().to(device=DEV, dtype=dtype)
+
+
+def q16(x, dtype=torch.float16):
+    """round-trip through the storage dtype so the reference sees the same inputs"""
+    return x.to(dtype).float()
+
+
+CONV_CASES = [
+    # N, Cin, Cout, H, k, stride, upsample
+    (2, 64, 64, 16, 3, 1, False),
+    (2, 320, 320, 16, 3, 1, False),       # bn=160 path
+    (1, 128, 256, 8, 3, 2, False),        # stride 2
+    (2, 64, 128, 8, 3, 1, True),          # fused nearest-2x upsample
+    (2, 128, 64, 8, 1, 1, False),         # 1x1
+    (1, 8, 64, 16, 3, 1, False),          # Cin=8 (padded 4->8 conv_in), non-aligned K
+    (1, 16, 32, 32, 3, 2, False),         # cond-embedding shapes, non-aligned
+    (1, 96, 256, 8, 3, 2, False),
+    (2, 320, 4, 16, 3, 1, False),         # conv_out: Cout=4
+    (1, 128, 3, 16, 3, 1, False),         # VAE conv_out: Cout=3 (scalar stores)
+    (3, 64, 64, 5, 3, 1, False),          # ragged M (75 pixels)
+    (1, 1280, 1280, 8, 3, 1, False),      # deep K, split-K path
+]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,k,stride,up", CONV_CASES)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_conv_gemm(N, Cin, Cout, H, k, stride, up, dtype):
+    from edgestyle_amd import ops
+    if dtype == torch.bfloat16 and Cin > 320:
+        pytest.skip("bf16 covered on the smaller cases")
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    x = q16(torch.randn(N, Cin, H, H, generator=g), dtype)
+    w = q16(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k), dtype)
+    b = torch.randn(Cout, generator=g) * 0.1
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    ref = F.conv2d(xin, w, b, stride=stride, padding=k // 2)
+    pw = ops.pack_weight(w, b, dtype, DEV)
+    y = ops.conv_gemm(nhwc(x, dtype), pw, stride=stride, upsample=up)
+    torch.cuda.synchronize()
+    tol = 3e-3 if dtype == torch.float16 else 2e-2
+    assert y.shape == (N, ref.shape[2], ref.shape[3], Cout)
+    assert rel_err(y.permute(0, 3, 1, 2), ref) < tol
+
+
+def test_conv_gemm_vae_asymmetric_pad():
+    """VAE encoder downsample: F.pad(0,1,0,1) + conv stride 2 padding 0"""
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = q16(torch.randn(1, 64, 16, 16, generator=g))
+    w = q16(torch.randn(64, 64, 3, 3, generator=g) / 24)
+    b = torch.randn(64, generator=g) * 0.1
+    ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2, padding=0)
+    y = ops.conv_gemm(nhwc(x), ops.pack_weight(w, b, torch.float16, DEV), stride=2, pad=0, out_hw=(8, 8))
+    assert rel_err(y.permute(0, 3, 1, 2), ref) < 3e-3
+
+
+def test_conv_gemm_epilogue_concat_temb_residual_silu_scale():
+    from edgestyle_amd import ops, lib
+    g = torch.Generator().manual_seed(5)
+    N, C1, C2, Cout, H = 2, 128, 64, 128, 8
+    x1 = q16(torch.randn(N, C1, H, H, generator=g))
+    x2 = q16(torch.randn(N, C2, H, H, generator=g))
+    w = q16(torch.randn(Cout, C1 + C2, 3, 3, generator=g) / math.sqrt(9 * (C1 + C2)))
+    b = torch.randn(Cout, generator=g) * 0.1
+    temb = q16(torch.randn(N, 512, generator=g))
+    res = q16(torch.randn(N, Cout, H, H, generator=g))
+    off = 256
+    ref = F.conv2d(torch.cat([x1, x2], 1), w, b, padding=1) + temb[:, off:off + Cout, None, None]
+    ref = F.silu(ref) * 0.7 + res
+    pw = ops.pack_weight(w, b, torch.float16, DEV)
+    tdev = temb.to(DEV, torch.float16)
+    sdev = torch.tensor([0.7], device=DEV)
+    for splitk in (1, 3):
+        y = ops.conv_gemm(nhwc(x1), pw, x2=nhwc(x2), temb=tdev[:, off:], residual=nhwc(res), act=lib.ACT_SILU,
+                          out_scale_dev=sdev, splitk=splitk)
+        assert rel_err(y.permute(0, 3, 1, 2), ref) < 3e-3, splitk
+
+
+@pytest.mark.parametrize("M,K,Nout", [(2, 320, 1280), (154, 768, 640), (512, 320, 960), (300, 1280, 320)])
+def test_linear(M, K, Nout):
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(M)
+    x = q16(torch.randn(M, K, generator=g))
+    w = q16(torch.randn(Nout, K, generator=g) / math.sqrt(K))
+    b = torch.randn(Nout, generator=g) * 0.1
+    y = ops.linear(x.to(DEV, torch.float16), ops.pack_weight(w, b, torch.float16, DEV))
+    assert rel_err(y, F.linear(x, w, b)) < 3e-3
+
+
+def test_linear_geglu():
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(11)
+    M, K, inner = 200, 320, 1280
+    x = q16(torch.randn(M, K, generator=g))
+    w = q16(torch.randn(2 * inner, K, generator=g) / math.sqrt(K))
+    b = torch.randn(2 * inner, generator=g) * 0.1
+    hidden, gate = F.linear(x, w, b).chunk(2, dim=-1)
+    ref = hidden * F.gelu(gate)
+    y = ops.linear(x.to(DEV, torch.float16), ops.pack_weight(w, b, torch.float16, DEV, geglu=True))
+    assert y.shape == (M, inner)
+    assert rel_err(y, ref) < 3e-3
+
+
+ATTN_CASES = [
+    # N, heads, Sq, Skv, d
+    (2, 8, 256, 256, 40),
+    (2, 8, 200, 77, 40),       # cross-attention, ragged both sides
+    (1, 8, 128, 128, 80),
+    (1, 8, 64, 64, 160),
+    (2, 4, 256, 77, 16),
+    (2, 4, 64, 64, 32),
+    (1, 4, 16, 16, 64),
+    (1, 1, 256, 256, 512),     # VAE mid-block attention
+    (1, 8, 1024, 1024, 40),
+]
+
+
+@pytest.mark.parametrize("N,heads,Sq,Skv,d", ATTN_CASES)
+def test_attention(N, heads, Sq, Skv, d):
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(Sq + d)
+    C = heads * d
+    q = q16(torch.randn(N, Sq, C, generator=g))
+    k = q16(torch.randn(N, Skv, C, generator=g))
+    v = q16(torch.randn(N, Skv, C, generator=g))
+    qh, kh, vh = (t.view(N, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(N, Sq, C)
+    y = ops.attention(q.to(DEV, torch.float16), k.to(DEV, torch.float16), v.to(DEV, torch.float16), heads)
+    assert rel_err(y, ref) < 4e-3
+
+
+def test_attention_forced_rescale_and_strided_qkv():
+    """online-softmax rescale branch: a late key dominates; q/k/v are column slices of one fused [N,S,3C] buffer"""
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(0)
+    N, heads, S, d = 1, 2, 192, 40
+    C = heads * d
+    qkv = torch.randn(N, S, 3 * C, generator=g)
+    qkv[:, 150, C:2 * C] *= 8.0            # key 150 (third tile) spikes
+    qkv = q16(qkv)
+    q, k, v = qkv.split(C, dim=-1)
+    qh, kh, vh = (t.reshape(N, S, heads, d).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(N, S, C)
+    dq = qkv.to(DEV, torch.float16)
+    y = ops.attention(dq[:, :, :C], dq[:, :, C:2 * C], dq[:, :, 2 * C:], heads)
+    assert rel_err(y, ref) < 4e-3
+
+
+@pytest.mark.parametrize("N,C1,C2,H,silu,eps", [(2, 320, 0, 16, True, 1e-5), (2, 1280, 640, 8, True, 1e-5),
+                                                (1, 64, 0, 32, False, 1e-6), (2, 1280, 1280, 8, True, 1e-5),
+                                                (1, 128, 0, 64, True, 1e-6)])
+def test_group_norm(N, C1, C2, H, silu, eps):
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(C1 + C2)
+    C = C1 + C2
+    x = q16(torch.randn(N, C, H, H, generator=g) * 2 + 0.5)
+    gamma = 1 + 0.1 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    ref = F.group_norm(x, 32, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    x1 = nhwc(x[:, :C1])
+    x2 = nhwc(x[:, C1:]) if C2 else None
+    y = ops.group_norm(x1, gamma.to(DEV), beta.to(DEV), 32, eps, silu, x2=x2)
+    assert rel_err(y.permute(0, 3, 1, 2), ref) < 3e-3
+
+
+@pytest.mark.parametrize("M,C", [(300, 320), (77, 640), (64, 1280), (5, 64)])
+def test_layer_norm(M, C):
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(C)
+    x = q16(torch.randn(M, C, generator=g) * 3 + 1)
+    gamma = 1 + 0.1 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    y = ops.layer_norm(x.to(DEV, torch.float16), gamma.to(DEV), beta.to(DEV))
+    assert rel_err(y, F.layer_norm(x, (C,), gamma, beta)) < 3e-3
+
+
+@pytest.mark.parametrize("C,S,N", [(64, 16, 2), (320, 8, 2), (1280, 8, 1), (320, 64, 2)])
+def test_fusion_block_vs_reference_restatement(C, S, N):
+    """es_fusion_block == interleave_tensors + ControlNetBlock (MC:23-63, 479-501) from the oracle"""
+    from edgestyle_amd import ops
+    from oracle import sd15_oracle as O
+    g = torch.Generator().manual_seed(C + S)
+    p = "blk"
+    sd = {
+        f"{p}.first_conv.weight": torch.randn(3 * C, 2, 1, 1, generator=g) * 0.7,
+        f"{p}.first_conv.bias": torch.randn(3 * C, generator=g) * 0.1,
+        f"{p}.first_normalization.weight": q16(1 + 0.1 * torch.randn(3 * C, S, S, generator=g)),
+        f"{p}.first_normalization.bias": q16(0.1 * torch.randn(3 * C, S, S, generator=g)),
+        f"{p}.second_conv.weight": torch.randn(C, 3, 1, 1, generator=g) * 0.6,
+        f"{p}.second_conv.bias": torch.randn(C, generator=g) * 0.1,
+        f"{p}.second_normalization.weight": q16(1 + 0.1 * torch.randn(C, S, S, generator=g)),
+        f"{p}.second_normalization.bias": q16(0.1 * torch.randn(C, S, S, generator=g)),
+        f"{p}.third_conv.weight": torch.randn(C, 1, 1, 1, generator=g),
+        f"{p}.third_conv.bias": torch.randn(C, generator=g) * 0.1,
+    }
+    res = [q16(torch.randn(N, C, S, S, generator=g)) for _ in range(6)]
+    scales = [1.0, 0.5, 1.0, 2.0, 1.0, 0.0]
+    ref = O.controlnet_block(sd, p, O.interleave_tensors([r * s for r, s in zip(res, scales)]))
+    params = ops.pack_fusion_params(sd, p, torch.float16, DEV)
+    # nets 1,3,5 live in one batched buffer [3N, HW, C] like the batched openpose pass
+    pose = torch.cat([nhwc(res[1]), nhwc(res[3]), nhwc(res[5])]).reshape(3 * N, S * S, C)
+    r = [nhwc(res[0]), pose[0:], nhwc(res[2]), pose[N:], nhwc(res[4]), pose[2 * N:]]
+    y = ops.fusion_block(r, [S * S * C] * 6, params, N, S * S, C, scales)
+    y = y.reshape(N, S, S, C).permute(0, 3, 1, 2)
+    assert rel_err(y, ref) < 4e-3
+
+
+def test_timestep_embedding():
+    from edgestyle_amd import ops
+    from oracle import sd15_oracle as O
+    t = torch.tensor([981.0, 1.0, 500.0])
+    y = ops.timestep_embedding(t.to(DEV), 320, torch.float16)
+    ref = O.timestep_sinusoid(t, 320)
+    assert float((y.float().cpu() - ref).abs().max()) < 2e-3
+
+
+def test_cfg_ddim_step_matches_oracle_scheduler():
+    from edgestyle_amd import ops
+    from edgestyle_amd.schedulers import DDIMScheduler
+    from oracle import sd15_oracle as O
+    g = torch.Generator().manual_seed(9)
+    B, H = 2, 8
+    sched = O.DDIM()
+    ts = sched.set_timesteps(10)
+    lat = torch.randn(B, 4, H, H, generator=g)
+    eps = q16(torch.randn(2 * B, 4, H, H, generator=g))
+    gs = 7.5
+    e = eps[:B] + gs * (eps[B:] - eps[:B])
+    step = 3
+    ref = sched.step(e, int(ts[step]), lat)
+    mine = DDIMScheduler()
+    mine.set_timesteps(10)
+    assert mine.timesteps.tolist() == ts.tolist()
+    coef = mine.coef_table().to(DEV)
+    latd = lat.permute(0, 2, 3, 1).contiguous().to(DEV)
+    model_in = torch.zeros(2 * B, H, H, 8, dtype=torch.float16, device=DEV)
+    idx = torch.tensor([step], dtype=torch.int32, device=DEV)
+    ops.cfg_ddim_step(nhwc(eps), latd, model_in, coef, idx, gs, True)
+    assert rel_err(latd.permute(0, 3, 1, 2), ref) < 1e-5
+    assert rel_err(model_in[:B, :, :, :4].permute(0, 3, 1, 2), ref) < 2e-3
+    assert torch.equal(model_in[:B], model_in[B:]) and float(model_in[..., 4:].abs().max()) == 0.0
+    ops.incr(idx)
+    assert int(idx.item()) == step + 1
+
+
+def test_layout_conversions_and_add_and_vae_sample():
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    y = ops.nchw_to_nhwc(x.to(DEV), torch.float16, cpad=8)
+    assert y.shape == (2, 8, 8, 8) and float(y[..., 4:].abs().max()) == 0
+    assert rel_err(y[..., :4].permute(0, 3, 1, 2), x) < 1e-3
+    z = ops.nhwc_to_nchw(y, channels=4, scale=0.5, shift=0.5, clamp01=True)
+    assert rel_err(z, (q16(x) / 2 + 0.5).clamp(0, 1)) < 1e-3
+    a = torch.randn(64, 40, generator=g)
+    b = torch.randn(64, 40, generator=g)
+    s = ops.add(a.to(DEV, torch.float16), b.to(DEV, torch.float16))
+    assert rel_err(s, q16(a) + q16(b)) < 1e-3
+    mom = q16(torch.randn(2, 8, 8, 8, generator=g))            # NCHW moments
+    noise = torch.randn(2, 4, 8, 8, generator=g)
+    mean, logvar = mom.chunk(2, dim=1)
+    ref = (mean + torch.exp(0.5 * logvar.clamp(-30, 20)) * noise) * 0.18215
+    zz = ops.vae_sample(nhwc(mom), noise.to(DEV), 4, 8, 0.18215)
+    assert rel_err(zz[..., :4].permute(0, 3, 1, 2), ref) < 2e-3 and float(zz[..., 4:].abs().max()) == 0
+
+
+def test_errors_are_loud():
+    from edgestyle_amd import ops, lib
+    x = torch.zeros(1, 4, 4, 12, dtype=torch.float16, device=DEV)    # 12 channels: not a multiple of 8
+    pw = ops.pack_weight(torch.zeros(8, 16, 1, 1), None, torch.float16, DEV)
+    with pytest.raises(lib.EdgeStyleHipError):
+        ops.conv_gemm(x, pw)
+    with pytest.raises(lib.EdgeStyleHipError):
+        ops.attention(torch.zeros(1, 8, 36, dtype=torch.float16, device=DEV),
+                      torch.zeros(1, 8, 36, dtype=torch.float16, device=DEV),
+                      torch.zeros(1, 8, 36, dtype=torch.float16, device=DEV), heads=1)   # d=36 unsupported
