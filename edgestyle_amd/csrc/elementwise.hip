@@ -110,6 +110,12 @@ __global__ void vae_sample_kernel(const T* __restrict__ mom, const float* __rest
 
 __global__ void incr_kernel(int* ctr) { *ctr += 1; }
 
+__global__ void gather_row_kernel(const float* __restrict__ table, const int* __restrict__ idx,
+                                  float* __restrict__ out, int row_len) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < row_len) out[i] = table[(size_t)(*idx) * row_len + i];
+}
+
 inline unsigned nblk(long long n, int b = 256) { return (unsigned)((n + b - 1) / b); }
 
 }  // namespace
@@ -201,4 +207,11 @@ extern "C" int es_incr(int32_t* ctr, void* stream) {
   if (!ctr) { es_set_error("es_incr: null pointer"); return -1; }
   hipLaunchKernelGGL(incr_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ctr);
   ES_RET("es_incr");
+}
+
+extern "C" int es_gather_row(const float* table, const int32_t* idx, float* out, int row_len, void* stream) {
+  if (!table || !idx || !out || row_len < 1) { es_set_error("es_gather_row: bad arguments"); return -1; }
+  hipLaunchKernelGGL(gather_row_kernel, dim3(nblk(row_len)), dim3(256), 0, (hipStream_t)stream, table, idx, out,
+                     row_len);
+  ES_RET("es_gather_row");
 }

@@ -1,0 +1,377 @@
+"""Host-side executors: SD1.5 UNet / ControlNet / AutoencoderKL / fusion blocks as sequences of C-ABI kernel launches.
+
+Everything here is plumbing: weights are packed once into the layouts the kernels want (NHWC activations,
+[Cout][ky,kx,Cin] K-contiguous weights, fused QKV / KV projections, GEGLU-interleaved FF rows, LoRA folded into
+private copies, all ResnetBlock time projections concatenated into ONE GEMM) and `forward` is a flat list of
+`ops.*` launches on the current HIP stream — no torch arithmetic on the hot path, so a whole denoising step
+captures into one hipGraph.
+
+Module trees and forward order follow diffusers==0.26.3 (UNet2DConditionModel, ControlNetModel, AutoencoderKL) as
+called from model/controllora.py:150-254 and model/edgestyle_pipeline.py:477-557; key names are the diffusers
+state-dict names (edgestyle_amd/weights.py).
+"""
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import lib as L
+from . import ops
+from .config import UNetConfig, VAEConfig
+
+SD = Dict[str, torch.Tensor]
+
+
+def fold_lora(sd: SD) -> SD:
+    """W <- W + B.A for every `<linear>.lora_layer.{down,up}.weight` pair, into a NEW dict (the reference's
+    fuse_lora mutates the tied UNet parameters in place, CL:728-777 — we never do)."""
+    out = {k: v for k, v in sd.items() if ".lora_layer." not in k}
+    for k in sd:
+        if k.endswith(".lora_layer.down.weight"):
+            base = k[: -len(".lora_layer.down.weight")]
+            up = sd[base + ".lora_layer.up.weight"].float()
+            out[base + ".weight"] = sd[base + ".weight"].float() + up @ sd[k].float()
+    return out
+
+
+class _Packer:
+    """Packs on the target device (torch used for data movement only)."""
+
+    def __init__(self, sd: SD, dtype, device):
+        self.sd, self.dtype, self.device = sd, dtype, device
+
+    def t(self, key):
+        return self.sd[key].to(self.device, torch.float32)
+
+    def conv(self, p: str, cin_pad: Optional[int] = None, geglu=False, cout_pad=None) -> ops.PackedWeight:
+        b = self.sd.get(p + ".bias")
+        return ops.pack_weight(self.t(p + ".weight"), None if b is None else b.to(self.device), self.dtype,
+                               self.device, geglu=geglu, cin_pad=cin_pad, cout_pad=cout_pad)
+
+    def cat(self, ps: Sequence[str], bias: bool) -> ops.PackedWeight:
+        w = torch.cat([self.t(p + ".weight") for p in ps], 0)
+        b = torch.cat([self.t(p + ".bias") for p in ps], 0) if bias else None
+        return ops.pack_weight(w, b, self.dtype, self.device)
+
+    def norm(self, p: str) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self.t(p + ".weight").contiguous(), self.t(p + ".bias").contiguous()
+
+
+class Resnet:
+    def __init__(self, pk: _Packer, p: str, groups: int, eps: float, temb_off: Optional[int]):
+        self.n1, self.n2 = pk.norm(p + ".norm1"), pk.norm(p + ".norm2")
+        self.conv1, self.conv2 = pk.conv(p + ".conv1"), pk.conv(p + ".conv2")
+        self.short = pk.conv(p + ".conv_shortcut") if (p + ".conv_shortcut.weight") in pk.sd else None
+        self.groups, self.eps, self.temb_off = groups, eps, temb_off
+        self.cout = self.conv1.cout
+
+    def __call__(self, x, tproj, x2=None):
+        h = ops.group_norm(x, self.n1[0], self.n1[1], self.groups, self.eps, True, x2=x2)
+        temb = None if self.temb_off is None else tproj[:, self.temb_off:]
+        h = ops.conv_gemm(h, self.conv1, temb=temb)
+        h = ops.group_norm(h, self.n2[0], self.n2[1], self.groups, self.eps, True)
+        xs = ops.conv_gemm(x, self.short, x2=x2) if self.short is not None else x
+        return ops.conv_gemm(h, self.conv2, residual=xs)
+
+
+class Transformer:
+    """Transformer2DModel(use_linear_projection=False) + one BasicTransformerBlock."""
+
+    def __init__(self, pk: _Packer, p: str, heads: int, groups: int):
+        tb = p + ".transformer_blocks.0"
+        self.norm = pk.norm(p + ".norm")
+        self.proj_in, self.proj_out = pk.conv(p + ".proj_in"), pk.conv(p + ".proj_out")
+        self.ln1, self.ln2, self.ln3 = pk.norm(tb + ".norm1"), pk.norm(tb + ".norm2"), pk.norm(tb + ".norm3")
+        self.qkv = pk.cat([tb + ".attn1.to_q", tb + ".attn1.to_k", tb + ".attn1.to_v"], bias=False)
+        self.o1 = pk.conv(tb + ".attn1.to_out.0")
+        self.q2 = pk.conv(tb + ".attn2.to_q")
+        self.kv2 = pk.cat([tb + ".attn2.to_k", tb + ".attn2.to_v"], bias=False)
+        self.o2 = pk.conv(tb + ".attn2.to_out.0")
+        self.ff1 = pk.conv(tb + ".ff.net.0.proj", geglu=True)
+        self.ff2 = pk.conv(tb + ".ff.net.2")
+        self.heads, self.groups = heads, groups
+        self.c = self.proj_in.cout
+
+    def context(self, ehs):
+        """K/V projection of the text states [N,77,D] -> [N,77,2C]; constant over the denoising loop."""
+        return ops.linear(ehs, self.kv2)
+
+    def __call__(self, x, kv):
+        N, H, W, C = x.shape
+        h = ops.group_norm(x, self.norm[0], self.norm[1], self.groups, 1e-6, False)
+        tok = ops.conv_gemm(h, self.proj_in).reshape(N, H * W, C)
+        n = ops.layer_norm(tok, *self.ln1)
+        qkv = ops.linear(n, self.qkv)
+        a = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], self.heads)
+        tok = ops.linear(a, self.o1, residual=tok)
+        n = ops.layer_norm(tok, *self.ln2)
+        q = ops.linear(n, self.q2)
+        a = ops.attention(q, kv[:, :, :C], kv[:, :, C:], self.heads)
+        tok = ops.linear(a, self.o2, residual=tok)
+        n = ops.layer_norm(tok, *self.ln3)
+        f = ops.linear(n, self.ff1)
+        tok = ops.linear(f, self.ff2, residual=tok)
+        return ops.conv_gemm(tok.reshape(N, H, W, C), self.proj_out, residual=x)
+
+
+class Encoder:
+    """conv_in + time_embedding + down_blocks + mid_block: the part a ControlNet shares with the UNet (CL:623-632)."""
+
+    def __init__(self, sd: SD, cfg: UNetConfig, dtype, device, extra_resnets: Sequence[str] = ()):
+        sd = fold_lora(sd)
+        self.cfg, self.dtype, self.device = cfg, dtype, device
+        pk = self.pk = _Packer(sd, dtype, device)
+        g, eps, heads = cfg.norm_num_groups, cfg.norm_eps, cfg.num_heads
+        self.in_pad = (cfg.in_channels + 7) // 8 * 8
+        self.conv_in = pk.conv("conv_in", cin_pad=self.in_pad)
+        self.t1, self.t2 = pk.conv("time_embedding.linear_1"), pk.conv("time_embedding.linear_2")
+        # every resnet's time_emb_proj concatenated into one GEMM; offsets handed to the resnets
+        names = []
+        ch = cfg.block_out_channels
+        for i in range(len(ch)):
+            for j in range(cfg.layers_per_block):
+                names.append(f"down_blocks.{i}.resnets.{j}")
+        names += ["mid_block.resnets.0", "mid_block.resnets.1"] + list(extra_resnets)
+        offs, o = {}, 0
+        for nme in names:
+            offs[nme] = o
+            o += sd[nme + ".time_emb_proj.weight"].shape[0]
+        self.tproj = pk.cat([n + ".time_emb_proj" for n in names], bias=True)
+        self.temb_offs = offs
+        self.down: List[List[Tuple[Resnet, Optional[Transformer]]]] = []
+        self.downsample: List[Optional[ops.PackedWeight]] = []
+        for i in range(len(ch)):
+            blk = []
+            for j in range(cfg.layers_per_block):
+                r = Resnet(pk, f"down_blocks.{i}.resnets.{j}", g, eps, offs[f"down_blocks.{i}.resnets.{j}"])
+                a = Transformer(pk, f"down_blocks.{i}.attentions.{j}", heads, g) if cfg.down_has_attn[i] else None
+                blk.append((r, a))
+            self.down.append(blk)
+            self.downsample.append(pk.conv(f"down_blocks.{i}.downsamplers.0.conv") if i != len(ch) - 1 else None)
+        self.mid0 = Resnet(pk, "mid_block.resnets.0", g, eps, offs["mid_block.resnets.0"])
+        self.mid_attn = Transformer(pk, "mid_block.attentions.0", heads, g)
+        self.mid1 = Resnet(pk, "mid_block.resnets.1", g, eps, offs["mid_block.resnets.1"])
+
+    # ---- pieces -------------------------------------------------------------------------------------------
+    def transformers(self) -> List[Transformer]:
+        out = [a for blk in self.down for (_, a) in blk if a is not None]
+        return out + [self.mid_attn]
+
+    def context(self, ehs) -> List[torch.Tensor]:
+        return [t.context(ehs) for t in self.transformers()]
+
+    def time_proj(self, t_dev: torch.Tensor, step_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """CL:150-157 + every ResnetBlock2D.time_emb_proj(silu(emb)) in one shot -> [N, sum(Cout)]."""
+        e = ops.timestep_embedding(t_dev, self.cfg.block_out_channels[0], self.dtype)
+        e = ops.linear(e, self.t1, act=L.ACT_SILU)
+        e = ops.linear(e, self.t2, act=L.ACT_SILU)     # emb is only ever consumed through silu(emb)
+        return ops.linear(e, self.tproj)
+
+    def run(self, h, tproj, ctx: List[torch.Tensor]):
+        skips = [h]
+        ci = 0
+        for i, blk in enumerate(self.down):
+            for r, a in blk:
+                h = r(h, tproj)
+                if a is not None:
+                    h = a(h, ctx[ci]); ci += 1
+                skips.append(h)
+            if self.downsample[i] is not None:
+                h = ops.conv_gemm(h, self.downsample[i], stride=2)
+                skips.append(h)
+        h = self.mid0(h, tproj)
+        h = self.mid_attn(h, ctx[ci])
+        h = self.mid1(h, tproj)
+        return skips, h
+
+
+class UNet(Encoder):
+    def __init__(self, sd: SD, cfg: UNetConfig, dtype, device):
+        n = len(cfg.block_out_channels)
+        extra = [f"up_blocks.{i}.resnets.{j}" for i in range(n) for j in range(cfg.layers_per_block + 1)]
+        super().__init__(sd, cfg, dtype, device, extra_resnets=extra)
+        pk, g, eps, heads = self.pk, cfg.norm_num_groups, cfg.norm_eps, cfg.num_heads
+        self.up: List[List[Tuple[Resnet, Optional[Transformer]]]] = []
+        self.upsample: List[Optional[ops.PackedWeight]] = []
+        for i in range(n):
+            blk = []
+            for j in range(cfg.layers_per_block + 1):
+                nm = f"up_blocks.{i}.resnets.{j}"
+                r = Resnet(pk, nm, g, eps, self.temb_offs[nm])
+                a = Transformer(pk, f"up_blocks.{i}.attentions.{j}", heads, g) if cfg.up_has_attn[i] else None
+                blk.append((r, a))
+            self.up.append(blk)
+            self.upsample.append(pk.conv(f"up_blocks.{i}.upsamplers.0.conv") if i != n - 1 else None)
+        self.norm_out = pk.norm("conv_norm_out")
+        self.conv_out = pk.conv("conv_out")
+        del self.pk
+
+    def transformers(self):
+        return super().transformers() + [a for blk in self.up for (_, a) in blk if a is not None]
+
+    def forward(self, x, tproj, ctx, down_res: Optional[Sequence] = None, mid_res=None, out=None):
+        """x: [N,H,W,in_pad] -> noise prediction [N,H,W,out_channels] (PL:500-510)."""
+        h = ops.conv_gemm(x, self.conv_in)
+        skips, h = self.run(h, tproj, ctx)
+        if down_res is not None:
+            skips = [ops.add(s, r.reshape(s.shape)) for s, r in zip(skips, down_res)]
+        if mid_res is not None:
+            h = ops.add(h, mid_res.reshape(h.shape))
+        ci = len(super().transformers())
+        cfg = self.cfg
+        for i, blk in enumerate(self.up):
+            for r, a in blk:
+                h = r(h, tproj, x2=skips.pop())
+                if a is not None:
+                    h = a(h, ctx[ci]); ci += 1
+            if self.upsample[i] is not None:
+                h = ops.conv_gemm(h, self.upsample[i], upsample=True)
+        h = ops.group_norm(h, self.norm_out[0], self.norm_out[1], cfg.norm_num_groups, cfg.norm_eps, True)
+        return ops.conv_gemm(h, self.conv_out, out=out)
+
+
+class ControlNet(Encoder):
+    """ControlNetModel / CachedControlNetModel / (fused) ControlLoRAModel body (CL:58-290)."""
+
+    def __init__(self, sd: SD, cfg: UNetConfig, dtype, device, uses_vae: bool = False):
+        super().__init__(sd, cfg, dtype, device)
+        pk = self.pk
+        table = cfg.residual_table()
+        self.zero = [pk.conv(f"controlnet_down_blocks.{i}") for i in range(len(table) - 1)]
+        self.zero_mid = pk.conv("controlnet_mid_block")
+        self.uses_vae = uses_vae
+        self.cond = None
+        if not uses_vae and "controlnet_cond_embedding.conv_in.weight" in pk.sd:
+            ce = cfg.conditioning_embedding_out_channels
+            p = "controlnet_cond_embedding"
+            self.cond = [pk.conv(p + ".conv_in", cin_pad=8)]
+            self.cond += [pk.conv(f"{p}.blocks.{i}") for i in range(2 * (len(ce) - 1))]
+            self.cond.append(pk.conv(p + ".conv_out"))
+        del self.pk
+
+    def embed_cond(self, img):
+        """ControlNetConditioningEmbedding: img [N,H,W,8(3 real)] -> [N,H/8,W/8,C0]; once per image (PL:660-662)."""
+        h = ops.conv_gemm(img, self.cond[0], act=L.ACT_SILU)
+        for i, pw in enumerate(self.cond[1:-1]):
+            h = ops.conv_gemm(h, pw, stride=2 if i % 2 == 1 else 1, act=L.ACT_SILU)
+        return ops.conv_gemm(h, self.cond[-1])
+
+    def embed_latent(self, z):
+        """VAEControlNetConditioningEmbedding tail: conv_vae_out IS conv_in (CL:36,41,595-598). z: [N,h,w,in_pad]"""
+        return ops.conv_gemm(z, self.conv_in)
+
+    def forward(self, x, tproj, ctx, conds: Sequence[torch.Tensor], out_scale: float = 1.0,
+                out_scale_dev=None):
+        """x: [N,H,W,in_pad]; conds: k pre-embedded [N,H,W,C0] tensors -> the pass runs at batch k*N with shared
+        weights (tproj/ctx must already be k*N rows).  Returns (13 residual tensors [k*N,HW,C])."""
+        k = len(conds)
+        N, H, W, _ = x.shape
+        c0 = self.conv_in.cout
+        h0 = torch.empty((k * N, H, W, c0), dtype=x.dtype, device=x.device)
+        for i, c in enumerate(conds):                       # sample = conv_in(sample) + cond   (CL:197-203)
+            ops.conv_gemm(x, self.conv_in, residual=c, out=h0[i * N:(i + 1) * N])
+        skips, h = self.run(h0, tproj, ctx)
+        res = [ops.conv_gemm(s, z, out_scale=out_scale, out_scale_dev=out_scale_dev)
+               for s, z in zip(skips, self.zero)]
+        res.append(ops.conv_gemm(h, self.zero_mid, out_scale=out_scale, out_scale_dev=out_scale_dev))
+        return res
+
+
+class Fusion:
+    """13 ControlNetBlocks (MC:103-114, 160-169)."""
+
+    def __init__(self, sd: SD, cfg: UNetConfig, dtype, device, sample_size: Optional[int] = None):
+        self.table = cfg.residual_table(sample_size)
+        self.params = []
+        for i in range(len(self.table)):
+            p = f"multi_controlnet_down_blocks.{i}" if i < len(self.table) - 1 else "multi_controlnet_mid_block"
+            self.params.append(ops.pack_fusion_params(sd, p, dtype, device))
+
+    def forward(self, res_per_net: Sequence[Sequence[torch.Tensor]], bs: Sequence[Sequence[int]], N: int,
+                scales: Sequence[float], scales_dev=None):
+        """res_per_net[i][lvl]: tensor view whose data_ptr is sample 0 of net i at level lvl."""
+        outs = []
+        for lvl, (c, s) in enumerate(self.table):
+            r = [res_per_net[i][lvl] for i in range(6)]
+            outs.append(ops.fusion_block(r, [bs[i][lvl] for i in range(6)], self.params[lvl], N, s * s, c, scales,
+                                         scales_dev).reshape(N, s, s, c))
+        return outs
+
+
+class VAE:
+    def __init__(self, sd: SD, cfg: VAEConfig, dtype, device, decoder: bool = True, encoder: bool = True):
+        self.cfg, self.dtype, self.device = cfg, dtype, device
+        pk = _Packer(sd, dtype, device)
+        g, eps = cfg.norm_num_groups, cfg.norm_eps
+        ch = cfg.block_out_channels
+        n = len(ch)
+        self.lat_pad = (cfg.latent_channels + 7) // 8 * 8
+
+        def mid(side):
+            a = f"{side}.mid_block.attentions.0"
+            return dict(r0=Resnet(pk, f"{side}.mid_block.resnets.0", g, eps, None),
+                        gn=pk.norm(a + ".group_norm"),
+                        qkv=pk.cat([a + ".to_q", a + ".to_k", a + ".to_v"], bias=True),
+                        o=pk.conv(a + ".to_out.0"),
+                        r1=Resnet(pk, f"{side}.mid_block.resnets.1", g, eps, None))
+        if encoder:
+            self.e_in = pk.conv("encoder.conv_in", cin_pad=8)
+            self.e_down = []
+            for i in range(n):
+                rs = [Resnet(pk, f"encoder.down_blocks.{i}.resnets.{j}", g, eps, None)
+                      for j in range(cfg.layers_per_block)]
+                ds = pk.conv(f"encoder.down_blocks.{i}.downsamplers.0.conv") if i != n - 1 else None
+                self.e_down.append((rs, ds))
+            self.e_mid = mid("encoder")
+            self.e_norm = pk.norm("encoder.conv_norm_out")
+            self.e_out = pk.conv("encoder.conv_out")
+            self.quant = pk.conv("quant_conv")
+        if decoder:
+            self.post_quant = pk.conv("post_quant_conv", cin_pad=self.lat_pad, cout_pad=8)
+            self.d_in = pk.conv("decoder.conv_in", cin_pad=8)
+            self.d_mid = mid("decoder")
+            self.d_up = []
+            for i in range(n):
+                rs = [Resnet(pk, f"decoder.up_blocks.{i}.resnets.{j}", g, eps, None)
+                      for j in range(cfg.layers_per_block + 1)]
+                us = pk.conv(f"decoder.up_blocks.{i}.upsamplers.0.conv") if i != n - 1 else None
+                self.d_up.append((rs, us))
+            self.d_norm = pk.norm("decoder.conv_norm_out")
+            self.d_out = pk.conv("decoder.conv_out")
+
+    def _mid(self, m, h):
+        cfg = self.cfg
+        h = m["r0"](h, None)
+        N, H, W, C = h.shape
+        n = ops.group_norm(h, m["gn"][0], m["gn"][1], cfg.norm_num_groups, cfg.norm_eps, False).reshape(N, H * W, C)
+        qkv = ops.linear(n, m["qkv"])
+        a = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], 1)
+        h = ops.linear(a, m["o"], residual=h.reshape(N, H * W, C)).reshape(N, H, W, C)
+        return m["r1"](h, None)
+
+    def encode_moments(self, img):
+        """img: [N,H,W,8 (3 real)] -> moments [N,H/8,W/8,2L]"""
+        cfg = self.cfg
+        h = ops.conv_gemm(img, self.e_in)
+        for rs, ds in self.e_down:
+            for r in rs:
+                h = r(h, None)
+            if ds is not None:     # F.pad(0,1,0,1) + conv s2 p0
+                h = ops.conv_gemm(h, ds, stride=2, pad=0, out_hw=(h.shape[1] // 2, h.shape[2] // 2))
+        h = self._mid(self.e_mid, h)
+        h = ops.group_norm(h, self.e_norm[0], self.e_norm[1], cfg.norm_num_groups, cfg.norm_eps, True)
+        h = ops.conv_gemm(h, self.e_out)
+        return ops.conv_gemm(h, self.quant)
+
+    def decode(self, z):
+        """z: [N,h,w,lat_pad] (already divided by scaling_factor) -> image [N,8h,8w,3]"""
+        cfg = self.cfg
+        h = ops.conv_gemm(z, self.post_quant)
+        h = ops.conv_gemm(h, self.d_in)
+        h = self._mid(self.d_mid, h)
+        for rs, us in self.d_up:
+            for r in rs:
+                h = r(h, None)
+            if us is not None:
+                h = ops.conv_gemm(h, us, upsample=True)
+        h = ops.group_norm(h, self.d_norm[0], self.d_norm[1], cfg.norm_num_groups, cfg.norm_eps, True)
+        return ops.conv_gemm(h, self.d_out)

@@ -78,6 +78,7 @@ SYMBOLS = {
     "es_add": (C.c_int, [_P, _P, _P, _L, _I, _P]),
     "es_vae_sample": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "es_incr": (C.c_int, [_P, _P]),
+    "es_gather_row": (C.c_int, [_P, _P, _P, _I, _P]),
 }
 
 _lib = None

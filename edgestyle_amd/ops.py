@@ -59,42 +59,44 @@ def choose_bn(cout: int) -> int:
 
 
 def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype, device, geglu: bool = False,
-                cin_pad: Optional[int] = None) -> PackedWeight:
-    """weight: [Cout, Cin, k, k] (conv) or [Cout, Cin] (linear), fp32 CPU -> packed device tensor.
+                cin_pad: Optional[int] = None, cout_pad: Optional[int] = None) -> PackedWeight:
+    """weight: [Cout, Cin, k, k] (conv) or [Cout, Cin] (linear) fp32, on any device -> packed tensor on `device`.
 
     GEGLU (ff.net.0.proj, out = 2*inner): rows are re-ordered in blocks of 32 = [16 hidden | 16 gate] so that
     the GEMM epilogue finds hidden and gate of the same output column in adjacent MFMA fragments.
+    `cout_pad` appends zero output channels (used to hand 4-channel latents on as 8-channel NHWC tensors).
     """
     if weight.dim() == 2:
         weight = weight[:, :, None, None]
+    weight = weight.to(device=device, dtype=torch.float32)
     cout, cin, k, _ = weight.shape
     cp = cin_pad or ((cin + 7) // 8 * 8)
-    w = weight.float().permute(0, 2, 3, 1)                      # [Cout, k, k, Cin]
+    w = weight.permute(0, 2, 3, 1)                              # [Cout, k, k, Cin]
     if cp != cin:
         w = torch.nn.functional.pad(w, (0, cp - cin))
     w = w.reshape(cout, k * k * cp)
-    b = None if bias is None else bias.float().clone()
+    b = None if bias is None else bias.to(device=device, dtype=torch.float32)
     if geglu:
         inner = cout // 2
         assert inner % 16 == 0
-        idx = torch.arange(cout)
+        idx = torch.arange(cout, device=device)
         blk, within = idx // 32, idx % 32
         src = torch.where(within < 16, blk * 16 + within, inner + blk * 16 + (within - 16))
         w = w[src]
         if b is not None:
             b = b[src]
-    bn = 128 if geglu else choose_bn(cout)
-    rows = (cout + bn - 1) // bn * bn
+    cout_eff = cout_pad or cout
+    bn = 128 if geglu else choose_bn(cout_eff)
+    rows = (cout_eff + bn - 1) // bn * bn
     ktrue = w.shape[1]
     kpad = (ktrue + BK - 1) // BK * BK
-    wp = torch.zeros(rows, kpad, dtype=torch.float32)
-    wp[:cout, :ktrue] = w
+    wp = torch.zeros(rows, kpad, dtype=dtype, device=device)
+    wp[:cout, :ktrue] = w.to(dtype)
     bp = None
     if b is not None:
-        bp = torch.zeros(rows, dtype=torch.float32)
+        bp = torch.zeros(rows, dtype=torch.float32, device=device)
         bp[:cout] = b
-        bp = bp.to(device)
-    return PackedWeight(wp.to(device=device, dtype=dtype), bp, cout, cp, k, bn, geglu)
+    return PackedWeight(wp, bp, cout_eff, cp, k, bn, geglu)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -292,6 +294,11 @@ def cfg_ddim_step(noise: torch.Tensor, latents: torch.Tensor, model_in: torch.Te
 
 def incr(ctr: torch.Tensor):
     L.check(L.load().es_incr(_ptr(ctr), _stream()), "es_incr")
+
+
+def gather_row(table: torch.Tensor, idx: torch.Tensor, out: torch.Tensor):
+    """out[:] = table[idx[0]] (fp32), selected on the device"""
+    L.check(L.load().es_gather_row(_ptr(table), _ptr(idx), _ptr(out), out.numel(), _stream()), "es_gather_row")
 
 
 _fusion_scratch = {}

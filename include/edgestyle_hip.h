@@ -137,6 +137,9 @@ int es_vae_sample(const void* moments, const float* noise_nchw, void* z, int N, 
                   float scaling, int dtype, void* stream);
 /* dst (int32 device) += 1  — advances the step counter inside a captured graph */
 int es_incr(int32_t* ctr, void* stream);
+/* out[0..row_len) = table[*idx][0..row_len) — selects this step's timestep / conditioning-scale row inside a
+ * captured graph (PL:435, PL:464-470) so a replay needs no host-side scalar update */
+int es_gather_row(const float* table, const int32_t* idx, float* out, int row_len, void* stream);
 
 #ifdef __cplusplus
 }
