@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""Headline benchmark: 512x512 try-on images/sec @ 50 DDIM steps, 6-cond ControlNet (BASELINE.json).
+
+  python bench.py --gpus 1 --steps K --warmup W          # one process, cuda:0
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: condition embedding (3 VAE encodes + 3 openpose conv
+stacks on the CFG-duplicated batch, PL:629-664) -> 50 x [6 ControlNet passes -> 13 fusion blocks -> UNet -> CFG ->
+DDIM] -> VAE decode -> [0,1] image, inputs already resident in HBM.  Weights are seeded
+random-init SD1.5-shaped tensors (no checkpoints exist offline), data is synthetic.
+
+Prints ONE JSON line on rank 0 with the contract fields plus `roofline` (implicit-GEMM conv/linear kernel, MFMA
+bound) and `cpu_baseline` (the CPU oracle timed on this host's cores on one denoising step).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_pipeline(device, dtype, seed=0, tiny=False, keep_cpu=False):
+    from edgestyle_amd import config as C, weights as W
+    from edgestyle_amd.models import (UNet2DConditionModel, ControlNetModel, ControlLoRAModel, AutoencoderKL,
+                                      EdgeStyleMultiControlNetModel)
+    from edgestyle_amd.pipeline import EdgeStyleStableDiffusionControlNetPipeline
+    ucfg, vcfg = (C.tiny_unet(), C.tiny_vae()) if tiny else (C.sd15_unet(), C.sd15_vae())
+    rank = 4 if tiny else 32
+    gen_dev = "cpu" if keep_cpu else device
+    ws = dict(
+        unet=W.random_state_dict(W.unet_shapes(ucfg), seed, "unet.", device=gen_dev),
+        openpose=W.random_state_dict(W.controlnet_shapes(ucfg), seed, "openpose.", device=gen_dev),
+        lora0=W.random_state_dict(W.controllora_saved_shapes(ucfg, rank), seed, "controlnet_0.", device=gen_dev),
+        lora1=W.random_state_dict(W.controllora_saved_shapes(ucfg, rank), seed, "controlnet_1.", device=gen_dev),
+        fusion=W.random_state_dict(W.fusion_shapes(ucfg), seed, "fusion.", device=gen_dev),
+        vae=W.random_state_dict(W.vae_shapes(vcfg), seed, "vae.", device=gen_dev),
+    )
+    unet = UNet2DConditionModel(ws["unet"], ucfg, dtype).to(device)
+    vae = AutoencoderKL(ws["vae"], vcfg, dtype).to(device)
+    pose = ControlNetModel(ws["openpose"], ucfg, dtype).to(device)
+    nets = []
+    for key in ("lora0", "lora1"):
+        n = ControlLoRAModel(ws[key], ucfg, dtype, lora_linear_rank=rank, uses_vae=True)
+        n.set_autoencoder(vae)
+        n.tie_weights(unet)                                   # TT:259-261
+        nets.append(n.to(device))
+    mc = EdgeStyleMultiControlNetModel([nets[0], pose, nets[1], pose, nets[1], pose], ucfg)   # TT:50, TT:252-258
+    mc.load_state_dict(ws["fusion"])
+    mc.to(device)
+    pipe = EdgeStyleStableDiffusionControlNetPipeline(vae=vae, unet=unet, controlnet=mc).to(device)
+    return pipe, ws, ucfg, vcfg
+
+
+def make_inputs(ucfg, vcfg, B, device, seed=42):
+    """SURVEY.md §8d synthetic inputs, seed 42 (TT:274); image conds in [-1,1], pose conds in [0,1] (TT:29-48)."""
+    g = torch.Generator().manual_seed(seed)
+    s = ucfg.sample_size
+    res = s * vcfg.scale
+    lat = torch.randn(B, 4, s, s, generator=g)
+    pe = torch.randn(B, 77, ucfg.cross_attention_dim, generator=g) * 0.5
+    ne = torch.randn(B, 77, ucfg.cross_attention_dim, generator=g) * 0.5
+    imgs = []
+    for i in range(6):
+        u = torch.rand(1, 3, res, res, generator=g)
+        imgs.append((u * 2 - 1 if i % 2 == 0 else u).to(device))
+    cond_noise = [torch.randn(2 * B, 4, s, s, generator=g) if i % 2 == 0 else None for i in range(6)]
+    return lat, pe.to(device), ne.to(device), imgs, cond_noise
+
+
+def gemm_roofline(pipe, call):
+    """Run the workload once eagerly with HIP events around every es_conv_gemm launch (on the launch stream) and
+    price the kernel against the dense fp16 MFMA peak with ALGORITHMIC flops (2*M*Cout*Ktrue, unpadded)."""
+    from edgestyle_amd import ops
+    recs = []
+    ops.PROFILE = recs
+    pipe.use_graph = False
+    try:
+        call()
+        torch.cuda.synchronize()
+    finally:
+        ops.PROFILE = None
+        pipe.use_graph = True
+    tot_f = tot_t = 0.0
+    f3 = t3 = 0.0
+    for flops, k, e0, e1 in recs:
+        ms = e0.elapsed_time(e1)
+        tot_f += flops
+        tot_t += ms
+        if k == 3:
+            f3 += flops
+            t3 += ms
+    n = len(recs)
+    ach = tot_f / (tot_t * 1e-3) / 1e12
+    out = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv3x3/1x1/linear)", "achieved": round(ach, 2),
+           "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+           "launches": n, "avg_launch_us": round(tot_t * 1e3 / max(n, 1), 2),
+           "algorithmic_gflop_per_launch": round(tot_f / max(n, 1) / 1e9, 3),
+           "conv3x3_only": {"achieved": round(f3 / (t3 * 1e-3) / 1e12, 2) if t3 else None,
+                            "frac": round(f3 / (t3 * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4) if t3 else None},
+           "how": "HIP events around every launch of one eager pass of the same workload, after the timed region"}
+    return out
+
+
+def cpu_baseline(ws, ucfg, B, steps_total, tiny):
+    """The CPU oracle (plain PyTorch fp32 restatement of the reference diffusers pipeline) on this host's cores:
+    ONE full 6-cond denoising step at the benchmark batch, extrapolated to the 50-step loop."""
+    from oracle import sd15_oracle as O
+    from tests.helpers import oracle_nets
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cws = {k: {kk: vv.float().cpu() for kk, vv in v.items()} for k, v in ws.items() if k != "vae"}
+    g = torch.Generator().manual_seed(1)
+    N, s, c0 = 2 * B, ucfg.sample_size, ucfg.block_out_channels[0]
+    x = torch.randn(N, 4, s, s, generator=g)
+    ehs = torch.randn(N, 77, ucfg.cross_attention_dim, generator=g) * 0.5
+    conds = [torch.randn(N, c0, s, s, generator=g) * 0.3 for _ in range(6)]
+    t0 = time.time()
+    with torch.no_grad():
+        O.denoise_step(cws["unet"], ucfg, cws["fusion"], oracle_nets(cws, ucfg), x, 501, ehs, conds, [1.0] * 6)
+    dt = time.time() - t0
+    return {"value": round(B / (dt * steps_total), 6), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 of {steps_total} denoising steps (6 ControlNets + fusion + UNet, CFG batch {N}) = {dt:.1f} s, "
+                      f"x{steps_total}; condition embedding and VAE decode excluded"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step (BASELINE config 2: 1, config 3: 8)")
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--tiny", action="store_true", help="width-reduced config (plumbing check only, not the metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")          # RCCL over xGMI
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+
+    pipe, ws, ucfg, vcfg = build_pipeline(device, dtype, tiny=args.tiny)
+    B = args.batch
+    from edgestyle_amd.dist import shard_seed, gather_images
+    lat, pe, ne, imgs, cn = make_inputs(ucfg, vcfg, B, device, seed=shard_seed(42, rank, B))
+
+    out = {}
+
+    def one():
+        r = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image=imgs, latents=lat, guidance_scale=7.5,
+                 num_inference_steps=args.ddim_steps, output_type="pt", cond_noise=cn)
+        out["img"] = gather_images(r.images, world)          # the single RCCL gather of the path
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1) if args.steps else args.warmup):
+        one()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        img = out["img"]
+        assert img.shape[0] == B * world and bool(torch.isfinite(img).all()), "non-finite output image"
+        line = {
+            "metric": "512x512 try-on images/sec @ 50 DDIM steps (6-cond ControlNet)",
+            "value": round(world * B * args.steps / dt, 4), "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "bf16",
+            "data": "synthetic (seeded random-init SD1.5-shaped weights, random conds/latents/prompt embeds, seed 42)",
+            "config": {"workload": ("TINY plumbing config" if args.tiny else
+                                    f"BASELINE configs[{1 if B == 1 else 2}]: full 6-cond edgestyle_multicontrolnet + controllora, "
+                                    f"512x512, {args.ddim_steps} DDIM steps, CFG 7.5, batch={B}/GPU, hipGraph-captured step, "
+                                    "cond embedding + VAE decode included"),
+                       "images_per_gpu": B, "ddim_steps": args.ddim_steps, "parallelism": f"dp{world} (independent images, one RCCL gather)"},
+        }
+        if not args.no_roofline:
+            line["roofline"] = gemm_roofline(pipe, one)
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(ws, ucfg, B, args.ddim_steps, args.tiny)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -91,9 +91,9 @@ class Transformer:
         self.heads, self.groups = heads, groups
         self.c = self.proj_in.cout
 
-    def context(self, ehs):
+    def context(self, ehs, out=None):
         """K/V projection of the text states [N,77,D] -> [N,77,2C]; constant over the denoising loop."""
-        return ops.linear(ehs, self.kv2)
+        return ops.linear(ehs, self.kv2, out=out)
 
     def __call__(self, x, kv):
         N, H, W, C = x.shape
@@ -156,8 +156,13 @@ class Encoder:
         out = [a for blk in self.down for (_, a) in blk if a is not None]
         return out + [self.mid_attn]
 
-    def context(self, ehs) -> List[torch.Tensor]:
-        return [t.context(ehs) for t in self.transformers()]
+    def context(self, ehs, outs: Optional[List[torch.Tensor]] = None) -> List[torch.Tensor]:
+        """`outs` (a previous result of matching shape) is overwritten in place: pointers baked into a captured
+        graph stay valid across pipeline calls."""
+        tr = self.transformers()
+        if outs is not None and outs[0].shape[0] == ehs.shape[0]:
+            return [t.context(ehs, o) for t, o in zip(tr, outs)]
+        return [t.context(ehs) for t in tr]
 
     def time_proj(self, t_dev: torch.Tensor, step_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
         """CL:150-157 + every ResnetBlock2D.time_emb_proj(silu(emb)) in one shot -> [N, sum(Cout)]."""
@@ -327,6 +332,11 @@ class VAE:
             self.quant = pk.conv("quant_conv")
         if decoder:
             self.post_quant = pk.conv("post_quant_conv", cin_pad=self.lat_pad, cout_pad=8)
+            # decode(latents / scaling_factor) (PL:552-557) with the division folded into the 1x1 weights
+            b = sd.get("post_quant_conv.bias")
+            self.post_quant_scaled = ops.pack_weight(
+                pk.t("post_quant_conv.weight") / cfg.scaling_factor, None if b is None else b.to(device), dtype,
+                device, cin_pad=self.lat_pad, cout_pad=8)
             self.d_in = pk.conv("decoder.conv_in", cin_pad=8)
             self.d_mid = mid("decoder")
             self.d_up = []
@@ -362,10 +372,11 @@ class VAE:
         h = ops.conv_gemm(h, self.e_out)
         return ops.conv_gemm(h, self.quant)
 
-    def decode(self, z):
-        """z: [N,h,w,lat_pad] (already divided by scaling_factor) -> image [N,8h,8w,3]"""
+    def decode(self, z, unscaled_latents: bool = False):
+        """z: [N,h,w,lat_pad] -> image [N,8h,8w,3].  unscaled_latents: z is the scheduler's latents and the
+        1/scaling_factor of PL:553-554 is applied by the (pre-scaled) post_quant weights."""
         cfg = self.cfg
-        h = ops.conv_gemm(z, self.post_quant)
+        h = ops.conv_gemm(z, self.post_quant_scaled if unscaled_latents else self.post_quant)
         h = ops.conv_gemm(h, self.d_in)
         h = self._mid(self.d_mid, h)
         for rs, us in self.d_up:

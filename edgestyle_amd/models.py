@@ -225,7 +225,8 @@ class ControlNetModel(_HipModel):
         return self._engine
 
     # -- conditioning -------------------------------------------------------------------------------------------
-    def preprocess_image(self, image: torch.Tensor, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def preprocess_image(self, image: torch.Tensor, noise: Optional[torch.Tensor] = None,
+                         generator: Optional[torch.Generator] = None) -> torch.Tensor:
         """CL:289-290: run the conditioning embedding once per image. image [N,3,H,W] -> [N,C0,H/8,W/8] (NCHW view)."""
         eng = self.engine
         img = _as_nhwc(image, self.dtype, self.device, 8)
@@ -307,8 +308,8 @@ class AutoencoderKL(_HipModel):
         mom = self.engine.encode_moments(_as_nhwc(x, self.dtype, self.device, 8))
         return SimpleNamespace(latent_dist=_LatentDist(self, mom))
 
-    def decode_nhwc(self, z_nhwc: torch.Tensor) -> torch.Tensor:
-        return self.engine.decode(z_nhwc)
+    def decode_nhwc(self, z_nhwc: torch.Tensor, unscaled_latents: bool = False) -> torch.Tensor:
+        return self.engine.decode(z_nhwc, unscaled_latents)
 
     def decode(self, z: torch.Tensor, return_dict: bool = True, generator=None):
         """PL:552-557: z [B,4,h,w] (already divided by scaling_factor) -> image [B,3,8h,8w] in [-1,1]."""
@@ -633,11 +634,12 @@ class StepRunner:
 
     def set_context(self, ehs: torch.Tensor):
         """ehs: [N,77,D] device dtype. Computes every cross-attention K/V projection once (constant over the loop)."""
-        self.ctx_unet = self.unet.engine.context(ehs)
+        self.ctx_unet = self.unet.engine.context(ehs, self.ctx_unet)
+        old = self.ctx_nets or [None] * len(self.groups)
         self.ctx_nets = []
-        for net, pos in self.groups:
+        for (net, pos), o in zip(self.groups, old):
             k = len(pos)
-            self.ctx_nets.append(net.engine.context(ehs.repeat(k, 1, 1) if k > 1 else ehs))
+            self.ctx_nets.append(net.engine.context(ehs.repeat(k, 1, 1) if k > 1 else ehs, o))
 
     def step(self, x: torch.Tensor, t_rows: torch.Tensor, conds: Sequence[torch.Tensor], scales: Sequence[float],
              scales_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:

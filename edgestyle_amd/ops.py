@@ -13,6 +13,7 @@ import torch
 from . import lib as L
 
 _DT = {torch.float16: L.ES_F16, torch.bfloat16: L.ES_BF16}
+PROFILE = None      # set to a list by bench.py to time every es_conv_gemm launch with HIP events
 BK = 64
 BM = 128
 
@@ -167,6 +168,14 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     if splitk > 1:
         ws = _get_workspace(splitk * M * pw.rows_padded * 4, x.device)
         d.workspace = ws.data_ptr()
+    if PROFILE is not None:           # bench.py roofline leg: HIP events on the launch stream around this launch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(L.load().es_conv_gemm(C.byref(d), _stream()), "es_conv_gemm")
+        e1.record()
+        cin_true = (C1 + C2)
+        PROFILE.append((2.0 * M * pw.cout * k * k * cin_true, k, e0, e1))
+        return out
     L.check(L.load().es_conv_gemm(C.byref(d), _stream()), "es_conv_gemm")
     return out
 

@@ -1,0 +1,331 @@
+"""StableDiffusionControlNetPipeline / EdgeStyleStableDiffusionControlNetPipeline call surface over the HIP path.
+
+Follows model/edgestyle_pipeline.py:91-664 step for step (citations inline).  What changes is *how* it runs:
+
+* the six conditioning images are embedded once per call (the cached semantics, PL:660-662 / CL:289-290);
+  the stock pipeline the reference's test script uses would re-run a VAE encode with a fresh global-RNG sample
+  every step (CL:38-42, CL:199-203) — non-deterministic and 6.7 TFLOP/step of redundant work — so both pipeline
+  names here use the cached semantics and the VAE sample noise comes from `generator` (or `cond_noise=`);
+* one denoising step (6 ControlNet passes as 3 batched passes -> 13 fusion blocks -> UNet -> CFG -> DDIM) is
+  captured once into a hipGraph and replayed; timestep, DDIM coefficients and conditioning scales are device tables
+  indexed by a device-side step counter, so a replay needs no host work;
+* latents stay fp32 NHWC on the device for the whole loop; VAE decode and the [0,1] post-process are kernels.
+"""
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import Any, Callable, Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import ops
+from .lib import EdgeStyleHipError
+from .models import (AutoencoderKL, ControlNetModel, EdgeStyleMultiControlNetModel, StepRunner,
+                     UNet2DConditionModel, _as_nhwc, _as_nchw_view)
+from .schedulers import DDIMScheduler
+
+
+@dataclass
+class StableDiffusionPipelineOutput:
+    images: Any
+    nsfw_content_detected: Optional[List[bool]] = None
+
+
+class _Loop:
+    """Static device buffers + the captured step graph for one (B, cfg) shape."""
+
+    def __init__(self, pipe, B: int, cfg_on: bool, h: int, w: int):
+        dev, dt = pipe.device, pipe.dtype
+        unet = pipe.unet
+        self.B, self.cfg_on, self.h, self.w = B, cfg_on, h, w
+        self.N = N = 2 * B if cfg_on else B
+        Lc, Lp = unet.cfg.in_channels, unet.engine.in_pad
+        c0 = unet.cfg.block_out_channels[0]
+        self.runner = pipe._runner
+        k = self.runner.kmax
+        self.latents = torch.zeros((B, h, w, Lc), dtype=torch.float32, device=dev)
+        self.model_in = torch.zeros((N, h, w, Lp), dtype=dt, device=dev)
+        self.noise = torch.zeros((N, h, w, unet.cfg.out_channels), dtype=dt, device=dev)
+        self.conds = [torch.zeros((N, h, w, c0), dtype=dt, device=dev) for _ in range(6)]
+        self.ehs = torch.zeros((N, 77, unet.cfg.cross_attention_dim), dtype=dt, device=dev)
+        self.step_idx = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.t_rows = torch.zeros((k * N,), dtype=torch.float32, device=dev)
+        self.scales_cur = torch.ones((6,), dtype=torch.float32, device=dev)
+        self.t_table = None
+        self.scale_table = None
+        self.coef = None
+        self.graph = None
+        self.guidance_scale = None
+        self.steps = None
+
+    def one_step(self):
+        """Everything between PL:435 and PL:522 for the step selected by the device counter."""
+        ops.gather_row(self.t_table, self.step_idx, self.t_rows)
+        ops.gather_row(self.scale_table, self.step_idx, self.scales_cur)
+        self.runner.step(self.model_in, self.t_rows, self.conds, [1.0] * 6, self.scales_cur, out=self.noise)
+        ops.cfg_ddim_step(self.noise, self.latents, self.model_in, self.coef, self.step_idx,
+                          float(self.guidance_scale), self.cfg_on)
+        ops.incr(self.step_idx)
+
+
+class StableDiffusionControlNetPipeline:
+    """Keeps the constructor / from_pretrained / __call__ surface TT:263-275 and TT:326-359 use."""
+
+    def __init__(self, vae: AutoencoderKL, text_encoder=None, tokenizer=None, unet: UNet2DConditionModel = None,
+                 controlnet: EdgeStyleMultiControlNetModel = None, scheduler=None, safety_checker=None,
+                 feature_extractor=None, image_encoder=None, requires_safety_checker: bool = False):
+        if unet is None or controlnet is None or vae is None:
+            raise ValueError("vae, unet and controlnet are required")
+        if isinstance(controlnet, (list, tuple)):
+            raise ValueError("pass an EdgeStyleMultiControlNetModel (the reference's fused 6-net model)")
+        self.vae, self.text_encoder, self.tokenizer = vae, text_encoder, tokenizer
+        self.unet, self.controlnet = unet, controlnet
+        self.scheduler = scheduler or DDIMScheduler()
+        self.safety_checker = None
+        self.vae_scale_factor = vae.cfg.scale
+        self.device = unet.device
+        self.dtype = unet.dtype
+        self.use_graph = True
+        self._runner = None
+        self._loops: Dict[Any, _Loop] = {}
+
+    @classmethod
+    def from_pretrained(cls, path=None, **components):
+        components.pop("torch_dtype", None)
+        if "scheduler" not in components:
+            components["scheduler"] = DDIMScheduler()
+        return cls(**{k: v for k, v in components.items() if k in (
+            "vae", "text_encoder", "tokenizer", "unet", "controlnet", "scheduler", "safety_checker",
+            "feature_extractor", "image_encoder", "requires_safety_checker")})
+
+    def to(self, device):
+        self.device = torch.device(device)
+        for m in (self.unet, self.controlnet, self.vae):
+            m.to(self.device)
+        if self.text_encoder is not None and hasattr(self.text_encoder, "to"):
+            self.text_encoder.to("cpu")          # CLIP text encode is outside the hot path
+        self._runner = None
+        self._loops.clear()
+        return self
+
+    @property
+    def _execution_device(self):
+        return self.device
+
+    # ------------------------------------------------------------------------------------------------------
+    def encode_prompt(self, prompt, negative_prompt, do_cfg, prompt_embeds=None, negative_prompt_embeds=None):
+        """PL:315-325.  With tensors given this is a pass-through; strings need the transformers CLIP encoder."""
+        if prompt_embeds is None:
+            if self.tokenizer is None or self.text_encoder is None:
+                raise ValueError("pass prompt_embeds/negative_prompt_embeds, or build the pipeline with a "
+                                 "tokenizer and text_encoder")
+            prompt_embeds = self._clip(prompt)
+        if do_cfg and negative_prompt_embeds is None:
+            if self.tokenizer is None or self.text_encoder is None:
+                raise ValueError("negative_prompt_embeds required for guidance_scale > 1")
+            n = prompt_embeds.shape[0]
+            neg = negative_prompt if negative_prompt is not None else ""
+            negative_prompt_embeds = self._clip([neg] * n if isinstance(neg, str) else neg)
+        return prompt_embeds, negative_prompt_embeds
+
+    def _clip(self, text):
+        text = [text] if isinstance(text, str) else list(text)
+        tok = self.tokenizer(text, padding="max_length", max_length=self.tokenizer.model_max_length,
+                             truncation=True, return_tensors="pt")
+        with torch.no_grad():
+            return self.text_encoder(tok.input_ids)[0].float()
+
+    def check_inputs(self, image, prompt, prompt_embeds, controlnet_conditioning_scale, starts, ends):
+        n = len(self.controlnet.nets)
+        if prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`.")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError("Cannot forward both `prompt` and `prompt_embeds`.")
+        if not isinstance(image, (list, tuple)) or len(image) != n:
+            raise ValueError(f"For multiple controlnets: `image` must be a list of {n} conditioning images")
+        if isinstance(controlnet_conditioning_scale, (list, tuple)) and len(controlnet_conditioning_scale) != n:
+            raise ValueError("`controlnet_conditioning_scale` must have one entry per ControlNet")
+        if len(starts) != n or len(ends) != n:
+            raise ValueError("`control_guidance_start`/`end` must have one entry per ControlNet")
+        for s, e in zip(starts, ends):
+            if s >= e:
+                raise ValueError(f"control guidance start: {s} cannot be larger or equal to control guidance end: {e}.")
+            if s < 0.0 or e > 1.0:
+                raise ValueError("control guidance start/end must lie in [0, 1]")
+
+    def prepare_image(self, image, batch_size, do_cfg, net, noise=None, generator=None):
+        """PL:629-664: -> fp32 [b,3,H,W] -> repeat -> CFG duplicate -> one-time embedding -> NHWC [N,h,w,C0]."""
+        if not torch.is_tensor(image):
+            arr = np.asarray(image, dtype=np.float32)
+            if arr.ndim == 3:
+                arr = arr[None]
+            if arr.max() > 1.5:
+                arr = arr / 255.0                       # VaeImageProcessor.preprocess(do_normalize=False)
+            image = torch.from_numpy(arr).permute(0, 3, 1, 2)
+        image = image.to(torch.float32)
+        if image.shape[0] == 1:
+            image = image.repeat_interleave(batch_size, dim=0)          # PL:647-653
+        elif image.shape[0] != batch_size:
+            raise ValueError("condition image batch must be 1 or equal to the prompt batch")
+        if do_cfg:
+            image = torch.cat([image] * 2)                              # PL:657-658
+        if tuple(image.shape[1:2]) == (3,):
+            emb = net.preprocess_image(image.to(self.device), noise=noise, generator=generator)
+        else:
+            emb = image                                                 # already embedded [N,C0,h,w]
+        return _as_nhwc(emb, self.dtype, self.device)
+
+    def prepare_latents(self, batch_size, channels, h, w, generator, latents=None):
+        """PL:585-627 (latents drawn on the CPU generator so results do not depend on the device RNG stream)."""
+        shape = (batch_size, channels, h, w)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an "
+                             f"effective batch size of {batch_size}.")
+        if latents is None:
+            if isinstance(generator, list):
+                latents = torch.cat([torch.randn((1,) + shape[1:], generator=g, dtype=torch.float32)
+                                     for g in generator])
+            else:
+                latents = torch.randn(shape, generator=generator, dtype=torch.float32)
+        elif tuple(latents.shape) != shape:
+            raise ValueError(f"latents shape {tuple(latents.shape)} != {shape}")
+        return latents.to(torch.float32) * self.scheduler.init_noise_sigma
+
+    # ------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, prompt: Union[str, List[str], None] = None, image=None, height: Optional[int] = None,
+                 width: Optional[int] = None, num_inference_steps: int = 50, timesteps=None,
+                 guidance_scale: float = 7.5, negative_prompt=None, num_images_per_prompt: int = 1,
+                 eta: float = 0.0, generator=None, latents: Optional[torch.Tensor] = None,
+                 prompt_embeds: Optional[torch.Tensor] = None,
+                 negative_prompt_embeds: Optional[torch.Tensor] = None, output_type: str = "pil",
+                 return_dict: bool = True, controlnet_conditioning_scale: Union[float, List[float]] = 1.0,
+                 guess_mode: bool = False, control_guidance_start: Union[float, List[float]] = 0.0,
+                 control_guidance_end: Union[float, List[float]] = 1.0,
+                 callback_on_step_end: Optional[Callable] = None, cond_noise: Optional[Sequence] = None, **kwargs):
+        if guess_mode:
+            raise NotImplementedError("guess_mode is outside the EdgeStyle hot path (SURVEY.md §8f)")
+        if eta != 0.0:
+            raise NotImplementedError("only the deterministic DDIM update (eta = 0) is implemented")
+        if timesteps is not None:
+            raise NotImplementedError("custom timesteps are not supported (the reference path itself is broken: PL:697)")
+        if self.device.type != "cuda":
+            raise EdgeStyleHipError("the pipeline runs only on an MI355X: call .to('cuda') first")
+        if not isinstance(self.scheduler, DDIMScheduler):
+            raise EdgeStyleHipError("the fused step kernel implements DDIM; assign a DDIMScheduler")
+        nn = len(self.controlnet.nets)
+        # PL:243-265 broadcast guidance windows
+        if not isinstance(control_guidance_start, list):
+            control_guidance_start = [control_guidance_start] * nn
+        if not isinstance(control_guidance_end, list):
+            control_guidance_end = [control_guidance_end] * nn
+        self.check_inputs(image, prompt, prompt_embeds, controlnet_conditioning_scale, control_guidance_start,
+                          control_guidance_end)
+        if isinstance(controlnet_conditioning_scale, (int, float)):                 # PL:295-300
+            controlnet_conditioning_scale = [float(controlnet_conditioning_scale)] * nn
+        do_cfg = guidance_scale > 1.0
+        prompt_embeds, negative_prompt_embeds = self.encode_prompt(prompt, negative_prompt, do_cfg, prompt_embeds,
+                                                                   negative_prompt_embeds)
+        if num_images_per_prompt != 1:
+            prompt_embeds = prompt_embeds.repeat_interleave(num_images_per_prompt, dim=0)
+            if negative_prompt_embeds is not None:
+                negative_prompt_embeds = negative_prompt_embeds.repeat_interleave(num_images_per_prompt, dim=0)
+        B = prompt_embeds.shape[0]
+        ehs = torch.cat([negative_prompt_embeds, prompt_embeds]) if do_cfg else prompt_embeds     # PL:329-330
+
+        if self._runner is None:
+            self._runner = StepRunner(self.unet, self.controlnet)
+
+        # PL:352-377 — condition images, embedded ONCE
+        conds = []
+        for i, (img, net) in enumerate(zip(image, self.controlnet.nets)):
+            nz = None if cond_noise is None else cond_noise[i]
+            conds.append(self.prepare_image(img, B, do_cfg, net, noise=nz, generator=generator))
+        h, w = conds[0].shape[1:3]
+
+        # PL:382-398
+        ts = self.scheduler.set_timesteps(num_inference_steps)
+        T = len(ts)
+        lat = self.prepare_latents(B, self.unet.cfg.in_channels, h, w, generator, latents)
+
+        key = (B, do_cfg, h, w)
+        loop = self._loops.get(key)
+        if loop is None:
+            loop = self._loops[key] = _Loop(self, B, do_cfg, h, w)
+        N, k = loop.N, self._runner.kmax
+        # PL:419-427 controlnet_keep folded into a per-step scale table
+        keep = [[1.0 - float(i / T < s or (i + 1) / T > e)
+                 for s, e in zip(control_guidance_start, control_guidance_end)] for i in range(T)]
+        scale_table = torch.tensor([[c * kk for c, kk in zip(controlnet_conditioning_scale, row)] for row in keep],
+                                   dtype=torch.float32)
+        dev = self.device
+        regraph = (loop.steps != T) or (loop.guidance_scale != float(guidance_scale)) or loop.graph is None
+        loop.steps, loop.guidance_scale = T, float(guidance_scale)
+        if loop.t_table is None or loop.t_table.shape[0] != T:
+            loop.t_table = torch.empty((T, k * N), dtype=torch.float32, device=dev)
+            loop.scale_table = torch.empty((T, 6), dtype=torch.float32, device=dev)
+            loop.coef = torch.empty((T, 4), dtype=torch.float32, device=dev)
+            regraph = True
+        loop.t_table.copy_(ts.float()[:, None].expand(T, k * N))
+        loop.scale_table.copy_(scale_table)
+        loop.coef.copy_(self.scheduler.coef_table())
+        loop.step_idx.zero_()
+        loop.latents.copy_(lat.permute(0, 2, 3, 1))
+        mi = lat.permute(0, 2, 3, 1).to(self.dtype)
+        loop.model_in.zero_()
+        loop.model_in[:B, ..., : mi.shape[-1]] = mi.to(dev)                        # PL:443-447
+        if do_cfg:
+            loop.model_in[B:, ..., : mi.shape[-1]] = mi.to(dev)
+        for dst, src in zip(loop.conds, conds):
+            dst.copy_(src)
+        loop.ehs.copy_(ehs.to(dev, self.dtype))
+        self._runner.set_context(loop.ehs)
+
+        # PL:435-543 — the denoising loop
+        if callback_on_step_end is not None or not self.use_graph:
+            for i in range(T):
+                loop.one_step()
+                if callback_on_step_end is not None:
+                    out = callback_on_step_end(self, i, int(ts[i]), {"latents": _as_nchw_view(loop.latents)})
+                    if out and "latents" in out:
+                        loop.latents.copy_(out["latents"].permute(0, 2, 3, 1))
+        else:
+            start = 0
+            if regraph:
+                loop.one_step()                       # eager step 0: sizes the split-K workspace, warms kernels
+                start = 1
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                saved = loop.step_idx.clone()
+                with torch.cuda.graph(g):
+                    loop.one_step()
+                loop.graph = g
+                loop.step_idx.copy_(saved)            # capture does not execute; keep the counter where it was
+            for _ in range(start, T):
+                loop.graph.replay()
+
+        if output_type == "latent":
+            img = _as_nchw_view(loop.latents).clone()
+        else:
+            # PL:552-557 decode(latents / scaling_factor); PL:570-572 (x/2+0.5).clamp(0,1)
+            # model_in[:B] already holds the final latents in the compute dtype, channel-padded (es_cfg_ddim_step)
+            dec = self.vae.decode_nhwc(loop.model_in[:B], unscaled_latents=True)
+            img = ops.nhwc_to_nchw(dec, channels=3, scale=0.5, shift=0.5, clamp01=True)
+            if output_type in ("np", "pil"):
+                arr = img.permute(0, 2, 3, 1).cpu().numpy()
+                if output_type == "pil":
+                    from PIL import Image
+                    img = [Image.fromarray((a * 255).round().astype("uint8")) for a in arr]
+                else:
+                    img = arr
+            elif output_type != "pt":
+                raise ValueError(f"unknown output_type {output_type}")
+        if not return_dict:
+            return (img, None)
+        return StableDiffusionPipelineOutput(images=img, nsfw_content_detected=None)
+
+
+class EdgeStyleStableDiffusionControlNetPipeline(StableDiffusionControlNetPipeline):
+    """model/edgestyle_pipeline.py:57-664 — same call surface; the cached-condition semantics it adds over the stock
+    pipeline are what both classes implement here."""
+    pass

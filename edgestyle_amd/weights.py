@@ -231,10 +231,10 @@ def fusion_shapes(cfg: UNetConfig, num_nets: int = NUM_CONTROLNETS, sample_size:
 # deterministic random init
 # ----------------------------------------------------------------------------------------------------------------
 def _init_one(key: str, shape, seed: int, device="cpu") -> torch.Tensor:
-    g = torch.Generator(device="cpu")
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)          # cpu: bit-identical everywhere; cuda: fast path for bench weights
     g.manual_seed((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
-    x = torch.randn(shape, generator=g, dtype=torch.float32)
-    leaf = key.rsplit(".", 2)
+    x = torch.randn(shape, generator=g, dtype=torch.float32, device=dev)
     is_norm = any(t in key for t in (".norm", "_norm", "normalization"))
     if key.endswith(".bias"):
         return x * 0.02
@@ -255,9 +255,9 @@ def _init_one(key: str, shape, seed: int, device="cpu") -> torch.Tensor:
     return x * (gain / (fan_in ** 0.5))
 
 
-def random_state_dict(shapes: Shapes, seed: int = 0, prefix: str = "") -> Dict[str, torch.Tensor]:
-    """fp32 CPU tensors; `prefix` only salts the seed (so unet / openpose / vae differ), keys stay unprefixed."""
-    return OrderedDict((k, _init_one(prefix + k, s, seed)) for k, s in shapes.items())
+def random_state_dict(shapes: Shapes, seed: int = 0, prefix: str = "", device="cpu") -> Dict[str, torch.Tensor]:
+    """fp32 tensors; `prefix` only salts the seed (so unet / openpose / vae differ), keys stay unprefixed."""
+    return OrderedDict((k, _init_one(prefix + k, s, seed, device)) for k, s in shapes.items())
 
 
 # ----------------------------------------------------------------------------------------------------------------

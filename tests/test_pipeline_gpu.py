@@ -1,0 +1,147 @@
+"""End-to-end parity of the HIP pipeline against the CPU oracle pipeline (tiny config), PSNR >= 40 dB on the decoded
+image (north_star tolerance), graph replay == eager, drop-in call-surface checks."""
+import math
+
+import pytest
+import torch
+
+from edgestyle_amd import config as C
+from tests.helpers import make_weights, quantize, rel_err, oracle_nets
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def psnr(a, b, peak=1.0):
+    mse = float(((a.float().cpu() - b.float().cpu()) ** 2).mean())
+    return 10 * math.log10(peak * peak / max(mse, 1e-20))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from edgestyle_amd.models import (UNet2DConditionModel, ControlNetModel, ControlLoRAModel, AutoencoderKL,
+                                      EdgeStyleMultiControlNetModel)
+    from edgestyle_amd.pipeline import StableDiffusionControlNetPipeline
+    ucfg, vcfg = C.tiny_unet(), C.tiny_vae()
+    ws = {k: quantize(v) for k, v in make_weights(ucfg, vcfg).items()}
+    unet = UNet2DConditionModel(ws["unet"], ucfg, torch.float16)
+    vae = AutoencoderKL(ws["vae"], vcfg)
+    pose = ControlNetModel(ws["openpose"], ucfg, torch.float16)
+    l0 = ControlLoRAModel(ws["lora0"], ucfg, lora_linear_rank=4, uses_vae=True)
+    l1 = ControlLoRAModel(ws["lora1"], ucfg, lora_linear_rank=4, uses_vae=True)
+    for n in (l0, l1):
+        n.set_autoencoder(vae)
+        n.tie_weights(unet)
+    mc = EdgeStyleMultiControlNetModel([l0, pose, l1, pose, l1, pose])
+    mc.load_state_dict(ws["fusion"])
+    pipe = StableDiffusionControlNetPipeline.from_pretrained(None, vae=vae, unet=unet, controlnet=mc,
+                                                             safety_checker=None, torch_dtype=torch.float16)
+    pipe = pipe.to(DEV)
+    return pipe, ws, ucfg, vcfg
+
+
+def _inputs(ucfg, B, seed=42):
+    g = torch.Generator().manual_seed(seed)
+    s, c0 = ucfg.sample_size, ucfg.block_out_channels[0]
+    lat = torch.randn(B, 4, s, s, generator=g)
+    pe = (torch.randn(B, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+    ne = (torch.randn(B, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+    conds = [(torch.randn(1, c0, s, s, generator=g) * 0.3).half().float() for _ in range(6)]
+    return lat, pe, ne, conds
+
+
+@pytest.mark.parametrize("B,steps,gs", [(1, 4, 7.5), (2, 10, 3.5), (1, 3, 1.0)])
+def test_pipeline_vs_oracle_psnr(built, B, steps, gs):
+    from oracle import sd15_oracle as O
+    pipe, ws, ucfg, vcfg = built
+    lat, pe, ne, conds = _inputs(ucfg, B)
+    N = 2 * B if gs > 1 else B
+    oconds = [c.repeat(N, 1, 1, 1) for c in conds]
+    ref = O.pipeline(ws["unet"], ucfg, ws["fusion"], oracle_nets(ws, ucfg), ws["vae"], vcfg, lat, pe, ne, oconds,
+                     num_inference_steps=steps, guidance_scale=gs)
+    out = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, latents=lat, guidance_scale=gs,
+               num_inference_steps=steps, output_type="pt").images
+    assert out.shape == ref.shape
+    p = psnr(out, ref)
+    assert p >= 40.0, p
+    # second call reuses the captured graph and static buffers; eager must agree bit for bit with replay
+    out2 = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, latents=lat, guidance_scale=gs,
+                num_inference_steps=steps, output_type="pt").images
+    assert torch.equal(out, out2)
+    pipe.use_graph = False
+    try:
+        out3 = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, latents=lat, guidance_scale=gs,
+                    num_inference_steps=steps, output_type="pt").images
+    finally:
+        pipe.use_graph = True
+    assert torch.equal(out, out3)
+
+
+def test_pipeline_raw_images_guidance_window_and_outputs(built):
+    """[1,3,H,W] condition images go through VAE-encode / openpose conv stack once (PL:660-662); control guidance
+    window (PL:419-427) and scale list honoured; latent / np / pil outputs."""
+    from oracle import sd15_oracle as O
+    pipe, ws, ucfg, vcfg = built
+    g = torch.Generator().manual_seed(7)
+    s = ucfg.sample_size
+    res = s * 8
+    lat, pe, ne, _ = _inputs(ucfg, 1, seed=5)
+    imgs = [(torch.rand(1, 3, res, res, generator=g) * (2 if i % 2 == 0 else 1) - (1 if i % 2 == 0 else 0)).half().float()
+            for i in range(6)]
+    noise = [torch.randn(2, 4, s, s, generator=g) if i % 2 == 0 else None for i in range(6)]
+    nets = oracle_nets(ws, ucfg)
+    oconds = []
+    for i in range(6):
+        im2 = torch.cat([imgs[i]] * 2)
+        if i % 2 == 0:
+            oconds.append(O.vae_cond_embedding(nets[i][0], ws["vae"], vcfg, im2, noise[i]))
+        else:
+            oconds.append(O.cond_embedding(ws["openpose"], ucfg, im2))
+    scales = [1.0, 0.5, 1.0, 1.0, 0.7, 1.0]
+    ref = O.pipeline(ws["unet"], ucfg, ws["fusion"], nets, ws["vae"], vcfg, lat, pe, ne, oconds, num_inference_steps=5,
+                     guidance_scale=5.0, scales=scales, control_guidance_start=0.0, control_guidance_end=0.6,
+                     decode=False)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=imgs, latents=lat, guidance_scale=5.0,
+              num_inference_steps=5, controlnet_conditioning_scale=scales, control_guidance_end=0.6, cond_noise=noise)
+    out = pipe(output_type="latent", **kw).images
+    assert rel_err(out, ref) < 3e-2
+    arr = pipe(output_type="np", **kw).images
+    assert arr.shape == (1, res, res, 3) and arr.min() >= 0 and arr.max() <= 1
+    pil = pipe(output_type="pil", **kw).images
+    assert pil[0].size == (res, res)
+
+
+def test_multicontrolnet_and_unet_call_surface(built):
+    """EdgeStyleMultiControlNetModel.__call__ (MC:116-171) + UNet2DConditionModel.__call__ chained the way
+    OnnxUNetAndControlnets.forward does (export_onnx.py:43-74), NCHW in / NCHW out."""
+    from oracle import sd15_oracle as O
+    pipe, ws, ucfg, vcfg = built
+    g = torch.Generator().manual_seed(11)
+    s, c0 = ucfg.sample_size, ucfg.block_out_channels[0]
+    x = torch.randn(2, 4, s, s, generator=g).half().float()
+    ehs = (torch.randn(2, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+    conds = [(torch.randn(2, c0, s, s, generator=g) * 0.3).half().float() for _ in range(6)]
+    scales = [1.0] * 6
+    down, mid = pipe.controlnet(x.to(DEV), 261, encoder_hidden_states=ehs.to(DEV),
+                                controlnet_cond=[c.to(DEV) for c in conds], conditioning_scale=scales,
+                                guess_mode=False, return_dict=False)
+    assert len(down) == 12 and [tuple(d.shape) for d in down] == [(2, c, sz, sz) for c, sz in ucfg.residual_table()[:-1]]
+    rd, rm = O.multicontrolnet_forward(ws["fusion"], oracle_nets(ws, ucfg), x, 261, ehs, conds, scales)
+    for a, b in zip(down + [mid], rd + [rm]):
+        assert rel_err(a, b) < 2e-2
+    noise = pipe.unet(x.to(DEV), 261, encoder_hidden_states=ehs.to(DEV), down_block_additional_residuals=down,
+                      mid_block_additional_residual=mid, return_dict=False)[0]
+    ref = O.unet_forward(ws["unet"], ucfg, x, 261, ehs, rd, rm)
+    assert tuple(noise.shape) == (2, 4, s, s) and rel_err(noise, ref) < 2e-2
+
+
+def test_errors_match_reference_behaviour(built):
+    pipe, ws, ucfg, vcfg = built
+    lat, pe, ne, conds = _inputs(ucfg, 1)
+    with pytest.raises(ValueError):
+        pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds[:5], latents=lat)       # 5 images for 6 nets
+    with pytest.raises(ValueError):
+        pipe(image=conds, latents=lat)                                                        # no prompt at all
+    with pytest.raises(ValueError):
+        pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, latents=lat, control_guidance_start=0.8,
+             control_guidance_end=0.2)
