@@ -26,6 +26,23 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def host_cores() -> int:
+    """Threads the CPU baseline may use: the scheduler affinity / cgroup quota of this process, capped at the GPU box's
+    per-GPU CPU share (16).  Oversubscribing OpenMP threads on a quota-limited box stalls for minutes."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("ES_BENCH_THREADS", "16"))))
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def build_pipeline(device, dtype, seed=0, tiny=False, keep_cpu=False):
     from edgestyle_amd import config as C, weights as W
     from edgestyle_amd.models import (UNet2DConditionModel, ControlNetModel, ControlLoRAModel, AutoencoderKL,
@@ -113,7 +130,7 @@ def cpu_baseline(ws, ucfg, B, steps_total, tiny):
     ONE full 6-cond denoising step at the benchmark batch, extrapolated to the 50-step loop."""
     from oracle import sd15_oracle as O
     from tests.helpers import oracle_nets
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     cws = {k: {kk: vv.float().cpu() for kk, vv in v.items()} for k, v in ws.items() if k != "vae"}
     g = torch.Generator().manual_seed(1)
@@ -155,6 +172,9 @@ def main():
     device = torch.device("cuda", local_rank)
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
 
+    import faulthandler
+    faulthandler.dump_traceback_later(600, repeat=True, file=sys.stderr)     # where are we, if something stalls
+    log(f"rank {rank}/{world}: building weights + packing on {device}")
     pipe, ws, ucfg, vcfg = build_pipeline(device, dtype, tiny=args.tiny)
     B = args.batch
     from edgestyle_amd.dist import shard_seed, gather_images
@@ -172,8 +192,10 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 1) if args.steps else args.warmup):
+    for i in range(max(args.warmup, 1) if args.steps else args.warmup):
         one()
+        torch.cuda.synchronize()
+        log(f"warmup {i} done")
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -185,6 +207,7 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
 
+    log(f"timed region done: {dt:.3f} s for {args.steps} step(s)")
     if rank == 0:
         img = out["img"]
         assert img.shape[0] == B * world and bool(torch.isfinite(img).all()), "non-finite output image"
@@ -202,8 +225,11 @@ def main():
         }
         if not args.no_roofline:
             line["roofline"] = gemm_roofline(pipe, one)
+            log("roofline leg done")
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(ws, ucfg, B, args.ddim_steps, args.tiny)
+            log("cpu baseline done")
+        faulthandler.cancel_dump_traceback_later()
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -24,64 +24,43 @@ ES_DEVICE int gn_pixels_per_block(int HW) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const es_gn_desc p) {
-  __shared__ float gs[GN_MAX_GROUPS * 2];
+  // LDS: per-(pixel-slot, channel) partial sums, then one thread per group adds them in a FIXED order
+  // (bitwise reproducible: no float atomics anywhere).
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n = blockIdx.y, chunk = blockIdx.x;
   const int C = p.C1 + p.C2, CH8 = C / 8, cpg = C / p.groups;
   const int ppb = gn_pixels_per_block(p.HW);
   const int p0 = chunk * ppb;
   const int p1 = min(p0 + ppb, p.HW);
-  for (int i = threadIdx.x; i < p.groups * 2; i += 256) gs[i] = 0.f;
-  __syncthreads();
-  const int lanes_used = (256 / CH8) * CH8;          // threads that own a (pixel-slot, chunk)
-  if (CH8 <= 256) {
-    if ((int)threadIdx.x < lanes_used) {
-      const int q = threadIdx.x % CH8, ps = threadIdx.x / CH8, pstride = 256 / CH8;
-      const int c = q * 8;
-      const bool second = c >= p.C1;
-      const T* src = second ? (const T*)p.x2 : (const T*)p.x;
-      const int cs = second ? p.C2 : p.C1, cc = second ? c - p.C1 : c;
-      float s[8], ss[8];
+  const int PS = CH8 <= 256 ? 256 / CH8 : 1;          // pixel slots processed concurrently
+  float* csum = (float*)smem;                        // [PS][C]
+  float* csq = csum + PS * C;                        // [PS][C]
+  for (int q = threadIdx.x; q < PS * CH8; q += 256) {
+    const int ps = q / CH8, qq = q - ps * CH8;
+    const int c = qq * 8;
+    const bool second = c >= p.C1;
+    const T* src = second ? (const T*)p.x2 : (const T*)p.x;
+    const int cs = second ? p.C2 : p.C1, cc = second ? c - p.C1 : c;
+    float s[8], ss[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
-      for (int px = p0 + ps; px < p1; px += pstride) {
-        const auto v = as_vec8<T>(*(const u32x4*)(src + ((size_t)n * p.HW + px) * cs + cc));
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+    for (int px = p0 + ps; px < p1; px += PS) {
+      const auto v = as_vec8<T>(*(const u32x4*)(src + ((size_t)n * p.HW + px) * cs + cc));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float f = to_f32(v[e]); s[e] += f; ss[e] += f * f; }
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int gi = (c + e) / cpg;
-        atomicAdd(&gs[gi * 2], s[e]);
-        atomicAdd(&gs[gi * 2 + 1], ss[e]);
-      }
+      for (int e = 0; e < 8; ++e) { const float f = to_f32(v[e]); s[e] += f; ss[e] += f * f; }
     }
-  } else {
-    // wide tensors (C > 2048): each thread strides over chunks
-    for (int q = threadIdx.x; q < CH8; q += 256) {
-      const int c = q * 8;
-      const bool second = c >= p.C1;
-      const T* src = second ? (const T*)p.x2 : (const T*)p.x;
-      const int cs = second ? p.C2 : p.C1, cc = second ? c - p.C1 : c;
-      float s[8], ss[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
-      for (int px = p0; px < p1; ++px) {
-        const auto v = as_vec8<T>(*(const u32x4*)(src + ((size_t)n * p.HW + px) * cs + cc));
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float f = to_f32(v[e]); s[e] += f; ss[e] += f * f; }
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int gi = (c + e) / cpg;
-        atomicAdd(&gs[gi * 2], s[e]);
-        atomicAdd(&gs[gi * 2 + 1], ss[e]);
-      }
-    }
+    for (int e = 0; e < 8; ++e) { csum[ps * C + c + e] = s[e]; csq[ps * C + c + e] = ss[e]; }
   }
   __syncthreads();
   const int nchunk = gridDim.x;
-  for (int i = threadIdx.x; i < p.groups * 2; i += 256)
-    p.partials[((size_t)n * nchunk + chunk) * p.groups * 2 + i] = gs[i];
+  for (int gi = threadIdx.x; gi < p.groups; gi += 256) {
+    float s = 0.f, ss = 0.f;
+    for (int ps = 0; ps < PS; ++ps)
+      for (int c = gi * cpg; c < (gi + 1) * cpg; ++c) { s += csum[ps * C + c]; ss += csq[ps * C + c]; }
+    float* o = p.partials + ((size_t)n * nchunk + chunk) * p.groups * 2 + gi * 2;
+    o[0] = s; o[1] = ss;
+  }
 }
 
 template <typename T>
@@ -184,7 +163,10 @@ int launch_gn(const es_gn_desc& d, hipStream_t st) {
   int ppb = d.HW / GN_MAX_CHUNK;
   if (ppb < 16) ppb = 16;
   const int nchunk = (d.HW + ppb - 1) / ppb;
-  hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(nchunk, d.N), dim3(256), 0, st, d);
+  const int CH8 = C / 8;
+  const int PS = CH8 <= 256 ? 256 / CH8 : 1;
+  const size_t lds_stats = (size_t)2 * PS * C * sizeof(float);
+  hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(nchunk, d.N), dim3(256), lds_stats, st, d);
   const long long total = (long long)d.HW * (C / 8);
   int blocks = (int)((total + 256 * 4 - 1) / (256 * 4));
   if (blocks < 1) blocks = 1;
