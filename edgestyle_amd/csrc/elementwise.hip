@@ -215,3 +215,13 @@ extern "C" int es_gather_row(const float* table, const int32_t* idx, float* out,
                      row_len);
   ES_RET("es_gather_row");
 }
+
+extern "C" size_t es_sizeof_desc(int which) {
+  switch (which) {
+    case 0: return sizeof(es_gemm_desc);
+    case 1: return sizeof(es_attn_desc);
+    case 2: return sizeof(es_gn_desc);
+    case 3: return sizeof(es_fusion_desc);
+    default: return 0;
+  }
+}

@@ -63,6 +63,7 @@ _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
 SYMBOLS = {
     "es_abi_version": (C.c_int, []),
     "es_last_error": (C.c_char_p, []),
+    "es_sizeof_desc": (C.c_size_t, [_I]),
     "es_conv_gemm": (C.c_int, [C.POINTER(GemmDesc), _P]),
     "es_conv_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
     "es_attention": (C.c_int, [C.POINTER(AttnDesc), _P]),
@@ -104,6 +105,10 @@ def load():
         fn.argtypes = args
     if lib.es_abi_version() != 1:
         raise EdgeStyleHipError("libedgestyle_hip.so ABI version mismatch")
+    for i, st in enumerate((GemmDesc, AttnDesc, GnDesc, FusionDesc)):
+        if lib.es_sizeof_desc(i) != C.sizeof(st):
+            raise EdgeStyleHipError(f"descriptor layout mismatch for {st.__name__}: C {lib.es_sizeof_desc(i)} "
+                                    f"vs ctypes {C.sizeof(st)}")
     _lib = lib
     return lib
 

@@ -25,6 +25,8 @@ enum { ES_ACT_NONE = 0, ES_ACT_SILU = 1, ES_ACT_GEGLU = 2 };
 
 #define ES_ABI_VERSION 1
 int es_abi_version(void);
+/* sizeof the descriptor structs as compiled (0 gemm, 1 attn, 2 gn, 3 fusion): lets a binding verify its mirror */
+size_t es_sizeof_desc(int which);
 const char* es_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -103,3 +103,17 @@ def test_full_step_matches_oracle(setup):
     from tests.helpers import tiny_step_check
     err = tiny_step_check(DEV)
     assert err < 2e-2, err
+
+
+def test_hip_step_and_pipeline_vs_committed_golden(setup):
+    """HIP path vs tests/golden/*.safetensors (written by tests/golden/make_golden.py from the oracle)."""
+    import os
+    from safetensors.torch import load_file
+    from edgestyle_amd.models import StepRunner
+    ucfg, vcfg, ws = setup
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    g = load_file(os.path.join(gold, "tiny_step.safetensors"))
+    runner = StepRunner.from_state_dicts(ws, ucfg, torch.float16, DEV)
+    out = runner.step_nchw(g["x"].to(DEV), 501, g["ehs"].to(DEV), [g[f"cond{i}"].to(DEV) for i in range(6)],
+                           [1.0, 0.8, 1.0, 1.0, 0.5, 1.0])
+    assert float((out.float().cpu() - g["noise_pred"]).abs().max()) < 2e-2

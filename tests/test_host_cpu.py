@@ -1,0 +1,171 @@
+"""CPU suite: host logic of the product package (no GPU, no compute calls): C-ABI surface, weight packing,
+on-disk layout round trips, reference error behaviour, scheduler tables, sharding."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from edgestyle_amd import config as C, weights as W, ops, lib
+from edgestyle_amd.models import (UNet2DConditionModel, ControlNetModel, ControlLoRAModel, FusedControlLoRAModel,
+                                  AutoencoderKL, EdgeStyleMultiControlNetModel, unet_config_from_json)
+from edgestyle_amd.schedulers import DDIMScheduler
+from edgestyle_amd.dist import shard_range, shard_seed
+from tests.helpers import make_weights
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_library_loads_and_exports_every_declared_symbol():
+    assert os.path.exists(lib.LIB_PATH), "build with __graft_entry__.build()"
+    header = open(os.path.join(ROOT, "include", "edgestyle_hip.h")).read()
+    declared = set(re.findall(r"\b(es_[a-z0-9_]+)\s*\(", header))
+    declared = {d for d in declared if not d.endswith("_desc") or d == "es_sizeof_desc"}
+    assert declared == set(lib.SYMBOLS), declared ^ set(lib.SYMBOLS)
+    h = ctypes.CDLL(lib.LIB_PATH)
+    for name in declared:
+        assert getattr(h, name) is not None
+    L = lib.load()
+    assert L.es_abi_version() == 1
+    # struct layouts agree with the C side (sizes are what the kernels index with)
+    for i, st in enumerate((lib.GemmDesc, lib.AttnDesc, lib.GnDesc, lib.FusionDesc)):
+        assert L.es_sizeof_desc(i) == ctypes.sizeof(st)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libedgestyle_hip.so")
+    with pytest.raises(lib.EdgeStyleHipError):
+        lib.load()
+
+
+def test_cpu_device_is_refused_not_emulated():
+    ucfg = C.tiny_unet()
+    unet = UNet2DConditionModel(W.random_state_dict(W.unet_shapes(ucfg)), ucfg)
+    with pytest.raises(lib.EdgeStyleHipError):
+        unet(torch.zeros(1, 4, 16, 16), 1, torch.zeros(1, 77, ucfg.cross_attention_dim))
+
+
+def test_pack_weight_layout():
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(24, 16, 3, 3, generator=g)
+    b = torch.randn(24, generator=g)
+    pw = ops.pack_weight(w, b, torch.float32, "cpu")
+    assert pw.w.shape == (128, 192) and pw.bn == 128 and pw.cout == 24 and pw.cin == 16 and pw.ksize == 3
+    # K index = (ky*3+kx)*Cin + c
+    assert float(pw.w[5, (1 * 3 + 2) * 16 + 7]) == float(w[5, 7, 1, 2])
+    assert float(pw.w[24:].abs().max()) == 0 and float(pw.w[:, 144:].abs().max()) == 0 and torch.equal(pw.bias[:24], b)
+    assert ops.choose_bn(320) == 160 and ops.choose_bn(640) == 128 and ops.choose_bn(960) == 160 and ops.choose_bn(4) == 128
+    # Cin 4 -> 8 zero padding (conv_in), Cout 4 -> 8 zero rows (post_quant)
+    p2 = ops.pack_weight(torch.ones(4, 4, 1, 1), torch.ones(4), torch.float32, "cpu", cin_pad=8, cout_pad=8)
+    assert p2.cin == 8 and p2.cout == 8 and float(p2.w[:4, :4].sum()) == 16 and float(p2.w.sum()) == 16
+    # GEGLU: packed rows in blocks of 32 = [16 hidden | 16 gate]
+    inner = 64
+    wg = torch.arange(2 * inner, dtype=torch.float32)[:, None].repeat(1, 8)
+    pg = ops.pack_weight(wg, torch.arange(2 * inner, dtype=torch.float32), torch.float32, "cpu", geglu=True)
+    rows = pg.w[: 2 * inner, 0].tolist()
+    assert rows[:16] == list(range(0, 16)) and rows[16:32] == list(range(inner, inner + 16))
+    assert rows[32:48] == list(range(16, 32)) and rows[48:64] == list(range(inner + 16, inner + 32))
+    assert pg.bias[:32].tolist() == rows[:32]
+
+
+def test_splitk_heuristic_bounds():
+    for M, rows, bn, kpad in [(128, 1280, 128, 11520), (8192, 320, 160, 2880), (65536, 1280, 128, 11520), (2, 1280, 128, 320)]:
+        s = ops.choose_splitk(M, rows, bn, kpad)
+        assert 1 <= s <= kpad // 64
+
+
+def test_controllora_state_dict_is_lora_plus_zero_convs_only():
+    ucfg = C.tiny_unet()
+    ws = make_weights(ucfg, C.tiny_vae())
+    unet = UNet2DConditionModel(ws["unet"], ucfg)
+    net = ControlLoRAModel(ws["lora0"], ucfg, lora_linear_rank=4, uses_vae=True)
+    with pytest.raises(lib.EdgeStyleHipError):
+        net.full_state_dict()                                   # tie_weights first (TT:259-261)
+    net.tie_weights(unet)
+    full = net.full_state_dict()
+    assert full["down_blocks.1.resnets.0.conv1.weight"] is ws["unet"]["down_blocks.1.resnets.0.conv1.weight"]
+    saved = net.state_dict()
+    assert set(saved) == set(W.controllora_saved_shapes(ucfg, 4))          # CL:600-606
+    assert all(k.split(".")[0] not in W.SKIP_LAYERS or ".lora_layer." in k for k in saved)
+    fused = net.fuse()
+    assert isinstance(fused, FusedControlLoRAModel) and not any(".lora_layer." in k for k in fused.state_dict())
+    k = "mid_block.attentions.0.transformer_blocks.0.ff.net.2"
+    want = ws["unet"][k + ".weight"] + ws["lora0"][k + ".lora_layer.up.weight"] @ ws["lora0"][k + ".lora_layer.down.weight"]
+    assert torch.allclose(fused.state_dict()[k + ".weight"], want, atol=1e-6)
+    assert torch.equal(ws["unet"][k + ".weight"], unet.state_dict()[k + ".weight"])   # tied UNet tensor untouched
+
+
+def test_multicontrolnet_directory_layout_round_trip(tmp_path):
+    """save_pretrained / from_pretrained (MC:213-282, MC:289-430) incl. load_pattern de-duplication and errors"""
+    ucfg, vcfg = C.tiny_unet(), C.tiny_vae()
+    ws = make_weights(ucfg, vcfg)
+    unet = UNet2DConditionModel(ws["unet"], ucfg)
+    vae = AutoencoderKL(ws["vae"], vcfg)
+    pose = ControlNetModel(ws["openpose"], ucfg)
+    l0 = ControlLoRAModel(ws["lora0"], ucfg, lora_linear_rank=4, uses_vae=True)
+    l1 = ControlLoRAModel(ws["lora1"], ucfg, lora_linear_rank=4, uses_vae=True)
+    mc = EdgeStyleMultiControlNetModel([l0, pose, l1, pose, l1, pose])
+    mc.load_state_dict(ws["fusion"])
+    d = str(tmp_path / "controlnet")
+    mc.save_pretrained(d, save_pattern=C.CONTROLNET_PATTERN)
+    assert sorted(os.listdir(d)) == ["controlnet_0", "controlnet_1", "diffusion_pytorch_model.safetensors"]
+    with pytest.raises(ValueError):
+        EdgeStyleMultiControlNetModel.from_pretrained(d, controlnet_class=ControlLoRAModel)              # no load_pattern
+    with pytest.raises(ValueError):
+        EdgeStyleMultiControlNetModel.from_pretrained(d, controlnet_class=ControlLoRAModel,
+                                                      load_pattern=C.CONTROLNET_PATTERN,
+                                                      static_controlnets=[None, pose, None, pose, None, pose])  # no vae
+    with pytest.raises(ValueError):
+        EdgeStyleMultiControlNetModel.from_pretrained(d, controlnet_class=ControlLoRAModel, vae=vae,
+                                                      load_pattern=C.CONTROLNET_PATTERN)                 # nets missing
+    with pytest.raises(ValueError):
+        EdgeStyleMultiControlNetModel.from_pretrained(str(tmp_path / "nope"), load_pattern=[0])
+    m2 = EdgeStyleMultiControlNetModel.from_pretrained(d, vae=vae, controlnet_class=ControlLoRAModel,
+                                                       load_pattern=C.CONTROLNET_PATTERN,
+                                                       static_controlnets=[None, pose, None, pose, None, pose])
+    assert m2.nets[2] is m2.nets[4] and m2.nets[1] is pose and m2.nets[0] is not m2.nets[2]    # MC:379-398
+    assert [len(p) for _, p in m2.groups()] == [1, 3, 2]
+    for k, v in ws["fusion"].items():
+        assert torch.equal(m2.state_dict()[k], v)
+    for k, v in ws["lora1"].items():
+        assert torch.equal(m2.nets[2].state_dict()[k], v)
+    assert m2.nets[0].config.uses_vae and m2.nets[0].config.lora_linear_rank == 4
+    bad = dict(ws["fusion"])
+    bad.pop("multi_controlnet_mid_block.third_conv.bias")
+    with pytest.raises(RuntimeError):
+        m2.load_state_dict(bad)
+    # unet / vae round trip + config mapping from a diffusers-style config.json
+    unet.save_pretrained(str(tmp_path / "sd" / "unet"))
+    u2 = UNet2DConditionModel.from_pretrained(str(tmp_path / "sd"), subfolder="unet", torch_dtype=torch.float16)
+    assert u2.cfg == ucfg and torch.equal(u2.state_dict()["conv_in.weight"], ws["unet"]["conv_in.weight"])
+    cfg = unet_config_from_json({"block_out_channels": [320, 640, 1280, 1280], "attention_head_dim": 8,
+                                 "cross_attention_dim": 768, "down_block_types": ["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"]})
+    assert cfg == C.sd15_unet()
+
+
+def test_ddim_scheduler_tables_match_oracle():
+    from oracle import sd15_oracle as O
+    s, o = DDIMScheduler(), O.DDIM()
+    assert s.set_timesteps(50).tolist() == o.set_timesteps(50).tolist()
+    tab = s.coef_table()
+    assert tab.shape == (50, 4)
+    x, e = torch.randn(1, 4, 8, 8), torch.randn(1, 4, 8, 8)
+    for i in (0, 17, 49):
+        c = tab[i]
+        mine = c[2] * (x - c[1] * e) / c[0] + c[3] * e
+        assert torch.allclose(mine, o.step(e, int(s.timesteps[i]), x), atol=1e-5)
+    with pytest.raises(ValueError):
+        s.set_timesteps(2000)
+
+
+def test_shard_ranges_cover_and_seeds_are_world_size_independent():
+    for n, w in [(64, 8), (64, 1), (10, 4), (3, 8), (0, 2)]:
+        spans = [shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+    assert [shard_seed(42, r, 8) for r in range(8)] == [42 + 8 * r for r in range(8)]
+    with pytest.raises(ValueError):
+        shard_range(4, 4, 4)
