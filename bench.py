@@ -91,38 +91,35 @@ def make_inputs(ucfg, vcfg, B, device, seed=42):
     return lat, pe.to(device), ne.to(device), imgs, cond_noise
 
 
-def gemm_roofline(pipe, call):
-    """Run the workload once eagerly with HIP events around every es_conv_gemm launch (on the launch stream) and
-    price the kernel against the dense fp16 MFMA peak with ALGORITHMIC flops (2*M*Cout*Ktrue, unpadded)."""
-    from edgestyle_amd import ops
-    recs = []
-    ops.PROFILE = recs
-    pipe.use_graph = False
-    try:
-        call()
-        torch.cuda.synchronize()
-    finally:
-        ops.PROFILE = None
-        pipe.use_graph = True
-    tot_f = tot_t = 0.0
-    f3 = t3 = 0.0
-    for flops, k, e0, e1 in recs:
-        ms = e0.elapsed_time(e1)
-        tot_f += flops
-        tot_t += ms
-        if k == 3:
-            f3 += flops
-            t3 += ms
-    n = len(recs)
-    ach = tot_f / (tot_t * 1e-3) / 1e12
-    out = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv3x3/1x1/linear)", "achieved": round(ach, 2),
-           "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-           "launches": n, "avg_launch_us": round(tot_t * 1e3 / max(n, 1), 2),
-           "algorithmic_gflop_per_launch": round(tot_f / max(n, 1) / 1e9, 3),
-           "conv3x3_only": {"achieved": round(f3 / (t3 * 1e-3) / 1e12, 2) if t3 else None,
-                            "frac": round(f3 / (t3 * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4) if t3 else None},
-           "how": "HIP events around every launch of one eager pass of the same workload, after the timed region"}
-    return out
+def gemm_roofline(pipe):
+    """Price the implicit-GEMM kernel against the dense fp16 MFMA peak with ALGORITHMIC flops (2*M*Cout*k*k*Cin) over
+    the es_conv_gemm launches of one captured denoising step (the unit replayed 50x per image = 96 % of the image's
+    FLOPs).  Launch durations are in-kernel s_memrealtime stamps (min workgroup start .. max workgroup end) taken
+    while the step replays as a hipGraph: host-side HIP events cannot see inside a graph replay, and around eager
+    launches they mostly measure host enqueue gaps.  The rocprofv3 summary under profiles/ gives the same averages."""
+    res = pipe.profile_one_step()
+    tot_f = sum(m[0] for m, _ in res)
+    tot_t = sum(t for _, t in res)
+    f3 = sum(m[0] for m, _ in res if m[1] == 3)
+    t3 = sum(t for m, t in res if m[1] == 3)
+    shapes = {}
+    for (fl, k, shp), t in res:
+        a = shapes.setdefault(shp, [0, 0.0, 0.0])
+        a[0] += 1; a[1] += t; a[2] += fl
+    if os.environ.get("ES_DUMP_GEMM"):
+        log("GEMM shapes of one step by total time: (M, Cout, K, stride, splitk, bn) calls total_us avg_us TFLOP/s")
+        for shp, (c, t, fl) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:45]:
+            log(f"  {shp} {c} {t * 1e6:.0f} {t / c * 1e6:.1f} {fl / t / 1e12:.0f}")
+    n = len(res)
+    ach = tot_f / tot_t / 1e12
+    return {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv3x3/1x1/linear)", "achieved": round(ach, 2),
+            "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "launches_per_step": n, "avg_launch_us": round(tot_t * 1e6 / max(n, 1), 2),
+            "algorithmic_gflop_per_launch": round(tot_f / max(n, 1) / 1e9, 3),
+            "gemm_time_per_step_ms": round(tot_t * 1e3, 3),
+            "conv3x3_only": {"achieved": round(f3 / t3 / 1e12, 2) if t3 else None,
+                             "frac": round(f3 / t3 / 1e12 / MFMA_PEAK_TFLOPS, 4) if t3 else None},
+            "how": "in-kernel s_memrealtime stamps on every es_conv_gemm launch of one hipGraph-replayed denoising step"}
 
 
 def cpu_baseline(ws, ucfg, B, steps_total, tiny):
@@ -224,7 +221,7 @@ def main():
                        "images_per_gpu": B, "ddim_steps": args.ddim_steps, "parallelism": f"dp{world} (independent images, one RCCL gather)"},
         }
         if not args.no_roofline:
-            line["roofline"] = gemm_roofline(pipe, one)
+            line["roofline"] = gemm_roofline(pipe)
             log("roofline leg done")
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(ws, ucfg, B, args.ddim_steps, args.tiny)

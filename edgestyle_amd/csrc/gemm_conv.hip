@@ -1,16 +1,22 @@
 // Implicit-GEMM convolution / linear for gfx950 on MFMA 16x16x32 (f16|bf16 in, fp32 accumulate).
 //
-//   D[cout][pixel] = sum_k W[cout][k] * X[pixel][k]      (swapped orientation: A operand = weights,
-//                                                         B operand = im2col'd activations)
-// so every lane ends up with 4 CONSECUTIVE output channels of one pixel -> 8-byte NHWC stores, and the
-// per-channel epilogue terms (bias, time-embedding add) are 4-wide vector loads.
+//   D[cout][pixel] = sum_k W[cout][k] * X[pixel][k]      (A operand = weights, B operand = im2col'd activations)
 //
 // Tile: BM=128 pixels x BN (128|160) couts x BK=64, 256 threads = 4 waves as 2(M) x 2(N); each wave owns
-// 64 pixels x BN/2 couts = 4 x (4|5) MFMA fragments.  Operands are staged global -> registers -> LDS
-// (16-byte chunks, XOR-swizzled rows of 128 B so ds_read_b128 fragment reads are bank-conflict free),
-// double-buffered in LDS with the next tile's global loads in flight behind the current tile's MFMAs;
-// one barrier per K-step.  The activation loader does the im2col on the fly: 3x3/1x1, stride 1|2,
-// nearest-2x upsample, and channel-concat of two sources (UNet skip connections) are address math only.
+// 64 pixels x BN/2 couts = 4 x (4|5) MFMA fragments.
+//
+// Staging is LDS-DMA (`global_load_lds_dwordx4`): every wave-instruction copies 8 tile rows x 128 B straight from
+// global memory into LDS — no VGPR round trip and no ds_write traffic (ds_write_b128 tops out at ~79 B/clk/CU, which
+// capped the register-staged version of this kernel).  The DMA destination is lane-linear, so the XOR swizzle that
+// makes the ds_read_b128 fragment reads bank-conflict free is applied to the per-lane SOURCE address (LDS slot p of
+// row r holds global chunk p ^ (r & 7)) and again on the read.  The im2col is address math on that source pointer:
+// 3x3/1x1, stride 1|2, nearest-2x upsample and the channel concat of two tensors (UNet skip connections) select
+// the row pointer; padded taps point at a 16-byte zero page.  Two LDS stages: the DMA of K-step k+1 is in flight
+// behind the MFMAs of K-step k, one barrier per K-step, 2 workgroups per CU.
+//
+// Epilogue: bias / per-sample time-embedding add / SiLU / GEGLU / conditioning scale are applied in registers
+// (fp32), the tile is transposed through LDS, and the residual add + store run as full-line 16-byte accesses along
+// the NHWC channel dim (a lane-owns-4-channels direct store serialised on partial-line write round trips).
 #include "common.h"
 #include "../../include/edgestyle_hip.h"
 
@@ -19,88 +25,44 @@ namespace {
 constexpr int BM = 128;
 constexpr int BK = 64;
 
-struct EpiArgs {
-  const float* bias;
-  const void* temb;
-  const void* residual;
-  const float* out_scale_dev;
-  void* out;
-  int M, Cout, Cstore, HWout, temb_stride, act;
-  float out_scale;
-};
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
 
-template <typename T>
-ES_DEVICE void epilogue_quad(const EpiArgs& e, int m, int c0, float v[4], float scale) {
-  // plain / SiLU epilogue for 4 consecutive channels c0..c0+3 of pixel m
-  if (m >= e.M || c0 >= e.Cout) return;
-  const int n = m / e.HWout;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int c = c0 + r;
-    if (c < e.Cout) {
-      float x = v[r];
-      if (e.bias) x += e.bias[c];
-      if (e.temb) x += to_f32(((const T*)e.temb)[(size_t)n * e.temb_stride + c]);
-      if (e.act == ES_ACT_SILU) x = silu_f(x);
-      x *= scale;
-      if (e.residual) x += to_f32(((const T*)e.residual)[(size_t)m * e.Cstore + c]);
-      v[r] = x;
-    }
-  }
-  T* o = (T*)e.out + (size_t)m * e.Cstore + c0;
-  if (c0 + 3 < e.Cout && (e.Cstore & 3) == 0) {
-    typename Traits<T>::vec4 pk;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) pk[r] = from_f32<T>(v[r]);
-    *(typename Traits<T>::vec4*)o = pk;
-  } else {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (c0 + r < e.Cout) o[r] = from_f32<T>(v[r]);
-  }
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+ES_DEVICE void glds16(const void* src, char* lds_wave_base) {
+  // 64 lanes x 16 B: LDS[lds_wave_base + lane*16 ...] <- *src (per-lane source, wave-uniform destination base)
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
 template <typename T>
-ES_DEVICE void epilogue_geglu_quad(const EpiArgs& e, int m, int c_hidden, float h[4], float g[4], float scale) {
-  // packed weight rows: [.. 16 hidden | 16 gate ..]; c_hidden = packed row of the hidden quad, gate = +16
-  if (m >= e.M || c_hidden >= e.Cout) return;
-  const int blk = c_hidden >> 5, within = c_hidden & 31;      // within < 16
-  const int oc = blk * 16 + within;                          // output column in [0, Cout/2)
-  typename Traits<T>::vec4 pk;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float hv = h[r], gv = g[r];
-    if (e.bias) { hv += e.bias[c_hidden + r]; gv += e.bias[c_hidden + 16 + r]; }
-    float x = hv * gelu_f(gv) * scale;
-    if (e.residual) x += to_f32(((const T*)e.residual)[(size_t)m * e.Cstore + oc + r]);
-    pk[r] = from_f32<T>(x);
-  }
-  *(typename Traits<T>::vec4*)((T*)e.out + (size_t)m * e.Cstore + oc) = pk;
+ES_DEVICE void store_elems(T* o, const float* v, int n) {
+  for (int r = 0; r < n; ++r) o[r] = from_f32<T>(v[r]);
 }
 
 template <typename T, int BN, bool ALIGNED>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const es_gemm_desc p, const int M, const int nk) {
-  constexpr int FM = 4;            // pixel fragments per wave (64 pixels)
-  constexpr int FN = BN / 32;      // cout fragments per wave (BN/2 couts)
-  constexpr int WROWS = BN / 32;   // weight rows per loader thread
-  constexpr int XT = BM * BK * 2;  // bytes
+  constexpr int FM = 4;              // pixel fragments per wave (64 pixels)
+  constexpr int FN = BN / 32;        // cout fragments per wave (BN/2 couts)
+  constexpr int WI = BN / 32;        // weight DMA instructions per wave per K-step (8 rows each)
+  constexpr int XT = BM * BK * 2;    // bytes per stage
   constexpr int WT = BN * BK * 2;
+  constexpr int EROW = BN * 2 + 16;  // epilogue tile row stride (bytes), padded against bank conflicts
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 1, wn = wave >> 1;
   const int tile_m = blockIdx.x, tile_n = blockIdx.y, z = blockIdx.z;
+  if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 
-  // split-K range
   const int ks0 = (int)(((long long)nk * z) / p.splitk);
   const int ks1 = (int)(((long long)nk * (z + 1)) / p.splitk);
 
   // ---------------- loader state ----------------
-  const int kc = tid & 7;
-  const int r0 = tid >> 3;
-  const int swz = (kc ^ (r0 & 7)) << 4;
+  const int lrow = lane >> 3;                      // row inside an 8-row DMA group
+  const int kc = (lane & 7) ^ (lrow & 7);          // global chunk that lands in LDS slot (lane & 7) of that row
   const int Ctot = p.C1 + p.C2;
   const int Ktrue = p.ksize * p.ksize * Ctot;
   const int Hin = p.Hsrc << p.upsample, Win = p.Wsrc << p.upsample;
@@ -109,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const es_gemm_desc p,
   int iy0[4], ix0[4], nb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = tile_m * BM + r0 + 32 * i;
+    const int m = tile_m * BM + 32 * wave + 8 * i + lrow;
     if (m < M) {
       const int n = m / HWout;
       const int rem = m - n * HWout;
@@ -121,9 +83,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const es_gemm_desc p,
       iy0[i] = -(1 << 20); ix0[i] = -(1 << 20); nb[i] = 0;
     }
   }
-  const T* wbase = (const T*)p.w + (size_t)(tile_n * BN + r0) * p.Kpad + kc * 8;
+  const T* wbase = (const T*)p.w + (size_t)(tile_n * BN + (BN / 4) * wave + lrow) * p.Kpad + kc * 8;
 
-  // running (tap, channel) position of this thread's chunk
   int tap, cpos;
   {
     const int kg = ks0 * BK + (ALIGNED ? 0 : kc * 8);
@@ -131,11 +92,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const es_gemm_desc p,
     cpos = kg - tap * Ctot;
   }
 
-  u32x4 xr[4], wr[WROWS];
-  auto load_tile = [&](int ks) {
-    // weights
+  auto issue_tile = [&](int ks, int stage) {
+    char* xs = smem + stage * (XT + WT);
+    char* ws = xs + XT;
+    // weights: WI instructions of 8 rows
 #pragma unroll
-    for (int i = 0; i < WROWS; ++i) wr[i] = *(const u32x4*)(wbase + (size_t)(32 * i) * p.Kpad + (size_t)ks * BK);
+    for (int i = 0; i < WI; ++i)
+      glds16(wbase + (size_t)(8 * i) * p.Kpad + (size_t)ks * BK, ws + ((BN / 4) * wave + 8 * i) * 128);
     // activations (im2col on the fly)
     const int c = ALIGNED ? cpos + kc * 8 : cpos;
     const bool kvalid = ALIGNED ? true : (ks * BK + kc * 8 < Ktrue);
@@ -149,14 +112,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const es_gemm_desc p,
     for (int i = 0; i < 4; ++i) {
       const int iy = iy0[i] + ky, ix = ix0[i] + kx;
       const bool ok = kvalid && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (ok) {
-        const int pix = nb[i] + (iy >> p.upsample) * p.Wsrc + (ix >> p.upsample);
-        v = *(const u32x4*)(src + (size_t)pix * cs + cc);
-      }
-      xr[i] = v;
+      const int pix = nb[i] + (iy >> p.upsample) * p.Wsrc + (ix >> p.upsample);
+      const void* sp = ok ? (const void*)(src + (size_t)pix * cs + cc) : (const void*)g_zero16;
+      glds16(sp, xs + (32 * wave + 8 * i) * 128);
     }
-    // advance to the next K-step
     cpos += BK;
     while (cpos >= Ctot) { cpos -= Ctot; ++tap; }
   };
@@ -167,18 +126,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const es_gemm_desc p,
 #pragma unroll
     for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (ks0 < ks1) load_tile(ks0);
+  if (ks0 < ks1) issue_tile(ks0, 0);
 
   const int frow = lane & 15, fq = lane >> 4;
   for (int ks = ks0; ks < ks1; ++ks) {
-    char* xs = smem + ((ks - ks0) & 1) * (XT + WT);
-    char* ws = xs + XT;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *(u32x4*)(xs + (r0 + 32 * i) * 128 + swz) = xr[i];
-#pragma unroll
-    for (int i = 0; i < WROWS; ++i) *(u32x4*)(ws + (r0 + 32 * i) * 128 + swz) = wr[i];
-    __syncthreads();
-    if (ks + 1 < ks1) load_tile(ks + 1);
+    const int stage = (ks - ks0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of tile ks has landed
+    __syncthreads();                                   // ... everyone's has; everyone finished tile ks-1
+    if (ks + 1 < ks1) issue_tile(ks + 1, stage ^ 1);
+    const char* xs = smem + stage * (XT + WT);
+    const char* ws = xs + XT;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       typename Traits<T>::vec8 xa[FM], wa[FN];
@@ -199,74 +156,154 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const es_gemm_desc p,
     }
   }
 
-  // ---------------- epilogue ----------------
-  const int mbase = tile_m * BM + wm * 64 + frow;
-  const int cbase = tile_n * BN + wn * (BN / 2) + fq * 4;
+  // ---------------- split-K: raw fp32 partials (16 B per lane) ----------------
+  const int prow = wm * 64 + frow;                        // + j*16 : pixel row inside the tile
+  const int pcol = wn * (BN / 2) + fq * 4;                // + i*16 : cout column inside the tile
   if (p.splitk > 1) {
     float* wsp = p.workspace + (size_t)z * M * p.rows_padded;
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
-      const int m = mbase + j * 16;
+      const int m = tile_m * BM + prow + j * 16;
       if (m < M) {
 #pragma unroll
-        for (int i = 0; i < FN; ++i) *(f32x4*)(wsp + (size_t)m * p.rows_padded + cbase + i * 16) = acc[i][j];
+        for (int i = 0; i < FN; ++i)
+          *(f32x4*)(wsp + (size_t)m * p.rows_padded + tile_n * BN + pcol + i * 16) = acc[i][j];
       }
     }
+    if (p.prof && tid == 0) atomicMax(p.prof + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     return;
   }
-  EpiArgs e;
-  e.bias = p.bias; e.temb = p.temb; e.residual = p.residual; e.out_scale_dev = p.out_scale_dev; e.out = p.out;
-  e.M = M; e.Cout = p.Cout; e.Cstore = (p.act == ES_ACT_GEGLU) ? p.Cout / 2 : p.Cout; e.HWout = HWout;
-  e.temb_stride = p.temb_stride; e.act = p.act; e.out_scale = p.out_scale;
+
+  // ---------------- epilogue phase A: registers -> LDS tile [pixel][cout] in T ----------------
+  const bool geglu = p.act == ES_ACT_GEGLU;
+  const int Cstore = geglu ? p.Cout / 2 : p.Cout;
   float scale = p.out_scale;
   if (p.out_scale_dev) scale *= *p.out_scale_dev;
-  if (p.act == ES_ACT_GEGLU) {
-    if constexpr (FN % 2 == 0) {
+  f32x4 bias[FN];
 #pragma unroll
-      for (int j = 0; j < FM; ++j)
+  for (int i = 0; i < FN; ++i)
+    bias[i] = p.bias ? *(const f32x4*)(p.bias + tile_n * BN + pcol + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();                                        // all waves are done reading the stage buffers
+  char* et = smem;
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    const int m = tile_m * BM + prow + j * 16;
+    const int n = (m < M ? m : M - 1) / HWout;
+    if (geglu) {
+      if constexpr (FN % 2 == 0) {
 #pragma unroll
         for (int i = 0; i < FN; i += 2) {
-          float h[4], g[4];
+          typename Traits<T>::vec4 pk;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { h[r] = acc[i][j][r]; g[r] = acc[i + 1][j][r]; }
-          epilogue_geglu_quad<T>(e, mbase + j * 16, cbase + i * 16, h, g, scale);
+          for (int r = 0; r < 4; ++r) {
+            const float hv = acc[i][j][r] + bias[i][r], gv = acc[i + 1][j][r] + bias[i + 1][r];
+            pk[r] = from_f32<T>(hv * gelu_f(gv) * scale);
+          }
+          *(typename Traits<T>::vec4*)(et + (prow + j * 16) * EROW + ((wn * (BN / 2) + i * 16) / 2 + fq * 4) * 2) = pk;
         }
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < FM; ++j)
+      }
+    } else {
 #pragma unroll
       for (int i = 0; i < FN; ++i) {
-        float v[4];
+        const int c = tile_n * BN + pcol + i * 16;
+        float tv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.temb && c < p.Cout) {
+          const T* tp = (const T*)p.temb + (size_t)n * p.temb_stride + c;
+          if (c + 3 < p.Cout) {
+            const auto t4 = *(const typename Traits<T>::vec4*)tp;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-        epilogue_quad<T>(e, mbase + j * 16, cbase + i * 16, v, scale);
+            for (int r = 0; r < 4; ++r) tv[r] = to_f32(t4[r]);
+          } else {
+            for (int r = 0; r < 4 && c + r < p.Cout; ++r) tv[r] = to_f32(tp[r]);
+          }
+        }
+        typename Traits<T>::vec4 pk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = acc[i][j][r] + bias[i][r] + tv[r];
+          if (p.act == ES_ACT_SILU) x = silu_f(x);
+          pk[r] = from_f32<T>(x * scale);
+        }
+        *(typename Traits<T>::vec4*)(et + (prow + j * 16) * EROW + (pcol + i * 16) * 2) = pk;
       }
+    }
   }
+  __syncthreads();
+
+  // ---------------- epilogue phase B: coalesced residual add + store along the channel dim ----------------
+  const int BNo = geglu ? BN / 2 : BN;                    // tile width in stored channels
+  const int c_tile = tile_n * BNo;
+  T* outp = (T*)p.out;
+  const T* resp = (const T*)p.residual;
+  if ((Cstore & 7) == 0) {
+    const int CH = BNo / 8;
+    for (int idx = tid; idx < BM * CH; idx += 256) {
+      const int row = idx / CH, ch = idx - row * CH;
+      const int m = tile_m * BM + row, c = c_tile + ch * 8;
+      if (m < M && c < Cstore) {
+        auto v = as_vec8<T>(*(const u32x4*)(et + row * EROW + ch * 16));
+        if (resp) {
+          const auto rv = as_vec8<T>(*(const u32x4*)(resp + (size_t)m * Cstore + c));
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(rv[e]));
+        }
+        *(typename Traits<T>::vec8*)(outp + (size_t)m * Cstore + c) = v;
+      }
+    }
+  } else {
+    // narrow outputs (conv_out: 4 or 3 channels): scalar tail path
+    for (int idx = tid; idx < BM * BNo; idx += 256) {
+      const int row = idx / BNo, cc = idx - row * BNo;
+      const int m = tile_m * BM + row, c = c_tile + cc;
+      if (m < M && c < Cstore) {
+        float x = to_f32(*(const T*)(et + row * EROW + cc * 2));
+        if (resp) x += to_f32(resp[(size_t)m * Cstore + c]);
+        outp[(size_t)m * Cstore + c] = from_f32<T>(x);
+      }
+    }
+  }
+  if (p.prof && tid == 0) atomicMax(p.prof + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const es_gemm_desc p, const int M) {
-  const int quads = p.rows_padded / 4;
+  // one thread = 8 consecutive channels of one pixel: sum the fp32 partials, then the same epilogue
+  const int oct = p.rows_padded / 8;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long long)M * quads) return;
-  const int m = (int)(idx / quads);
-  const int c0 = (int)(idx - (long long)m * quads) * 4;
+  if (idx >= (long long)M * oct) return;
+  const int m = (int)(idx / oct);
+  const int c0 = (int)(idx - (long long)m * oct) * 8;
   if (c0 >= p.Cout) return;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int z = 0; z < p.splitk; ++z)
-    s += *(const f32x4*)(p.workspace + ((size_t)z * M + m) * p.rows_padded + c0);
-  EpiArgs e;
-  e.bias = p.bias; e.temb = p.temb; e.residual = p.residual; e.out_scale_dev = p.out_scale_dev; e.out = p.out;
-  e.M = M; e.Cout = p.Cout; e.Cstore = p.Cout; e.HWout = p.Hout * p.Wout;
-  e.temb_stride = p.temb_stride; e.act = p.act; e.out_scale = p.out_scale;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < p.splitk; ++z) {
+    const float* w = p.workspace + ((size_t)z * M + m) * p.rows_padded + c0;
+    s0 += *(const f32x4*)w;
+    s1 += *(const f32x4*)(w + 4);
+  }
+  float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
   float scale = p.out_scale;
   if (p.out_scale_dev) scale *= *p.out_scale_dev;
-  float v[4] = {s[0], s[1], s[2], s[3]};
-  epilogue_quad<T>(e, m, c0, v, scale);
+  const int n = m / (p.Hout * p.Wout);
+  const int nv = p.Cout - c0 < 8 ? p.Cout - c0 : 8;
+  for (int r = 0; r < nv; ++r) {
+    float x = v[r];
+    if (p.bias) x += p.bias[c0 + r];
+    if (p.temb) x += to_f32(((const T*)p.temb)[(size_t)n * p.temb_stride + c0 + r]);
+    if (p.act == ES_ACT_SILU) x = silu_f(x);
+    x = to_f32(from_f32<T>(x * scale));                   // same rounding point as the fused epilogue
+    if (p.residual) x += to_f32(((const T*)p.residual)[(size_t)m * p.Cout + c0 + r]);
+    v[r] = x;
+  }
+  T* o = (T*)p.out + (size_t)m * p.Cout + c0;
+  if (nv == 8 && (p.Cout & 7) == 0) {
+    typename Traits<T>::vec8 pk;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) pk[r] = from_f32<T>(v[r]);
+    *(typename Traits<T>::vec8*)o = pk;
+  } else {
+    store_elems<T>(o, v, nv);
+  }
 }
-
-
 
 template <typename T>
 int launch(const es_gemm_desc& d, hipStream_t st) {
@@ -290,7 +327,7 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
   else             { if (aligned) ES_LAUNCH(160, true); else ES_LAUNCH(160, false); }
 #undef ES_LAUNCH
   if (d.splitk > 1) {
-    const long long total = (long long)M * (d.rows_padded / 4);
+    const long long total = (long long)M * (d.rows_padded / 8);
     hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, M);
   }
   return hipGetLastError() == hipSuccess ? 0 : -2;

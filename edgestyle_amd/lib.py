@@ -16,6 +16,7 @@ class GemmDesc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("x2", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("temb", C.c_void_p),
         ("residual", C.c_void_p), ("out_scale_dev", C.c_void_p), ("out", C.c_void_p), ("workspace", C.c_void_p),
+        ("prof", C.c_void_p),
         ("N", C.c_int32), ("Hsrc", C.c_int32), ("Wsrc", C.c_int32), ("C1", C.c_int32), ("C2", C.c_int32),
         ("Hout", C.c_int32), ("Wout", C.c_int32), ("Cout", C.c_int32),
         ("rows_padded", C.c_int32), ("Kpad", C.c_int32),

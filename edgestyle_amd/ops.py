@@ -13,7 +13,33 @@ import torch
 from . import lib as L
 
 _DT = {torch.float16: L.ES_F16, torch.bfloat16: L.ES_BF16}
-PROFILE = None      # set to a list by bench.py to time every es_conv_gemm launch with HIP events
+PROFILE = None      # set to a Profiler by bench.py: every es_conv_gemm launch gets an in-kernel timing slot
+
+
+class Profiler:
+    """Per-launch durations as executed (also inside a hipGraph replay, where host-side events cannot look):
+    each workgroup of an instrumented launch atomically mins its start / maxes its end s_memrealtime stamp
+    (100 MHz constant clock) into a device slot; duration = (max end - min start) * 10 ns."""
+
+    def __init__(self, device, capacity: int = 8192):
+        self.slots = torch.empty((capacity, 2), dtype=torch.int64, device=device)
+        self.meta = []
+        self.reset()
+
+    def reset(self):
+        self.slots[:, 0] = 1 << 62
+        self.slots[:, 1] = 0
+
+    def next(self, meta) -> int:
+        i = len(self.meta)
+        if i >= self.slots.shape[0]:
+            raise L.EdgeStyleHipError("Profiler capacity exceeded")
+        self.meta.append(meta)
+        return self.slots[i].data_ptr()
+
+    def results(self, first: int = 0):
+        s = self.slots[first:len(self.meta)].cpu().tolist()
+        return [(m, (e - b) * 1e-8) for m, (b, e) in zip(self.meta[first:], s) if e > 0]
 BK = 64
 BM = 128
 
@@ -168,14 +194,9 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     if splitk > 1:
         ws = _get_workspace(splitk * M * pw.rows_padded * 4, x.device)
         d.workspace = ws.data_ptr()
-    if PROFILE is not None:           # bench.py roofline leg: HIP events on the launch stream around this launch
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        L.check(L.load().es_conv_gemm(C.byref(d), _stream()), "es_conv_gemm")
-        e1.record()
-        cin_true = (C1 + C2)
-        PROFILE.append((2.0 * M * pw.cout * k * k * cin_true, k, e0, e1))
-        return out
+    if PROFILE is not None:           # bench.py roofline leg: in-kernel s_memrealtime stamps for this launch
+        d.prof = PROFILE.next((2.0 * M * pw.cout * k * k * (C1 + C2), k, (M, pw.cout, k * k * (C1 + C2), stride,
+                                                                             splitk, pw.bn)))
     L.check(L.load().es_conv_gemm(C.byref(d), _stream()), "es_conv_gemm")
     return out
 

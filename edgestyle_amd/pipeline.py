@@ -325,6 +325,29 @@ class StableDiffusionControlNetPipeline:
         return StableDiffusionPipelineOutput(images=img, nsfw_content_detected=None)
 
 
+    def profile_one_step(self):
+        """Re-capture the step graph of the most recent call with in-kernel timing stamps on every es_conv_gemm
+        launch, replay ONE step, and return [(meta, seconds)] (ops.Profiler).  Used by bench.py's roofline leg."""
+        if not self._loops:
+            raise EdgeStyleHipError("run the pipeline once before profiling")
+        loop = list(self._loops.values())[-1]
+        prof = ops.Profiler(self.device)
+        torch.cuda.synchronize()
+        ops.PROFILE = prof
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loop.one_step()
+        finally:
+            ops.PROFILE = None
+        prof.reset()
+        loop.step_idx.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        return prof.results()
+
+
 class EdgeStyleStableDiffusionControlNetPipeline(StableDiffusionControlNetPipeline):
     """model/edgestyle_pipeline.py:57-664 — same call surface; the cached-condition semantics it adds over the stock
     pipeline are what both classes implement here."""

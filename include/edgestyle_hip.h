@@ -49,6 +49,8 @@ typedef struct {
   const float* out_scale_dev; /* optional device scalar multiplied into the result (conditioning_scale) */
   void* out;              /* [N, Hout, Wout, Cout_store] dtype */
   float* workspace;       /* split-K partials [splitk][M][rows_padded] fp32 (NULL if splitk == 1) */
+  unsigned long long* prof; /* optional device u64[2]: every workgroup atomically mins its start / maxes its end
+                               s_memrealtime stamp (100 MHz) -> launch duration as executed inside a hipGraph */
   int32_t N, Hsrc, Wsrc, C1, C2;
   int32_t Hout, Wout, Cout;   /* Cout = true GEMM N (before GEGLU halving) */
   int32_t rows_padded, Kpad;  /* packed weight geometry */
