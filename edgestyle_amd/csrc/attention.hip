@@ -142,39 +142,46 @@ __global__ __launch_bounds__(256) void attention_kernel(const es_attn_desc p) {
       }
     }
     // ---- online softmax (per query = per lane column) ----
+    // VALU budget matters more than MFMA at head_dim 40/80: raw-score max, then ONE fma + v_exp per score
+    // (scale*log2e folded into the fma), key masking only on the ragged last tile, O rescale skipped when no
+    // query of the wave raised its running max.
+    const bool ragged = kv0 + KVT > p.Skv;
     typename Traits<T>::vec8 pb[QF][KF / 2];
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
-      float mx = -1e30f;
+      if (ragged) {
+#pragma unroll
+        for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kv0 + kf * 16 + g * 4 + r >= p.Skv) s[f][kf][r] = -3.0e38f;
+      }
+      float mx = s[f][0][0];
 #pragma unroll
       for (int kf = 0; kf < KF; ++kf)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kv0 + kf * 16 + g * 4 + r;
-          float v = s[f][kf][r] * sl2;
-          v = key < p.Skv ? v : -1e30f;
-          s[f][kf][r] = v;
-          mx = fmaxf(mx, v);
-        }
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[f][kf][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mnew = fmaxf(mrun[f], mx);
-      const float alpha = exp2f(mrun[f] - mnew);
+      const float mnew = fmaxf(mrun[f], mx * sl2);          // sl2 > 0: max commutes with the scaling
+      const float alpha = __builtin_amdgcn_exp2f(mrun[f] - mnew);
       mrun[f] = mnew;
       float rs = 0.f;
 #pragma unroll
       for (int kf = 0; kf < KF; ++kf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = exp2f(s[f][kf][r] - mnew);
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[f][kf][r], sl2, -mnew));
           s[f][kf][r] = e;
           rs += e;
         }
       rs += __shfl_xor(rs, 16, 64);
       rs += __shfl_xor(rs, 32, 64);
       lrun[f] = lrun[f] * alpha + rs;
+      if (!__all(alpha == 1.0f)) {
 #pragma unroll
-      for (int j = 0; j < DF; ++j) o[f][j] *= alpha;
+        for (int j = 0; j < DF; ++j) o[f][j] *= alpha;
+      }
       // P^T as B operand: k index 8g+j <-> key 32*sx + 16*(j>>2) + 4g + (j&3)
 #pragma unroll
       for (int sx = 0; sx < KF / 2; ++sx) {

@@ -46,13 +46,25 @@ ES_DEVICE void load_z(const es_fusion_desc& p, int n, size_t off, int c, float z
     }
 }
 
-ES_DEVICE void reduce_partials(const float* part, int nchunk, float cnt, float eps, float& mean, float& rstd) {
-  float s = 0.f, ss = 0.f;
-  for (int k = 0; k < nchunk; ++k) { s += part[k * 2]; ss += part[k * 2 + 1]; }
+ES_DEVICE void reduce_partials(const float* part, int nchunk, float cnt, float eps, float& mean, float& rstd,
+                               float* red /* LDS [4] */) {
+  // wave 0 loads the (<= 64) partial pairs in parallel and reduces them with shuffles (fixed order): no per-thread
+  // serial chain of dependent global loads in front of the streaming loop
+  if (threadIdx.x < 64) {
+    const int k = threadIdx.x;
+    float s = k < nchunk ? part[k * 2] : 0.f;
+    float ss = k < nchunk ? part[k * 2 + 1] : 0.f;
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    if (k == 0) { red[0] = s; red[1] = ss; }
+  }
+  __syncthreads();
+  const float s = red[0], ss = red[1];
   mean = s / cnt;
   float var = ss / cnt - mean * mean;
   var = var < 0.f ? 0.f : var;
   rstd = rsqrtf(var + eps);
+  __syncthreads();
 }
 
 template <typename T>
@@ -87,7 +99,7 @@ __global__ __launch_bounds__(256) void fusion_pass_b(const es_fusion_desc p, con
   const long long items = (long long)p.HW * CH8;
   float mean1, rstd1;
   reduce_partials(p.scratch + ((size_t)n * 2 + 0) * FU_MAX_CHUNK * 2, nchunk, 3.f * (float)p.C * (float)p.HW,
-                  p.eps, mean1, rstd1);
+                  p.eps, mean1, rstd1, red);
   float s = 0.f, ss = 0.f;
   T* U = (T*)p.u + (size_t)n * p.HW * p.C;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
@@ -134,8 +146,9 @@ __global__ __launch_bounds__(256) void fusion_pass_c(const es_fusion_desc p, con
   const int CH8 = p.C / 8;
   const long long items = (long long)p.HW * CH8;
   float mean2, rstd2;
+  __shared__ float red[4];
   reduce_partials(p.scratch + ((size_t)n * 2 + 1) * FU_MAX_CHUNK * 2, nchunk, (float)p.C * (float)p.HW, p.eps,
-                  mean2, rstd2);
+                  mean2, rstd2, red);
   const T* U = (const T*)p.u + (size_t)n * p.HW * p.C;
   T* O = (T*)p.out + (size_t)n * p.HW * p.C;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {

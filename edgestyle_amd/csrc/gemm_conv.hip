@@ -11,8 +11,9 @@
 // makes the ds_read_b128 fragment reads bank-conflict free is applied to the per-lane SOURCE address (LDS slot p of
 // row r holds global chunk p ^ (r & 7)) and again on the read.  The im2col is address math on that source pointer:
 // 3x3/1x1, stride 1|2, nearest-2x upsample and the channel concat of two tensors (UNet skip connections) select
-// the row pointer; padded taps point at a 16-byte zero page.  Two LDS stages: the DMA of K-step k+1 is in flight
-// behind the MFMAs of K-step k, one barrier per K-step, 2 workgroups per CU.
+// the row pointer; padded taps point at a 16-byte zero page.  LDS ring of 2 stages (2 workgroups per CU) or 4 stages
+// (1 workgroup per CU, for grids too small to double up): the DMAs of the next STAGES-1 K-steps are in flight behind
+// the MFMAs of the current one (counted s_waitcnt vmcnt + raw s_barrier), one barrier per K-step.
 //
 // Epilogue: bias / per-sample time-embedding add / SiLU / GEGLU / conditioning scale are applied in registers
 // (fp32), the tile is transposed through LDS, and the residual add + store run as full-line 16-byte accesses along
@@ -40,14 +41,16 @@ ES_DEVICE void store_elems(T* o, const float* v, int n) {
   for (int r = 0; r < n; ++r) o[r] = from_f32<T>(v[r]);
 }
 
-template <typename T, int BN, bool ALIGNED>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const es_gemm_desc p, const int M, const int nk) {
+template <typename T, int BN, bool ALIGNED, int STAGES>
+__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void conv_gemm_kernel(const es_gemm_desc p, const int M,
+                                                                            const int nk) {
   constexpr int FM = 4;              // pixel fragments per wave (64 pixels)
   constexpr int FN = BN / 32;        // cout fragments per wave (BN/2 couts)
   constexpr int WI = BN / 32;        // weight DMA instructions per wave per K-step (8 rows each)
   constexpr int XT = BM * BK * 2;    // bytes per stage
   constexpr int WT = BN * BK * 2;
   constexpr int EROW = BN * 2 + 16;  // epilogue tile row stride (bytes), padded against bank conflicts
+  constexpr int NI = 4 + WI;         // LDS-DMA instructions per wave per K-step
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -68,10 +71,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const es_gemm_desc p,
   const int Hin = p.Hsrc << p.upsample, Win = p.Wsrc << p.upsample;
   const int HWout = p.Hout * p.Wout;
 
-  int iy0[4], ix0[4], nb[4];
+  // Per-row im2col state.  Fast path (no upsample): the source pixel of tap (ky,kx) is rbase + ky*Wsrc + kx, valid iff
+  // bit (ky*3+kx) of vmask is set, so a K-step costs one add + one select per row.  Upsampled sources keep (iy0, ix0).
+  int iy0[4], ix0[4], nb[4], rbase[4];
+  unsigned vmask[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = tile_m * BM + 32 * wave + 8 * i + lrow;
+    iy0[i] = -(1 << 20); ix0[i] = -(1 << 20); nb[i] = 0; rbase[i] = 0; vmask[i] = 0u;
     if (m < M) {
       const int n = m / HWout;
       const int rem = m - n * HWout;
@@ -79,11 +86,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const es_gemm_desc p,
       iy0[i] = oy * p.stride - p.pad;
       ix0[i] = ox * p.stride - p.pad;
       nb[i] = n * p.Hsrc * p.Wsrc;
-    } else {
-      iy0[i] = -(1 << 20); ix0[i] = -(1 << 20); nb[i] = 0;
+      rbase[i] = nb[i] + iy0[i] * p.Wsrc + ix0[i];
+      for (int t = 0; t < p.ksize * p.ksize; ++t) {
+        const int ky = p.ksize == 3 ? t / 3 : 0, kx = p.ksize == 3 ? t - 3 * (t / 3) : 0;
+        if ((unsigned)(iy0[i] + ky) < (unsigned)Hin && (unsigned)(ix0[i] + kx) < (unsigned)Win) vmask[i] |= 1u << t;
+      }
     }
   }
   const T* wbase = (const T*)p.w + (size_t)(tile_n * BN + (BN / 4) * wave + lrow) * p.Kpad + kc * 8;
+  unsigned long long zpage = (unsigned long long)(const void*)g_zero16;
+  asm volatile("" : "+v"(zpage));                    // keep the zero-page address in registers across the K loop
 
   int tap, cpos;
   {
@@ -95,26 +107,34 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const es_gemm_desc p,
   auto issue_tile = [&](int ks, int stage) {
     char* xs = smem + stage * (XT + WT);
     char* ws = xs + XT;
-    // weights: WI instructions of 8 rows
 #pragma unroll
     for (int i = 0; i < WI; ++i)
       glds16(wbase + (size_t)(8 * i) * p.Kpad + (size_t)ks * BK, ws + ((BN / 4) * wave + 8 * i) * 128);
-    // activations (im2col on the fly)
     const int c = ALIGNED ? cpos + kc * 8 : cpos;
     const bool kvalid = ALIGNED ? true : (ks * BK + kc * 8 < Ktrue);
     int ky = 0, kx = 0;
-    if (p.ksize == 3) { ky = tap / 3; kx = tap - ky * 3; }
+    if (p.ksize == 3) { ky = (tap * 11) >> 5; kx = tap - ky * 3; }       // tap in [0,9): tap/3 without a divide
     const bool second = c >= p.C1;
     const T* src = second ? (const T*)p.x2 : (const T*)p.x;
     const int cs = second ? p.C2 : p.C1;
     const int cc = second ? c - p.C1 : c;
+    if (!p.upsample) {
+      const int tapoff = ky * p.Wsrc + kx;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int iy = iy0[i] + ky, ix = ix0[i] + kx;
-      const bool ok = kvalid && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
-      const int pix = nb[i] + (iy >> p.upsample) * p.Wsrc + (ix >> p.upsample);
-      const void* sp = ok ? (const void*)(src + (size_t)pix * cs + cc) : (const void*)g_zero16;
-      glds16(sp, xs + (32 * wave + 8 * i) * 128);
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = kvalid && ((vmask[i] >> tap) & 1u);
+        const unsigned long long a = (unsigned long long)(const void*)(src + (size_t)(unsigned)(rbase[i] + tapoff) * cs + cc);
+        glds16((const void*)(ok ? a : zpage), xs + (32 * wave + 8 * i) * 128);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+        const bool ok = kvalid && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+        const int pix = nb[i] + (iy >> 1) * p.Wsrc + (ix >> 1);
+        const unsigned long long a = (unsigned long long)(const void*)(src + (size_t)(unsigned)pix * cs + cc);
+        glds16((const void*)(ok ? a : zpage), xs + (32 * wave + 8 * i) * 128);
+      }
     }
     cpos += BK;
     while (cpos >= Ctot) { cpos -= Ctot; ++tap; }
@@ -126,14 +146,23 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const es_gemm_desc p,
 #pragma unroll
     for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (ks0 < ks1) issue_tile(ks0, 0);
+  // prologue: STAGES-1 tiles in flight
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (ks0 + s < ks1) issue_tile(ks0 + s, s);
 
   const int frow = lane & 15, fq = lane >> 4;
+  int stage = 0, istage = STAGES - 1;
   for (int ks = ks0; ks < ks1; ++ks) {
-    const int stage = (ks - ks0) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of tile ks has landed
-    __syncthreads();                                   // ... everyone's has; everyone finished tile ks-1
-    if (ks + 1 < ks1) issue_tile(ks + 1, stage ^ 1);
+    // tile ks must have landed; up to STAGES-2 younger tiles (NI DMA instructions each) may stay in flight
+    if (STAGES > 2 && ks + STAGES - 2 < ks1) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * NI) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                      // everyone's DMA of tile ks landed; everyone finished tile ks-1
+    if (ks + STAGES - 1 < ks1) issue_tile(ks + STAGES - 1, istage);
+    istage = istage + 1 == STAGES ? 0 : istage + 1;
     const char* xs = smem + stage * (XT + WT);
     const char* ws = xs + XT;
 #pragma unroll
@@ -154,6 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const es_gemm_desc p,
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(wa[i], xa[j], acc[i][j]);
     }
+    stage = stage + 1 == STAGES ? 0 : stage + 1;
   }
 
   // ---------------- split-K: raw fp32 partials (16 B per lane) ----------------
@@ -312,10 +342,13 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
   const int Ctot = d.C1 + d.C2;
   const bool aligned = (Ctot % BK == 0) && (d.C1 % BK == 0);
   dim3 grid((M + BM - 1) / BM, d.rows_padded / d.bn, d.splitk);
-  const size_t lds = 2 * (size_t)(BM + d.bn) * BK * 2;
-#define ES_LAUNCH(BNV, AL)                                                                                  \
+  // Pipeline depth: 2 stages x 2 workgroups per CU by default; 3-4 stages (1 workgroup per CU) selectable for tuning.
+  int stages = d.stages;
+  if (stages == 0) stages = 2;   // measured (tools/gemm_bench.py): 2 stages x 2 workgroups/CU beats a 3-4 deep ring at 1/CU on every step shape
+#define ES_LAUNCH(BNV, AL, ST)                                                                              \
   do {                                                                                                      \
-    auto kfn = conv_gemm_kernel<T, BNV, AL>;                                                                \
+    auto kfn = conv_gemm_kernel<T, BNV, AL, ST>;                                                            \
+    const size_t lds = (size_t)ST * (BM + BNV) * BK * 2;                                                    \
     static bool attr_set = false;                                                                           \
     if (!attr_set) {                                                                                        \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
@@ -323,8 +356,13 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
     }                                                                                                       \
     hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, d, M, nk);                                            \
   } while (0)
-  if (d.bn == 128) { if (aligned) ES_LAUNCH(128, true); else ES_LAUNCH(128, false); }
-  else             { if (aligned) ES_LAUNCH(160, true); else ES_LAUNCH(160, false); }
+#define ES_LAUNCH_ST(BNV, AL)                                                                               \
+  do {                                                                                                      \
+    if (stages == 2) ES_LAUNCH(BNV, AL, 2); else if (stages == 3) ES_LAUNCH(BNV, AL, 3); else ES_LAUNCH(BNV, AL, 4); \
+  } while (0)
+  if (d.bn == 128) { if (aligned) ES_LAUNCH_ST(128, true); else ES_LAUNCH(128, false, 2); }
+  else             { if (aligned) ES_LAUNCH_ST(160, true); else ES_LAUNCH(160, false, 2); }
+#undef ES_LAUNCH_ST
 #undef ES_LAUNCH
   if (d.splitk > 1) {
     const long long total = (long long)M * (d.rows_padded / 8);
@@ -355,6 +393,7 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
   if (d->splitk > 1 && (!d->workspace || d->act == ES_ACT_GEGLU)) { es_set_error("es_conv_gemm: splitk needs workspace and no GEGLU"); return -1; }
   if (d->act == ES_ACT_GEGLU && (d->bn != 128 || d->Cout % 32)) { es_set_error("es_conv_gemm: GEGLU needs bn=128, Cout%32==0"); return -1; }
   if (d->N < 1 || d->Hout < 1 || d->Wout < 1) { es_set_error("es_conv_gemm: empty problem"); return -1; }
+  if (d->stages != 0 && (d->stages < 2 || d->stages > 4)) { es_set_error("es_conv_gemm: stages must be 0 (auto), 2, 3 or 4"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   int rc = d->dtype == ES_F16 ? launch<f16>(*d, st) : launch<bf16>(*d, st);
   if (rc) es_set_error("es_conv_gemm: launch failed");

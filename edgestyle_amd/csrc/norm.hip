@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int GN_MAX_CHUNK = 32;
+constexpr int GN_MAX_CHUNK = 64;
 constexpr int GN_MAX_GROUPS = 64;
 
 ES_DEVICE int gn_pixels_per_block(int HW) {
@@ -71,18 +71,30 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const es_gn_desc p, const
   float* scale = (float*)smem;         // [C]
   float* shift = scale + C;            // [C]
   float* gstat = shift + C;            // [groups*2] mean, rstd
-  for (int gi = threadIdx.x; gi < p.groups; gi += 256) {
-    float s = 0.f, ss = 0.f;
-    for (int k = 0; k < nchunk; ++k) {
-      const float* pp = p.partials + ((size_t)n * nchunk + k) * p.groups * 2 + gi * 2;
-      s += pp[0]; ss += pp[1];
+  float* red = gstat + 2 * p.groups;   // [slices][groups*2] partial sums of the partials
+  {
+    // all 256 threads reduce the [nchunk][groups*2] partials: column = (group, stat), rows split into slices;
+    // independent loads per thread (no serial latency chain), fixed summation order (bitwise reproducible)
+    const int cols = 2 * p.groups;
+    const int slices = 256 / cols;
+    const int col = threadIdx.x % cols, sl = threadIdx.x / cols;
+    if (sl < slices) {
+      float acc = 0.f;
+      const float* pp = p.partials + (size_t)n * nchunk * cols + col;
+      for (int k = sl; k < nchunk; k += slices) acc += pp[(size_t)k * cols];
+      red[sl * cols + col] = acc;
     }
-    const float cnt = (float)cpg * (float)p.HW;
-    const float mean = s / cnt;
-    float var = ss / cnt - mean * mean;
-    var = var < 0.f ? 0.f : var;
-    gstat[gi * 2] = mean;
-    gstat[gi * 2 + 1] = rsqrtf(var + p.eps);
+    __syncthreads();
+    for (int gi = threadIdx.x; gi < p.groups; gi += 256) {
+      float s = 0.f, ss = 0.f;
+      for (int k = 0; k < slices; ++k) { s += red[k * cols + gi * 2]; ss += red[k * cols + gi * 2 + 1]; }
+      const float cnt = (float)cpg * (float)p.HW;
+      const float mean = s / cnt;
+      float var = ss / cnt - mean * mean;
+      var = var < 0.f ? 0.f : var;
+      gstat[gi * 2] = mean;
+      gstat[gi * 2 + 1] = rsqrtf(var + p.eps);
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -171,7 +183,7 @@ int launch_gn(const es_gn_desc& d, hipStream_t st) {
   int blocks = (int)((total + 256 * 4 - 1) / (256 * 4));
   if (blocks < 1) blocks = 1;
   if (blocks > 1024) blocks = 1024;
-  const size_t lds = (size_t)(2 * C + 2 * d.groups) * sizeof(float);
+  const size_t lds = (size_t)(2 * C + 2 * d.groups + 256) * sizeof(float);
   hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(blocks, d.N), dim3(256), lds, st, d, nchunk);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

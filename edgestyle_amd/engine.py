@@ -213,10 +213,16 @@ class UNet(Encoder):
     def transformers(self):
         return super().transformers() + [a for blk in self.up for (_, a) in blk if a is not None]
 
-    def forward(self, x, tproj, ctx, down_res: Optional[Sequence] = None, mid_res=None, out=None):
-        """x: [N,H,W,in_pad] -> noise prediction [N,H,W,out_channels] (PL:500-510)."""
+    def encode(self, x, tproj, ctx):
+        """conv_in + down blocks + mid block: independent of the ControlNet residuals, so it can run concurrently
+        with the ControlNet passes on another stream."""
         h = ops.conv_gemm(x, self.conv_in)
-        skips, h = self.run(h, tproj, ctx)
+        return self.run(h, tproj, ctx)
+
+    def forward(self, x, tproj, ctx, down_res: Optional[Sequence] = None, mid_res=None, out=None, encoded=None):
+        """x: [N,H,W,in_pad] -> noise prediction [N,H,W,out_channels] (PL:500-510)."""
+        skips, h = encoded if encoded is not None else self.encode(x, tproj, ctx)
+        skips = list(skips)
         if down_res is not None:
             skips = [ops.add(s, r.reshape(s.shape)) for s, r in zip(skips, down_res)]
         if mid_res is not None:

@@ -615,6 +615,8 @@ class StepRunner:
         self.kmax = max(len(p) for _, p in self.groups)
         self.ctx_unet = None
         self.ctx_nets = None
+        self.concurrent = True
+        self._streams = None
 
     @classmethod
     def from_state_dicts(cls, ws: Dict[str, Dict[str, torch.Tensor]], ucfg: UNetConfig, dtype, device,
@@ -643,22 +645,50 @@ class StepRunner:
 
     def step(self, x: torch.Tensor, t_rows: torch.Tensor, conds: Sequence[torch.Tensor], scales: Sequence[float],
              scales_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """x: [N,h,w,8] NHWC; t_rows: fp32 device [kmax*N] (all equal to the timestep); conds: 6 x [N,h,w,C0] NHWC."""
+        """x: [N,h,w,8] NHWC; t_rows: fp32 device [kmax*N] (all equal to the timestep); conds: 6 x [N,h,w,C0] NHWC.
+
+        The three batched ControlNet passes and the UNet's own down+mid path do not depend on each other (the
+        residuals are only added after the UNet's down path, PL:500-510), so they run as four concurrent chains on
+        separate HIP streams (forked from / joined into the current stream, hence capturable as parallel hipGraph
+        branches): at batch 1 a single chain's kernels cannot fill 256 CUs."""
         N = x.shape[0]
         nn = len(self.controlnet.nets)
         res_per_net, bs = [None] * nn, [None] * nn
-        for gi, (net, pos) in enumerate(self.groups):
+        ue = self.unet.engine
+        results = {}
+
+        def cn_chain(gi):
+            net, pos = self.groups[gi]
             eng = net.engine
-            k = len(pos)
-            tproj = eng.time_proj(t_rows[: k * N])
-            res = eng.forward(x, tproj, self.ctx_nets[gi], [conds[p] for p in pos])
+            tproj = eng.time_proj(t_rows[: len(pos) * N])
+            results[gi] = eng.forward(x, tproj, self.ctx_nets[gi], [conds[p] for p in pos])
+
+        def unet_chain():
+            tproj = ue.time_proj(t_rows[:N])
+            results["unet"] = (tproj, ue.encode(x, tproj, self.ctx_unet))
+
+        chains = [lambda gi=gi: cn_chain(gi) for gi in range(len(self.groups))] + [unet_chain]
+        if self.concurrent:
+            main = torch.cuda.current_stream()
+            if self._streams is None:
+                self._streams = [torch.cuda.Stream(device=self.device) for _ in chains]
+            for i, (fn, st) in enumerate(zip(chains, self._streams)):
+                st.wait_stream(main)
+                with torch.cuda.stream(st), ops.lane(i + 1):
+                    fn()
+            for st in self._streams:
+                main.wait_stream(st)
+        else:
+            for fn in chains:
+                fn()
+        for gi, (net, pos) in enumerate(self.groups):
+            res = results[gi]
             for j, p in enumerate(pos):
                 res_per_net[p] = [r[j * N:] for r in res]
                 bs[p] = [r.stride(0) for r in res]
         fused = self.controlnet.engine.forward(res_per_net, bs, N, scales, scales_dev)
-        ue = self.unet.engine
-        tproj = ue.time_proj(t_rows[:N])
-        return ue.forward(x, tproj, self.ctx_unet, fused[:-1], fused[-1], out=out)
+        tproj, enc = results["unet"]
+        return ue.forward(x, tproj, self.ctx_unet, fused[:-1], fused[-1], out=out, encoded=enc)
 
     def step_nchw(self, sample, timestep, ehs, conds, scales):
         """Convenience for tests: NCHW fp32 in / NCHW out."""

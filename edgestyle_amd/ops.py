@@ -13,6 +13,28 @@ import torch
 from . import lib as L
 
 _DT = {torch.float16: L.ES_F16, torch.bfloat16: L.ES_BF16}
+LANE = 0            # scratch-buffer namespace: concurrent chains on different HIP streams must not share scratch
+
+
+class lane:
+    """with ops.lane(i): ... — kernels launched inside use scratch buffers (split-K workspace, GroupNorm partials)
+    private to lane i, so independent chains can run concurrently on separate streams."""
+
+    def __init__(self, i: int):
+        self.i = i
+
+    def __enter__(self):
+        global LANE
+        self.prev, LANE = LANE, self.i
+
+    def __exit__(self, *a):
+        global LANE
+        LANE = self.prev
+
+
+import os as _os
+SPLITK_TARGET = int(_os.environ.get("ES_SPLITK_TARGET", "320"))   # workgroups a split-K launch aims for
+FORCE_STAGES = 0    # tuning knob (tools/gemm_bench.py): 0 = kernel picks the LDS ring depth
 PROFILE = None      # set to a Profiler by bench.py: every es_conv_gemm launch gets an in-kernel timing slot
 
 
@@ -133,11 +155,12 @@ _workspace = {}
 
 
 def _get_workspace(nbytes: int, device) -> torch.Tensor:
+    device = (device, LANE)
     ws = _workspace.get(device)
     if ws is None or ws.numel() * 4 < nbytes:
         if torch.cuda.is_current_stream_capturing():
             raise L.EdgeStyleHipError("split-K workspace too small during graph capture; run one eager warm-up first")
-        ws = torch.empty(max(nbytes // 4, 1 << 22), dtype=torch.float32, device=device)
+        ws = torch.empty(max(nbytes // 4, 1 << 22), dtype=torch.float32, device=device[0])
         _workspace[device] = ws
     return ws
 
@@ -145,9 +168,9 @@ def _get_workspace(nbytes: int, device) -> torch.Tensor:
 def choose_splitk(M: int, rows_padded: int, bn: int, kpad: int) -> int:
     tiles = ((M + BM - 1) // BM) * (rows_padded // bn)
     nk = kpad // BK
-    if tiles >= 160 or nk < 8:
+    if tiles >= SPLITK_TARGET // 2 or nk < 8:
         return 1
-    s = min(max(1, 320 // tiles), nk // 4, 32)
+    s = min(max(1, SPLITK_TARGET // tiles), nk // 4, 32)
     return max(1, s)
 
 
@@ -155,7 +178,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
               upsample: bool = False, x2: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None,
               residual: Optional[torch.Tensor] = None, act: int = L.ACT_NONE, out_scale: float = 1.0,
               out_scale_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-              out_hw=None, splitk: Optional[int] = None) -> torch.Tensor:
+              out_hw=None, splitk: Optional[int] = None, stages: int = 0) -> torch.Tensor:
     """x: [N,H,W,C1] (+ x2 [N,H,W,C2]); returns [N,Hout,Wout,Cout] (Cout/2 for GEGLU)."""
     N, H, W, C1 = x.shape
     C2 = 0 if x2 is None else x2.shape[3]
@@ -191,6 +214,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     d.upsample = 1 if upsample else 0
     d.temb_stride = temb.stride(0) if temb is not None else 0
     d.act, d.splitk, d.bn, d.dtype, d.out_scale = act_i, splitk, pw.bn, _dt(x), out_scale
+    d.stages = stages or FORCE_STAGES
     if splitk > 1:
         ws = _get_workspace(splitk * M * pw.rows_padded * 4, x.device)
         d.workspace = ws.data_ptr()
@@ -245,7 +269,7 @@ def group_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups:
     N, H, W, C1 = x.shape
     C2 = 0 if x2 is None else x2.shape[3]
     out = torch.empty((N, H, W, C1 + C2), dtype=x.dtype, device=x.device)
-    key = (x.device, N, groups)
+    key = (x.device, N, groups, LANE)
     part = _gn_partials.get(key)
     if part is None:
         part = torch.empty(L.load().es_group_norm_partials_bytes(N, groups) // 4, dtype=torch.float32, device=x.device)

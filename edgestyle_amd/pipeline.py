@@ -334,12 +334,15 @@ class StableDiffusionControlNetPipeline:
         prof = ops.Profiler(self.device)
         torch.cuda.synchronize()
         ops.PROFILE = prof
+        was = self._runner.concurrent
+        self._runner.concurrent = False      # serial chains: each launch is timed with the GPU to itself
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 loop.one_step()
         finally:
             ops.PROFILE = None
+            self._runner.concurrent = was
         prof.reset()
         loop.step_idx.zero_()
         torch.cuda.synchronize()
