@@ -5,13 +5,13 @@
 // Tile: BM=128 pixels x BN (128|160) couts x BK=64, 256 threads = 4 waves as 2(M) x 2(N); each wave owns
 // 64 pixels x BN/2 couts = 4 x (4|5) MFMA fragments.
 //
-// Staging is LDS-DMA (`global_load_lds_dwordx4`): every wave-instruction copies 8 tile rows x 128 B straight from
+// Staging is LDS-DMA (`buffer_load_dwordx4 ... lds`): every wave-instruction copies 8 tile rows x 128 B straight from
 // global memory into LDS — no VGPR round trip and no ds_write traffic (ds_write_b128 tops out at ~79 B/clk/CU, which
 // capped the register-staged version of this kernel).  The DMA destination is lane-linear, so the XOR swizzle that
 // makes the ds_read_b128 fragment reads bank-conflict free is applied to the per-lane SOURCE address (LDS slot p of
 // row r holds global chunk p ^ (r & 7)) and again on the read.  The im2col is address math on that source pointer:
 // 3x3/1x1, stride 1|2, nearest-2x upsample and the channel concat of two tensors (UNet skip connections) select
-// the row pointer; padded taps point at a 16-byte zero page.  LDS ring of 2 stages (2 workgroups per CU) or 4 stages
+// the row offset; padded taps are out-of-range offsets that the buffer descriptor's range check zero-fills.  LDS ring of 2 stages (2 workgroups per CU) or 4 stages
 // (1 workgroup per CU, for grids too small to double up): the DMAs of the next STAGES-1 K-steps are in flight behind
 // the MFMAs of the current one (counted s_waitcnt vmcnt + raw s_barrier), one barrier per K-step.
 //
@@ -26,15 +26,7 @@ namespace {
 constexpr int BM = 128;
 constexpr int BK = 64;
 
-__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
-
-typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
-
-ES_DEVICE void glds16(const void* src, char* lds_wave_base) {
-  // 64 lanes x 16 B: LDS[lds_wave_base + lane*16 ...] <- *src (per-lane source, wave-uniform destination base)
-  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
-}
 
 template <typename T>
 ES_DEVICE void store_elems(T* o, const float* v, int n) {
@@ -71,14 +63,18 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void conv_gemm_kernel(con
   const int Hin = p.Hsrc << p.upsample, Win = p.Wsrc << p.upsample;
   const int HWout = p.Hout * p.Wout;
 
-  // Per-row im2col state.  Fast path (no upsample): the source pixel of tap (ky,kx) is rbase + ky*Wsrc + kx, valid iff
-  // bit (ky*3+kx) of vmask is set, so a K-step costs one add + one select per row.  Upsampled sources keep (iy0, ix0).
-  int iy0[4], ix0[4], nb[4], rbase[4];
-  unsigned vmask[4];
+  // Per-row im2col state: output pixel -> top-left source coordinate.  The loader uses raw buffer loads to LDS
+  // (`buffer_load_dwordx4 ... offen lds`): the per-lane byte offset goes in a VGPR, the per-K-step uniform part
+  // (channel offset inside the pixel, K offset of the weight row) in the scalar offset, and a padded / out-of-range
+  // tap is simply an offset beyond the descriptor's num_records — the hardware range check zero-fills it, so there
+  // is no zero page, no select on pointers and no 64-bit address arithmetic in the K loop.  Offsets per (tap, source)
+  // are recomputed only when the tap or the concat source changes (every Cin/64 K-steps), not every K-step.
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  int iy0[4], ix0[4], nb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = tile_m * BM + 32 * wave + 8 * i + lrow;
-    iy0[i] = -(1 << 20); ix0[i] = -(1 << 20); nb[i] = 0; rbase[i] = 0; vmask[i] = 0u;
+    iy0[i] = -(1 << 20); ix0[i] = -(1 << 20); nb[i] = 0;
     if (m < M) {
       const int n = m / HWout;
       const int rem = m - n * HWout;
@@ -86,16 +82,18 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void conv_gemm_kernel(con
       iy0[i] = oy * p.stride - p.pad;
       ix0[i] = ox * p.stride - p.pad;
       nb[i] = n * p.Hsrc * p.Wsrc;
-      rbase[i] = nb[i] + iy0[i] * p.Wsrc + ix0[i];
-      for (int t = 0; t < p.ksize * p.ksize; ++t) {
-        const int ky = p.ksize == 3 ? t / 3 : 0, kx = p.ksize == 3 ? t - 3 * (t / 3) : 0;
-        if ((unsigned)(iy0[i] + ky) < (unsigned)Hin && (unsigned)(ix0[i] + kx) < (unsigned)Win) vmask[i] |= 1u << t;
-      }
     }
   }
-  const T* wbase = (const T*)p.w + (size_t)(tile_n * BN + (BN / 4) * wave + lrow) * p.Kpad + kc * 8;
-  unsigned long long zpage = (unsigned long long)(const void*)g_zero16;
-  asm volatile("" : "+v"(zpage));                    // keep the zero-page address in registers across the K loop
+  const auto rW = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.w, (short)0, (int)((size_t)p.rows_padded * p.Kpad * 2), 0x00020000);
+  const auto rX1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.x, (short)0, (int)((size_t)p.N * p.Hsrc * p.Wsrc * p.C1 * 2), 0x00020000);
+  const auto rX2 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.x2 ? p.x2 : p.x), (short)0, (int)((size_t)p.N * p.Hsrc * p.Wsrc * (p.x2 ? p.C2 : p.C1) * 2), 0x00020000);
+  unsigned woff[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i)
+    woff[i] = (unsigned)(((size_t)(tile_n * BN + (BN / 4) * wave + 8 * i + lrow) * p.Kpad + kc * 8) * 2);
 
   int tap, cpos;
   {
@@ -103,38 +101,55 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void conv_gemm_kernel(con
     tap = kg / Ctot;
     cpos = kg - tap * Ctot;
   }
+  unsigned voff[4] = {OOB, OOB, OOB, OOB};
+  int cur_tap = -1, cur_second = -1;
+  auto row_offsets = [&](int tp, int cs, int chan) {      // byte offset of (row i, tap tp, channel chan) or OOB
+    int ky = 0, kx = 0;
+    if (p.ksize == 3) { ky = (tp * 11) >> 5; kx = tp - ky * 3; }       // tp in [0,9): tp/3 without a divide
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+      const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+      const int pix = nb[i] + (iy >> p.upsample) * p.Wsrc + (ix >> p.upsample);
+      voff[i] = ok ? (unsigned)(((size_t)pix * cs + chan) * 2) : OOB;
+    }
+  };
 
   auto issue_tile = [&](int ks, int stage) {
     char* xs = smem + stage * (XT + WT);
     char* ws = xs + XT;
+    const int soff_w = ks * (BK * 2);
 #pragma unroll
     for (int i = 0; i < WI; ++i)
-      glds16(wbase + (size_t)(8 * i) * p.Kpad + (size_t)ks * BK, ws + ((BN / 4) * wave + 8 * i) * 128);
-    const int c = ALIGNED ? cpos + kc * 8 : cpos;
-    const bool kvalid = ALIGNED ? true : (ks * BK + kc * 8 < Ktrue);
-    int ky = 0, kx = 0;
-    if (p.ksize == 3) { ky = (tap * 11) >> 5; kx = tap - ky * 3; }       // tap in [0,9): tap/3 without a divide
-    const bool second = c >= p.C1;
-    const T* src = second ? (const T*)p.x2 : (const T*)p.x;
-    const int cs = second ? p.C2 : p.C1;
-    const int cc = second ? c - p.C1 : c;
-    if (!p.upsample) {
-      const int tapoff = ky * p.Wsrc + kx;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(ws + ((BN / 4) * wave + 8 * i) * 128), 16, (int)woff[i], soff_w, 0, 0);
+    if constexpr (ALIGNED) {
+      const int second = cpos >= p.C1 ? 1 : 0;            // wave-uniform: a K-step never straddles taps or sources
+      const int cs = second ? p.C2 : p.C1;
+      const int cc = second ? cpos - p.C1 : cpos;
+      if (tap != cur_tap || second != cur_second) {
+        row_offsets(tap, cs, kc * 8);
+        cur_tap = tap; cur_second = second;
+      }
+      if (second) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool ok = kvalid && ((vmask[i] >> tap) & 1u);
-        const unsigned long long a = (unsigned long long)(const void*)(src + (size_t)(unsigned)(rbase[i] + tapoff) * cs + cc);
-        glds16((const void*)(ok ? a : zpage), xs + (32 * wave + 8 * i) * 128);
+        for (int i = 0; i < 4; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, (lptr_t)(xs + (32 * wave + 8 * i) * 128), 16, (int)voff[i], cc * 2, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rX1, (lptr_t)(xs + (32 * wave + 8 * i) * 128), 16, (int)voff[i], cc * 2, 0, 0);
       }
     } else {
+      // small-Cin layers (conv_in, cond embedding): tap and channel differ per lane, single source
+      if (ks * BK + kc * 8 < Ktrue) {
+        row_offsets(tap, p.C1, cpos);
+      } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int iy = iy0[i] + ky, ix = ix0[i] + kx;
-        const bool ok = kvalid && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
-        const int pix = nb[i] + (iy >> 1) * p.Wsrc + (ix >> 1);
-        const unsigned long long a = (unsigned long long)(const void*)(src + (size_t)(unsigned)pix * cs + cc);
-        glds16((const void*)(ok ? a : zpage), xs + (32 * wave + 8 * i) * 128);
+        for (int i = 0; i < 4; ++i) voff[i] = OOB;
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rX1, (lptr_t)(xs + (32 * wave + 8 * i) * 128), 16, (int)voff[i], 0, 0, 0);
     }
     cpos += BK;
     while (cpos >= Ctot) { cpos -= Ctot; ++tap; }
@@ -161,28 +176,42 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void conv_gemm_kernel(con
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();                      // everyone's DMA of tile ks landed; everyone finished tile ks-1
-    if (ks + STAGES - 1 < ks1) issue_tile(ks + STAGES - 1, istage);
-    istage = istage + 1 == STAGES ? 0 : istage + 1;
     const char* xs = smem + stage * (XT + WT);
     const char* ws = xs + XT;
+    // Fragment reads are software-pipelined against the MFMAs: the reads of the second 32-deep half are in flight
+    // behind the first half's MFMAs, and the next tile's DMA issue (address math + 9 LDS-DMA instructions) sits
+    // between the two read groups where it covers the first group's LDS latency.
+    typename Traits<T>::vec8 xa0[FM], wa0[FN], xa1[FM], wa1[FN];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      typename Traits<T>::vec8 xa[FM], wa[FN];
-#pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        const int row = wm * 64 + j * 16 + frow;
-        xa[j] = as_vec8<T>(*(const u32x4*)(xs + row * 128 + (((4 * s + fq) ^ (row & 7)) << 4)));
-      }
-#pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        const int row = wn * (BN / 2) + i * 16 + frow;
-        wa[i] = as_vec8<T>(*(const u32x4*)(ws + row * 128 + (((4 * s + fq) ^ (row & 7)) << 4)));
-      }
-#pragma unroll
-      for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(wa[i], xa[j], acc[i][j]);
+    for (int j = 0; j < FM; ++j) {
+      const int row = wm * 64 + j * 16 + frow;
+      xa0[j] = as_vec8<T>(*(const u32x4*)(xs + row * 128 + (((0 + fq) ^ (row & 7)) << 4)));
     }
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      const int row = wn * (BN / 2) + i * 16 + frow;
+      wa0[i] = as_vec8<T>(*(const u32x4*)(ws + row * 128 + (((0 + fq) ^ (row & 7)) << 4)));
+    }
+    if (ks + STAGES - 1 < ks1) issue_tile(ks + STAGES - 1, istage);
+    istage = istage + 1 == STAGES ? 0 : istage + 1;
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const int row = wm * 64 + j * 16 + frow;
+      xa1[j] = as_vec8<T>(*(const u32x4*)(xs + row * 128 + (((4 + fq) ^ (row & 7)) << 4)));
+    }
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      const int row = wn * (BN / 2) + i * 16 + frow;
+      wa1[i] = as_vec8<T>(*(const u32x4*)(ws + row * 128 + (((4 + fq) ^ (row & 7)) << 4)));
+    }
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(wa0[i], xa0[j], acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(wa1[i], xa1[j], acc[i][j]);
     stage = stage + 1 == STAGES ? 0 : stage + 1;
   }
 
@@ -388,6 +417,9 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
   if (d->rows_padded % d->bn || d->rows_padded < d->Cout) { es_set_error("es_conv_gemm: bad rows_padded"); return -1; }
   if (d->Kpad % BK || d->Kpad < Ktrue) { es_set_error("es_conv_gemm: bad Kpad"); return -1; }
   if (d->C1 % 8 || d->C2 % 8 || (d->C2 && !d->x2)) { es_set_error("es_conv_gemm: channels must be multiples of 8"); return -1; }
+  if (d->C2 && (d->C1 % BK || d->C2 % BK)) { es_set_error("es_conv_gemm: concatenated sources need C1, C2 multiples of 64"); return -1; }
+  if ((size_t)d->N * d->Hsrc * d->Wsrc * (d->C1 > d->C2 ? d->C1 : d->C2) * 2 >= 0x7FFFFFFFull ||
+      (size_t)d->rows_padded * d->Kpad * 2 >= 0x7FFFFFFFull) { es_set_error("es_conv_gemm: operand larger than 2 GiB (32-bit buffer offsets)"); return -1; }
   if (d->ksize != 1 && d->ksize != 3) { es_set_error("es_conv_gemm: ksize must be 1 or 3"); return -1; }
   if (d->splitk < 1 || d->splitk > d->Kpad / BK) { es_set_error("es_conv_gemm: bad splitk"); return -1; }
   if (d->splitk > 1 && (!d->workspace || d->act == ES_ACT_GEGLU)) { es_set_error("es_conv_gemm: splitk needs workspace and no GEGLU"); return -1; }
