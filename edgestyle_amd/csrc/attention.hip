@@ -14,7 +14,7 @@
 namespace {
 
 template <typename T, int KS /* QK k-steps of 32: DPAD = 32*KS */, int DF /* dv fragments of 16 */, int QF, int KVT>
-__global__ __launch_bounds__(256) void attention_kernel(const es_attn_desc p) {
+__global__ __launch_bounds__(256, (QF == 1 && KS <= 3) ? 3 : (KS <= 5 ? 2 : 1)) void attention_kernel(const es_attn_desc p) {
   constexpr int DPAD = 32 * KS;
   constexpr int DVP = 16 * DF;
   constexpr int KROW = DPAD * 2 + 16;   // bytes per K row in LDS (+16 B pad)
@@ -23,6 +23,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const es_attn_desc p) {
   constexpr int KCH = DPAD / 8;         // 16-byte chunks per K row
   constexpr int VCH = DVP / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // two LDS buffers for the K/V tile: tile t+1 is written while the other waves may still read tile t, so the loop
+  // needs ONE barrier per tile (d <= 160; the 512-wide VAE head keeps a single buffer and two barriers)
+  constexpr bool DBUF = KS <= 5;
+  constexpr int TILE_BYTES = KVT * KROW + KVT * VROW;
   char* ks_ = smem;
   char* vs_ = smem + KVT * KROW;
 
@@ -54,57 +58,55 @@ __global__ __launch_bounds__(256) void attention_kernel(const es_attn_desc p) {
   }
 
   // zero the K pad chunks once (they multiply the zero Q pad; must not be NaN garbage)
-  for (int i = tid; i < KVT * KCH; i += 256) {
-    const int r = i / KCH, c = i - r * KCH;
-    if (c >= dch) *(u32x4*)(ks_ + r * KROW + c * 16) = u32x4{0u, 0u, 0u, 0u};
-  }
-  for (int i = tid; i < KVT * VCH; i += 256) {
-    const int r = i / VCH, c = i - r * VCH;
-    if (c >= dch) *(u32x4*)(vs_ + r * VROW + c * 16) = u32x4{0u, 0u, 0u, 0u};
+  for (int b = 0; b < (DBUF ? 2 : 1); ++b) {
+    for (int i = tid; i < KVT * KCH; i += 256) {
+      const int r = i / KCH, c = i - r * KCH;
+      if (c >= dch) *(u32x4*)(ks_ + b * TILE_BYTES + r * KROW + c * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+    for (int i = tid; i < KVT * VCH; i += 256) {
+      const int r = i / VCH, c = i - r * VCH;
+      if (c >= dch) *(u32x4*)(vs_ + b * TILE_BYTES + r * VROW + c * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
   }
 
-  // staging: chunks of the K/V tile handled by this thread
-  constexpr int KPT = (KVT * KCH + 255) / 256;   // K chunks per thread (upper bound)
-  constexpr int VPT = (KVT * VCH + 255) / 256;
-  u32x4 kr[KPT], vr[VPT];
-  const int nch = KVT * dch;                     // valid chunks per tile (same for K and V)
-  auto load_kv = [&](int kv0) {
+  // staging: chunks of the K/V tile handled by this thread.  Raw buffer loads with the hardware range check do the
+  // predication: a chunk this thread does not own, or a key row >= Skv, is an out-of-range offset and reads as zero —
+  // no branches, no selects, no 64-bit address math per tile (one 32-bit add per chunk).
+  constexpr int KPT = (KVT * KCH + 255) / 256;   // chunks per thread (upper bound; K and V tiles have equal counts)
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  u32x4 kr[KPT], vr[KPT];
+  const int nch = KVT * dch;                     // valid chunks per tile
+  const auto rK = __builtin_amdgcn_make_buffer_rsrc((void*)K, (short)0, (int)(((size_t)(p.Skv - 1) * p.ldk + d) * 2), 0x00020000);
+  const auto rV = __builtin_amdgcn_make_buffer_rsrc((void*)V, (short)0, (int)(((size_t)(p.Skv - 1) * p.ldv + d) * 2), 0x00020000);
+  unsigned koff[KPT], voffs[KPT];
+  int klds[KPT], vlds[KPT];
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) {
+    const int idx = tid + i * 256;
+    const bool own = idx < nch;
+    const int r = own ? idx / dch : 0;
+    const int c = own ? idx - r * dch : 0;
+    koff[i] = own ? (unsigned)((r * p.ldk + c * 8) * 2) : OOB;
+    voffs[i] = own ? (unsigned)((r * p.ldv + c * 8) * 2) : OOB;
+    klds[i] = own ? r * KROW + c * 16 : -1;
+    vlds[i] = own ? r * VROW + c * 16 : -1;
+  }
+  const unsigned kstep = (unsigned)(KVT * p.ldk * 2), vstep = (unsigned)(KVT * p.ldv * 2);
+  auto load_kv = [&]() {                          // loads the NEXT tile and advances the offsets
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
-      const int idx = tid + i * 256;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (idx < nch) {
-        const int r = idx / dch, c = idx - r * dch;
-        if (kv0 + r < p.Skv) v = *(const u32x4*)(K + (size_t)(kv0 + r) * p.ldk + c * 8);
-      }
-      kr[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-      const int idx = tid + i * 256;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (idx < nch) {
-        const int r = idx / dch, c = idx - r * dch;
-        if (kv0 + r < p.Skv) v = *(const u32x4*)(V + (size_t)(kv0 + r) * p.ldv + c * 8);
-      }
-      vr[i] = v;
+      kr[i] = __builtin_amdgcn_raw_buffer_load_b128(rK, (int)koff[i], 0, 0);
+      vr[i] = __builtin_amdgcn_raw_buffer_load_b128(rV, (int)voffs[i], 0, 0);
+      koff[i] = koff[i] >= OOB ? OOB : koff[i] + kstep;
+      voffs[i] = voffs[i] >= OOB ? OOB : voffs[i] + vstep;
     }
   };
-  auto store_kv = [&]() {
+  auto store_kv = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
-      const int idx = tid + i * 256;
-      if (idx < nch) {
-        const int r = idx / dch, c = idx - r * dch;
-        *(u32x4*)(ks_ + r * KROW + c * 16) = kr[i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-      const int idx = tid + i * 256;
-      if (idx < nch) {
-        const int r = idx / dch, c = idx - r * dch;
-        *(u32x4*)(vs_ + r * VROW + c * 16) = vr[i];
+      if (klds[i] >= 0) {
+        *(u32x4*)(ks_ + buf * TILE_BYTES + klds[i]) = kr[i];
+        *(u32x4*)(vs_ + buf * TILE_BYTES + vlds[i]) = vr[i];
       }
     }
   };
@@ -119,26 +121,31 @@ __global__ __launch_bounds__(256) void attention_kernel(const es_attn_desc p) {
   }
   const float sl2 = p.scale * 1.4426950408889634f;
 
-  load_kv(0);
+  load_kv();
+  if (DBUF) { store_kv(0); if (KVT < p.Skv) load_kv(); }
+  int buf = 0;
   for (int kv0 = 0; kv0 < p.Skv; kv0 += KVT) {
-    __syncthreads();               // previous tile fully consumed (and pad zeroing visible on first pass)
-    store_kv();
-    __syncthreads();
-    if (kv0 + KVT < p.Skv) load_kv(kv0 + KVT);
+    if (DBUF) {
+      __syncthreads();             // tile kv0 (written last iteration / prologue) visible; tile kv0-KVT fully consumed
+    } else {
+      __syncthreads();             // previous tile fully consumed (and pad zeroing visible on first pass)
+      store_kv(0);
+      __syncthreads();
+      if (kv0 + KVT < p.Skv) load_kv();
+    }
+    const char* kb = ks_ + buf * TILE_BYTES;
+    const char* vb = vs_ + buf * TILE_BYTES;
 
-    // ---- S^T = K Q^T ----
+    // ---- S^T = K Q^T ----  (first K-step starts the chain from a literal zero accumulator)
     f32x4 s[QF][KF];
-#pragma unroll
-    for (int f = 0; f < QF; ++f)
-#pragma unroll
-      for (int kf = 0; kf < KF; ++kf) s[f][kf] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ksx = 0; ksx < KS; ++ksx) {
 #pragma unroll
       for (int kf = 0; kf < KF; ++kf) {
-        const auto ka = as_vec8<T>(*(const u32x4*)(ks_ + (kf * 16 + col) * KROW + (4 * ksx + g) * 16));
+        const auto ka = as_vec8<T>(*(const u32x4*)(kb + (kf * 16 + col) * KROW + (4 * ksx + g) * 16));
 #pragma unroll
-        for (int f = 0; f < QF; ++f) s[f][kf] = mfma16(ka, qf[f][ksx], s[f][kf]);
+        for (int f = 0; f < QF; ++f)
+          s[f][kf] = mfma16(ka, qf[f][ksx], ksx == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : s[f][kf]);
       }
     }
     // ---- online softmax (per query = per lane column) ----
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const es_attn_desc p) {
         for (int kf = 0; kf < KF; ++kf)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (kv0 + kf * 16 + g * 4 + r >= p.Skv) s[f][kf][r] = -3.0e38f;
+            s[f][kf][r] = (kv0 + kf * 16 + g * 4 + r >= p.Skv) ? -3.0e38f : s[f][kf][r];
       }
       float mx = s[f][0][0];
 #pragma unroll
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const es_attn_desc p) {
       for (int j = 0; j < DF; ++j) {
         // lane 4q+pp of each 16-lane group supplies row q, columns 4pp..4pp+3 of its 4x16 block
         const int q = col >> 2, pp = col & 3;
-        const char* base = vs_ + (32 * sx + 4 * g + q) * VROW + (j * 16 + 4 * pp) * 2;
+        const char* base = vb + (32 * sx + 4 * g + q) * VROW + (j * 16 + 4 * pp) * 2;
         const u32x2 lo = lds_read_tr16(base);
         const u32x2 hi = lds_read_tr16(base + 16 * VROW);
         const u32x4 av = {lo[0], lo[1], hi[0], hi[1]};
@@ -206,6 +213,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const es_attn_desc p) {
 #pragma unroll
         for (int f = 0; f < QF; ++f) o[f][j] = mfma16(va, pb[f][sx], o[f][j]);
       }
+    }
+    if (DBUF) {
+      // tile kv0+KVT (in registers since the top of this iteration) -> the other buffer; then fetch kv0+2*KVT
+      if (kv0 + KVT < p.Skv) {
+        store_kv(buf ^ 1);
+        if (kv0 + 2 * KVT < p.Skv) load_kv();
+      }
+      buf ^= 1;
     }
   }
 
@@ -231,7 +246,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const es_attn_desc p) {
 
 template <typename T, int KS, int DF, int QF, int KVT>
 int launch_attn(const es_attn_desc& d, hipStream_t st) {
-  constexpr int lds = KVT * (32 * KS * 2 + 16) + KVT * (16 * DF * 2 + 16);
+  constexpr int lds = (KS <= 5 ? 2 : 1) * (KVT * (32 * KS * 2 + 16) + KVT * (16 * DF * 2 + 16));
   auto kfn = attention_kernel<T, KS, DF, QF, KVT>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -245,12 +260,14 @@ int launch_attn(const es_attn_desc& d, hipStream_t st) {
 
 template <typename T>
 int dispatch(const es_attn_desc& d, hipStream_t st) {
+  // 32 queries per wave (128 per block) only when that still yields >= 2 blocks per CU; else 16 per wave
+  const bool big = (long long)((d.Sq + 127) / 128) * d.heads * d.N >= 512;
   switch (d.d) {
     case 8: case 16: return launch_attn<T, 1, 1, 2, 64>(d, st);
     case 24: case 32: return launch_attn<T, 1, 2, 2, 64>(d, st);
-    case 40: case 48: return launch_attn<T, 2, 3, 2, 64>(d, st);
+    case 40: case 48: return big ? launch_attn<T, 2, 3, 2, 64>(d, st) : launch_attn<T, 2, 3, 1, 64>(d, st);
     case 64: return launch_attn<T, 2, 4, 2, 64>(d, st);
-    case 80: return launch_attn<T, 3, 5, 2, 64>(d, st);
+    case 80: return big ? launch_attn<T, 3, 5, 2, 64>(d, st) : launch_attn<T, 3, 5, 1, 64>(d, st);
     case 128: return launch_attn<T, 4, 8, 2, 64>(d, st);
     case 160: return launch_attn<T, 5, 10, 2, 64>(d, st);
     case 512: return launch_attn<T, 16, 32, 1, 32>(d, st);

@@ -337,6 +337,10 @@ class StableDiffusionControlNetPipeline:
         was = self._runner.concurrent
         self._runner.concurrent = False      # serial chains: each launch is timed with the GPU to itself
         try:
+            loop.step_idx.zero_()
+            loop.one_step()                  # eager serial warm-up: sizes lane-0 scratch outside the capture
+            prof.meta.clear()
+            torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 loop.one_step()
