@@ -155,6 +155,8 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="width-reduced config (plumbing check only, not the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-throughput-mode", action="store_true",
+                    help="skip the extra batch-8 (BASELINE configs[2]) measurement reported beside the headline value")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -223,6 +225,24 @@ def main():
         if not args.no_roofline:
             line["roofline"] = gemm_roofline(pipe)
             log("roofline leg done")
+        if not args.no_throughput_mode and world == 1 and B != 8 and not args.tiny:
+            # BASELINE configs[2]: same path, 8 images per step (hipGraph-captured, throughput mode); reported beside
+            # the headline value, never instead of it
+            lat8, pe8, ne8, imgs8, cn8 = make_inputs(ucfg, vcfg, 8, device, seed=42)
+
+            def one8():
+                return pipe(prompt_embeds=pe8, negative_prompt_embeds=ne8, image=imgs8, latents=lat8, guidance_scale=7.5,
+                            num_inference_steps=args.ddim_steps, output_type="pt", cond_noise=cn8).images
+            one8()
+            torch.cuda.synchronize()
+            t8 = time.perf_counter()
+            img8 = one8()
+            torch.cuda.synchronize()
+            t8 = time.perf_counter() - t8
+            assert bool(torch.isfinite(img8).all())
+            line["throughput_mode"] = {"workload": "BASELINE configs[2]: same path, batch=8 per step", "value": round(8 / t8, 4),
+                                       "unit": "images/s", "ms_per_step": round(t8 * 1e3, 1), "steps": 1}
+            log(f"throughput mode (batch 8): {8 / t8:.3f} images/s")
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(ws, ucfg, B, args.ddim_steps, args.tiny)
             log("cpu baseline done")

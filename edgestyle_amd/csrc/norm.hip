@@ -54,10 +54,20 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const es_gn_desc p) {
   }
   __syncthreads();
   const int nchunk = gridDim.x;
-  for (int gi = threadIdx.x; gi < p.groups; gi += 256) {
-    float s = 0.f, ss = 0.f;
-    for (int ps = 0; ps < PS; ++ps)
-      for (int c = gi * cpg; c < (gi + 1) * cpg; ++c) { s += csum[ps * C + c]; ss += csq[ps * C + c]; }
+  // L lanes per group walk the group's PS*cpg LDS entries, then a fixed xor tree folds them: no serial tail
+  const int L = p.groups <= 32 ? 8 : 4;
+  const int gi = threadIdx.x / L, l = threadIdx.x % L;
+  float s = 0.f, ss = 0.f;
+  if (gi < p.groups) {
+    const int items = PS * cpg;
+    for (int it = l; it < items; it += L) {
+      const int ps = it / cpg, c = gi * cpg + (it - ps * cpg);
+      s += csum[ps * C + c];
+      ss += csq[ps * C + c];
+    }
+  }
+  for (int o = 1; o < L; o <<= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+  if (gi < p.groups && l == 0) {
     float* o = p.partials + ((size_t)n * nchunk + chunk) * p.groups * 2 + gi * 2;
     o[0] = s; o[1] = ss;
   }
