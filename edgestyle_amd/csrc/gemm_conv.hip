@@ -23,7 +23,6 @@
 
 namespace {
 
-constexpr int BM = 128;
 constexpr int BK = 64;
 
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -33,12 +32,16 @@ ES_DEVICE void store_elems(T* o, const float* v, int n) {
   for (int r = 0; r < n; ++r) o[r] = from_f32<T>(v[r]);
 }
 
-template <typename T, int BN, bool ALIGNED, int STAGES>
-__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void conv_gemm_kernel(const es_gemm_desc p, const int M,
-                                                                            const int nk) {
+template <typename T, int BM, int BN, bool ALIGNED, int STAGES>
+__global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void conv_gemm_kernel(const es_gemm_desc p,
+                                                                                              const int M,
+                                                                                              const int nk) {
+  constexpr int NW = BM / 32;        // waves: (BM/64) along pixels x 2 along couts; each owns 64 px x BN/2 couts
+  constexpr int NT = NW * 64;
   constexpr int FM = 4;              // pixel fragments per wave (64 pixels)
   constexpr int FN = BN / 32;        // cout fragments per wave (BN/2 couts)
-  constexpr int WI = BN / 32;        // weight DMA instructions per wave per K-step (8 rows each)
+  constexpr int WP = BN / 8;         // weight DMA pieces per K-step (8 rows each), dealt round-robin-by-block to waves
+  constexpr int WI = (WP + NW - 1) / NW;
   constexpr int XT = BM * BK * 2;    // bytes per stage
   constexpr int WT = BN * BK * 2;
   constexpr int EROW = BN * 2 + 16;  // epilogue tile row stride (bytes), padded against bank conflicts
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void conv_gemm_kernel(con
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % (BM / 64), wn = wave / (BM / 64);
   const int tile_m = blockIdx.x, tile_n = blockIdx.y, z = blockIdx.z;
   if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 
@@ -92,8 +95,10 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void conv_gemm_kernel(con
       (void*)(p.x2 ? p.x2 : p.x), (short)0, (int)((size_t)p.N * p.Hsrc * p.Wsrc * (p.x2 ? p.C2 : p.C1) * 2), 0x00020000);
   unsigned woff[WI];
 #pragma unroll
-  for (int i = 0; i < WI; ++i)
-    woff[i] = (unsigned)(((size_t)(tile_n * BN + (BN / 4) * wave + 8 * i + lrow) * p.Kpad + kc * 8) * 2);
+  for (int i = 0; i < WI; ++i) {
+    const int piece = wave * WI + i;               // 8 weight rows; pieces beyond the tile read out of range (zeros)
+    woff[i] = piece < WP ? (unsigned)(((size_t)(tile_n * BN + 8 * piece + lrow) * p.Kpad + kc * 8) * 2) : OOB;
+  }
 
   int tap, cpos;
   {
@@ -121,7 +126,8 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void conv_gemm_kernel(con
     const int soff_w = ks * (BK * 2);
 #pragma unroll
     for (int i = 0; i < WI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(ws + ((BN / 4) * wave + 8 * i) * 128), 16, (int)woff[i], soff_w, 0, 0);
+      if (wave * WI + i < WP)                         // wave-uniform
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(ws + (wave * WI + i) * 1024), 16, (int)woff[i], soff_w, 0, 0);
     if constexpr (ALIGNED) {
       const int second = cpos >= p.C1 ? 1 : 0;            // wave-uniform: a K-step never straddles taps or sources
       const int cs = second ? p.C2 : p.C1;
@@ -193,7 +199,6 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void conv_gemm_kernel(con
       wa0[i] = as_vec8<T>(*(const u32x4*)(ws + row * 128 + (((0 + fq) ^ (row & 7)) << 4)));
     }
     if (ks + STAGES - 1 < ks1) issue_tile(ks + STAGES - 1, istage);
-    istage = istage + 1 == STAGES ? 0 : istage + 1;
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
       const int row = wm * 64 + j * 16 + frow;
@@ -212,6 +217,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void conv_gemm_kernel(con
     for (int i = 0; i < FN; ++i)
 #pragma unroll
       for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(wa1[i], xa1[j], acc[i][j]);
+    istage = istage + 1 == STAGES ? 0 : istage + 1;
     stage = stage + 1 == STAGES ? 0 : stage + 1;
   }
 
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void conv_gemm_kernel(con
   const T* resp = (const T*)p.residual;
   if ((Cstore & 7) == 0) {
     const int CH = BNo / 8;
-    for (int idx = tid; idx < BM * CH; idx += 256) {
+    for (int idx = tid; idx < BM * CH; idx += NT) {
       const int row = idx / CH, ch = idx - row * CH;
       const int m = tile_m * BM + row, c = c_tile + ch * 8;
       if (m < M && c < Cstore) {
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void conv_gemm_kernel(con
     }
   } else {
     // narrow outputs (conv_out: 4 or 3 channels): scalar tail path
-    for (int idx = tid; idx < BM * BNo; idx += 256) {
+    for (int idx = tid; idx < BM * BNo; idx += NT) {
       const int row = idx / BNo, cc = idx - row * BNo;
       const int m = tile_m * BM + row, c = c_tile + cc;
       if (m < M && c < Cstore) {
@@ -370,27 +376,33 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
   const int nk = d.Kpad / BK;
   const int Ctot = d.C1 + d.C2;
   const bool aligned = (Ctot % BK == 0) && (d.C1 % BK == 0);
-  dim3 grid((M + BM - 1) / BM, d.rows_padded / d.bn, d.splitk);
-  // Pipeline depth: 2 stages x 2 workgroups per CU by default; 3-4 stages (1 workgroup per CU) selectable for tuning.
+  // Pixel tile: 128 rows x 4 waves (2 workgroups/CU) by default; 256 rows x 8 waves (1 workgroup/CU) selectable (bm).
+  const int tn = d.rows_padded / d.bn;
+  int bm = d.bm;
+  if (bm == 0) bm = 128;   // measured: 2 independent 128-row workgroups per CU beat one 256-row 8-wave workgroup on every shape
+  dim3 grid((M + bm - 1) / bm, tn, d.splitk);
   int stages = d.stages;
-  if (stages == 0) stages = 2;   // measured (tools/gemm_bench.py): 2 stages x 2 workgroups/CU beats a 3-4 deep ring at 1/CU on every step shape
-#define ES_LAUNCH(BNV, AL, ST)                                                                              \
+  if (stages == 0) stages = 2;   // measured (tools/gemm_bench.py): 2 stages x 2 workgroups/CU beats a 3-4 deep ring at 1/CU
+#define ES_LAUNCH(BMV, BNV, AL, ST)                                                                         \
   do {                                                                                                      \
-    auto kfn = conv_gemm_kernel<T, BNV, AL, ST>;                                                            \
-    const size_t lds = (size_t)ST * (BM + BNV) * BK * 2;                                                    \
+    auto kfn = conv_gemm_kernel<T, BMV, BNV, AL, ST>;                                                       \
+    const size_t lds = (size_t)ST * (BMV + BNV) * BK * 2;                                                   \
     static bool attr_set = false;                                                                           \
     if (!attr_set) {                                                                                        \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
       attr_set = true;                                                                                      \
     }                                                                                                       \
-    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, d, M, nk);                                            \
+    hipLaunchKernelGGL(kfn, grid, dim3(BMV * 2), lds, st, d, M, nk);                                        \
   } while (0)
-#define ES_LAUNCH_ST(BNV, AL)                                                                               \
+#define ES_LAUNCH_ST(BNV)                                                                                   \
   do {                                                                                                      \
-    if (stages == 2) ES_LAUNCH(BNV, AL, 2); else if (stages == 3) ES_LAUNCH(BNV, AL, 3); else ES_LAUNCH(BNV, AL, 4); \
+    if (bm == 256) ES_LAUNCH(256, BNV, true, 2);                                                            \
+    else if (stages == 2) ES_LAUNCH(128, BNV, true, 2);                                                     \
+    else if (stages == 3) ES_LAUNCH(128, BNV, true, 3);                                                     \
+    else ES_LAUNCH(128, BNV, true, 4);                                                                      \
   } while (0)
-  if (d.bn == 128) { if (aligned) ES_LAUNCH_ST(128, true); else ES_LAUNCH(128, false, 2); }
-  else             { if (aligned) ES_LAUNCH_ST(160, true); else ES_LAUNCH(160, false, 2); }
+  if (d.bn == 128) { if (aligned) ES_LAUNCH_ST(128); else ES_LAUNCH(128, 128, false, 2); }
+  else             { if (aligned) ES_LAUNCH_ST(160); else ES_LAUNCH(128, 160, false, 2); }
 #undef ES_LAUNCH_ST
 #undef ES_LAUNCH
   if (d.splitk > 1) {
@@ -425,6 +437,8 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
   if (d->splitk > 1 && (!d->workspace || d->act == ES_ACT_GEGLU)) { es_set_error("es_conv_gemm: splitk needs workspace and no GEGLU"); return -1; }
   if (d->act == ES_ACT_GEGLU && (d->bn != 128 || d->Cout % 32)) { es_set_error("es_conv_gemm: GEGLU needs bn=128, Cout%32==0"); return -1; }
   if (d->N < 1 || d->Hout < 1 || d->Wout < 1) { es_set_error("es_conv_gemm: empty problem"); return -1; }
+  if (d->bm != 0 && d->bm != 128 && d->bm != 256) { es_set_error("es_conv_gemm: bm must be 0 (auto), 128 or 256"); return -1; }
+  if (d->bm == 256 && (d->C1 % BK || d->C2 % BK || d->splitk != 1)) { es_set_error("es_conv_gemm: bm=256 needs 64-aligned channels and splitk=1"); return -1; }
   if (d->stages != 0 && (d->stages < 2 || d->stages > 4)) { es_set_error("es_conv_gemm: stages must be 0 (auto), 2, 3 or 4"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   int rc = d->dtype == ES_F16 ? launch<f16>(*d, st) : launch<bf16>(*d, st);

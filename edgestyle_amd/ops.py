@@ -34,6 +34,7 @@ class lane:
 
 import os as _os
 SPLITK_TARGET = int(_os.environ.get("ES_SPLITK_TARGET", "320"))   # workgroups a split-K launch aims for
+FORCE_BM = 0        # tuning knob: 0 = kernel picks the pixel tile (128 / 256)
 FORCE_STAGES = 0    # tuning knob (tools/gemm_bench.py): 0 = kernel picks the LDS ring depth
 PROFILE = None      # set to a Profiler by bench.py: every es_conv_gemm launch gets an in-kernel timing slot
 
@@ -215,6 +216,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     d.temb_stride = temb.stride(0) if temb is not None else 0
     d.act, d.splitk, d.bn, d.dtype, d.out_scale = act_i, splitk, pw.bn, _dt(x), out_scale
     d.stages = stages or FORCE_STAGES
+    d.bm = FORCE_BM
     if splitk > 1:
         ws = _get_workspace(splitk * M * pw.rows_padded * 4, x.device)
         d.workspace = ws.data_ptr()

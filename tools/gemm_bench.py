@@ -24,7 +24,7 @@ SHAPES_B8 = [(16, 64, 320, 320, 3), (48, 64, 320, 320, 3), (16, 32, 640, 640, 3)
              (16, 16, 1280, 10240, 1)]
 
 
-def bench(shape, stages, R=8, dtype=torch.float16, splitk=None):
+def bench(shape, stages, R=8, dtype=torch.float16, splitk=None, bm=0):
     N, H, Cin, Cout, k = shape
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
@@ -34,6 +34,7 @@ def bench(shape, stages, R=8, dtype=torch.float16, splitk=None):
                            torch.randn(Cout, generator=g, device=dev) * 0.1, dtype, dev, geglu=geglu) for _ in range(R)]
     outs = [None] * R
     ops.FORCE_STAGES = stages
+    ops.FORCE_BM = bm
     try:
         for i in range(R):
             outs[i] = ops.conv_gemm(x, pws[i], splitk=splitk)
@@ -49,6 +50,7 @@ def bench(shape, stages, R=8, dtype=torch.float16, splitk=None):
             best = min(best, e0.elapsed_time(e1) / R)
     finally:
         ops.FORCE_STAGES = 0
+        ops.FORCE_BM = 0
     M = N * H * H
     flops = 2.0 * M * Cout * k * k * Cin
     sk = splitk or (1 if geglu else ops.choose_splitk(M, pws[0].rows_padded, pws[0].bn, pws[0].kpad))
@@ -59,15 +61,22 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stages", default="2,3,4")
     ap.add_argument("--shapes", default="b1")
+    ap.add_argument("--bm", default="0")
     a = ap.parse_args()
     st = [int(s) for s in a.stages.split(",")]
     shapes = SHAPES_B1 if a.shapes == "b1" else SHAPES_B8
-    print("shape(N,H,Cin,Cout,k)  M  splitk | " + " | ".join(f"st{s}: us TF/s" for s in st), flush=True)
+    bms = [int(b) for b in a.bm.split(",")]
+    print("shape(N,H,Cin,Cout,k)  M  splitk | " + " | ".join(f"st{s}/bm{b}: us TF/s" for s in st for b in bms), flush=True)
     for shp in shapes:
         cells = []
         for s in st:
-            us, tf, sk = bench(shp, s)
-            cells.append(f"{us:7.1f} {tf:5.0f}")
+          for b in bms:
+            try:
+                us, tf, sk = bench(shp, s, bm=b, splitk=1 if b == 256 else None)
+                cells.append(f"{us:7.1f} {tf:5.0f}")
+            except Exception as e:
+                cells.append(f"  n/a ({str(e)[:30]})")
+                sk = 0
         print(f"{shp}  M={shp[0]*shp[1]*shp[1]} sk={sk} | " + " | ".join(cells), flush=True)
 
 
