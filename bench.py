@@ -103,7 +103,11 @@ def gemm_roofline(pipe):
     f3 = sum(m[0] for m, _ in res if m[1] == 3)
     t3 = sum(t for m, t in res if m[1] == 3)
     shapes = {}
-    for (fl, k, shp), t in res:
+    if os.environ.get("ES_DUMP_GEMM"):
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "gemm_step_launches.json"), "w") as f:
+            json.dump([dict(geom=m[3], seconds=t) for m, t in res], f)
+    for (fl, k, shp, _g), t in res:
         a = shapes.setdefault(shp, [0, 0.0, 0.0])
         a[0] += 1; a[1] += t; a[2] += fl
     if os.environ.get("ES_DUMP_GEMM"):
@@ -155,6 +159,8 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="width-reduced config (plumbing check only, not the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches (needed under rocprofv3 --pmc, which cannot "
+                                                            "collect counters through a hipGraph replay)")
     ap.add_argument("--no-throughput-mode", action="store_true",
                     help="skip the extra batch-8 (BASELINE configs[2]) measurement reported beside the headline value")
     args = ap.parse_args()
@@ -176,6 +182,8 @@ def main():
     log(f"rank {rank}/{world}: building weights + packing on {device}")
     pipe, ws, ucfg, vcfg = build_pipeline(device, dtype, tiny=args.tiny)
     B = args.batch
+    if args.no_graph:
+        pipe.use_graph = False
     from edgestyle_amd.dist import shard_seed, gather_images
     lat, pe, ne, imgs, cn = make_inputs(ucfg, vcfg, B, device, seed=shard_seed(42, rank, B))
 

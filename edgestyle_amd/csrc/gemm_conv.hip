@@ -52,7 +52,19 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % (BM / 64), wn = wave / (BM / 64);
-  const int tile_m = blockIdx.x, tile_n = blockIdx.y, z = blockIdx.z;
+  // XCD-aware tile mapping.  Workgroups are dealt round-robin to the 8 XCDs (private L2 each), so linear block id b
+  // runs on XCD b % 8.  Give every XCD one CONTIGUOUS chunk of the tile list, ordered so that consecutive tiles share
+  // the larger operand: weights larger than activations (small M, deep layers) -> tile_m fastest, an XCD owns whole
+  // (tile_n, k-slice) columns and each weight byte crosses the fabric once instead of 8 times; otherwise tile_n fastest.
+  int tile_m, tile_n, z;
+  {
+    const int tm = (M + BM - 1) / BM, tn = p.rows_padded / BN;
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);      // bijective for any nwg
+    if (p.xcd_m_fastest) { tile_m = w % tm; const int t = w / tm; tile_n = t % tn; z = t / tn; }
+    else                 { tile_n = w % tn; const int t = w / tn; tile_m = t % tm; z = t / tm; }
+  }
   if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 
   const int ks0 = (int)(((long long)nk * z) / p.splitk);
@@ -380,7 +392,7 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
   const int tn = d.rows_padded / d.bn;
   int bm = d.bm;
   if (bm == 0) bm = 128;   // measured: 2 independent 128-row workgroups per CU beat one 256-row 8-wave workgroup on every shape
-  dim3 grid((M + bm - 1) / bm, tn, d.splitk);
+  dim3 grid(((M + bm - 1) / bm) * tn * d.splitk);
   int stages = d.stages;
   if (stages == 0) stages = 2;   // measured (tools/gemm_bench.py): 2 stages x 2 workgroups/CU beats a 3-4 deep ring at 1/CU
 #define ES_LAUNCH(BMV, BNV, AL, ST)                                                                         \

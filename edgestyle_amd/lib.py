@@ -22,7 +22,7 @@ class GemmDesc(C.Structure):
         ("rows_padded", C.c_int32), ("Kpad", C.c_int32),
         ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("upsample", C.c_int32), ("temb_stride", C.c_int32), ("act", C.c_int32), ("splitk", C.c_int32),
-        ("bn", C.c_int32), ("dtype", C.c_int32), ("stages", C.c_int32), ("bm", C.c_int32), ("out_scale", C.c_float),
+        ("bn", C.c_int32), ("dtype", C.c_int32), ("stages", C.c_int32), ("xcd_m_fastest", C.c_int32), ("bm", C.c_int32), ("out_scale", C.c_float),
     ]
 
 

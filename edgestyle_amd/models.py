@@ -616,7 +616,7 @@ class StepRunner:
         self.kmax = max(len(p) for _, p in self.groups)
         self.ctx_unet = None
         self.ctx_nets = None
-        self.concurrent = True
+        self.concurrent = os.environ.get("ES_SERIAL") != "1"     # ES_SERIAL=1: one chain at a time (profiling)
         self._streams = None
 
     @classmethod

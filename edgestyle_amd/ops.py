@@ -34,6 +34,7 @@ class lane:
 
 import os as _os
 SPLITK_TARGET = int(_os.environ.get("ES_SPLITK_TARGET", "320"))   # workgroups a split-K launch aims for
+XCD_ORDER = -1      # tuning knob: -1 auto, 0 tile_n fastest, 1 tile_m fastest
 FORCE_BM = 0        # tuning knob: 0 = kernel picks the pixel tile (128 / 256)
 FORCE_STAGES = 0    # tuning knob (tools/gemm_bench.py): 0 = kernel picks the LDS ring depth
 PROFILE = None      # set to a Profiler by bench.py: every es_conv_gemm launch gets an in-kernel timing slot
@@ -216,13 +217,19 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     d.temb_stride = temb.stride(0) if temb is not None else 0
     d.act, d.splitk, d.bn, d.dtype, d.out_scale = act_i, splitk, pw.bn, _dt(x), out_scale
     d.stages = stages or FORCE_STAGES
+    # XCD chunk order: keep the larger operand's tiles together on one XCD (see conv_gemm_kernel)
+    d.xcd_m_fastest = (1 if (splitk == 1 and M <= 2048 and pw.w.numel() > x.numel() + (x2.numel() if x2 is not None else 0)) else 0) \
+        if XCD_ORDER < 0 else XCD_ORDER
     d.bm = FORCE_BM
     if splitk > 1:
         ws = _get_workspace(splitk * M * pw.rows_padded * 4, x.device)
         d.workspace = ws.data_ptr()
     if PROFILE is not None:           # bench.py roofline leg: in-kernel s_memrealtime stamps for this launch
-        d.prof = PROFILE.next((2.0 * M * pw.cout * k * k * (C1 + C2), k, (M, pw.cout, k * k * (C1 + C2), stride,
-                                                                             splitk, pw.bn)))
+        d.prof = PROFILE.next((2.0 * M * pw.cout * k * k * (C1 + C2), k,
+                               (M, pw.cout, k * k * (C1 + C2), stride, splitk, pw.bn),
+                               dict(N=N, H=H, W=W, C1=C1, C2=C2, cout=pw.cout, k=k, stride=stride, pad=pad,
+                                    upsample=bool(upsample), geglu=pw.geglu, splitk=splitk, Hout=Hout, Wout=Wout,
+                                    residual=residual is not None, temb=temb is not None)))
     L.check(L.load().es_conv_gemm(C.byref(d), _stream()), "es_conv_gemm")
     return out
 

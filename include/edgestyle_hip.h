@@ -62,6 +62,7 @@ typedef struct {
   int32_t bn;                 /* N tile the weights were packed for: 128 or 160 */
   int32_t dtype;
   int32_t stages;             /* LDS ring depth: 0 = auto, 2 (2 workgroups/CU), 3 or 4 (1 workgroup/CU) */
+  int32_t xcd_m_fastest;      /* tile order inside an XCD's chunk: 1 = tile_m fastest (weights are the larger operand) */
   int32_t bm;                 /* pixel tile: 0 = auto, 128 (4 waves) or 256 (8 waves, large M only) */
   float out_scale;
 } es_gemm_desc;

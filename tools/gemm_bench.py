@@ -62,10 +62,12 @@ def main():
     ap.add_argument("--stages", default="2,3,4")
     ap.add_argument("--shapes", default="b1")
     ap.add_argument("--bm", default="0")
+    ap.add_argument("--xcd", default="-1")
     a = ap.parse_args()
     st = [int(s) for s in a.stages.split(",")]
     shapes = SHAPES_B1 if a.shapes == "b1" else SHAPES_B8
     bms = [int(b) for b in a.bm.split(",")]
+    ops.XCD_ORDER = int(a.xcd)
     print("shape(N,H,Cin,Cout,k)  M  splitk | " + " | ".join(f"st{s}/bm{b}: us TF/s" for s in st for b in bms), flush=True)
     for shp in shapes:
         cells = []
