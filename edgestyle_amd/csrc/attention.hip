@@ -14,7 +14,7 @@
 namespace {
 
 template <typename T, int KS /* QK k-steps of 32: DPAD = 32*KS */, int DF /* dv fragments of 16 */, int QF, int KVT>
-__global__ __launch_bounds__(256, (QF == 1 && KS <= 3) ? 3 : (KS <= 5 ? 2 : 1)) void attention_kernel(const es_attn_desc p) {
+__global__ __launch_bounds__(256, (QF == 1 && KS <= 3) ? 3 : ((KS <= 5 && QF <= 2) ? 2 : 1)) void attention_kernel(const es_attn_desc p) {
   constexpr int DPAD = 32 * KS;
   constexpr int DVP = 16 * DF;
   constexpr int KROW = DPAD * 2 + 16;   // bytes per K row in LDS (+16 B pad)
@@ -262,6 +262,7 @@ template <typename T>
 int dispatch(const es_attn_desc& d, hipStream_t st) {
   // 32 queries per wave (128 per block) only when that still yields >= 2 blocks per CU; else 16 per wave
   const bool big = (long long)((d.Sq + 127) / 128) * d.heads * d.N >= 512;
+  // (64 queries per wave was measured slower: 309 registers -> one wave per SIMD)
   switch (d.d) {
     case 8: case 16: return launch_attn<T, 1, 1, 2, 64>(d, st);
     case 24: case 32: return launch_attn<T, 1, 2, 2, 64>(d, st);

@@ -35,6 +35,7 @@ class lane:
 import os as _os
 SPLITK_TARGET = int(_os.environ.get("ES_SPLITK_TARGET", "320"))   # workgroups a split-K launch aims for
 XCD_ORDER = -1      # tuning knob: -1 auto, 0 tile_n fastest, 1 tile_m fastest
+FORCE_BN = 0        # tuning knob: 0 = per-launch choice between the legal N tiles
 FORCE_BM = 0        # tuning knob: 0 = kernel picks the pixel tile (128 / 256)
 FORCE_STAGES = 0    # tuning knob (tools/gemm_bench.py): 0 = kernel picks the LDS ring depth
 PROFILE = None      # set to a Profiler by bench.py: every es_conv_gemm launch gets an in-kernel timing slot
@@ -167,6 +168,29 @@ def _get_workspace(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
+def choose_launch_bn(M: int, pw: "PackedWeight") -> int:
+    """N tile for this launch.  The packed layout only requires rows_padded % bn == 0, so both 128 and 160 are legal
+    for 640/1280/1920/... couts; pick the one that wastes fewer workgroup rounds (512 resident workgroups: 256 CUs x 2):
+    e.g. M=16384, N=640 is 640 tiles (1.25 rounds) at bn=128 but exactly 512 at bn=160."""
+    if pw.geglu:
+        return 128
+    tm = (M + BM - 1) // BM
+    best, best_cost = pw.bn, None
+    for bn in (160, 128):                       # ties go to the wider tile (more MFMAs per DMA instruction)
+        if pw.rows_padded % bn:
+            continue
+        tiles = tm * (pw.rows_padded // bn)
+        if tiles <= 256:                        # at most one workgroup per CU: duration of one tile
+            cost = float(bn)
+        elif tiles <= 512:                      # some CUs host two workgroups (each then runs ~1.6x longer)
+            cost = bn * (1.0 + 0.6 * (tiles - 256) / 256.0)
+        else:                                   # full rounds of 512 resident workgroups
+            cost = -(-tiles // 512) * bn * 1.6
+        if best_cost is None or cost < best_cost:
+            best, best_cost = bn, cost
+    return best
+
+
 def choose_splitk(M: int, rows_padded: int, bn: int, kpad: int) -> int:
     tiles = ((M + BM - 1) // BM) * (rows_padded // bn)
     nk = kpad // BK
@@ -200,8 +224,9 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     if out is None:
         out = torch.empty((N, Hout, Wout, cstore), dtype=x.dtype, device=x.device)
     M = N * Hout * Wout
+    bn = choose_launch_bn(M, pw) if FORCE_BN == 0 else FORCE_BN
     if splitk is None:
-        splitk = 1 if pw.geglu else choose_splitk(M, pw.rows_padded, pw.bn, pw.kpad)
+        splitk = 1 if pw.geglu else choose_splitk(M, pw.rows_padded, bn, pw.kpad)
     d = L.GemmDesc()
     d.x, d.x2, d.w = x.data_ptr(), (x2.data_ptr() if x2 is not None else None), pw.w.data_ptr()
     d.bias = pw.bias.data_ptr() if pw.bias is not None else None
@@ -215,7 +240,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     d.ksize, d.stride, d.pad = k, stride, pad
     d.upsample = 1 if upsample else 0
     d.temb_stride = temb.stride(0) if temb is not None else 0
-    d.act, d.splitk, d.bn, d.dtype, d.out_scale = act_i, splitk, pw.bn, _dt(x), out_scale
+    d.act, d.splitk, d.bn, d.dtype, d.out_scale = act_i, splitk, bn, _dt(x), out_scale
     d.stages = stages or FORCE_STAGES
     # XCD chunk order: keep the larger operand's tiles together on one XCD (see conv_gemm_kernel)
     d.xcd_m_fastest = (1 if (splitk == 1 and M <= 2048 and pw.w.numel() > x.numel() + (x2.numel() if x2 is not None else 0)) else 0) \
