@@ -116,8 +116,15 @@ def gemm_roofline(pipe):
             log(f"  {shp} {c} {t * 1e6:.0f} {t / c * 1e6:.1f} {fl / t / 1e12:.0f}")
     n = len(res)
     ach = tot_f / tot_t / 1e12
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "r01_gemm_pmc_traffic_b1.json")
+    if os.path.exists(tp):   # HBM-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
+        try:                  # gfx950 corrections applied) over the same 494 launches replayed stand-alone; see DESIGN.md §7
+            traffic = json.load(open(tp)).get("conv_gemm_kernel", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
     return {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv3x3/1x1/linear)", "achieved": round(ach, 2),
-            "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
             "launches_per_step": n, "avg_launch_us": round(tot_t * 1e6 / max(n, 1), 2),
             "algorithmic_gflop_per_launch": round(tot_f / max(n, 1) / 1e9, 3),
             "gemm_time_per_step_ms": round(tot_t * 1e3, 3),
