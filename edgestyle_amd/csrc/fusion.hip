@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int FU_MAX_CHUNK = 64;
+constexpr int FU_MAX_CHUNK = 256;
 
 ES_DEVICE float block_sum(float v, float* red) {
   v = wave_sum(v);
@@ -51,12 +51,11 @@ ES_DEVICE void reduce_partials(const float* part, int nchunk, float cnt, float e
   // wave 0 loads the (<= 64) partial pairs in parallel and reduces them with shuffles (fixed order): no per-thread
   // serial chain of dependent global loads in front of the streaming loop
   if (threadIdx.x < 64) {
-    const int k = threadIdx.x;
-    float s = k < nchunk ? part[k * 2] : 0.f;
-    float ss = k < nchunk ? part[k * 2 + 1] : 0.f;
+    float s = 0.f, ss = 0.f;
+    for (int k = threadIdx.x; k < nchunk; k += 64) { s += part[k * 2]; ss += part[k * 2 + 1]; }   // <= 4 per lane
     s = wave_sum(s);
     ss = wave_sum(ss);
-    if (k == 0) { red[0] = s; red[1] = ss; }
+    if (threadIdx.x == 0) { red[0] = s; red[1] = ss; }
   }
   __syncthreads();
   const float s = red[0], ss = red[1];
@@ -169,7 +168,7 @@ __global__ __launch_bounds__(256) void fusion_pass_c(const es_fusion_desc p, con
 template <typename T>
 int launch_fusion(const es_fusion_desc& d, hipStream_t st) {
   const long long items = (long long)d.HW * (d.C / 8);
-  int nchunk = (int)(items / 1024);
+  int nchunk = (int)(items / 512);
   if (nchunk < 1) nchunk = 1;
   if (nchunk > FU_MAX_CHUNK) nchunk = FU_MAX_CHUNK;
   dim3 grid(nchunk, d.N);

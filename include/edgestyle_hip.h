@@ -104,7 +104,7 @@ int es_layer_norm(const void* x, void* out, const float* gamma, const float* bet
  * res[i]: residual of net i, [N, HW, C] dtype (batch stride res_bs[i] elements so nets batched together can be
  * addressed in place).  Params are repacked pixel-major: w1[C][3][2], b1[C][3], g1/be1[HW][C][3] (dtype),
  * w2[C][3], b2[C], g2/be2[HW][C] (dtype), w3[C], b3[C] (fp32 unless noted).
- * scratch: fp32 [N][2][nchunk<=64][2] partial sums; u: dtype [N,HW,C] intermediate; out: [N,HW,C] dtype. */
+ * scratch: fp32 [N][2][nchunk<=256][2] partial sums; u: dtype [N,HW,C] intermediate; out: [N,HW,C] dtype. */
 typedef struct {
   const void* res[6];
   int64_t res_bs[6];
