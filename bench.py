@@ -43,12 +43,17 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def build_pipeline(device, dtype, seed=0, tiny=False, keep_cpu=False):
+def build_pipeline(device, dtype, seed=0, tiny=False, keep_cpu=False, resolution=512):
     from edgestyle_amd import config as C, weights as W
     from edgestyle_amd.models import (UNet2DConditionModel, ControlNetModel, ControlLoRAModel, AutoencoderKL,
                                       EdgeStyleMultiControlNetModel)
     from edgestyle_amd.pipeline import EdgeStyleStableDiffusionControlNetPipeline
     ucfg, vcfg = (C.tiny_unet(), C.tiny_vae()) if tiny else (C.sd15_unet(), C.sd15_vae())
+    if resolution != ucfg.sample_size * vcfg.scale:
+        import dataclasses
+        # outside the reference's domain (its fusion blocks are hard-wired to 512x512, MC:73-102): LN planes of the
+        # new size are random-init like everything else (BASELINE config 5)
+        ucfg = dataclasses.replace(ucfg, sample_size=resolution // vcfg.scale)
     rank = 4 if tiny else 32
     gen_dev = "cpu" if keep_cpu else device
     ws = dict(
@@ -163,6 +168,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step (BASELINE config 2: 1, config 3: 8)")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--resolution", type=int, default=512, help="512 (the metric) or 768 (BASELINE config 5 stress)")
     ap.add_argument("--tiny", action="store_true", help="width-reduced config (plumbing check only, not the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -187,7 +193,7 @@ def main():
     import faulthandler
     faulthandler.dump_traceback_later(600, repeat=True, file=sys.stderr)     # where are we, if something stalls
     log(f"rank {rank}/{world}: building weights + packing on {device}")
-    pipe, ws, ucfg, vcfg = build_pipeline(device, dtype, tiny=args.tiny)
+    pipe, ws, ucfg, vcfg = build_pipeline(device, dtype, tiny=args.tiny, resolution=args.resolution)
     B = args.batch
     if args.no_graph:
         pipe.use_graph = False
@@ -233,14 +239,14 @@ def main():
             "data": "synthetic (seeded random-init SD1.5-shaped weights, random conds/latents/prompt embeds, seed 42)",
             "config": {"workload": ("TINY plumbing config" if args.tiny else
                                     f"BASELINE configs[{1 if B == 1 else 2}]: full 6-cond edgestyle_multicontrolnet + controllora, "
-                                    f"512x512, {args.ddim_steps} DDIM steps, CFG 7.5, batch={B}/GPU, hipGraph-captured step, "
+                                    f"{args.resolution}x{args.resolution}, {args.ddim_steps} DDIM steps, CFG 7.5, batch={B}/GPU, hipGraph-captured step, "
                                     "cond embedding + VAE decode included"),
                        "images_per_gpu": B, "ddim_steps": args.ddim_steps, "parallelism": f"dp{world} (independent images, one RCCL gather)"},
         }
         if not args.no_roofline:
             line["roofline"] = gemm_roofline(pipe)
             log("roofline leg done")
-        if not args.no_throughput_mode and world == 1 and B != 8 and not args.tiny:
+        if not args.no_throughput_mode and world == 1 and B != 8 and not args.tiny and args.resolution == 512:
             # BASELINE configs[2]: same path, 8 images per step (hipGraph-captured, throughput mode); reported beside
             # the headline value, never instead of it
             lat8, pe8, ne8, imgs8, cn8 = make_inputs(ucfg, vcfg, 8, device, seed=42)

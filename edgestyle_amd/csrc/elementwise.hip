@@ -48,6 +48,43 @@ __global__ void cfg_ddim_kernel(const T* __restrict__ noise, float* __restrict__
 }
 
 template <typename T>
+__global__ void cfg_unipc_kernel(const T* __restrict__ noise, float* __restrict__ lat, float* __restrict__ last,
+                                 float* __restrict__ m0b, float* __restrict__ m1b, T* __restrict__ model_in,
+                                 const float* __restrict__ coef, const int* __restrict__ step_idx, float gs, int B,
+                                 int HW, int L, int Ls, int cfg) {
+  // One UniPC (bh2, order <= 2, predict_x0) step as a linear recombination with host-computed per-step scalars:
+  //   x0  = (x - sigma*eps)/alpha                                   convert_model_output
+  //   xc  = use_c ? cl*last + cm0*m0 + cm1*m1 + cmt*x0 : x          multistep_uni_c_bh_update
+  //   x'  = px*xc + pm0*x0 + pm1*m0                                 multistep_uni_p_bh_update
+  //   history: m1 <- m0, m0 <- x0, last <- xc
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)B * HW * L;
+  if (i >= total) return;
+  const long long mi = (i / L) * Ls + (i % L);
+  const long long mtotal = (long long)B * HW * Ls;
+  const float* c = coef + (size_t)(*step_idx) * 12;
+  float eps;
+  if (cfg) {
+    const float eu = to_f32(noise[i]), ec = to_f32(noise[total + i]);
+    eps = eu + gs * (ec - eu);
+  } else {
+    eps = to_f32(noise[i]);
+  }
+  const float x = lat[i];
+  const float x0 = (x - c[1] * eps) / c[0];
+  const float m0 = m0b[i], m1 = m1b[i];
+  const float xc = c[2] != 0.f ? c[3] * last[i] + c[4] * m0 + c[5] * m1 + c[6] * x0 : x;
+  const float xn = c[7] * xc + c[8] * x0 + c[9] * m0;
+  m1b[i] = m0;
+  m0b[i] = x0;
+  last[i] = xc;
+  lat[i] = xn;
+  const T xt = from_f32<T>(xn);
+  model_in[mi] = xt;
+  if (cfg) model_in[mtotal + mi] = xt;
+}
+
+template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int N, int C, int HW,
                                     int Cpad) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -160,6 +197,24 @@ extern "C" int es_cfg_ddim_step(const void* noise, float* latents, void* model_i
     hipLaunchKernelGGL(cfg_ddim_kernel<bf16>, dim3(nblk(n)), dim3(256), 0, st, (const bf16*)noise, latents,
                        (bf16*)model_in, coef, step_idx, guidance_scale, B, HW, L, Lstride, cfg);
   ES_RET("es_cfg_ddim_step");
+}
+
+extern "C" int es_cfg_unipc_step(const void* noise, float* latents, float* last_sample, float* m0, float* m1,
+                                 void* model_in, const float* coef, const int32_t* step_idx, float guidance_scale,
+                                 int B, int HW, int L, int Lstride, int cfg, int dtype, void* stream) {
+  if (!noise || !latents || !last_sample || !m0 || !m1 || !model_in || !coef || !step_idx || B < 1 || HW < 1 ||
+      L < 1 || Lstride < L) {
+    es_set_error("es_cfg_unipc_step: bad arguments"); return -1;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)B * HW * L;
+  if (dtype == ES_F16)
+    hipLaunchKernelGGL(cfg_unipc_kernel<f16>, dim3(nblk(n)), dim3(256), 0, st, (const f16*)noise, latents,
+                       last_sample, m0, m1, (f16*)model_in, coef, step_idx, guidance_scale, B, HW, L, Lstride, cfg);
+  else
+    hipLaunchKernelGGL(cfg_unipc_kernel<bf16>, dim3(nblk(n)), dim3(256), 0, st, (const bf16*)noise, latents,
+                       last_sample, m0, m1, (bf16*)model_in, coef, step_idx, guidance_scale, B, HW, L, Lstride, cfg);
+  ES_RET("es_cfg_unipc_step");
 }
 
 extern "C" int es_nchw_f32_to_nhwc(const float* in, void* out, int N, int C, int HW, int Cpad, int dtype,

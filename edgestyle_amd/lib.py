@@ -75,6 +75,7 @@ SYMBOLS = {
     "es_fusion_scratch_bytes": (C.c_size_t, [_I]),
     "es_timestep_embedding": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "es_cfg_ddim_step": (C.c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P]),
+    "es_cfg_unipc_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P]),
     "es_nchw_f32_to_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "es_nhwc_to_nchw_f32": (C.c_int, [_P, _P, _I, _I, _I, _I, _F, _F, _I, _I, _P]),
     "es_add": (C.c_int, [_P, _P, _P, _L, _I, _P]),

@@ -380,6 +380,14 @@ def cfg_ddim_step(noise: torch.Tensor, latents: torch.Tensor, model_in: torch.Te
                                       _stream()), "es_cfg_ddim_step")
 
 
+def cfg_unipc_step(noise, latents, last_sample, m0, m1, model_in, coef, step_idx, guidance_scale: float, cfg: bool):
+    """UniPC counterpart of cfg_ddim_step; last_sample/m0/m1 are fp32 [B,H,W,L] state tensors (in place)."""
+    B, H, W, Lc = latents.shape
+    L.check(L.load().es_cfg_unipc_step(_ptr(noise), _ptr(latents), _ptr(last_sample), _ptr(m0), _ptr(m1),
+                                       _ptr(model_in), _ptr(coef), _ptr(step_idx), guidance_scale, B, H * W, Lc,
+                                       model_in.shape[3], 1 if cfg else 0, _dt(noise), _stream()), "es_cfg_unipc_step")
+
+
 def incr(ctr: torch.Tensor):
     L.check(L.load().es_incr(_ptr(ctr), _stream()), "es_incr")
 

@@ -22,7 +22,7 @@ from . import ops
 from .lib import EdgeStyleHipError
 from .models import (AutoencoderKL, ControlNetModel, EdgeStyleMultiControlNetModel, StepRunner,
                      UNet2DConditionModel, _as_nhwc, _as_nchw_view)
-from .schedulers import DDIMScheduler
+from .schedulers import DDIMScheduler, UniPCMultistepScheduler
 
 
 @dataclass
@@ -51,6 +51,8 @@ class _Loop:
         self.step_idx = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.t_rows = torch.zeros((k * N,), dtype=torch.float32, device=dev)
         self.scales_cur = torch.ones((6,), dtype=torch.float32, device=dev)
+        self.hist = [torch.zeros((B, h, w, Lc), dtype=torch.float32, device=dev) for _ in range(3)]   # UniPC state
+        self.unipc = False
         self.t_table = None
         self.scale_table = None
         self.coef = None
@@ -63,8 +65,12 @@ class _Loop:
         ops.gather_row(self.t_table, self.step_idx, self.t_rows)
         ops.gather_row(self.scale_table, self.step_idx, self.scales_cur)
         self.runner.step(self.model_in, self.t_rows, self.conds, [1.0] * 6, self.scales_cur, out=self.noise)
-        ops.cfg_ddim_step(self.noise, self.latents, self.model_in, self.coef, self.step_idx,
-                          float(self.guidance_scale), self.cfg_on)
+        if self.unipc:
+            ops.cfg_unipc_step(self.noise, self.latents, self.hist[0], self.hist[1], self.hist[2], self.model_in,
+                               self.coef, self.step_idx, float(self.guidance_scale), self.cfg_on)
+        else:
+            ops.cfg_ddim_step(self.noise, self.latents, self.model_in, self.coef, self.step_idx,
+                              float(self.guidance_scale), self.cfg_on)
         ops.incr(self.step_idx)
 
 
@@ -211,8 +217,9 @@ class StableDiffusionControlNetPipeline:
             raise NotImplementedError("custom timesteps are not supported (the reference path itself is broken: PL:697)")
         if self.device.type != "cuda":
             raise EdgeStyleHipError("the pipeline runs only on an MI355X: call .to('cuda') first")
-        if not isinstance(self.scheduler, DDIMScheduler):
-            raise EdgeStyleHipError("the fused step kernel implements DDIM; assign a DDIMScheduler")
+        if not isinstance(self.scheduler, (DDIMScheduler, UniPCMultistepScheduler)):
+            raise EdgeStyleHipError("the fused step kernels implement DDIM (the BASELINE metric) and UniPC (TT:273); "
+                                    "assign edgestyle_amd.schedulers.DDIMScheduler or UniPCMultistepScheduler")
         nn = len(self.controlnet.nets)
         # PL:243-265 broadcast guidance windows
         if not isinstance(control_guidance_start, list):
@@ -259,13 +266,18 @@ class StableDiffusionControlNetPipeline:
         scale_table = torch.tensor([[c * kk for c, kk in zip(controlnet_conditioning_scale, row)] for row in keep],
                                    dtype=torch.float32)
         dev = self.device
-        regraph = (loop.steps != T) or (loop.guidance_scale != float(guidance_scale)) or loop.graph is None
-        loop.steps, loop.guidance_scale = T, float(guidance_scale)
-        if loop.t_table is None or loop.t_table.shape[0] != T:
+        unipc = isinstance(self.scheduler, UniPCMultistepScheduler)
+        regraph = (loop.steps != T) or (loop.guidance_scale != float(guidance_scale)) or loop.graph is None \
+            or loop.unipc != unipc
+        loop.steps, loop.guidance_scale, loop.unipc = T, float(guidance_scale), unipc
+        cw = 12 if unipc else 4
+        if loop.t_table is None or loop.t_table.shape[0] != T or loop.coef.shape[1] != cw:
             loop.t_table = torch.empty((T, k * N), dtype=torch.float32, device=dev)
             loop.scale_table = torch.empty((T, 6), dtype=torch.float32, device=dev)
-            loop.coef = torch.empty((T, 4), dtype=torch.float32, device=dev)
+            loop.coef = torch.empty((T, cw), dtype=torch.float32, device=dev)
             regraph = True
+        for hbuf in loop.hist:
+            hbuf.zero_()
         loop.t_table.copy_(ts.float()[:, None].expand(T, k * N))
         loop.scale_table.copy_(scale_table)
         loop.coef.copy_(self.scheduler.coef_table())

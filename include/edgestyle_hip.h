@@ -133,6 +133,15 @@ int es_timestep_embedding(const float* t, void* out, int N, int dim, int dtype, 
 int es_cfg_ddim_step(const void* noise, float* latents, void* model_in, const float* coef, const int32_t* step_idx,
                      float guidance_scale, int B, int HW, int L, int Lstride, int cfg, int dtype, void* stream);
 
+/* CFG combine + one UniPCMultistepScheduler step (the scheduler the reference's callers swap in, TT:273 / APP:118):
+ * bh2, solver_order <= 2, predict_x0, epsilon prediction.  The corrector/predictor updates are linear in
+ * {last_sample, m0, m1, x0}; coef: device fp32 [steps][12] = {alpha_t, sigma_t, use_corrector, c_last, c_m0, c_m1,
+ * c_x0, p_x, p_x0, p_m0, 0, 0} computed on the host (edgestyle_amd/schedulers.py).  last_sample/m0/m1: fp32 state
+ * [B,HW,L], zero before the first step. */
+int es_cfg_unipc_step(const void* noise, float* latents, float* last_sample, float* m0, float* m1, void* model_in,
+                      const float* coef, const int32_t* step_idx, float guidance_scale, int B, int HW, int L,
+                      int Lstride, int cfg, int dtype, void* stream);
+
 /* Layout / dtype conversion at the drop-in boundary (callers hand NCHW fp32, TT:328-359). */
 int es_nchw_f32_to_nhwc(const float* in, void* out, int N, int C, int HW, int Cpad, int dtype, void* stream);
 int es_nhwc_to_nchw_f32(const void* in, float* out, int N, int C, int HW, int Cstride, float scale, float shift,

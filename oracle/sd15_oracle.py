@@ -393,3 +393,111 @@ def pipeline(unet_sd, unet_cfg, fusion_sd, nets, vae_sd, vae_cfg, latents, promp
         return latents
     img = vae_decode(vae_sd, vae_cfg, latents / vae_cfg.scaling_factor)   # PL:552-557
     return (img / 2 + 0.5).clamp(0, 1)                          # PL:570-572 postprocess, output_type="pt"
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# UniPCMultistepScheduler (the scheduler every reference caller swaps in: TT:273, APP:118, INF:538) — restated
+# from the published algorithm of diffusers==0.26.3 `schedulers/scheduling_unipc_multistep.py` (B(h) form "bh2",
+# solver_order 2, predict_x0, lower_order_final, epsilon prediction; betas/steps_offset/timestep_spacing taken from
+# the SD1.5 scheduler config via from_config).  PARITY UNPINNED like the other [D] blocks.
+# ----------------------------------------------------------------------------------------------------------------
+class UniPC:
+    def __init__(self, num_train=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1, solver_order=2,
+                 timestep_spacing="leading"):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.num_train, self.steps_offset, self.solver_order = num_train, steps_offset, solver_order
+        self.timestep_spacing = timestep_spacing
+        self.init_noise_sigma = 1.0
+
+    def set_timesteps(self, n: int):
+        import numpy as np
+        if self.timestep_spacing == "linspace":
+            ts = np.linspace(0, self.num_train - 1, n + 1).round()[::-1][:-1].copy().astype(np.int64)
+        elif self.timestep_spacing == "leading":
+            ratio = self.num_train // (n + 1)
+            ts = (np.arange(0, n + 1) * ratio).round()[::-1][:-1].copy().astype(np.int64) + self.steps_offset
+        else:
+            raise ValueError(self.timestep_spacing)
+        ac = self.alphas_cumprod.double().numpy()
+        sig = ((1 - ac) / ac) ** 0.5
+        sigmas = np.interp(ts, np.arange(0, len(sig)), sig)
+        sigmas = np.concatenate([sigmas, [((1 - ac[0]) / ac[0]) ** 0.5]])
+        self.sigmas = torch.from_numpy(sigmas).double()
+        self.timesteps = torch.from_numpy(ts)
+        self.model_outputs = [None] * self.solver_order
+        self.lower_order_nums, self.last_sample, self.step_index, self.this_order = 0, None, 0, 1
+        return self.timesteps
+
+    @staticmethod
+    def _alpha_sigma(sigma):
+        alpha = 1.0 / (sigma ** 2 + 1.0) ** 0.5
+        return alpha, sigma * alpha
+
+    def _rb(self, rks, hh, order):
+        h_phi_1 = torch.expm1(hh)
+        h_phi_k = h_phi_1 / hh - 1
+        B_h = torch.expm1(hh)                                   # bh2
+        fact, R, b = 1, [], []
+        for i in range(1, order + 1):
+            R.append(torch.pow(rks, i - 1))
+            b.append(h_phi_k * fact / B_h)
+            fact *= i + 1
+            h_phi_k = h_phi_k / hh - 1 / fact
+        return torch.stack(R), torch.stack(b), h_phi_1, B_h
+
+    def _lams(self, idx):
+        a, s = self._alpha_sigma(self.sigmas[idx])
+        return a, s, torch.log(a) - torch.log(s)
+
+    def _uni_p(self, sample, order):
+        m0, x = self.model_outputs[-1], sample
+        a_t, s_t, l_t = self._lams(self.step_index + 1)
+        a_0, s_0, l_0 = self._lams(self.step_index)
+        h = l_t - l_0
+        rks, D1s = [], []
+        for i in range(1, order):
+            _, _, l_i = self._lams(self.step_index - i)
+            rk = (l_i - l_0) / h
+            rks.append(rk)
+            D1s.append((self.model_outputs[-(i + 1)] - m0) / rk)
+        rks.append(torch.tensor(1.0, dtype=torch.float64))
+        R, b, h_phi_1, B_h = self._rb(torch.stack(rks), -h, order)
+        x_t = (s_t / s_0) * x - a_t * h_phi_1 * m0
+        if D1s:
+            rhos_p = torch.tensor([0.5], dtype=torch.float64) if order == 2 else torch.linalg.solve(R[:-1, :-1], b[:-1])
+            x_t = x_t - a_t * B_h * sum(r * d for r, d in zip(rhos_p, D1s))
+        return x_t
+
+    def _uni_c(self, model_t, last_sample, order):
+        m0, x = self.model_outputs[-1], last_sample
+        a_t, s_t, l_t = self._lams(self.step_index)
+        a_0, s_0, l_0 = self._lams(self.step_index - 1)
+        h = l_t - l_0
+        rks, D1s = [], []
+        for i in range(1, order):
+            _, _, l_i = self._lams(self.step_index - (i + 1))
+            rk = (l_i - l_0) / h
+            rks.append(rk)
+            D1s.append((self.model_outputs[-(i + 1)] - m0) / rk)
+        rks.append(torch.tensor(1.0, dtype=torch.float64))
+        R, b, h_phi_1, B_h = self._rb(torch.stack(rks), -h, order)
+        rhos_c = torch.tensor([0.5], dtype=torch.float64) if order == 1 else torch.linalg.solve(R, b)
+        corr = sum(r * d for r, d in zip(rhos_c[:-1], D1s)) if D1s else 0.0
+        return (s_t / s_0) * x - a_t * h_phi_1 * m0 - a_t * B_h * (corr + rhos_c[-1] * (model_t - m0))
+
+    def step(self, eps, t: int, sample):
+        sample = sample.double()
+        a_t, s_t = self._alpha_sigma(self.sigmas[self.step_index])
+        x0 = (sample - s_t * eps.double()) / a_t                                # convert_model_output (epsilon, predict_x0)
+        if self.step_index > 0 and self.last_sample is not None:
+            sample = self._uni_c(x0, self.last_sample, self.this_order)
+        self.model_outputs = self.model_outputs[1:] + [x0]
+        this_order = min(self.solver_order, len(self.timesteps) - self.step_index)   # lower_order_final
+        self.this_order = min(this_order, self.lower_order_nums + 1)
+        self.last_sample = sample
+        prev = self._uni_p(sample, self.this_order)
+        if self.lower_order_nums < self.solver_order:
+            self.lower_order_nums += 1
+        self.step_index += 1
+        return prev.float()

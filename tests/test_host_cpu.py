@@ -169,3 +169,38 @@ def test_shard_ranges_cover_and_seeds_are_world_size_independent():
     assert [shard_seed(42, r, 8) for r in range(8)] == [42 + 8 * r for r in range(8)]
     with pytest.raises(ValueError):
         shard_range(4, 4, 4)
+
+
+def test_unipc_coefficient_table_reproduces_oracle_trajectory():
+    """The product scheduler only exports linear-recombination coefficients (the arithmetic is es_cfg_unipc_step);
+    applying them in float64 must reproduce the oracle's UniPC restatement step for step."""
+    from oracle import sd15_oracle as O
+    from edgestyle_amd.schedulers import UniPCMultistepScheduler
+    for n in (50, 5, 2):
+        s = UniPCMultistepScheduler.from_config({"steps_offset": 1, "timestep_spacing": "leading", "foo": 1})
+        ts = s.set_timesteps(n)
+        o = O.UniPC()
+        assert o.set_timesteps(n).tolist() == ts.tolist()
+        tab = s.coef_table().double()
+        assert tab.shape == (n, 12) and float(tab[0, 2]) == 0.0 and float(tab[1, 2]) == 1.0
+        g = torch.Generator().manual_seed(n)
+        xo = torch.randn(1, 4, 8, 8, generator=g)
+        xm, last, m0, m1 = xo.double(), torch.zeros(1, 4, 8, 8).double(), torch.zeros(1, 4, 8, 8).double(), torch.zeros(1, 4, 8, 8).double()
+        for i, t in enumerate(ts.tolist()):
+            eps = torch.randn(1, 4, 8, 8, generator=g)
+            xo = o.step(eps, t, xo)
+            c = tab[i]
+            x0 = (xm - c[1] * eps.double()) / c[0]
+            xc = c[3] * last + c[4] * m0 + c[5] * m1 + c[6] * x0 if c[2] != 0 else xm
+            xm, m1, m0, last = c[7] * xc + c[8] * x0 + c[9] * m0, m0, x0, xc
+            assert float((xm.float() - xo).abs().max() / xo.abs().max()) < 1e-5
+    # exactness property of the solver itself: with the true noise as model output it stays on the marginal
+    o = O.UniPC()
+    ts = o.set_timesteps(20)
+    x0t, nz = torch.randn(1, 4, 8, 8), torch.randn(1, 4, 8, 8)
+    a, sg = o._alpha_sigma(o.sigmas[0])
+    x = (a * x0t + sg * nz).float()
+    for t in ts.tolist():
+        x = o.step(nz, t, x)
+    a, sg = o._alpha_sigma(o.sigmas[-1])
+    assert float((x - (a * x0t + sg * nz).float()).abs().max()) < 1e-4
