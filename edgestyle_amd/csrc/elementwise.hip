@@ -24,13 +24,15 @@ __global__ void timestep_kernel(const float* __restrict__ t, T* __restrict__ out
 template <typename T>
 __global__ void cfg_ddim_kernel(const T* __restrict__ noise, float* __restrict__ lat, T* __restrict__ model_in,
                                 const float* __restrict__ coef, const int* __restrict__ step_idx, float gs, int B,
-                                int HW, int L, int Ls, int cfg) {
+                                int HW, int L, int Ls, int cfg, int nsteps) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)B * HW * L;
   if (i >= total) return;
   const long long mi = (i / L) * Ls + (i % L);         // model_in is channel-padded to Ls
   const long long mtotal = (long long)B * HW * Ls;
-  const float* c = coef + (size_t)(*step_idx) * 4;
+  int sidx = *step_idx;
+  sidx = sidx < 0 ? 0 : (sidx >= nsteps ? nsteps - 1 : sidx);
+  const float* c = coef + (size_t)sidx * 4;
   float eps;
   if (cfg) {
     const float eu = to_f32(noise[i]), ec = to_f32(noise[total + i]);
@@ -51,7 +53,7 @@ template <typename T>
 __global__ void cfg_unipc_kernel(const T* __restrict__ noise, float* __restrict__ lat, float* __restrict__ last,
                                  float* __restrict__ m0b, float* __restrict__ m1b, T* __restrict__ model_in,
                                  const float* __restrict__ coef, const int* __restrict__ step_idx, float gs, int B,
-                                 int HW, int L, int Ls, int cfg) {
+                                 int HW, int L, int Ls, int cfg, int nsteps) {
   // One UniPC (bh2, order <= 2, predict_x0) step as a linear recombination with host-computed per-step scalars:
   //   x0  = (x - sigma*eps)/alpha                                   convert_model_output
   //   xc  = use_c ? cl*last + cm0*m0 + cm1*m1 + cmt*x0 : x          multistep_uni_c_bh_update
@@ -62,7 +64,9 @@ __global__ void cfg_unipc_kernel(const T* __restrict__ noise, float* __restrict_
   if (i >= total) return;
   const long long mi = (i / L) * Ls + (i % L);
   const long long mtotal = (long long)B * HW * Ls;
-  const float* c = coef + (size_t)(*step_idx) * 12;
+  int sidx = *step_idx;
+  sidx = sidx < 0 ? 0 : (sidx >= nsteps ? nsteps - 1 : sidx);
+  const float* c = coef + (size_t)sidx * 12;
   float eps;
   if (cfg) {
     const float eu = to_f32(noise[i]), ec = to_f32(noise[total + i]);
@@ -148,9 +152,11 @@ __global__ void vae_sample_kernel(const T* __restrict__ mom, const float* __rest
 __global__ void incr_kernel(int* ctr) { *ctr += 1; }
 
 __global__ void gather_row_kernel(const float* __restrict__ table, const int* __restrict__ idx,
-                                  float* __restrict__ out, int row_len) {
+                                  float* __restrict__ out, int row_len, int nrows) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < row_len) out[i] = table[(size_t)(*idx) * row_len + i];
+  int r = *idx;
+  r = r < 0 ? 0 : (r >= nrows ? nrows - 1 : r);          // a counter past the table must never fault the GPU
+  if (i < row_len) out[i] = table[(size_t)r * row_len + i];
 }
 
 inline unsigned nblk(long long n, int b = 256) { return (unsigned)((n + b - 1) / b); }
@@ -184,36 +190,36 @@ extern "C" int es_timestep_embedding(const float* t, void* out, int N, int dim, 
 
 extern "C" int es_cfg_ddim_step(const void* noise, float* latents, void* model_in, const float* coef,
                                 const int32_t* step_idx, float guidance_scale, int B, int HW, int L, int Lstride,
-                                int cfg, int dtype, void* stream) {
-  if (!noise || !latents || !model_in || !coef || !step_idx || B < 1 || HW < 1 || L < 1 || Lstride < L) {
+                                int cfg, int nsteps, int dtype, void* stream) {
+  if (!noise || !latents || !model_in || !coef || !step_idx || B < 1 || HW < 1 || L < 1 || Lstride < L || nsteps < 1) {
     es_set_error("es_cfg_ddim_step: bad arguments"); return -1;
   }
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)B * HW * L;
   if (dtype == ES_F16)
     hipLaunchKernelGGL(cfg_ddim_kernel<f16>, dim3(nblk(n)), dim3(256), 0, st, (const f16*)noise, latents,
-                       (f16*)model_in, coef, step_idx, guidance_scale, B, HW, L, Lstride, cfg);
+                       (f16*)model_in, coef, step_idx, guidance_scale, B, HW, L, Lstride, cfg, nsteps);
   else
     hipLaunchKernelGGL(cfg_ddim_kernel<bf16>, dim3(nblk(n)), dim3(256), 0, st, (const bf16*)noise, latents,
-                       (bf16*)model_in, coef, step_idx, guidance_scale, B, HW, L, Lstride, cfg);
+                       (bf16*)model_in, coef, step_idx, guidance_scale, B, HW, L, Lstride, cfg, nsteps);
   ES_RET("es_cfg_ddim_step");
 }
 
 extern "C" int es_cfg_unipc_step(const void* noise, float* latents, float* last_sample, float* m0, float* m1,
                                  void* model_in, const float* coef, const int32_t* step_idx, float guidance_scale,
-                                 int B, int HW, int L, int Lstride, int cfg, int dtype, void* stream) {
+                                 int B, int HW, int L, int Lstride, int cfg, int nsteps, int dtype, void* stream) {
   if (!noise || !latents || !last_sample || !m0 || !m1 || !model_in || !coef || !step_idx || B < 1 || HW < 1 ||
-      L < 1 || Lstride < L) {
+      L < 1 || Lstride < L || nsteps < 1) {
     es_set_error("es_cfg_unipc_step: bad arguments"); return -1;
   }
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)B * HW * L;
   if (dtype == ES_F16)
     hipLaunchKernelGGL(cfg_unipc_kernel<f16>, dim3(nblk(n)), dim3(256), 0, st, (const f16*)noise, latents,
-                       last_sample, m0, m1, (f16*)model_in, coef, step_idx, guidance_scale, B, HW, L, Lstride, cfg);
+                       last_sample, m0, m1, (f16*)model_in, coef, step_idx, guidance_scale, B, HW, L, Lstride, cfg, nsteps);
   else
     hipLaunchKernelGGL(cfg_unipc_kernel<bf16>, dim3(nblk(n)), dim3(256), 0, st, (const bf16*)noise, latents,
-                       last_sample, m0, m1, (bf16*)model_in, coef, step_idx, guidance_scale, B, HW, L, Lstride, cfg);
+                       last_sample, m0, m1, (bf16*)model_in, coef, step_idx, guidance_scale, B, HW, L, Lstride, cfg, nsteps);
   ES_RET("es_cfg_unipc_step");
 }
 
@@ -264,10 +270,11 @@ extern "C" int es_incr(int32_t* ctr, void* stream) {
   ES_RET("es_incr");
 }
 
-extern "C" int es_gather_row(const float* table, const int32_t* idx, float* out, int row_len, void* stream) {
-  if (!table || !idx || !out || row_len < 1) { es_set_error("es_gather_row: bad arguments"); return -1; }
+extern "C" int es_gather_row(const float* table, const int32_t* idx, float* out, int row_len, int nrows,
+                             void* stream) {
+  if (!table || !idx || !out || row_len < 1 || nrows < 1) { es_set_error("es_gather_row: bad arguments"); return -1; }
   hipLaunchKernelGGL(gather_row_kernel, dim3(nblk(row_len)), dim3(256), 0, (hipStream_t)stream, table, idx, out,
-                     row_len);
+                     row_len, nrows);
   ES_RET("es_gather_row");
 }
 
@@ -277,6 +284,7 @@ extern "C" size_t es_sizeof_desc(int which) {
     case 1: return sizeof(es_attn_desc);
     case 2: return sizeof(es_gn_desc);
     case 3: return sizeof(es_fusion_desc);
+    case 4: return sizeof(es_ln_desc);
     default: return 0;
   }
 }

@@ -99,8 +99,12 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
       nb[i] = n * p.Hsrc * p.Wsrc;
     }
   }
+  int grp = 0;
+  if (p.ngroups > 1) grp = (tile_m >= p.mt_end[0]) + (tile_m >= p.mt_end[1]) + (tile_m >= p.mt_end[2]);
+  const void* wsel = p.ngroups > 1 ? p.w_g[grp] : p.w;
+  const float* bsel = p.ngroups > 1 ? p.bias_g[grp] : p.bias;
   const auto rW = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.w, (short)0, (int)((size_t)p.rows_padded * p.Kpad * 2), 0x00020000);
+      (void*)wsel, (short)0, (int)((size_t)p.rows_padded * p.Kpad * 2), 0x00020000);
   const auto rX1 = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.x, (short)0, (int)((size_t)p.N * p.Hsrc * p.Wsrc * p.C1 * 2), 0x00020000);
   const auto rX2 = __builtin_amdgcn_make_buffer_rsrc(
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
   f32x4 bias[FN];
 #pragma unroll
   for (int i = 0; i < FN; ++i)
-    bias[i] = p.bias ? *(const f32x4*)(p.bias + tile_n * BN + pcol + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bias[i] = bsel ? *(const f32x4*)(bsel + tile_n * BN + pcol + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();                                        // all waves are done reading the stage buffers
   char* et = smem;
 #pragma unroll
@@ -362,9 +366,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const es_gemm_desc p
   if (p.out_scale_dev) scale *= *p.out_scale_dev;
   const int n = m / (p.Hout * p.Wout);
   const int nv = p.Cout - c0 < 8 ? p.Cout - c0 : 8;
+  const float* bsel = p.bias;
+  if (p.ngroups > 1) {
+    const int tm = m >> 7;
+    bsel = p.bias_g[(tm >= p.mt_end[0]) + (tm >= p.mt_end[1]) + (tm >= p.mt_end[2])];
+  }
   for (int r = 0; r < nv; ++r) {
     float x = v[r];
-    if (p.bias) x += p.bias[c0 + r];
+    if (bsel) x += bsel[c0 + r];
     if (p.temb) x += to_f32(((const T*)p.temb)[(size_t)n * p.temb_stride + c0 + r]);
     if (p.act == ES_ACT_SILU) x = silu_f(x);
     x = to_f32(from_f32<T>(x * scale));                   // same rounding point as the fused epilogue
@@ -436,7 +445,14 @@ extern "C" size_t es_conv_gemm_workspace_bytes(const es_gemm_desc* d) {
 extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
   const int Ctot = d->C1 + d->C2;
   const int Ktrue = d->ksize * d->ksize * Ctot;
-  if (!d->x || !d->w || !d->out) { es_set_error("es_conv_gemm: null pointer"); return -1; }
+  if (!d->x || !d->out || (d->ngroups <= 1 && !d->w)) { es_set_error("es_conv_gemm: null pointer"); return -1; }
+  if (d->ngroups > 4) { es_set_error("es_conv_gemm: at most 4 groups"); return -1; }
+  if (d->ngroups > 1) {
+    const int tm = (d->N * d->Hout * d->Wout + 127) / 128;
+    for (int g = 0; g < d->ngroups; ++g)
+      if (!d->w_g[g] || d->mt_end[g] <= (g ? d->mt_end[g - 1] : 0)) { es_set_error("es_conv_gemm: bad group table"); return -1; }
+    if (d->mt_end[d->ngroups - 1] != tm || (d->N * d->Hout * d->Wout) % 128 || d->bm == 256) { es_set_error("es_conv_gemm: groups must tile M in whole 128-pixel tiles"); return -1; }
+  }
   if (d->bn != 128 && d->bn != 160) { es_set_error("es_conv_gemm: bn must be 128 or 160"); return -1; }
   if (d->rows_padded % d->bn || d->rows_padded < d->Cout) { es_set_error("es_conv_gemm: bad rows_padded"); return -1; }
   if (d->Kpad % BK || d->Kpad < Ktrue) { es_set_error("es_conv_gemm: bad Kpad"); return -1; }

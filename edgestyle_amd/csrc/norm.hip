@@ -107,11 +107,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const es_gn_desc p, const
     }
   }
   __syncthreads();
+  const float* gam = p.gamma;
+  const float* bet = p.beta;
+  if (p.ngroups > 1) {
+    const int g = (n >= p.n_end[0]) + (n >= p.n_end[1]) + (n >= p.n_end[2]);
+    gam = p.gamma_g[g];
+    bet = p.beta_g[g];
+  }
   for (int c = threadIdx.x; c < C; c += 256) {
     const int gi = c / cpg;
-    const float sc = p.gamma[c] * gstat[gi * 2 + 1];
+    const float sc = gam[c] * gstat[gi * 2 + 1];
     scale[c] = sc;
-    shift[c] = p.beta[c] - gstat[gi * 2] * sc;
+    shift[c] = bet[c] - gstat[gi * 2] * sc;
   }
   __syncthreads();
   const long long total = (long long)p.HW * CH8;
@@ -134,13 +141,26 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const es_gn_desc p, const
   }
 }
 
+struct LnGroups {
+  const float* gamma[4];
+  const float* beta[4];
+  int row_end[4];
+  int ngroups;
+};
+
 template <typename T, int VPL /* 16-byte chunks per lane */>
 __global__ __launch_bounds__(256) void layer_norm_kernel(const T* __restrict__ x, T* __restrict__ out,
                                                          const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, int M, int C, float eps) {
+                                                         const float* __restrict__ beta, int M, int C, float eps,
+                                                         const LnGroups grp) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
+  if (grp.ngroups > 1) {
+    const int g = (row >= grp.row_end[0]) + (row >= grp.row_end[1]) + (row >= grp.row_end[2]);
+    gamma = grp.gamma[g];
+    beta = grp.beta[g];
+  }
   const int CH8 = C / 8;
   const T* xr = x + (size_t)row * C;
   typename Traits<T>::vec8 v[VPL];
@@ -200,11 +220,11 @@ int launch_gn(const es_gn_desc& d, hipStream_t st) {
 
 template <typename T>
 int launch_ln(const void* x, void* out, const float* gamma, const float* beta, int M, int C, float eps,
-              hipStream_t st) {
+              hipStream_t st, const LnGroups grp = LnGroups{}) {
   const int CH8 = C / 8;
   const int vpl = (CH8 + 63) / 64;
   dim3 grid((M + 3) / 4);
-#define ES_LN(V) hipLaunchKernelGGL((layer_norm_kernel<T, V>), grid, dim3(256), 0, st, (const T*)x, (T*)out, gamma, beta, M, C, eps)
+#define ES_LN(V) hipLaunchKernelGGL((layer_norm_kernel<T, V>), grid, dim3(256), 0, st, (const T*)x, (T*)out, gamma, beta, M, C, eps, grp)
   if (vpl <= 1) ES_LN(1);
   else if (vpl <= 2) ES_LN(2);
   else if (vpl <= 3) ES_LN(3);
@@ -225,7 +245,11 @@ extern "C" size_t es_group_norm_partials_bytes(int N, int groups) {
 
 extern "C" int es_group_norm(const es_gn_desc* d, void* stream) {
   const int C = d->C1 + d->C2;
-  if (!d->x || !d->out || !d->gamma || !d->beta || !d->partials) { es_set_error("es_group_norm: null pointer"); return -1; }
+  if (!d->x || !d->out || !d->partials || (d->ngroups <= 1 && (!d->gamma || !d->beta))) { es_set_error("es_group_norm: null pointer"); return -1; }
+  if (d->ngroups > 4) { es_set_error("es_group_norm: at most 4 groups"); return -1; }
+  for (int g = 0; g < d->ngroups && d->ngroups > 1; ++g)
+    if (!d->gamma_g[g] || !d->beta_g[g]) { es_set_error("es_group_norm: null group parameter"); return -1; }
+  if (d->ngroups > 1 && d->n_end[d->ngroups - 1] != d->N) { es_set_error("es_group_norm: group table must cover N"); return -1; }
   if (d->C1 % 8 || d->C2 % 8 || (d->C2 && !d->x2)) { es_set_error("es_group_norm: channels must be multiples of 8"); return -1; }
   if (d->groups < 1 || d->groups > GN_MAX_GROUPS || C % d->groups) { es_set_error("es_group_norm: bad group count"); return -1; }
   if (C > 8192) { es_set_error("es_group_norm: C too large for the LDS tables"); return -1; }
@@ -245,5 +269,24 @@ extern "C" int es_layer_norm(const void* x, void* out, const float* gamma, const
                            : launch_ln<bf16>(x, out, gamma, beta, M, C, eps, st);
   if (rc == -3) es_set_error("es_layer_norm: C > 4096 unsupported");
   else if (rc) es_set_error("es_layer_norm: launch failed");
+  return rc;
+}
+
+extern "C" int es_layer_norm_grouped(const es_ln_desc* d, void* stream) {
+  if (!d->x || !d->out || d->C % 8 || d->M < 1 || d->ngroups < 1 || d->ngroups > 4) { es_set_error("es_layer_norm_grouped: bad arguments"); return -1; }
+  LnGroups grp;
+  grp.ngroups = d->ngroups;
+  for (int g = 0; g < 4; ++g) {
+    grp.gamma[g] = d->gamma_g[g < d->ngroups ? g : 0];
+    grp.beta[g] = d->beta_g[g < d->ngroups ? g : 0];
+    grp.row_end[g] = g < d->ngroups ? d->row_end[g] : d->M;
+    if (!grp.gamma[g] || !grp.beta[g]) { es_set_error("es_layer_norm_grouped: null parameter"); return -1; }
+  }
+  if (d->row_end[d->ngroups - 1] != d->M) { es_set_error("es_layer_norm_grouped: group table must cover M"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  int rc = d->dtype == ES_F16 ? launch_ln<f16>(d->x, d->out, grp.gamma[0], grp.beta[0], d->M, d->C, d->eps, st, grp)
+                              : launch_ln<bf16>(d->x, d->out, grp.gamma[0], grp.beta[0], d->M, d->C, d->eps, st, grp);
+  if (rc == -3) es_set_error("es_layer_norm_grouped: C > 4096 unsupported");
+  else if (rc) es_set_error("es_layer_norm_grouped: launch failed");
   return rc;
 }

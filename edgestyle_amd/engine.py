@@ -171,6 +171,10 @@ class Encoder:
         e = ops.linear(e, self.t2, act=L.ACT_SILU)     # emb is only ever consumed through silu(emb)
         return ops.linear(e, self.tproj)
 
+    @property
+    def tproj_width(self) -> int:
+        return self.tproj.cout
+
     def run(self, h, tproj, ctx: List[torch.Tensor]):
         skips = [h]
         ci = 0
@@ -392,3 +396,81 @@ class VAE:
                 h = ops.conv_gemm(h, us, upsample=True)
         h = ops.group_norm(h, self.d_norm[0], self.d_norm[1], cfg.norm_num_groups, cfg.norm_eps, True)
         return ops.conv_gemm(h, self.d_out)
+
+
+class GroupedEncoder:
+    """Several encoders of identical architecture but different weights (the 3 batched ControlNet passes + the UNet's
+    own conv_in/down/mid path of one denoising step) executed in LOCKSTEP as grouped launches over the
+    batch-concatenated activations [sum(n_g), H, W, C]: every conv/linear/GroupNorm/LayerNorm is ONE launch whose
+    M tiles / samples / rows select their group's weights, attention is one launch over the whole batch.  At batch 1
+    a single net's kernels (M = 2..6 samples) cannot fill 256 CUs; the grouped launch has 14 samples."""
+
+    def __init__(self, encoders: Sequence[Encoder], counts: Sequence[int]):
+        self.encs, self.counts = list(encoders), list(counts)
+        e0 = self.encs[0]
+        self.cfg = e0.cfg
+        for e in self.encs[1:]:
+            if e.cfg.block_out_channels != e0.cfg.block_out_channels or e.cfg.layers_per_block != e0.cfg.layers_per_block:
+                raise L.EdgeStyleHipError("grouped encoders must share the architecture")
+        self.ntot = sum(self.counts)
+        self.width = max(e.tproj_width for e in self.encs)
+
+    def groupable(self, hw_min: int) -> bool:
+        return len(self.encs) <= 4 and all((n * hw_min) % ops.BM == 0 for n in self.counts)
+
+    def time_proj(self, t_rows: torch.Tensor) -> torch.Tensor:
+        """[ntot, width]: each group's ResnetBlock time projections (offsets of down/mid blocks coincide)."""
+        out = torch.zeros((self.ntot, self.width), dtype=self.encs[0].dtype, device=t_rows.device)
+        a = 0
+        for e, n in zip(self.encs, self.counts):
+            out[a:a + n, : e.tproj_width].copy_(e.time_proj(t_rows[:n]))
+            a += n
+        return out
+
+    def _resnet(self, rs, x, tproj):
+        c = self.counts
+        r0 = rs[0]
+        h = ops.group_norm(x, [r.n1[0] for r in rs], [r.n1[1] for r in rs], r0.groups, r0.eps, True, group_n=c)
+        h = ops.conv_gemm(h, [r.conv1 for r in rs], temb=tproj[:, r0.temb_off:], group_n=c)
+        h = ops.group_norm(h, [r.n2[0] for r in rs], [r.n2[1] for r in rs], r0.groups, r0.eps, True, group_n=c)
+        xs = ops.conv_gemm(x, [r.short for r in rs], group_n=c) if r0.short is not None else x
+        return ops.conv_gemm(h, [r.conv2 for r in rs], residual=xs, group_n=c)
+
+    def _transformer(self, ts, x, kv):
+        c = self.counts
+        t0 = ts[0]
+        N, H, W, C = x.shape
+        rows = [n * H * W for n in c]
+        h = ops.group_norm(x, [t.norm[0] for t in ts], [t.norm[1] for t in ts], t0.groups, 1e-6, False, group_n=c)
+        tok = ops.conv_gemm(h, [t.proj_in for t in ts], group_n=c).reshape(N, H * W, C)
+        n = ops.layer_norm(tok, [t.ln1[0] for t in ts], [t.ln1[1] for t in ts], group_rows=rows)
+        qkv = ops.linear(n, [t.qkv for t in ts], group_n=rows)
+        a = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], t0.heads)
+        tok = ops.linear(a, [t.o1 for t in ts], residual=tok, group_n=rows)
+        n = ops.layer_norm(tok, [t.ln2[0] for t in ts], [t.ln2[1] for t in ts], group_rows=rows)
+        q = ops.linear(n, [t.q2 for t in ts], group_n=rows)
+        a = ops.attention(q, kv[:, :, :C], kv[:, :, C:], t0.heads)
+        tok = ops.linear(a, [t.o2 for t in ts], residual=tok, group_n=rows)
+        n = ops.layer_norm(tok, [t.ln3[0] for t in ts], [t.ln3[1] for t in ts], group_rows=rows)
+        f = ops.linear(n, [t.ff1 for t in ts], group_n=rows)
+        tok = ops.linear(f, [t.ff2 for t in ts], residual=tok, group_n=rows)
+        return ops.conv_gemm(tok.reshape(N, H, W, C), [t.proj_out for t in ts], residual=x, group_n=c)
+
+    def run(self, h, tproj, ctx: List[torch.Tensor]):
+        """h: [ntot,H,W,C0] (each group's conv_in(sample)+cond already applied) -> (skips, mid) over the whole batch."""
+        skips = [h]
+        ci = 0
+        e0 = self.encs[0]
+        for i, blk in enumerate(e0.down):
+            for j, (r, a) in enumerate(blk):
+                h = self._resnet([e.down[i][j][0] for e in self.encs], h, tproj)
+                if a is not None:
+                    h = self._transformer([e.down[i][j][1] for e in self.encs], h, ctx[ci]); ci += 1
+                skips.append(h)
+            if e0.downsample[i] is not None:
+                h = ops.conv_gemm(h, [e.downsample[i] for e in self.encs], stride=2, group_n=self.counts)
+                skips.append(h)
+        h = self._resnet([e.mid0 for e in self.encs], h, tproj)
+        h = self._transformer([e.mid_attn for e in self.encs], h, ctx[ci])
+        h = self._resnet([e.mid1 for e in self.encs], h, tproj)
+        return skips, h

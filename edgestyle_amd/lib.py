@@ -22,7 +22,9 @@ class GemmDesc(C.Structure):
         ("rows_padded", C.c_int32), ("Kpad", C.c_int32),
         ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("upsample", C.c_int32), ("temb_stride", C.c_int32), ("act", C.c_int32), ("splitk", C.c_int32),
-        ("bn", C.c_int32), ("dtype", C.c_int32), ("stages", C.c_int32), ("xcd_m_fastest", C.c_int32), ("bm", C.c_int32), ("out_scale", C.c_float),
+        ("bn", C.c_int32), ("dtype", C.c_int32),
+        ("ngroups", C.c_int32), ("mt_end", C.c_int32 * 4), ("w_g", C.c_void_p * 4), ("bias_g", C.c_void_p * 4),
+        ("stages", C.c_int32), ("xcd_m_fastest", C.c_int32), ("bm", C.c_int32), ("out_scale", C.c_float),
     ]
 
 
@@ -42,6 +44,15 @@ class GnDesc(C.Structure):
         ("gamma", C.c_void_p), ("beta", C.c_void_p), ("partials", C.c_void_p),
         ("N", C.c_int32), ("HW", C.c_int32), ("C1", C.c_int32), ("C2", C.c_int32), ("groups", C.c_int32),
         ("eps", C.c_float), ("silu", C.c_int32), ("dtype", C.c_int32),
+        ("ngroups", C.c_int32), ("n_end", C.c_int32 * 4), ("gamma_g", C.c_void_p * 4), ("beta_g", C.c_void_p * 4),
+    ]
+
+
+class LnDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("out", C.c_void_p), ("gamma_g", C.c_void_p * 4), ("beta_g", C.c_void_p * 4),
+        ("row_end", C.c_int32 * 4), ("ngroups", C.c_int32), ("M", C.c_int32), ("C", C.c_int32),
+        ("eps", C.c_float), ("dtype", C.c_int32),
     ]
 
 
@@ -74,14 +85,15 @@ SYMBOLS = {
     "es_fusion_block": (C.c_int, [C.POINTER(FusionDesc), _P]),
     "es_fusion_scratch_bytes": (C.c_size_t, [_I]),
     "es_timestep_embedding": (C.c_int, [_P, _P, _I, _I, _I, _P]),
-    "es_cfg_ddim_step": (C.c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P]),
-    "es_cfg_unipc_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _P]),
+    "es_cfg_ddim_step": (C.c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "es_cfg_unipc_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _P]),
     "es_nchw_f32_to_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "es_nhwc_to_nchw_f32": (C.c_int, [_P, _P, _I, _I, _I, _I, _F, _F, _I, _I, _P]),
     "es_add": (C.c_int, [_P, _P, _P, _L, _I, _P]),
     "es_vae_sample": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "es_incr": (C.c_int, [_P, _P]),
-    "es_gather_row": (C.c_int, [_P, _P, _P, _I, _P]),
+    "es_gather_row": (C.c_int, [_P, _P, _P, _I, _I, _P]),
+    "es_layer_norm_grouped": (C.c_int, [C.POINTER(LnDesc), _P]),
 }
 
 _lib = None
@@ -107,7 +119,7 @@ def load():
         fn.argtypes = args
     if lib.es_abi_version() != 1:
         raise EdgeStyleHipError("libedgestyle_hip.so ABI version mismatch")
-    for i, st in enumerate((GemmDesc, AttnDesc, GnDesc, FusionDesc)):
+    for i, st in enumerate((GemmDesc, AttnDesc, GnDesc, FusionDesc, LnDesc)):
         if lib.es_sizeof_desc(i) != C.sizeof(st):
             raise EdgeStyleHipError(f"descriptor layout mismatch for {st.__name__}: C {lib.es_sizeof_desc(i)} "
                                     f"vs ctypes {C.sizeof(st)}")

@@ -616,7 +616,13 @@ class StepRunner:
         self.kmax = max(len(p) for _, p in self.groups)
         self.ctx_unet = None
         self.ctx_nets = None
-        self.concurrent = os.environ.get("ES_SERIAL") != "1"     # ES_SERIAL=1: one chain at a time (profiling)
+        # execution of the four independent encoder chains of a step:
+        #   "grouped" — one lockstep pass of grouped launches over the batch-concatenated activations (default)
+        #   "streams" — one HIP stream per chain (parallel hipGraph branches)
+        #   "serial"  — one chain after the other (profiling)
+        self.mode = os.environ.get("ES_CHAIN_MODE", "serial" if os.environ.get("ES_SERIAL") == "1" else "grouped")
+        self._grouped = None
+        self.ctx_grouped = None
         self._streams = None
 
     @classmethod
@@ -643,6 +649,14 @@ class StepRunner:
         for (net, pos), o in zip(self.groups, old):
             k = len(pos)
             self.ctx_nets.append(net.engine.context(ehs.repeat(k, 1, 1) if k > 1 else ehs, o))
+        # batch-concatenated K/V projections for the grouped lockstep pass (static buffers: graph-stable pointers)
+        n_enc = len(self.ctx_nets[0])
+        cat = [torch.cat([c[i] for c in self.ctx_nets] + [self.ctx_unet[i]]) for i in range(n_enc)]
+        if self.ctx_grouped is not None and self.ctx_grouped[0].shape == cat[0].shape:
+            for dst, src in zip(self.ctx_grouped, cat):
+                dst.copy_(src)
+        else:
+            self.ctx_grouped = cat
 
     def step(self, x: torch.Tensor, t_rows: torch.Tensor, conds: Sequence[torch.Tensor], scales: Sequence[float],
              scales_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -657,6 +671,10 @@ class StepRunner:
         res_per_net, bs = [None] * nn, [None] * nn
         ue = self.unet.engine
         results = {}
+        if self.mode == "grouped":
+            out_t = self._step_grouped(x, t_rows, conds, scales, scales_dev, out)
+            if out_t is not None:
+                return out_t
 
         def cn_chain(gi):
             net, pos = self.groups[gi]
@@ -669,7 +687,7 @@ class StepRunner:
             results["unet"] = (tproj, ue.encode(x, tproj, self.ctx_unet))
 
         chains = [lambda gi=gi: cn_chain(gi) for gi in range(len(self.groups))] + [unet_chain]
-        if self.concurrent:
+        if self.mode == "streams":
             main = torch.cuda.current_stream()
             if self._streams is None:
                 self._streams = [torch.cuda.Stream(device=self.device) for _ in chains]
@@ -690,6 +708,45 @@ class StepRunner:
         fused = self.controlnet.engine.forward(res_per_net, bs, N, scales, scales_dev)
         tproj, enc = results["unet"]
         return ue.forward(x, tproj, self.ctx_unet, fused[:-1], fused[-1], out=out, encoded=enc)
+
+    def _step_grouped(self, x, t_rows, conds, scales, scales_dev, out):
+        """The three batched ControlNet passes and the UNet encoder as ONE lockstep pass of grouped launches."""
+        N = x.shape[0]
+        ue = self.unet.engine
+        encs = [net.engine for net, _ in self.groups] + [ue]
+        counts = [len(pos) * N for _, pos in self.groups] + [N]
+        if self._grouped is None or self._grouped.counts != counts:
+            self._grouped = E.GroupedEncoder(encs, counts)
+        ge = self._grouped
+        hw_min = (x.shape[1] >> (len(ue.cfg.block_out_channels) - 1)) * (x.shape[2] >> (len(ue.cfg.block_out_channels) - 1))
+        if not ge.groupable(hw_min):
+            return None                                   # tiny shapes: groups do not tile in 128-pixel units
+        ncn = sum(counts[:-1])
+        c0 = ue.conv_in.cout
+        h0 = torch.empty((ge.ntot, x.shape[1], x.shape[2], c0), dtype=x.dtype, device=x.device)
+        a = 0
+        for net, pos in self.groups:                      # sample = conv_in(sample) + cond   (CL:197-203)
+            for p in pos:
+                ops.conv_gemm(x, net.engine.conv_in, residual=conds[p], out=h0[a:a + N])
+                a += N
+        ops.conv_gemm(x, ue.conv_in, out=h0[a:a + N])
+        tproj = ge.time_proj(t_rows)
+        skips, h = ge.run(h0, tproj, self.ctx_grouped)
+        cn_counts = counts[:-1]
+        cn_engs = encs[:-1]
+        res = [ops.conv_gemm(s[:ncn], [e.zero[i] for e in cn_engs], group_n=cn_counts) for i, s in enumerate(skips)]
+        res.append(ops.conv_gemm(h[:ncn], [e.zero_mid for e in cn_engs], group_n=cn_counts))
+        nn = len(self.controlnet.nets)
+        res_per_net, bs = [None] * nn, [None] * nn
+        a = 0
+        for net, pos in self.groups:
+            for p in pos:
+                res_per_net[p] = [r[a:] for r in res]
+                bs[p] = [r.stride(0) for r in res]
+                a += N
+        fused = self.controlnet.engine.forward(res_per_net, bs, N, scales, scales_dev)
+        enc = ([s[ncn:] for s in skips], h[ncn:])
+        return ue.forward(x, tproj[ncn:], self.ctx_unet, fused[:-1], fused[-1], out=out, encoded=enc)
 
     def step_nchw(self, sample, timestep, ehs, conds, scales):
         """Convenience for tests: NCHW fp32 in / NCHW out."""

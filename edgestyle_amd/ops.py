@@ -5,8 +5,9 @@ Internal activation layout is NHWC ([N,H,W,C], dtype fp16/bf16); every wrapper l
 """
 import ctypes as C
 import math
+import os as _os
 from dataclasses import dataclass
-from typing import Optional
+from typing import Optional, Sequence
 
 import torch
 
@@ -32,9 +33,9 @@ class lane:
         LANE = self.prev
 
 
-import os as _os
 SPLITK_TARGET = int(_os.environ.get("ES_SPLITK_TARGET", "320"))   # workgroups a split-K launch aims for
 XCD_ORDER = -1      # tuning knob: -1 auto, 0 tile_n fastest, 1 tile_m fastest
+DEEP_RING = _os.environ.get("ES_DEEP_RING", "1") == "1"     # 4-stage ring for single-round grids on the main stream
 FORCE_BN = 0        # tuning knob: 0 = per-launch choice between the legal N tiles
 FORCE_BM = 0        # tuning knob: 0 = kernel picks the pixel tile (128 / 256)
 FORCE_STAGES = 0    # tuning knob (tools/gemm_bench.py): 0 = kernel picks the LDS ring depth
@@ -191,21 +192,46 @@ def choose_launch_bn(M: int, pw: "PackedWeight") -> int:
     return best
 
 
-def choose_splitk(M: int, rows_padded: int, bn: int, kpad: int) -> int:
+def choose_splitk(M: int, rows_padded: int, bn: int, kpad: int, target: Optional[int] = None) -> int:
+    target = target or SPLITK_TARGET
     tiles = ((M + BM - 1) // BM) * (rows_padded // bn)
     nk = kpad // BK
-    if tiles >= SPLITK_TARGET // 2 or nk < 8:
+    if tiles >= target // 2 or nk < 8:
         return 1
-    s = min(max(1, SPLITK_TARGET // tiles), nk // 4, 32)
+    s = min(max(1, target // tiles), nk // 4, 32)
     return max(1, s)
+
+
+def plan_launch(M: int, pw: "PackedWeight", bn: int):
+    """(splitk, stages).  On the serial main stream (LANE 0: UNet decoder, VAE) a GEMM whose grid fits ONE workgroup
+    per CU (<= 256) runs a 4-deep LDS ring — three K-steps of DMA in flight hide the HBM round trip that a 2-stage
+    ring exposes on weight-streaming layers (measured -10..-22 %).  Inside the concurrent ControlNet / UNet-encoder
+    chains (LANE > 0) kernels stay at 2 stages = 72 KB LDS, so workgroups of different chains can share a CU."""
+    if pw.geglu:
+        return 1, 2
+    deep = DEEP_RING and LANE == 0
+    splitk = choose_splitk(M, pw.rows_padded, bn, pw.kpad, 256 if deep else None)
+    tiles = ((M + BM - 1) // BM) * (pw.rows_padded // bn)
+    stages = 4 if (deep and tiles * splitk <= 256 and (pw.kpad // BK) // splitk >= 6) else 2
+    return splitk, stages
 
 
 def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Optional[int] = None,
               upsample: bool = False, x2: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None,
               residual: Optional[torch.Tensor] = None, act: int = L.ACT_NONE, out_scale: float = 1.0,
               out_scale_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-              out_hw=None, splitk: Optional[int] = None, stages: int = 0) -> torch.Tensor:
-    """x: [N,H,W,C1] (+ x2 [N,H,W,C2]); returns [N,Hout,Wout,Cout] (Cout/2 for GEGLU)."""
+              out_hw=None, splitk: Optional[int] = None, stages: int = 0,
+              group_n: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """x: [N,H,W,C1] (+ x2 [N,H,W,C2]); returns [N,Hout,Wout,Cout] (Cout/2 for GEGLU).
+
+    Grouped launch: `pw` is a list of PackedWeights of identical geometry and `group_n` the number of consecutive
+    samples of x each of them applies to (sum = N): one launch instead of len(pw)."""
+    pws = None
+    if isinstance(pw, (list, tuple)):
+        pws = list(pw)
+        pw = pws[0]
+        if len(pws) == 1:
+            pws = None
     N, H, W, C1 = x.shape
     C2 = 0 if x2 is None else x2.shape[3]
     if C1 + C2 != pw.cin:
@@ -226,7 +252,8 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     M = N * Hout * Wout
     bn = choose_launch_bn(M, pw) if FORCE_BN == 0 else FORCE_BN
     if splitk is None:
-        splitk = 1 if pw.geglu else choose_splitk(M, pw.rows_padded, bn, pw.kpad)
+        splitk, auto_stages = plan_launch(M, pw, bn)
+        stages = stages or auto_stages
     d = L.GemmDesc()
     d.x, d.x2, d.w = x.data_ptr(), (x2.data_ptr() if x2 is not None else None), pw.w.data_ptr()
     d.bias = pw.bias.data_ptr() if pw.bias is not None else None
@@ -243,12 +270,25 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     d.act, d.splitk, d.bn, d.dtype, d.out_scale = act_i, splitk, bn, _dt(x), out_scale
     d.stages = stages or FORCE_STAGES
     # XCD chunk order: keep the larger operand's tiles together on one XCD (see conv_gemm_kernel)
-    d.xcd_m_fastest = (1 if (splitk == 1 and M <= 2048 and pw.w.numel() > x.numel() + (x2.numel() if x2 is not None else 0)) else 0) \
+    d.xcd_m_fastest = (1 if (pws is None and splitk == 1 and M <= 2048 and pw.w.numel() > x.numel() + (x2.numel() if x2 is not None else 0)) else 0) \
         if XCD_ORDER < 0 else XCD_ORDER
     d.bm = FORCE_BM
     if splitk > 1:
         ws = _get_workspace(splitk * M * pw.rows_padded * 4, x.device)
         d.workspace = ws.data_ptr()
+    if pws is not None:
+        hw = Hout * Wout
+        if len(pws) > 4 or len(group_n) != len(pws) or sum(group_n) != N or any((n * hw) % BM for n in group_n):
+            raise L.EdgeStyleHipError("grouped conv_gemm: groups must cover N in whole 128-pixel tiles (<= 4 groups)")
+        d.ngroups = len(pws)
+        acc = 0
+        for g, (q, n) in enumerate(zip(pws, group_n)):
+            if (q.rows_padded, q.kpad, q.cout, q.cin, q.ksize, q.geglu) != (pw.rows_padded, pw.kpad, pw.cout, pw.cin, pw.ksize, pw.geglu):
+                raise L.EdgeStyleHipError("grouped conv_gemm: weight geometry differs between groups")
+            acc += n * hw // BM
+            d.mt_end[g] = acc
+            d.w_g[g] = q.w.data_ptr()
+            d.bias_g[g] = q.bias.data_ptr() if q.bias is not None else None
     if PROFILE is not None:           # bench.py roofline leg: in-kernel s_memrealtime stamps for this launch
         d.prof = PROFILE.next((2.0 * M * pw.cout * k * k * (C1 + C2), k,
                                (M, pw.cout, k * k * (C1 + C2), stride, splitk, pw.bn),
@@ -265,7 +305,8 @@ def linear(x: torch.Tensor, pw: PackedWeight, **kw) -> torch.Tensor:
     M = x.numel() // shp[-1]
     out = kw.pop("out", None)
     res = kw.pop("residual", None)
-    cstore = pw.cout // 2 if pw.geglu else pw.cout
+    p0 = pw[0] if isinstance(pw, (list, tuple)) else pw
+    cstore = p0.cout // 2 if p0.geglu else p0.cout
     y = conv_gemm(x.reshape(M, 1, 1, shp[-1]), pw,
                   residual=None if res is None else res.reshape(M, 1, 1, cstore),
                   out=None if out is None else out.reshape(M, 1, 1, cstore), **kw)
@@ -297,9 +338,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
 _gn_partials = {}
 
 
-def group_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool,
-               x2: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x: [N,H,W,C1] (+x2 [N,H,W,C2]) -> normalised [N,H,W,C1+C2]."""
+def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu: bool,
+               x2: Optional[torch.Tensor] = None, group_n: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """x: [N,H,W,C1] (+x2 [N,H,W,C2]) -> normalised [N,H,W,C1+C2].  gamma/beta may be lists (one per group of
+    `group_n` consecutive samples): one launch for several nets' GroupNorms."""
     N, H, W, C1 = x.shape
     C2 = 0 if x2 is None else x2.shape[3]
     out = torch.empty((N, H, W, C1 + C2), dtype=x.dtype, device=x.device)
@@ -310,17 +352,47 @@ def group_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups:
         _gn_partials[key] = part
     d = L.GnDesc()
     d.x, d.x2, d.out = x.data_ptr(), (x2.data_ptr() if x2 is not None else None), out.data_ptr()
-    d.gamma, d.beta, d.partials = gamma.data_ptr(), beta.data_ptr(), part.data_ptr()
+    if isinstance(gamma, (list, tuple)) and len(gamma) > 1:
+        if len(gamma) > 4 or len(group_n) != len(gamma) or sum(group_n) != N:
+            raise L.EdgeStyleHipError("grouped group_norm: bad group table")
+        d.ngroups = len(gamma)
+        acc = 0
+        for g, n in enumerate(group_n):
+            acc += n
+            d.n_end[g] = acc
+            d.gamma_g[g] = gamma[g].data_ptr()
+            d.beta_g[g] = beta[g].data_ptr()
+        d.partials = part.data_ptr()
+    else:
+        if isinstance(gamma, (list, tuple)):
+            gamma, beta = gamma[0], beta[0]
+        d.gamma, d.beta, d.partials = gamma.data_ptr(), beta.data_ptr(), part.data_ptr()
     d.N, d.HW, d.C1, d.C2, d.groups = N, H * W, C1, C2, groups
     d.eps, d.silu, d.dtype = eps, 1 if silu else 0, _dt(x)
     L.check(L.load().es_group_norm(C.byref(d), _stream()), "es_group_norm")
     return out
 
 
-def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+def layer_norm(x: torch.Tensor, gamma, beta, eps: float = 1e-5, group_rows: Optional[Sequence[int]] = None) -> torch.Tensor:
     Cc = x.shape[-1]
     M = x.numel() // Cc
     out = torch.empty_like(x)
+    if isinstance(gamma, (list, tuple)) and len(gamma) > 1:
+        if len(gamma) > 4 or len(group_rows) != len(gamma) or sum(group_rows) != M:
+            raise L.EdgeStyleHipError("grouped layer_norm: bad group table")
+        d = L.LnDesc()
+        d.x, d.out = x.data_ptr(), out.data_ptr()
+        acc = 0
+        for g, n in enumerate(group_rows):
+            acc += n
+            d.row_end[g] = acc
+            d.gamma_g[g] = gamma[g].data_ptr()
+            d.beta_g[g] = beta[g].data_ptr()
+        d.ngroups, d.M, d.C, d.eps, d.dtype = len(gamma), M, Cc, eps, _dt(x)
+        L.check(L.load().es_layer_norm_grouped(C.byref(d), _stream()), "es_layer_norm_grouped")
+        return out
+    if isinstance(gamma, (list, tuple)):
+        gamma, beta = gamma[0], beta[0]
     L.check(L.load().es_layer_norm(_ptr(x), _ptr(out), _ptr(gamma), _ptr(beta), M, Cc, eps, _dt(x), _stream()),
             "es_layer_norm")
     return out
@@ -376,8 +448,8 @@ def cfg_ddim_step(noise: torch.Tensor, latents: torch.Tensor, model_in: torch.Te
     """noise [2B|B,H,W,L] dtype; latents fp32 [B,H,W,L] (in place); model_in [2B|B,H,W,Ls] dtype (rewritten)."""
     B, H, W, Lc = latents.shape
     L.check(L.load().es_cfg_ddim_step(_ptr(noise), _ptr(latents), _ptr(model_in), _ptr(coef), _ptr(step_idx),
-                                      guidance_scale, B, H * W, Lc, model_in.shape[3], 1 if cfg else 0, _dt(noise),
-                                      _stream()), "es_cfg_ddim_step")
+                                      guidance_scale, B, H * W, Lc, model_in.shape[3], 1 if cfg else 0, coef.shape[0],
+                                      _dt(noise), _stream()), "es_cfg_ddim_step")
 
 
 def cfg_unipc_step(noise, latents, last_sample, m0, m1, model_in, coef, step_idx, guidance_scale: float, cfg: bool):
@@ -385,7 +457,8 @@ def cfg_unipc_step(noise, latents, last_sample, m0, m1, model_in, coef, step_idx
     B, H, W, Lc = latents.shape
     L.check(L.load().es_cfg_unipc_step(_ptr(noise), _ptr(latents), _ptr(last_sample), _ptr(m0), _ptr(m1),
                                        _ptr(model_in), _ptr(coef), _ptr(step_idx), guidance_scale, B, H * W, Lc,
-                                       model_in.shape[3], 1 if cfg else 0, _dt(noise), _stream()), "es_cfg_unipc_step")
+                                       model_in.shape[3], 1 if cfg else 0, coef.shape[0], _dt(noise), _stream()),
+            "es_cfg_unipc_step")
 
 
 def incr(ctr: torch.Tensor):
@@ -394,7 +467,8 @@ def incr(ctr: torch.Tensor):
 
 def gather_row(table: torch.Tensor, idx: torch.Tensor, out: torch.Tensor):
     """out[:] = table[idx[0]] (fp32), selected on the device"""
-    L.check(L.load().es_gather_row(_ptr(table), _ptr(idx), _ptr(out), out.numel(), _stream()), "es_gather_row")
+    L.check(L.load().es_gather_row(_ptr(table), _ptr(idx), _ptr(out), out.numel(), table.shape[0], _stream()),
+            "es_gather_row")
 
 
 _fusion_scratch = {}

@@ -346,8 +346,9 @@ class StableDiffusionControlNetPipeline:
         prof = ops.Profiler(self.device)
         torch.cuda.synchronize()
         ops.PROFILE = prof
-        was = self._runner.concurrent
-        self._runner.concurrent = False      # serial chains: each launch is timed with the GPU to itself
+        was = self._runner.mode
+        if was == "streams":
+            self._runner.mode = "serial"     # no overlapping chains: each launch is timed with the GPU to itself
         try:
             loop.step_idx.zero_()
             loop.one_step()                  # eager serial warm-up: sizes lane-0 scratch outside the capture
@@ -358,7 +359,7 @@ class StableDiffusionControlNetPipeline:
                 loop.one_step()
         finally:
             ops.PROFILE = None
-            self._runner.concurrent = was
+            self._runner.mode = was
         prof.reset()
         loop.step_idx.zero_()
         torch.cuda.synchronize()

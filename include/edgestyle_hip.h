@@ -25,7 +25,7 @@ enum { ES_ACT_NONE = 0, ES_ACT_SILU = 1, ES_ACT_GEGLU = 2 };
 
 #define ES_ABI_VERSION 1
 int es_abi_version(void);
-/* sizeof the descriptor structs as compiled (0 gemm, 1 attn, 2 gn, 3 fusion): lets a binding verify its mirror */
+/* sizeof the descriptor structs as compiled (0 gemm, 1 attn, 2 gn, 3 fusion, 4 ln): lets a binding verify its mirror */
 size_t es_sizeof_desc(int which);
 const char* es_last_error(void);
 
@@ -61,6 +61,13 @@ typedef struct {
   int32_t splitk;
   int32_t bn;                 /* N tile the weights were packed for: 128 or 160 */
   int32_t dtype;
+  /* Grouped launch: ngroups (<= 4) problems of identical geometry but different weights run as ONE launch over the
+   * batch-concatenated activations (the 3 batched ControlNet passes + the UNet encoder of a denoising step): M tiles
+   * [mt_end[g-1], mt_end[g]) (units of 128 pixels) use w_g[g] / bias_g[g].  ngroups <= 1: plain launch (w, bias). */
+  int32_t ngroups;
+  int32_t mt_end[4];
+  const void* w_g[4];
+  const float* bias_g[4];
   int32_t stages;             /* LDS ring depth: 0 = auto, 2 (2 workgroups/CU), 3 or 4 (1 workgroup/CU) */
   int32_t xcd_m_fastest;      /* tile order inside an XCD's chunk: 1 = tile_m fastest (weights are the larger operand) */
   int32_t bm;                 /* pixel tile: 0 = auto, 128 (4 waves) or 256 (8 waves, large M only) */
@@ -91,6 +98,11 @@ typedef struct {
   int32_t N, HW, C1, C2, groups;
   float eps;
   int32_t silu, dtype;
+  /* grouped launch: samples [n_end[g-1], n_end[g]) use gamma_g[g] / beta_g[g] (ngroups <= 1: gamma, beta) */
+  int32_t ngroups;
+  int32_t n_end[4];
+  const float* gamma_g[4];
+  const float* beta_g[4];
 } es_gn_desc;
 int es_group_norm(const es_gn_desc* d, void* stream);
 size_t es_group_norm_partials_bytes(int N, int groups);
@@ -98,6 +110,16 @@ size_t es_group_norm_partials_bytes(int N, int groups);
 /* LayerNorm over the last dim of [M, C] (BasicTransformerBlock.norm1/2/3), eps 1e-5. */
 int es_layer_norm(const void* x, void* out, const float* gamma, const float* beta, int M, int C, float eps,
                   int dtype, void* stream);
+/* grouped LayerNorm: rows [row_end[g-1], row_end[g]) use gamma_g[g] / beta_g[g] */
+typedef struct {
+  const void* x; void* out;
+  const float* gamma_g[4]; const float* beta_g[4];
+  int32_t row_end[4];
+  int32_t ngroups, M, C;
+  float eps;
+  int32_t dtype;
+} es_ln_desc;
+int es_layer_norm_grouped(const es_ln_desc* d, void* stream);
 
 /* EdgeStyle fusion block: interleave (model/edgestyle_multicontrolnet.py:479-501) + ControlNetBlock
  * (model/edgestyle_multicontrolnet.py:23-63) without materialising the interleaved tensor.
@@ -131,7 +153,8 @@ int es_timestep_embedding(const float* t, void* out, int N, int dim, int dtype, 
  * rewritten for the next step (CFG duplicate, PL:443-447).  coef: device fp32 table [steps][4] =
  * {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)}, row selected by *step_idx (device int32). */
 int es_cfg_ddim_step(const void* noise, float* latents, void* model_in, const float* coef, const int32_t* step_idx,
-                     float guidance_scale, int B, int HW, int L, int Lstride, int cfg, int dtype, void* stream);
+                     float guidance_scale, int B, int HW, int L, int Lstride, int cfg, int nsteps, int dtype,
+                     void* stream);   /* *step_idx is clamped to [0, nsteps) */
 
 /* CFG combine + one UniPCMultistepScheduler step (the scheduler the reference's callers swap in, TT:273 / APP:118):
  * bh2, solver_order <= 2, predict_x0, epsilon prediction.  The corrector/predictor updates are linear in
@@ -140,7 +163,7 @@ int es_cfg_ddim_step(const void* noise, float* latents, void* model_in, const fl
  * [B,HW,L], zero before the first step. */
 int es_cfg_unipc_step(const void* noise, float* latents, float* last_sample, float* m0, float* m1, void* model_in,
                       const float* coef, const int32_t* step_idx, float guidance_scale, int B, int HW, int L,
-                      int Lstride, int cfg, int dtype, void* stream);
+                      int Lstride, int cfg, int nsteps, int dtype, void* stream);
 
 /* Layout / dtype conversion at the drop-in boundary (callers hand NCHW fp32, TT:328-359). */
 int es_nchw_f32_to_nhwc(const float* in, void* out, int N, int C, int HW, int Cpad, int dtype, void* stream);
@@ -153,9 +176,9 @@ int es_vae_sample(const void* moments, const float* noise_nchw, void* z, int N, 
                   float scaling, int dtype, void* stream);
 /* dst (int32 device) += 1  — advances the step counter inside a captured graph */
 int es_incr(int32_t* ctr, void* stream);
-/* out[0..row_len) = table[*idx][0..row_len) — selects this step's timestep / conditioning-scale row inside a
+/* out[0..row_len) = table[clamp(*idx, 0, nrows-1)][0..row_len) — selects this step's timestep / conditioning-scale row inside a
  * captured graph (PL:435, PL:464-470) so a replay needs no host-side scalar update */
-int es_gather_row(const float* table, const int32_t* idx, float* out, int row_len, void* stream);
+int es_gather_row(const float* table, const int32_t* idx, float* out, int row_len, int nrows, void* stream);
 
 #ifdef __cplusplus
 }

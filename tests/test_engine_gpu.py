@@ -117,3 +117,30 @@ def test_hip_step_and_pipeline_vs_committed_golden(setup):
     out = runner.step_nchw(g["x"].to(DEV), 501, g["ehs"].to(DEV), [g[f"cond{i}"].to(DEV) for i in range(6)],
                            [1.0, 0.8, 1.0, 1.0, 0.5, 1.0])
     assert float((out.float().cpu() - g["noise_pred"]).abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("mode", ["grouped", "streams", "serial"])
+def test_full_step_chain_modes_match_oracle(mode):
+    """The three execution modes of the four independent encoder chains (grouped lockstep launches / parallel streams /
+    serial) against the oracle, at a latent size (64) where the groups tile in 128-pixel units so `grouped` really
+    runs grouped launches (tiny width keeps the CPU oracle fast)."""
+    import dataclasses
+    from oracle import sd15_oracle as O
+    from edgestyle_amd.models import StepRunner
+    ucfg = dataclasses.replace(C.tiny_unet(), sample_size=64)
+    ws = {k: quantize(v) for k, v in make_weights(ucfg, C.tiny_vae(), seed=5).items()}
+    g = torch.Generator().manual_seed(4)
+    N, s, c0 = 2, 64, ucfg.block_out_channels[0]
+    x = torch.randn(N, 4, s, s, generator=g).half().float()
+    ehs = (torch.randn(N, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+    conds = [(torch.randn(N, c0, s, s, generator=g) * 0.3).half().float() for _ in range(6)]
+    scales = [1.0, 0.7, 1.0, 1.0, 1.2, 1.0]
+    torch.set_num_threads(16)
+    ref = O.denoise_step(ws["unet"], ucfg, ws["fusion"], oracle_nets(ws, ucfg), x, 321, ehs, conds, scales)
+    runner = StepRunner.from_state_dicts(ws, ucfg, torch.float16, DEV)
+    runner.mode = mode
+    out = runner.step_nchw(x.to(DEV), 321, ehs.to(DEV), [c.to(DEV) for c in conds], scales)
+    if mode == "grouped":
+        assert runner._grouped is not None and runner._grouped.groupable(64)
+    err = float((out.float().cpu() - ref).abs().max())
+    assert err < 2e-2, err

@@ -29,7 +29,7 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     L = lib.load()
     assert L.es_abi_version() == 1
     # struct layouts agree with the C side (sizes are what the kernels index with)
-    for i, st in enumerate((lib.GemmDesc, lib.AttnDesc, lib.GnDesc, lib.FusionDesc)):
+    for i, st in enumerate((lib.GemmDesc, lib.AttnDesc, lib.GnDesc, lib.FusionDesc, lib.LnDesc)):
         assert L.es_sizeof_desc(i) == ctypes.sizeof(st)
 
 
