@@ -417,7 +417,8 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
   } while (0)
 #define ES_LAUNCH_ST(BNV)                                                                                   \
   do {                                                                                                      \
-    if (bm == 256) ES_LAUNCH(256, BNV, true, 2);                                                            \
+    if (bm == 256 && stages == 3) ES_LAUNCH(256, BNV, true, 3);                                             \
+    else if (bm == 256) ES_LAUNCH(256, BNV, true, 2);                                                       \
     else if (stages == 2) ES_LAUNCH(128, BNV, true, 2);                                                     \
     else if (stages == 3) ES_LAUNCH(128, BNV, true, 3);                                                     \
     else ES_LAUNCH(128, BNV, true, 4);                                                                      \

@@ -297,3 +297,35 @@ def test_errors_are_loud():
         ops.attention(torch.zeros(1, 8, 36, dtype=torch.float16, device=DEV),
                       torch.zeros(1, 8, 36, dtype=torch.float16, device=DEV),
                       torch.zeros(1, 8, 36, dtype=torch.float16, device=DEV), heads=1)   # d=36 unsupported
+
+
+def test_grouped_launches_equal_separate_launches():
+    """One grouped launch over the batch-concatenated activations == per-net launches (bit for bit): conv/linear with
+    temb + residual, GroupNorm, LayerNorm."""
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(12)
+    counts, H, C, Cout = [2, 6, 4, 2], 8, 64, 128         # 128 pixels per 2 samples: groups tile in 128-pixel units
+    N = sum(counts)
+    x = torch.randn(N, H, H, C, generator=g).to(DEV, torch.float16)
+    res = torch.randn(N, H, H, Cout, generator=g).to(DEV, torch.float16)
+    temb = torch.randn(N, 256, generator=g).to(DEV, torch.float16)
+    pws = [ops.pack_weight(torch.randn(Cout, C, 3, 3, generator=g) / 24, torch.randn(Cout, generator=g) * 0.1,
+                           torch.float16, DEV) for _ in counts]
+    yg = ops.conv_gemm(x, pws, temb=temb[:, 64:], residual=res, group_n=counts)
+    a = 0
+    for pw, n in zip(pws, counts):
+        ys = ops.conv_gemm(x[a:a + n], pw, temb=temb[a:a + n, 64:], residual=res[a:a + n])
+        assert torch.equal(yg[a:a + n], ys)
+        a += n
+    gam = [(1 + 0.1 * torch.randn(C, generator=g)).to(DEV) for _ in counts]
+    bet = [(0.1 * torch.randn(C, generator=g)).to(DEV) for _ in counts]
+    ng = ops.group_norm(x, gam, bet, 32, 1e-5, True, group_n=counts)
+    tok = x.reshape(N, H * H, C)
+    lg = ops.layer_norm(tok, gam, bet, group_rows=[n * H * H for n in counts])
+    a = 0
+    for i, n in enumerate(counts):
+        assert torch.equal(ng[a:a + n], ops.group_norm(x[a:a + n], gam[i], bet[i], 32, 1e-5, True))
+        assert torch.equal(lg[a:a + n], ops.layer_norm(tok[a:a + n].contiguous(), gam[i], bet[i]))
+        a += n
+    with pytest.raises(Exception):
+        ops.conv_gemm(x, pws, group_n=[3, 5, 4, 2])      # 3 samples x 64 px is not a whole number of 128-px tiles
