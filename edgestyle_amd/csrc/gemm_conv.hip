@@ -3,7 +3,9 @@
 //   D[cout][pixel] = sum_k W[cout][k] * X[pixel][k]      (A operand = weights, B operand = im2col'd activations)
 //
 // Tile: BM=128 pixels x BN (128|160) couts x BK=64, 256 threads = 4 waves as 2(M) x 2(N); each wave owns
-// 64 pixels x BN/2 couts = 4 x (4|5) MFMA fragments.
+// 64 pixels x BN/2 couts = 4 x (4|5) MFMA fragments.  Large launches use the big tile BM=256 x BN=320 (512 threads =
+// 8 waves as 4(M) x 2(N), 64 px x 160 couts per wave, one workgroup per CU): it moves half the L2->LDS bytes per
+// FLOP, which is what bounds the 128-pixel tile (tools/gemm_ablate.sh: its DMA stream alone takes longer than its MFMAs).
 //
 // Staging is LDS-DMA (`buffer_load_dwordx4 ... lds`): every wave-instruction copies 8 tile rows x 128 B straight from
 // global memory into LDS — no VGPR round trip and no ds_write traffic (ds_write_b128 tops out at ~79 B/clk/CU, which
@@ -25,6 +27,13 @@ namespace {
 
 constexpr int BK = 64;
 
+// Tool-only ablation builds (tools/gemm_ablate.sh): time the K loop with one ingredient removed.  Results are wrong
+// by construction; the product library is always built with ES_ABLATE == 0.
+//   1: no MFMA   2: no LDS-DMA inside the loop   4: no fragment reads inside the loop   8: no barrier / DMA wait
+#ifndef ES_ABLATE
+#define ES_ABLATE 0
+#endif
+
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <typename T>
@@ -44,7 +53,9 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
   constexpr int WI = (WP + NW - 1) / NW;
   constexpr int XT = BM * BK * 2;    // bytes per stage
   constexpr int WT = BN * BK * 2;
-  constexpr int EROW = BN * 2 + 16;  // epilogue tile row stride (bytes), padded against bank conflicts
+  constexpr int NPASS = ((size_t)BM * (BN * 2 + 16) > (size_t)STAGES * (BM + BN) * BK * 2) ? 2 : 1;   // epilogue passes
+  constexpr int BNP = BN / NPASS;    // couts staged per epilogue pass
+  constexpr int EROW = BNP * 2 + 16; // epilogue tile row stride (bytes), padded against bank conflicts
   constexpr int NI = 4 + WI;         // LDS-DMA instructions per wave per K-step
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -100,7 +111,10 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
     }
   }
   int grp = 0;
-  if (p.ngroups > 1) grp = (tile_m >= p.mt_end[0]) + (tile_m >= p.mt_end[1]) + (tile_m >= p.mt_end[2]);
+  if (p.ngroups > 1) {
+    const int t128 = tile_m * (BM / 128);              // group table is in 128-pixel units
+    grp = (t128 >= p.mt_end[0]) + (t128 >= p.mt_end[1]) + (t128 >= p.mt_end[2]);
+  }
   const void* wsel = p.ngroups > 1 ? p.w_g[grp] : p.w;
   const float* bsel = p.ngroups > 1 ? p.bias_g[grp] : p.bias;
   const auto rW = __builtin_amdgcn_make_buffer_rsrc(
@@ -190,20 +204,56 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
 
   const int frow = lane & 15, fq = lane >> 4;
   int stage = 0, istage = STAGES - 1;
+#if ES_ABLATE & 4
+  typename Traits<T>::vec8 xa0[FM], wa0[FN], xa1[FM], wa1[FN];
+#endif
   for (int ks = ks0; ks < ks1; ++ks) {
     // tile ks must have landed; up to STAGES-2 younger tiles (NI DMA instructions each) may stay in flight
-    if (STAGES > 2 && ks + STAGES - 2 < ks1) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * NI) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(ES_ABLATE & 8)) {
+      if (STAGES > 2 && ks + STAGES - 2 < ks1) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * NI) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();                    // everyone's DMA of tile ks landed; everyone finished tile ks-1
     }
-    __builtin_amdgcn_s_barrier();                      // everyone's DMA of tile ks landed; everyone finished tile ks-1
     const char* xs = smem + stage * (XT + WT);
     const char* ws = xs + XT;
     // Fragment reads are software-pipelined against the MFMAs: the reads of the second 32-deep half are in flight
     // behind the first half's MFMAs, and the next tile's DMA issue (address math + 9 LDS-DMA instructions) sits
     // between the two read groups where it covers the first group's LDS latency.
+    if constexpr (FN > 5) {
+      // big tile: 40 accumulator fragments per wave leave no room for all 28 operand fragments of a K-step, so the
+      // W fragments are streamed one ahead of their MFMAs; per accumulator the summation order is unchanged
+      // (32-deep half 0, then half 1).
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        typename Traits<T>::vec8 xa[FM];
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+          const int row = wm * 64 + j * 16 + frow;
+          xa[j] = as_vec8<T>(*(const u32x4*)(xs + row * 128 + (((4 * h + fq) ^ (row & 7)) << 4)));
+        }
+        auto wfrag = [&](int i) {
+          const int row = wn * (BN / 2) + i * 16 + frow;
+          return as_vec8<T>(*(const u32x4*)(ws + row * 128 + (((4 * h + fq) ^ (row & 7)) << 4)));
+        };
+        auto wcur = wfrag(0);
+        if (h == 0 && ks + STAGES - 1 < ks1) issue_tile(ks + STAGES - 1, istage);
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+          auto wnxt = wcur;
+          if (i + 1 < FN) wnxt = wfrag(i + 1);
+#pragma unroll
+          for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(wcur, xa[j], acc[i][j]);
+          wcur = wnxt;
+        }
+      }
+    } else {
+#if !(ES_ABLATE & 4)
     typename Traits<T>::vec8 xa0[FM], wa0[FN], xa1[FM], wa1[FN];
+#endif
+    if (!(ES_ABLATE & 4) || ks == ks0) {
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
       const int row = wm * 64 + j * 16 + frow;
@@ -214,7 +264,9 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
       const int row = wn * (BN / 2) + i * 16 + frow;
       wa0[i] = as_vec8<T>(*(const u32x4*)(ws + row * 128 + (((0 + fq) ^ (row & 7)) << 4)));
     }
-    if (ks + STAGES - 1 < ks1) issue_tile(ks + STAGES - 1, istage);
+    }
+    if (!(ES_ABLATE & 2) && ks + STAGES - 1 < ks1) issue_tile(ks + STAGES - 1, istage);
+    if (!(ES_ABLATE & 4) || ks == ks0) {
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
       const int row = wm * 64 + j * 16 + frow;
@@ -225,6 +277,13 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
       const int row = wn * (BN / 2) + i * 16 + frow;
       wa1[i] = as_vec8<T>(*(const u32x4*)(ws + row * 128 + (((4 + fq) ^ (row & 7)) << 4)));
     }
+    }
+#if ES_ABLATE & 1
+#pragma unroll
+    for (int j = 0; j < FM; ++j) { asm volatile("" ::"v"(xa0[j]), "v"(xa1[j])); }
+#pragma unroll
+    for (int i = 0; i < FN; ++i) { asm volatile("" ::"v"(wa0[i]), "v"(wa1[i])); }
+#else
 #pragma unroll
     for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -233,6 +292,8 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
     for (int i = 0; i < FN; ++i)
 #pragma unroll
       for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(wa1[i], xa1[j], acc[i][j]);
+#endif
+    }
     istage = istage + 1 == STAGES ? 0 : istage + 1;
     stage = stage + 1 == STAGES ? 0 : stage + 1;
   }
@@ -256,6 +317,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
   }
 
   // ---------------- epilogue phase A: registers -> LDS tile [pixel][cout] in T ----------------
+  // The big tile (256 x 320 outputs) does not fit the LDS at once: it runs two passes, one wave column (160 couts) each.
   const bool geglu = p.act == ES_ACT_GEGLU;
   const int Cstore = geglu ? p.Cout / 2 : p.Cout;
   float scale = p.out_scale;
@@ -264,82 +326,87 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
 #pragma unroll
   for (int i = 0; i < FN; ++i)
     bias[i] = bsel ? *(const f32x4*)(bsel + tile_n * BN + pcol + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
-  __syncthreads();                                        // all waves are done reading the stage buffers
   char* et = smem;
+  T* outp = (T*)p.out;
+  const T* resp = (const T*)p.residual;
 #pragma unroll
-  for (int j = 0; j < FM; ++j) {
-    const int m = tile_m * BM + prow + j * 16;
-    const int n = (m < M ? m : M - 1) / HWout;
-    if (geglu) {
-      if constexpr (FN % 2 == 0) {
+  for (int pass = 0; pass < NPASS; ++pass) {
+    __syncthreads();                                      // stage buffers / previous pass's tile no longer read
+    if (NPASS == 1 || wn == pass) {
 #pragma unroll
-        for (int i = 0; i < FN; i += 2) {
-          typename Traits<T>::vec4 pk;
+      for (int j = 0; j < FM; ++j) {
+        const int m = tile_m * BM + prow + j * 16;
+        const int n = (m < M ? m : M - 1) / HWout;
+        if (geglu) {
+          if constexpr (FN % 2 == 0 && NPASS == 1) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float hv = acc[i][j][r] + bias[i][r], gv = acc[i + 1][j][r] + bias[i + 1][r];
-            pk[r] = from_f32<T>(hv * gelu_f(gv) * scale);
+            for (int i = 0; i < FN; i += 2) {
+              typename Traits<T>::vec4 pk;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float hv = acc[i][j][r] + bias[i][r], gv = acc[i + 1][j][r] + bias[i + 1][r];
+                pk[r] = from_f32<T>(hv * gelu_f(gv) * scale);
+              }
+              *(typename Traits<T>::vec4*)(et + (prow + j * 16) * EROW + ((wn * (BN / 2) + i * 16) / 2 + fq * 4) * 2) = pk;
+            }
           }
-          *(typename Traits<T>::vec4*)(et + (prow + j * 16) * EROW + ((wn * (BN / 2) + i * 16) / 2 + fq * 4) * 2) = pk;
+        } else {
+#pragma unroll
+          for (int i = 0; i < FN; ++i) {
+            const int c = tile_n * BN + pcol + i * 16;
+            float tv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.temb && c < p.Cout) {
+              const T* tp = (const T*)p.temb + (size_t)n * p.temb_stride + c;
+              if (c + 3 < p.Cout) {
+                const auto t4 = *(const typename Traits<T>::vec4*)tp;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tv[r] = to_f32(t4[r]);
+              } else {
+                for (int r = 0; r < 4 && c + r < p.Cout; ++r) tv[r] = to_f32(tp[r]);
+              }
+            }
+            typename Traits<T>::vec4 pk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float x = acc[i][j][r] + bias[i][r] + tv[r];
+              if (p.act == ES_ACT_SILU) x = silu_f(x);
+              pk[r] = from_f32<T>(x * scale);
+            }
+            *(typename Traits<T>::vec4*)(et + (prow + j * 16) * EROW + (pcol - pass * BNP + i * 16) * 2) = pk;
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---------------- epilogue phase B: coalesced residual add + store along the channel dim ----------------
+    const int BNo = geglu ? BN / 2 : BNP;                 // tile width in stored channels (this pass)
+    const int c_tile = tile_n * (geglu ? BN / 2 : BN) + pass * BNP;
+    if ((Cstore & 7) == 0) {
+      const int CH = BNo / 8;
+      for (int idx = tid; idx < BM * CH; idx += NT) {
+        const int row = idx / CH, ch = idx - row * CH;
+        const int m = tile_m * BM + row, c = c_tile + ch * 8;
+        if (m < M && c < Cstore) {
+          auto v = as_vec8<T>(*(const u32x4*)(et + row * EROW + ch * 16));
+          if (resp) {
+            const auto rv = as_vec8<T>(*(const u32x4*)(resp + (size_t)m * Cstore + c));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(rv[e]));
+          }
+          *(typename Traits<T>::vec8*)(outp + (size_t)m * Cstore + c) = v;
         }
       }
     } else {
-#pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        const int c = tile_n * BN + pcol + i * 16;
-        float tv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.temb && c < p.Cout) {
-          const T* tp = (const T*)p.temb + (size_t)n * p.temb_stride + c;
-          if (c + 3 < p.Cout) {
-            const auto t4 = *(const typename Traits<T>::vec4*)tp;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) tv[r] = to_f32(t4[r]);
-          } else {
-            for (int r = 0; r < 4 && c + r < p.Cout; ++r) tv[r] = to_f32(tp[r]);
-          }
+      // narrow outputs (conv_out: 4 or 3 channels): scalar tail path
+      for (int idx = tid; idx < BM * BNo; idx += NT) {
+        const int row = idx / BNo, cc = idx - row * BNo;
+        const int m = tile_m * BM + row, c = c_tile + cc;
+        if (m < M && c < Cstore) {
+          float x = to_f32(*(const T*)(et + row * EROW + cc * 2));
+          if (resp) x += to_f32(resp[(size_t)m * Cstore + c]);
+          outp[(size_t)m * Cstore + c] = from_f32<T>(x);
         }
-        typename Traits<T>::vec4 pk;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float x = acc[i][j][r] + bias[i][r] + tv[r];
-          if (p.act == ES_ACT_SILU) x = silu_f(x);
-          pk[r] = from_f32<T>(x * scale);
-        }
-        *(typename Traits<T>::vec4*)(et + (prow + j * 16) * EROW + (pcol + i * 16) * 2) = pk;
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---------------- epilogue phase B: coalesced residual add + store along the channel dim ----------------
-  const int BNo = geglu ? BN / 2 : BN;                    // tile width in stored channels
-  const int c_tile = tile_n * BNo;
-  T* outp = (T*)p.out;
-  const T* resp = (const T*)p.residual;
-  if ((Cstore & 7) == 0) {
-    const int CH = BNo / 8;
-    for (int idx = tid; idx < BM * CH; idx += NT) {
-      const int row = idx / CH, ch = idx - row * CH;
-      const int m = tile_m * BM + row, c = c_tile + ch * 8;
-      if (m < M && c < Cstore) {
-        auto v = as_vec8<T>(*(const u32x4*)(et + row * EROW + ch * 16));
-        if (resp) {
-          const auto rv = as_vec8<T>(*(const u32x4*)(resp + (size_t)m * Cstore + c));
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(rv[e]));
-        }
-        *(typename Traits<T>::vec8*)(outp + (size_t)m * Cstore + c) = v;
-      }
-    }
-  } else {
-    // narrow outputs (conv_out: 4 or 3 channels): scalar tail path
-    for (int idx = tid; idx < BM * BNo; idx += NT) {
-      const int row = idx / BNo, cc = idx - row * BNo;
-      const int m = tile_m * BM + row, c = c_tile + cc;
-      if (m < M && c < Cstore) {
-        float x = to_f32(*(const T*)(et + row * EROW + cc * 2));
-        if (resp) x += to_f32(resp[(size_t)m * Cstore + c]);
-        outp[(size_t)m * Cstore + c] = from_f32<T>(x);
       }
     }
   }
@@ -400,7 +467,8 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
   // Pixel tile: 128 rows x 4 waves (2 workgroups/CU) by default; 256 rows x 8 waves (1 workgroup/CU) selectable (bm).
   const int tn = d.rows_padded / d.bn;
   int bm = d.bm;
-  if (bm == 0) bm = 128;   // measured: 2 independent 128-row workgroups per CU beat one 256-row 8-wave workgroup on every shape
+  if (d.bn == 320) bm = 256;
+  if (bm == 0) bm = 128;
   dim3 grid(((M + bm - 1) / bm) * tn * d.splitk);
   int stages = d.stages;
   if (stages == 0) stages = 2;   // measured (tools/gemm_bench.py): 2 stages x 2 workgroups/CU beats a 3-4 deep ring at 1/CU
@@ -423,8 +491,9 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
     else if (stages == 3) ES_LAUNCH(128, BNV, true, 3);                                                     \
     else ES_LAUNCH(128, BNV, true, 4);                                                                      \
   } while (0)
-  if (d.bn == 128) { if (aligned) ES_LAUNCH_ST(128); else ES_LAUNCH(128, 128, false, 2); }
-  else             { if (aligned) ES_LAUNCH_ST(160); else ES_LAUNCH(128, 160, false, 2); }
+  if (d.bn == 320)      { ES_LAUNCH(256, 320, true, 2); }
+  else if (d.bn == 128) { if (aligned) ES_LAUNCH_ST(128); else ES_LAUNCH(128, 128, false, 2); }
+  else                  { if (aligned) ES_LAUNCH_ST(160); else ES_LAUNCH(128, 160, false, 2); }
 #undef ES_LAUNCH_ST
 #undef ES_LAUNCH
   if (d.splitk > 1) {
@@ -452,9 +521,14 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
     const int tm = (d->N * d->Hout * d->Wout + 127) / 128;
     for (int g = 0; g < d->ngroups; ++g)
       if (!d->w_g[g] || d->mt_end[g] <= (g ? d->mt_end[g - 1] : 0)) { es_set_error("es_conv_gemm: bad group table"); return -1; }
-    if (d->mt_end[d->ngroups - 1] != tm || (d->N * d->Hout * d->Wout) % 128 || d->bm == 256) { es_set_error("es_conv_gemm: groups must tile M in whole 128-pixel tiles"); return -1; }
+    if (d->mt_end[d->ngroups - 1] != tm || (d->N * d->Hout * d->Wout) % 128) { es_set_error("es_conv_gemm: groups must tile M in whole 128-pixel tiles"); return -1; }
+    if (d->bm == 256 || d->bn == 320)
+      for (int g = 0; g < d->ngroups; ++g)
+        if (d->mt_end[g] & 1) { es_set_error("es_conv_gemm: 256-pixel tiles need groups of whole 256-pixel tiles"); return -1; }
   }
-  if (d->bn != 128 && d->bn != 160) { es_set_error("es_conv_gemm: bn must be 128 or 160"); return -1; }
+  if (d->bn != 128 && d->bn != 160 && d->bn != 320) { es_set_error("es_conv_gemm: bn must be 128, 160 or 320"); return -1; }
+  if (d->bn == 320 && (d->bm == 128 || d->C1 % BK || d->C2 % BK || (d->stages != 0 && d->stages != 2) || d->act == ES_ACT_GEGLU)) {
+    es_set_error("es_conv_gemm: bn=320 is the 256-pixel tile: 64-aligned channels, 2 stages, no GEGLU"); return -1; }
   if (d->rows_padded % d->bn || d->rows_padded < d->Cout) { es_set_error("es_conv_gemm: bad rows_padded"); return -1; }
   if (d->Kpad % BK || d->Kpad < Ktrue) { es_set_error("es_conv_gemm: bad Kpad"); return -1; }
   if (d->C1 % 8 || d->C2 % 8 || (d->C2 && !d->x2)) { es_set_error("es_conv_gemm: channels must be multiples of 8"); return -1; }
@@ -467,7 +541,7 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
   if (d->act == ES_ACT_GEGLU && (d->bn != 128 || d->Cout % 32)) { es_set_error("es_conv_gemm: GEGLU needs bn=128, Cout%32==0"); return -1; }
   if (d->N < 1 || d->Hout < 1 || d->Wout < 1) { es_set_error("es_conv_gemm: empty problem"); return -1; }
   if (d->bm != 0 && d->bm != 128 && d->bm != 256) { es_set_error("es_conv_gemm: bm must be 0 (auto), 128 or 256"); return -1; }
-  if (d->bm == 256 && (d->C1 % BK || d->C2 % BK || d->splitk != 1)) { es_set_error("es_conv_gemm: bm=256 needs 64-aligned channels and splitk=1"); return -1; }
+  if (d->bm == 256 && (d->C1 % BK || d->C2 % BK)) { es_set_error("es_conv_gemm: bm=256 needs 64-aligned channels"); return -1; }
   if (d->stages != 0 && (d->stages < 2 || d->stages > 4)) { es_set_error("es_conv_gemm: stages must be 0 (auto), 2, 3 or 4"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   int rc = d->dtype == ES_F16 ? launch<f16>(*d, st) : launch<bf16>(*d, st);

@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libedgestyle_hip.so")
+# ES_HIP_LIB: tools only (ablation / experimental kernel builds); the product always loads the in-tree library
+LIB_PATH = os.environ.get("ES_HIP_LIB") or os.path.join(_HERE, "lib", "libedgestyle_hip.so")
 
 ES_F16, ES_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2

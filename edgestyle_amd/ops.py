@@ -33,9 +33,8 @@ class lane:
         LANE = self.prev
 
 
-SPLITK_TARGET = int(_os.environ.get("ES_SPLITK_TARGET", "320"))   # workgroups a split-K launch aims for
 XCD_ORDER = -1      # tuning knob: -1 auto, 0 tile_n fastest, 1 tile_m fastest
-DEEP_RING = _os.environ.get("ES_DEEP_RING", "1") == "1"     # 4-stage ring for single-round grids on the main stream
+DEEP_RING = _os.environ.get("ES_DEEP_RING", "1") == "1"     # 4-stage LDS ring for launches of <= 1 workgroup per CU
 FORCE_BN = 0        # tuning knob: 0 = per-launch choice between the legal N tiles
 FORCE_BM = 0        # tuning knob: 0 = kernel picks the pixel tile (128 / 256)
 FORCE_STAGES = 0    # tuning knob (tools/gemm_bench.py): 0 = kernel picks the LDS ring depth
@@ -169,51 +168,71 @@ def _get_workspace(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
-def choose_launch_bn(M: int, pw: "PackedWeight") -> int:
-    """N tile for this launch.  The packed layout only requires rows_padded % bn == 0, so both 128 and 160 are legal
-    for 640/1280/1920/... couts; pick the one that wastes fewer workgroup rounds (512 resident workgroups: 256 CUs x 2):
-    e.g. M=16384, N=640 is 640 tiles (1.25 rounds) at bn=128 but exactly 512 at bn=160."""
-    if pw.geglu:
-        return 128
-    tm = (M + BM - 1) // BM
-    best, best_cost = pw.bn, None
-    for bn in (160, 128):                       # ties go to the wider tile (more MFMAs per DMA instruction)
-        if pw.rows_padded % bn:
-            continue
-        tiles = tm * (pw.rows_padded // bn)
-        if tiles <= 256:                        # at most one workgroup per CU: duration of one tile
-            cost = float(bn)
-        elif tiles <= 512:                      # some CUs host two workgroups (each then runs ~1.6x longer)
-            cost = bn * (1.0 + 0.6 * (tiles - 256) / 256.0)
-        else:                                   # full rounds of 512 resident workgroups
-            cost = -(-tiles // 512) * bn * 1.6
-        if best_cost is None or cost < best_cost:
-            best, best_cost = bn, cost
-    return best
+# Launch planner.  A launch is described by (bn, splitk, stages); its cost model below is in units of one K-step of a
+# 128-wide tile on a CU shared by two workgroups (~0.77 us) and was fitted on tools/gemm_tune.py sweeps over the
+# shapes of a batch-1 denoising step (total within 1.1 % of the per-shape best configuration, 6.4 % below the
+# previous tiles-vs-target rules):
+#   * 512 workgroups are resident at once (256 CUs x 2); a launch takes ceil(WGs / 512) rounds of one workgroup's time;
+#   * a 160-wide tile costs 1.25x a 128-wide one per K-step; a workgroup alone on its CU runs ~10 % faster;
+#   * split-K pays a reduce launch (~12 units) plus the fp32 slab round trip, needs >= 12 K-steps per slice and is
+#     never worth it for K <= 640.
+#   * the big tile (256 px x 320 couts, one workgroup per CU) does the work of two 160-wide workgroups in ~4 % less
+#     time (half the L2->LDS bytes); it only pays on launches of many rounds, so it is offered from 32k pixels up.
+PLAN_T160, PLAN_ALONE, PLAN_TFIX, PLAN_RED_FIX, PLAN_SLAB_BYTES_PER_UNIT = 1.25, 0.9, 2.0, 12.0, 4.0e6
+PLAN_T320, PLAN_BIG_MIN_M = 2.4, 32768
+BIG_TILE = _os.environ.get("ES_BIG_TILE", "0") == "1"      # opt-in: measured no end-to-end gain at batch 1 or 8
+PLAN_SLAB_BYTES_PER_UNIT = float(_os.environ.get("ES_PLAN_SLAB", PLAN_SLAB_BYTES_PER_UNIT))
+PLAN_RED_FIX = float(_os.environ.get("ES_PLAN_REDFIX", PLAN_RED_FIX))
+PLAN_MIN_SLICE, PLAN_NK_NOSPLIT, PLAN_RESIDENT = 12, 10, 512
 
 
-def choose_splitk(M: int, rows_padded: int, bn: int, kpad: int, target: Optional[int] = None) -> int:
-    target = target or SPLITK_TARGET
-    tiles = ((M + BM - 1) // BM) * (rows_padded // bn)
+def plan_gemm(M: int, rows_padded: int, kpad: int, geglu: bool = False, bns=(160, 128), allow_split: bool = True):
+    """(bn, splitk, stages) with the lowest modelled time among the legal N tiles (ties go to the wider tile)."""
+    if geglu:
+        return 128, 1, 2
     nk = kpad // BK
-    if tiles >= target // 2 or nk < 8:
-        return 1
-    s = min(max(1, target // tiles), nk // 4, 32)
-    return max(1, s)
+    best = None
+    for bn in bns:
+        if rows_padded % bn:
+            continue
+        if bn == 320 and M < PLAN_BIG_MIN_M and len(bns) > 1:
+            continue
+        bm = 256 if bn == 320 else BM
+        resident = PLAN_RESIDENT // 2 if bn == 320 else PLAN_RESIDENT
+        tiles = ((M + bm - 1) // bm) * (rows_padded // bn)
+        cands = [1]
+        if allow_split and tiles < PLAN_RESIDENT // 2 and nk > PLAN_NK_NOSPLIT:
+            cands += list(range(2, min(nk // PLAN_MIN_SLICE, 32) + 1))
+        for sk in cands:
+            wgs = tiles * sk
+            tk = PLAN_T320 if bn == 320 else (PLAN_T160 if bn == 160 else 1.0) * (PLAN_ALONE if wgs <= PLAN_RESIDENT // 2 else 1.0)
+            t = -(-wgs // resident) * ((nk / sk) * tk + PLAN_TFIX)
+            if sk > 1:
+                t += PLAN_RED_FIX + sk * M * rows_padded * 8.0 / PLAN_SLAB_BYTES_PER_UNIT
+            if best is None or t < best[0]:
+                best = (t, bn, sk, wgs)
+    if best is None:
+        raise L.EdgeStyleHipError(f"plan_gemm: rows_padded {rows_padded} fits neither N tile")
+    _, bn, sk, wgs = best
+    # one workgroup per CU at most: a 4-deep LDS ring (3 K-steps of DMA in flight) hides the HBM round trip that the
+    # 2-stage ring leaves exposed when no second workgroup shares the CU.  Not inside concurrent chains (LANE > 0,
+    # ES_CHAIN_MODE=streams): there 2 stages = 72 KB LDS let workgroups of different chains share a CU.
+    stages = 4 if (bn != 320 and DEEP_RING and LANE == 0 and wgs <= PLAN_RESIDENT // 2 and nk // sk >= 6) else 2
+    return bn, sk, stages
+
+
+def choose_launch_bn(M: int, pw: "PackedWeight") -> int:
+    return plan_gemm(M, pw.rows_padded, pw.kpad, pw.geglu)[0]
+
+
+def choose_splitk(M: int, rows_padded: int, bn: int, kpad: int) -> int:
+    return plan_gemm(M, rows_padded, kpad, bns=(bn,))[1]
 
 
 def plan_launch(M: int, pw: "PackedWeight", bn: int):
-    """(splitk, stages).  On the serial main stream (LANE 0: UNet decoder, VAE) a GEMM whose grid fits ONE workgroup
-    per CU (<= 256) runs a 4-deep LDS ring — three K-steps of DMA in flight hide the HBM round trip that a 2-stage
-    ring exposes on weight-streaming layers (measured -10..-22 %).  Inside the concurrent ControlNet / UNet-encoder
-    chains (LANE > 0) kernels stay at 2 stages = 72 KB LDS, so workgroups of different chains can share a CU."""
-    if pw.geglu:
-        return 1, 2
-    deep = DEEP_RING and LANE == 0
-    splitk = choose_splitk(M, pw.rows_padded, bn, pw.kpad, 256 if deep else None)
-    tiles = ((M + BM - 1) // BM) * (pw.rows_padded // bn)
-    stages = 4 if (deep and tiles * splitk <= 256 and (pw.kpad // BK) // splitk >= 6) else 2
-    return splitk, stages
+    """(splitk, stages) for a fixed N tile."""
+    _, sk, st = plan_gemm(M, pw.rows_padded, pw.kpad, pw.geglu, bns=(bn,))
+    return sk, st
 
 
 def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Optional[int] = None,
@@ -250,9 +269,12 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     if out is None:
         out = torch.empty((N, Hout, Wout, cstore), dtype=x.dtype, device=x.device)
     M = N * Hout * Wout
-    bn = choose_launch_bn(M, pw) if FORCE_BN == 0 else FORCE_BN
+    big_ok = BIG_TILE and C1 % BK == 0 and C2 % BK == 0 and not pw.geglu and \
+        (group_n is None or all((n * Hout * Wout) % 256 == 0 for n in group_n))
+    bn, auto_splitk, auto_stages = plan_gemm(M, pw.rows_padded, pw.kpad, pw.geglu,
+                                             bns=((320, 160, 128) if big_ok else (160, 128)) if FORCE_BN == 0 else (FORCE_BN,))
     if splitk is None:
-        splitk, auto_stages = plan_launch(M, pw, bn)
+        splitk = auto_splitk
         stages = stages or auto_stages
     d = L.GemmDesc()
     d.x, d.x2, d.w = x.data_ptr(), (x2.data_ptr() if x2 is not None else None), pw.w.data_ptr()
@@ -278,8 +300,9 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         d.workspace = ws.data_ptr()
     if pws is not None:
         hw = Hout * Wout
-        if len(pws) > 4 or len(group_n) != len(pws) or sum(group_n) != N or any((n * hw) % BM for n in group_n):
-            raise L.EdgeStyleHipError("grouped conv_gemm: groups must cover N in whole 128-pixel tiles (<= 4 groups)")
+        gran = 256 if bn == 320 else BM
+        if len(pws) > 4 or len(group_n) != len(pws) or sum(group_n) != N or any((n * hw) % gran for n in group_n):
+            raise L.EdgeStyleHipError(f"grouped conv_gemm: groups must cover N in whole {gran}-pixel tiles (<= 4 groups)")
         d.ngroups = len(pws)
         acc = 0
         for g, (q, n) in enumerate(zip(pws, group_n)):
@@ -291,7 +314,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
             d.bias_g[g] = q.bias.data_ptr() if q.bias is not None else None
     if PROFILE is not None:           # bench.py roofline leg: in-kernel s_memrealtime stamps for this launch
         d.prof = PROFILE.next((2.0 * M * pw.cout * k * k * (C1 + C2), k,
-                               (M, pw.cout, k * k * (C1 + C2), stride, splitk, pw.bn),
+                               (M, pw.cout, k * k * (C1 + C2), stride, splitk, bn),
                                dict(N=N, H=H, W=W, C1=C1, C2=C2, cout=pw.cout, k=k, stride=stride, pad=pad,
                                     upsample=bool(upsample), geglu=pw.geglu, splitk=splitk, Hout=Hout, Wout=Wout,
                                     residual=residual is not None, temb=temb is not None)))

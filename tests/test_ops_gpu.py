@@ -329,3 +329,57 @@ def test_grouped_launches_equal_separate_launches():
         a += n
     with pytest.raises(Exception):
         ops.conv_gemm(x, pws, group_n=[3, 5, 4, 2])      # 3 samples x 64 px is not a whole number of 128-px tiles
+
+
+def test_conv_gemm_big_tile_equals_small_tile():
+    """bn=320 (256-pixel x 320-cout tile, 8 waves, streamed W fragments, two-pass epilogue) must reproduce the
+    128-pixel tile bit for bit (same K order per accumulator) and match F.conv2d: concat + temb + residual + SiLU,
+    ragged M, split-K, grouped weights, 1x1, stride 2."""
+    from edgestyle_amd import ops, lib
+    g = torch.Generator().manual_seed(21)
+
+    def both(fn):
+        ops.FORCE_BN = 320
+        try:
+            big = fn()
+        finally:
+            ops.FORCE_BN = 0
+        return big, fn()
+
+    N, C1, C2, Cout, H = 3, 128, 64, 640, 12            # M = 432: one full + one ragged 256-pixel tile, 2 N tiles
+    x1 = q16(torch.randn(N, C1, H, H, generator=g))
+    x2 = q16(torch.randn(N, C2, H, H, generator=g))
+    w = q16(torch.randn(Cout, C1 + C2, 3, 3, generator=g) / math.sqrt(9 * (C1 + C2)))
+    b = torch.randn(Cout, generator=g) * 0.1
+    temb = q16(torch.randn(N, Cout, generator=g))
+    res = q16(torch.randn(N, Cout, H, H, generator=g))
+    ref = F.silu(F.conv2d(torch.cat([x1, x2], 1), w, b, padding=1) + temb[:, :, None, None]) + res
+    pw = ops.pack_weight(w, b, torch.float16, DEV)
+    tdev = temb.to(DEV, torch.float16)
+    for splitk in (1, 2):
+        big, small = both(lambda: ops.conv_gemm(nhwc(x1), pw, x2=nhwc(x2), temb=tdev, residual=nhwc(res),
+                                                act=lib.ACT_SILU, splitk=splitk))
+        assert torch.equal(big, small), splitk
+        assert rel_err(big.permute(0, 3, 1, 2), ref) < 3e-3
+    # stride 2 and 1x1, Cout = 320 (a single N tile)
+    w2 = q16(torch.randn(320, C1, 3, 3, generator=g) / math.sqrt(9 * C1))
+    pw2 = ops.pack_weight(w2, None, torch.float16, DEV)
+    big, small = both(lambda: ops.conv_gemm(nhwc(x1), pw2, stride=2))
+    assert torch.equal(big, small) and rel_err(big.permute(0, 3, 1, 2), F.conv2d(x1, w2, None, stride=2, padding=1)) < 3e-3
+    w3 = q16(torch.randn(960, C1, 1, 1, generator=g) / math.sqrt(C1))
+    pw3 = ops.pack_weight(w3, b[:1].repeat(960), torch.float16, DEV)
+    big, small = both(lambda: ops.conv_gemm(nhwc(x1), pw3))
+    assert torch.equal(big, small)
+    # grouped: 3 weight sets over 2 + 4 + 2 samples of 16x16 (256 pixels each)
+    counts, Hg = [2, 4, 2], 16
+    xg = torch.randn(sum(counts), Hg, Hg, C1, generator=g).to(DEV, torch.float16)
+    pws = [ops.pack_weight(torch.randn(320, C1, 3, 3, generator=g) / 34, torch.randn(320, generator=g) * 0.1,
+                           torch.float16, DEV) for _ in counts]
+    big, small = both(lambda: ops.conv_gemm(xg, pws, group_n=counts))
+    assert torch.equal(big, small)
+    with pytest.raises(Exception):                        # 128-pixel group boundaries cannot use 256-pixel tiles
+        ops.FORCE_BN = 320
+        try:
+            ops.conv_gemm(xg[:, :8, :8].contiguous(), pws, group_n=counts)   # 64-pixel samples: groups of 128/256/128 px
+        finally:
+            ops.FORCE_BN = 0
