@@ -11,9 +11,24 @@
 #include "common.h"
 #include "../../include/edgestyle_hip.h"
 
+// Tool-only build (-DES_ATTN_STAMPS): wave 0 of block (1,0,0) accumulates s_memtime deltas per loop phase into
+// es_attn_dbg (read back with es_attn_debug_read).  Perturbs the schedule; never compiled into the product library.
+#ifdef ES_ATTN_STAMPS
+__device__ unsigned long long es_attn_dbg[16];
+#define ES_STAMP(i)                                                                    \
+  do {                                                                                 \
+    const unsigned long long t_now = __builtin_amdgcn_s_memtime();                     \
+    dbg_acc[i] += t_now - t_prev;                                                      \
+    t_prev = t_now;                                                                    \
+  } while (0)
+#else
+#define ES_STAMP(i)
+#endif
+
 namespace {
 
-template <typename T, int KS /* QK k-steps of 32: DPAD = 32*KS */, int DF /* dv fragments of 16 */, int QF, int KVT>
+template <typename T, int KS /* QK k-steps of 32: DPAD = 32*KS */, int DF /* dv fragments of 16 */, int QF, int KVT,
+          bool ONES /* head_dim % 16 == 8: V pad column d holds 1.0, so the PV product also yields the row sum */>
 __global__ __launch_bounds__(256, (QF == 1 && KS <= 3) ? 3 : ((KS <= 5 && QF <= 2) ? 2 : 1)) void attention_kernel(const es_attn_desc p) {
   constexpr int DPAD = 32 * KS;
   constexpr int DVP = 16 * DF;
@@ -42,6 +57,7 @@ __global__ __launch_bounds__(256, (QF == 1 && KS <= 3) ? 3 : ((KS <= 5 && QF <= 
   const T* V = (const T*)p.v + (size_t)n * p.bsv + (size_t)h * d;
   T* O = (T*)p.o + (size_t)n * p.bso + (size_t)h * d;
 
+  const float sl2 = p.scale * 1.4426950408889634f;
   // Q^T fragments (B operand): lane holds Q[query = col][32*ks + 8*g .. +7]
   typename Traits<T>::vec8 qf[QF][KS];
 #pragma unroll
@@ -53,7 +69,11 @@ __global__ __launch_bounds__(256, (QF == 1 && KS <= 3) ? 3 : ((KS <= 5 && QF <= 
       const int ch = 4 * s + g;
       u32x4 v = {0u, 0u, 0u, 0u};
       if (ch < dch) v = *(const u32x4*)(Q + (size_t)qi * p.ldq + ch * 8);
-      qf[f][s] = as_vec8<T>(v);
+      auto qv = as_vec8<T>(v);
+      // fold softmax scale * log2(e) into Q once: the scores leave the MFMA ready for exp2
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qv[e] = from_f32<T>(to_f32(qv[e]) * sl2);
+      qf[f][s] = qv;
     }
   }
 
@@ -65,7 +85,9 @@ __global__ __launch_bounds__(256, (QF == 1 && KS <= 3) ? 3 : ((KS <= 5 && QF <= 
     }
     for (int i = tid; i < KVT * VCH; i += 256) {
       const int r = i / VCH, c = i - r * VCH;
-      if (c >= dch) *(u32x4*)(vs_ + b * TILE_BYTES + r * VROW + c * 16) = u32x4{0u, 0u, 0u, 0u};
+      // ONES: element d of every V row is 1.0 (f16 0x3C00 / bf16 0x3F80): row d of O^T accumulates sum_k P[k]
+      const unsigned one = (ONES && c == dch) ? (sizeof(T) == 2 && Traits<T>::is_bf16 ? 0x3F80u : 0x3C00u) : 0u;
+      if (c >= dch) *(u32x4*)(vs_ + b * TILE_BYTES + r * VROW + c * 16) = u32x4{one, 0u, 0u, 0u};
     }
   }
 
@@ -111,20 +133,30 @@ __global__ __launch_bounds__(256, (QF == 1 && KS <= 3) ? 3 : ((KS <= 5 && QF <= 
     }
   };
 
+  // Online softmax state per query (= per lane column).  The running reference m is kept NEGATED and splatted as
+  // the initial accumulator of the S^T MFMA chain, so S' = S*scale*log2e - m comes out of the matrix core and the
+  // softmax costs one v_exp per score (no subtract, no scale).  m is raised lazily: only when some score of the
+  // wave exceeds it by more than LAZY (2^8 headroom is harmless in fp32 accumulators and in fp16/bf16 P), and
+  // always on the first tile.
+  constexpr float LAZY = 8.0f;
   f32x4 o[QF][DF];
-  float mrun[QF], lrun[QF];
+  f32x4 negm[QF];
+  float lrun[QF];
 #pragma unroll
   for (int f = 0; f < QF; ++f) {
-    mrun[f] = -1e30f; lrun[f] = 0.f;
+    negm[f] = f32x4{0.f, 0.f, 0.f, 0.f}; lrun[f] = 0.f;
 #pragma unroll
     for (int j = 0; j < DF; ++j) o[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const float sl2 = p.scale * 1.4426950408889634f;
-
   load_kv();
   if (DBUF) { store_kv(0); if (KVT < p.Skv) load_kv(); }
   int buf = 0;
+#ifdef ES_ATTN_STAMPS
+  unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
   for (int kv0 = 0; kv0 < p.Skv; kv0 += KVT) {
+    ES_STAMP(0);                   // loop overhead / previous iteration's tail
     if (DBUF) {
       __syncthreads();             // tile kv0 (written last iteration / prologue) visible; tile kv0-KVT fully consumed
     } else {
@@ -133,6 +165,7 @@ __global__ __launch_bounds__(256, (QF == 1 && KS <= 3) ? 3 : ((KS <= 5 && QF <= 
       __syncthreads();
       if (kv0 + KVT < p.Skv) load_kv();
     }
+    ES_STAMP(1);                   // barrier
     const char* kb = ks_ + buf * TILE_BYTES;
     const char* vb = vs_ + buf * TILE_BYTES;
 
@@ -145,13 +178,16 @@ __global__ __launch_bounds__(256, (QF == 1 && KS <= 3) ? 3 : ((KS <= 5 && QF <= 
         const auto ka = as_vec8<T>(*(const u32x4*)(kb + (kf * 16 + col) * KROW + (4 * ksx + g) * 16));
 #pragma unroll
         for (int f = 0; f < QF; ++f)
-          s[f][kf] = mfma16(ka, qf[f][ksx], ksx == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : s[f][kf]);
+          s[f][kf] = mfma16(ka, qf[f][ksx], ksx == 0 ? negm[f] : s[f][kf]);
       }
     }
+#ifdef ES_ATTN_STAMPS
+    asm volatile("s_nop 0" ::"v"(s[0][0]), "v"(s[QF - 1][KF - 1]));   // wait for the S^T accumulators
+#endif
+    ES_STAMP(2);                   // K fragment reads + QK MFMAs
     // ---- online softmax (per query = per lane column) ----
-    // VALU budget matters more than MFMA at head_dim 40/80: raw-score max, then ONE fma + v_exp per score
-    // (scale*log2e folded into the fma), key masking only on the ragged last tile, O rescale skipped when no
-    // query of the wave raised its running max.
+    // VALU budget matters more than MFMA at head_dim 40/80 (v_exp issues at half rate): per score one v_exp, half a
+    // v_max3 and half a packed convert; key masking only on the ragged last tile.
     const bool ragged = kv0 + KVT > p.Skv;
     typename Traits<T>::vec8 pb[QF][KF / 2];
 #pragma unroll
@@ -165,29 +201,38 @@ __global__ __launch_bounds__(256, (QF == 1 && KS <= 3) ? 3 : ((KS <= 5 && QF <= 
       }
       float mx = s[f][0][0];
 #pragma unroll
-      for (int kf = 0; kf < KF; ++kf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[f][kf][r]);
+      for (int kf = 0; kf < KF; ++kf) {
+        mx = fmaxf(fmaxf(mx, s[f][kf][0]), s[f][kf][1]);
+        mx = fmaxf(fmaxf(mx, s[f][kf][2]), s[f][kf][3]);
+      }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mnew = fmaxf(mrun[f], mx * sl2);          // sl2 > 0: max commutes with the scaling
-      const float alpha = __builtin_amdgcn_exp2f(mrun[f] - mnew);
-      mrun[f] = mnew;
-      float rs = 0.f;
+      if (kv0 == 0 || !__all(mx <= LAZY)) {                 // wave-uniform: raise the reference of this wave's queries
+        const float dlt = kv0 == 0 ? mx : fmaxf(mx, 0.f);   // key 0 is always valid, so the first-tile max is finite
+        const float nm = negm[f][0] - dlt;
+        negm[f] = f32x4{nm, nm, nm, nm};
+#pragma unroll
+        for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[f][kf][r] -= dlt;
+        if (kv0 != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(-dlt);
+          lrun[f] *= alpha;
+#pragma unroll
+          for (int j = 0; j < DF; ++j) o[f][j] *= alpha;
+        }
+      }
 #pragma unroll
       for (int kf = 0; kf < KF; ++kf)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[f][kf][r], sl2, -mnew));
-          s[f][kf][r] = e;
-          rs += e;
-        }
-      rs += __shfl_xor(rs, 16, 64);
-      rs += __shfl_xor(rs, 32, 64);
-      lrun[f] = lrun[f] * alpha + rs;
-      if (!__all(alpha == 1.0f)) {
+        for (int r = 0; r < 4; ++r) s[f][kf][r] = __builtin_amdgcn_exp2f(s[f][kf][r]);
+      if constexpr (!ONES) {
+        float rs = 0.f;
 #pragma unroll
-        for (int j = 0; j < DF; ++j) o[f][j] *= alpha;
+        for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) rs += s[f][kf][r];
+        lrun[f] += rs;                                      // per-lane partial; the 4 key groups are summed at the end
       }
       // P^T as B operand: k index 8g+j <-> key 32*sx + 16*(j>>2) + 4g + (j&3)
 #pragma unroll
@@ -198,6 +243,10 @@ __global__ __launch_bounds__(256, (QF == 1 && KS <= 3) ? 3 : ((KS <= 5 && QF <= 
         pb[f][sx] = b;
       }
     }
+#ifdef ES_ATTN_STAMPS
+    asm volatile("s_nop 0" ::"v"(pb[0][0]), "v"(pb[QF - 1][KF / 2 - 1]));
+#endif
+    ES_STAMP(3);                   // softmax
     // ---- O^T += V^T P^T ----
 #pragma unroll
     for (int sx = 0; sx < KF / 2; ++sx) {
@@ -214,6 +263,10 @@ __global__ __launch_bounds__(256, (QF == 1 && KS <= 3) ? 3 : ((KS <= 5 && QF <= 
         for (int f = 0; f < QF; ++f) o[f][j] = mfma16(va, pb[f][sx], o[f][j]);
       }
     }
+#ifdef ES_ATTN_STAMPS
+    asm volatile("s_nop 0" ::"v"(o[0][0]), "v"(o[QF - 1][DF - 1]));
+#endif
+    ES_STAMP(4);                   // V reads + PV MFMAs
     if (DBUF) {
       // tile kv0+KVT (in registers since the top of this iteration) -> the other buffer; then fetch kv0+2*KVT
       if (kv0 + KVT < p.Skv) {
@@ -222,13 +275,26 @@ __global__ __launch_bounds__(256, (QF == 1 && KS <= 3) ? 3 : ((KS <= 5 && QF <= 
       }
       buf ^= 1;
     }
+    ES_STAMP(5);                   // staging: registers -> LDS, next global loads
   }
+#ifdef ES_ATTN_STAMPS
+  if (tid == 0 && blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0)
+    for (int i = 0; i < 8; ++i) es_attn_dbg[i] = dbg_acc[i];
+#endif
 
   // ---- epilogue: O[query][dv] = O^T / l ----
 #pragma unroll
   for (int f = 0; f < QF; ++f) {
     const int qi = q0 + f * 16 + col;
-    const float inv = 1.0f / lrun[f];
+    float l;
+    if constexpr (ONES) {
+      l = __shfl(o[f][DF - 1][0], 32 + col, 64);            // row d of O^T = fragment DF-1, lane group 2, register 0
+    } else {
+      l = lrun[f];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    }
+    const float inv = 1.0f / l;
     if (qi < p.Sq) {
 #pragma unroll
       for (int j = 0; j < DF; ++j) {
@@ -244,10 +310,10 @@ __global__ __launch_bounds__(256, (QF == 1 && KS <= 3) ? 3 : ((KS <= 5 && QF <= 
   }
 }
 
-template <typename T, int KS, int DF, int QF, int KVT>
+template <typename T, int KS, int DF, int QF, int KVT, bool ONES = false>
 int launch_attn(const es_attn_desc& d, hipStream_t st) {
   constexpr int lds = (KS <= 5 ? 2 : 1) * (KVT * (32 * KS * 2 + 16) + KVT * (16 * DF * 2 + 16));
-  auto kfn = attention_kernel<T, KS, DF, QF, KVT>;
+  auto kfn = attention_kernel<T, KS, DF, QF, KVT, ONES>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -264,9 +330,12 @@ int dispatch(const es_attn_desc& d, hipStream_t st) {
   const bool big = (long long)((d.Sq + 127) / 128) * d.heads * d.N >= 512;
   // (64 queries per wave was measured slower: 309 registers -> one wave per SIMD)
   switch (d.d) {
-    case 8: case 16: return launch_attn<T, 1, 1, 2, 64>(d, st);
-    case 24: case 32: return launch_attn<T, 1, 2, 2, 64>(d, st);
-    case 40: case 48: return big ? launch_attn<T, 2, 3, 2, 64>(d, st) : launch_attn<T, 2, 3, 1, 64>(d, st);
+    case 8: return launch_attn<T, 1, 1, 2, 64, true>(d, st);
+    case 16: return launch_attn<T, 1, 1, 2, 64>(d, st);
+    case 24: return launch_attn<T, 1, 2, 2, 64, true>(d, st);
+    case 32: return launch_attn<T, 1, 2, 2, 64>(d, st);
+    case 40: return big ? launch_attn<T, 2, 3, 2, 64, true>(d, st) : launch_attn<T, 2, 3, 1, 64, true>(d, st);
+    case 48: return big ? launch_attn<T, 2, 3, 2, 64>(d, st) : launch_attn<T, 2, 3, 1, 64>(d, st);
     case 64: return launch_attn<T, 2, 4, 2, 64>(d, st);
     case 80: return big ? launch_attn<T, 3, 5, 2, 64>(d, st) : launch_attn<T, 3, 5, 1, 64>(d, st);
     case 128: return launch_attn<T, 4, 8, 2, 64>(d, st);
@@ -279,6 +348,12 @@ int dispatch(const es_attn_desc& d, hipStream_t st) {
 }  // namespace
 
 extern "C" void es_set_error(const char* msg);
+
+#ifdef ES_ATTN_STAMPS
+extern "C" int es_attn_debug_read(unsigned long long* host16) {
+  return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(es_attn_dbg), 16 * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" int es_attention(const es_attn_desc* d, void* stream) {
   if (!d->q || !d->k || !d->v || !d->o) { es_set_error("es_attention: null pointer"); return -1; }

@@ -22,10 +22,12 @@ template <typename T> struct Traits;
 template <> struct Traits<f16> {
   typedef f16x8 vec8;
   typedef f16x4 vec4;
+  static constexpr bool is_bf16 = false;
 };
 template <> struct Traits<bf16> {
   typedef bf16x8 vec8;
   typedef bf16x4 vec4;
+  static constexpr bool is_bf16 = true;
 };
 
 ES_DEVICE f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
