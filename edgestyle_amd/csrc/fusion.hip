@@ -66,14 +66,31 @@ ES_DEVICE void reduce_partials(const float* part, int nchunk, float cnt, float e
   __syncthreads();
 }
 
+// The pass bodies take (block index bx of nb) explicitly so that one launch can cover one fusion block (grid.x = nb)
+// or all 13 of a denoising step (FusionBatch: grid.x = sum of the blocks' nb, looked up in a prefix table).
+struct FusionBatch {
+  es_fusion_desc d[ES_FUSION_MAX_BATCH];
+  int ab_end[ES_FUSION_MAX_BATCH];     // prefix sums of the pass A/B grids
+  int c_end[ES_FUSION_MAX_BATCH];      // prefix sums of the pass C grids
+  int count;
+};
+
+ES_DEVICE int batch_lookup(const int* end, int count, int b, int& bx, int& nb) {
+  int k = 0;
+  while (k + 1 < count && b >= end[k]) ++k;
+  const int start = k ? end[k - 1] : 0;
+  bx = b - start;
+  nb = end[k] - start;
+  return k;
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void fusion_pass_a(const es_fusion_desc p) {
+ES_DEVICE void fusion_a_body(const es_fusion_desc& p, const int bx, const int nb, const int n) {
   __shared__ float red[4];
-  const int n = blockIdx.y;
   const int CH8 = p.C / 8;
   const long long items = (long long)p.HW * CH8;
   float s = 0.f, ss = 0.f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+  for (long long i = (long long)bx * 256 + threadIdx.x; i < items; i += (long long)nb * 256) {
     const int c = (int)(i % CH8) * 8;
     float z[3][8];
     load_z<T>(p, n, (size_t)i * 8, c, z);
@@ -85,15 +102,14 @@ __global__ __launch_bounds__(256) void fusion_pass_a(const es_fusion_desc p) {
   s = block_sum(s, red);
   ss = block_sum(ss, red);
   if (threadIdx.x == 0) {
-    float* o = p.scratch + (((size_t)n * 2 + 0) * FU_MAX_CHUNK + blockIdx.x) * 2;
+    float* o = p.scratch + (((size_t)n * 2 + 0) * FU_MAX_CHUNK + bx) * 2;
     o[0] = s; o[1] = ss;
   }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void fusion_pass_b(const es_fusion_desc p, const int nchunk) {
+ES_DEVICE void fusion_b_body(const es_fusion_desc& p, const int bx, const int nchunk, const int n) {
   __shared__ float red[4];
-  const int n = blockIdx.y;
   const int CH8 = p.C / 8;
   const long long items = (long long)p.HW * CH8;
   float mean1, rstd1;
@@ -101,7 +117,7 @@ __global__ __launch_bounds__(256) void fusion_pass_b(const es_fusion_desc p, con
                   p.eps, mean1, rstd1, red);
   float s = 0.f, ss = 0.f;
   T* U = (T*)p.u + (size_t)n * p.HW * p.C;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+  for (long long i = (long long)bx * 256 + threadIdx.x; i < items; i += (long long)nchunk * 256) {
     const int c = (int)(i % CH8) * 8;
     float z[3][8];
     load_z<T>(p, n, (size_t)i * 8, c, z);
@@ -134,14 +150,13 @@ __global__ __launch_bounds__(256) void fusion_pass_b(const es_fusion_desc p, con
   s = block_sum(s, red);
   ss = block_sum(ss, red);
   if (threadIdx.x == 0) {
-    float* o = p.scratch + (((size_t)n * 2 + 1) * FU_MAX_CHUNK + blockIdx.x) * 2;
+    float* o = p.scratch + (((size_t)n * 2 + 1) * FU_MAX_CHUNK + bx) * 2;
     o[0] = s; o[1] = ss;
   }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void fusion_pass_c(const es_fusion_desc p, const int nchunk) {
-  const int n = blockIdx.y;
+ES_DEVICE void fusion_c_body(const es_fusion_desc& p, const int bx, const int nb, const int nchunk, const int n) {
   const int CH8 = p.C / 8;
   const long long items = (long long)p.HW * CH8;
   float mean2, rstd2;
@@ -150,7 +165,7 @@ __global__ __launch_bounds__(256) void fusion_pass_c(const es_fusion_desc p, con
                   mean2, rstd2, red);
   const T* U = (const T*)p.u + (size_t)n * p.HW * p.C;
   T* O = (T*)p.out + (size_t)n * p.HW * p.C;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+  for (long long i = (long long)bx * 256 + threadIdx.x; i < items; i += (long long)nb * 256) {
     const int c = (int)(i % CH8) * 8;
     const auto u = as_vec8<T>(*(const u32x4*)(U + (size_t)i * 8));
     const auto g = as_vec8<T>(*(const u32x4*)((const T*)p.g2 + (size_t)i * 8));
@@ -166,17 +181,69 @@ __global__ __launch_bounds__(256) void fusion_pass_c(const es_fusion_desc p, con
 }
 
 template <typename T>
-int launch_fusion(const es_fusion_desc& d, hipStream_t st) {
+__global__ __launch_bounds__(256) void fusion_pass_a(const es_fusion_desc p) { fusion_a_body<T>(p, blockIdx.x, gridDim.x, blockIdx.y); }
+template <typename T>
+__global__ __launch_bounds__(256) void fusion_pass_b(const es_fusion_desc p) { fusion_b_body<T>(p, blockIdx.x, gridDim.x, blockIdx.y); }
+template <typename T>
+__global__ __launch_bounds__(256) void fusion_pass_c(const es_fusion_desc p, const int nchunk) {
+  fusion_c_body<T>(p, blockIdx.x, gridDim.x, nchunk, blockIdx.y);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fusion_batch_a(const FusionBatch b) {
+  int bx, nb;
+  const int k = batch_lookup(b.ab_end, b.count, blockIdx.x, bx, nb);
+  fusion_a_body<T>(b.d[k], bx, nb, blockIdx.y);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void fusion_batch_b(const FusionBatch b) {
+  int bx, nb;
+  const int k = batch_lookup(b.ab_end, b.count, blockIdx.x, bx, nb);
+  fusion_b_body<T>(b.d[k], bx, nb, blockIdx.y);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void fusion_batch_c(const FusionBatch b) {
+  int bx, nb;
+  const int k = batch_lookup(b.c_end, b.count, blockIdx.x, bx, nb);
+  fusion_c_body<T>(b.d[k], bx, nb, b.ab_end[k] - (k ? b.ab_end[k - 1] : 0), blockIdx.y);
+}
+
+void fusion_grids(const es_fusion_desc& d, int& nchunk, int& cb) {
   const long long items = (long long)d.HW * (d.C / 8);
-  int nchunk = (int)(items / 512);
+  nchunk = (int)(items / 512);
   if (nchunk < 1) nchunk = 1;
   if (nchunk > FU_MAX_CHUNK) nchunk = FU_MAX_CHUNK;
+  cb = (int)((items + 255) / 256);
+  if (cb > 512) cb = 512;
+}
+
+template <typename T>
+int launch_fusion(const es_fusion_desc& d, hipStream_t st) {
+  int nchunk, cb;
+  fusion_grids(d, nchunk, cb);
   dim3 grid(nchunk, d.N);
   hipLaunchKernelGGL(fusion_pass_a<T>, grid, dim3(256), 0, st, d);
-  hipLaunchKernelGGL(fusion_pass_b<T>, grid, dim3(256), 0, st, d, nchunk);
-  int cb = (int)((items + 255) / 256);
-  if (cb > 512) cb = 512;
+  hipLaunchKernelGGL(fusion_pass_b<T>, grid, dim3(256), 0, st, d);
   hipLaunchKernelGGL(fusion_pass_c<T>, dim3(cb, d.N), dim3(256), 0, st, d, nchunk);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <typename T>
+int launch_fusion_batch(const es_fusion_desc* ds, int count, hipStream_t st) {
+  FusionBatch b;
+  int ab = 0, c = 0;
+  for (int k = 0; k < count; ++k) {
+    int nchunk, cb;
+    fusion_grids(ds[k], nchunk, cb);
+    b.d[k] = ds[k];
+    b.ab_end[k] = (ab += nchunk);
+    b.c_end[k] = (c += cb);
+  }
+  for (int k = count; k < ES_FUSION_MAX_BATCH; ++k) { b.d[k] = ds[0]; b.ab_end[k] = ab; b.c_end[k] = c; }
+  b.count = count;
+  hipLaunchKernelGGL(fusion_batch_a<T>, dim3(ab, ds[0].N), dim3(256), 0, st, b);
+  hipLaunchKernelGGL(fusion_batch_b<T>, dim3(ab, ds[0].N), dim3(256), 0, st, b);
+  hipLaunchKernelGGL(fusion_batch_c<T>, dim3(c, ds[0].N), dim3(256), 0, st, b);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -186,12 +253,31 @@ extern "C" void es_set_error(const char* msg);
 
 extern "C" size_t es_fusion_scratch_bytes(int N) { return (size_t)N * 2 * FU_MAX_CHUNK * 2 * sizeof(float); }
 
-extern "C" int es_fusion_block(const es_fusion_desc* d, void* stream) {
+static int fusion_check(const es_fusion_desc* d) {
   for (int i = 0; i < 6; ++i)
     if (!d->res[i]) { es_set_error("es_fusion_block: null residual pointer"); return -1; }
   if (!d->w1 || !d->b1 || !d->g1 || !d->be1 || !d->w2 || !d->b2 || !d->g2 || !d->be2 || !d->w3 || !d->b3 ||
       !d->scratch || !d->u || !d->out) { es_set_error("es_fusion_block: null pointer"); return -1; }
   if (d->C % 8 || d->N < 1 || d->HW < 1) { es_set_error("es_fusion_block: C must be a multiple of 8"); return -1; }
+  return 0;
+}
+
+extern "C" int es_fusion_blocks(const es_fusion_desc* ds, int count, void* stream) {
+  if (!ds || count < 1 || count > ES_FUSION_MAX_BATCH) { es_set_error("es_fusion_blocks: 1..13 blocks per call"); return -1; }
+  for (int k = 0; k < count; ++k) {
+    if (fusion_check(ds + k)) return -1;
+    if (ds[k].N != ds[0].N || ds[k].dtype != ds[0].dtype) { es_set_error("es_fusion_blocks: blocks must share N and dtype"); return -1; }
+    for (int j = 0; j < k; ++j)
+      if (ds[j].scratch == ds[k].scratch || ds[j].u == ds[k].u) { es_set_error("es_fusion_blocks: blocks need private scratch and u buffers"); return -1; }
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int rc = ds[0].dtype == ES_F16 ? launch_fusion_batch<f16>(ds, count, st) : launch_fusion_batch<bf16>(ds, count, st);
+  if (rc) es_set_error("es_fusion_blocks: launch failed");
+  return rc;
+}
+
+extern "C" int es_fusion_block(const es_fusion_desc* d, void* stream) {
+  if (fusion_check(d)) return -1;
   hipStream_t st = (hipStream_t)stream;
   int rc = d->dtype == ES_F16 ? launch_fusion<f16>(*d, st) : launch_fusion<bf16>(*d, st);
   if (rc) es_set_error("es_fusion_block: launch failed");

@@ -85,6 +85,7 @@ SYMBOLS = {
     "es_layer_norm": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _I, _P]),
     "es_fusion_block": (C.c_int, [C.POINTER(FusionDesc), _P]),
     "es_fusion_scratch_bytes": (C.c_size_t, [_I]),
+    "es_fusion_blocks": (C.c_int, [C.POINTER(FusionDesc), _I, _P]),
     "es_timestep_embedding": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "es_cfg_ddim_step": (C.c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _P]),
     "es_cfg_unipc_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -98,6 +99,9 @@ SYMBOLS = {
 }
 
 _lib = None
+
+
+FUSION_MAX_BATCH = 13     # ES_FUSION_MAX_BATCH
 
 
 class EdgeStyleHipError(RuntimeError):

@@ -497,11 +497,9 @@ def gather_row(table: torch.Tensor, idx: torch.Tensor, out: torch.Tensor):
 _fusion_scratch = {}
 
 
-def fusion_block(res, res_bs, params: dict, N: int, HW: int, Cc: int, scales, scales_dev=None,
-                 out: Optional[torch.Tensor] = None, eps: float = 1e-5) -> torch.Tensor:
-    """res: 6 tensors (or views) whose data_ptr() is sample 0 of net i; res_bs: 6 batch strides (elements)."""
+def _fusion_desc(res, res_bs, params: dict, N: int, HW: int, Cc: int, scales, scales_dev, out, eps, slot: int):
     t0 = res[0]
-    key = (t0.device, N)
+    key = (t0.device, N, slot)
     sc = _fusion_scratch.get(key)
     if sc is None:
         sc = torch.empty(L.load().es_fusion_scratch_bytes(N) // 4, dtype=torch.float32, device=t0.device)
@@ -519,8 +517,31 @@ def fusion_block(res, res_bs, params: dict, N: int, HW: int, Cc: int, scales, sc
         setattr(d, name, params[name].data_ptr())
     d.scratch, d.u, d.out = sc.data_ptr(), u.data_ptr(), out.data_ptr()
     d.N, d.HW, d.C, d.eps, d.dtype = N, HW, Cc, eps, _dt(t0)
+    return d, u, out
+
+
+def fusion_block(res, res_bs, params: dict, N: int, HW: int, Cc: int, scales, scales_dev=None,
+                 out: Optional[torch.Tensor] = None, eps: float = 1e-5) -> torch.Tensor:
+    """res: 6 tensors (or views) whose data_ptr() is sample 0 of net i; res_bs: 6 batch strides (elements)."""
+    d, _u, out = _fusion_desc(res, res_bs, params, N, HW, Cc, scales, scales_dev, out, eps, 0)
     L.check(L.load().es_fusion_block(C.byref(d), _stream()), "es_fusion_block")
     return out
+
+
+def fusion_blocks(blocks, N: int, scales, scales_dev=None, eps: float = 1e-5):
+    """All fusion blocks of a step in three launches.  blocks: list of (res, res_bs, params, HW, Cc) as for
+    fusion_block; returns the list of [N,HW,Cc] outputs."""
+    keep, outs = [], []
+    for k0 in range(0, len(blocks), L.FUSION_MAX_BATCH):
+        part = blocks[k0:k0 + L.FUSION_MAX_BATCH]
+        arr = (L.FusionDesc * len(part))()
+        for k, (res, res_bs, params, HW, Cc) in enumerate(part):
+            d, u, out = _fusion_desc(res, res_bs, params, N, HW, Cc, scales, scales_dev, None, eps, k0 + k)
+            arr[k] = d
+            keep.append(u)
+            outs.append(out)
+        L.check(L.load().es_fusion_blocks(arr, len(part), _stream()), "es_fusion_blocks")
+    return outs
 
 
 def pack_fusion_params(sd: dict, prefix: str, dtype, device) -> dict:

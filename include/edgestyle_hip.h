@@ -142,6 +142,11 @@ typedef struct {
 } es_fusion_desc;
 int es_fusion_block(const es_fusion_desc* d, void* stream);
 size_t es_fusion_scratch_bytes(int N);
+/* All fusion blocks of one denoising step (MC:103-114, 160-169: 12 down + 1 mid) in three launches instead of 3 per
+ * block: same arithmetic per block as es_fusion_block; every block needs its own scratch and u buffer; all share N and
+ * dtype. */
+#define ES_FUSION_MAX_BATCH 13
+int es_fusion_blocks(const es_fusion_desc* descs, int count, void* stream);
 
 /* Sinusoidal timestep features (diffusers Timesteps(dim, flip_sin_to_cos=True, freq_shift=0); CL:150-155):
  * out[n, :] = [cos(t_n f_i) | sin(t_n f_i)], dtype.  t: fp32 [N] device. */

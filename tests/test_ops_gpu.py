@@ -228,6 +228,28 @@ def test_fusion_block_vs_reference_restatement(C, S, N):
     assert rel_err(y, ref) < 4e-3
 
 
+def test_fusion_blocks_batched_equals_per_block():
+    """es_fusion_blocks (all blocks of a step in three launches) == es_fusion_block per block, bit for bit."""
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(77)
+    N, blocks = 2, []
+    for C, S in [(64, 16), (64, 16), (128, 8), (320, 8), (64, 32)]:
+        params = {"w1": torch.randn(C, 3, 2, generator=g), "b1": torch.randn(C, 3, generator=g) * 0.1,
+                  "g1": 1 + 0.1 * torch.randn(S * S, C, 3, generator=g), "be1": 0.1 * torch.randn(S * S, C, 3, generator=g),
+                  "w2": torch.randn(C, 3, generator=g), "b2": torch.randn(C, generator=g) * 0.1,
+                  "g2": 1 + 0.1 * torch.randn(S * S, C, generator=g), "be2": 0.1 * torch.randn(S * S, C, generator=g),
+                  "w3": torch.randn(C, generator=g), "b3": torch.randn(C, generator=g) * 0.1}
+        params = {k: v.to(DEV, torch.float16 if k in ("g1", "be1", "g2", "be2") else torch.float32).contiguous()
+                  for k, v in params.items()}
+        res = [torch.randn(N, S * S, C, generator=g).to(DEV, torch.float16) for _ in range(6)]
+        blocks.append((res, [S * S * C] * 6, params, S * S, C))
+    scales = [1.0, 0.5, 1.0, 2.0, 1.0, 0.25]
+    single = [ops.fusion_block(r, bs, p, N, hw, c, scales) for r, bs, p, hw, c in blocks]
+    batched = ops.fusion_blocks(blocks, N, scales)
+    for a, b in zip(single, batched):
+        assert torch.equal(a, b)
+
+
 def test_timestep_embedding():
     from edgestyle_amd import ops
     from oracle import sd15_oracle as O
