@@ -36,6 +36,14 @@ constexpr int BK = 64;
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// a / d for 0 <= a < 2^24, d >= 1, inv = 1.0f / d: the float quotient is off by at most one
+ES_DEVICE int fast_div(int a, int d, float inv) {
+  int q = (int)((float)a * inv);
+  const int r = a - q * d;
+  q += (r >= d) - (r < 0);
+  return q;
+}
+
 template <typename T>
 ES_DEVICE void store_elems(T* o, const float* v, int n) {
   for (int r = 0; r < n; ++r) o[r] = from_f32<T>(v[r]);
@@ -96,15 +104,29 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
   // is no zero page, no select on pointers and no 64-bit address arithmetic in the K loop.  Offsets per (tap, source)
   // are recomputed only when the tap or the concat source changes (every Cin/64 K-steps), not every K-step.
   constexpr unsigned OOB = 0xFFFFFF00u;
+  // (integer division costs ~40 VALU instructions and sits on every launch's critical path: linear layers skip it,
+  // convs use a float reciprocal + one correction step, exact below 2^24)
   int iy0[4], ix0[4], nb[4];
+  const bool small_m = M < (1 << 24);
+  const float inv_hw = 1.0f / (float)HWout, inv_w = 1.0f / (float)p.Wout;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = tile_m * BM + 32 * wave + 8 * i + lrow;
     iy0[i] = -(1 << 20); ix0[i] = -(1 << 20); nb[i] = 0;
     if (m < M) {
-      const int n = m / HWout;
-      const int rem = m - n * HWout;
-      const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+      int n, oy, ox;
+      if (HWout == 1) {
+        n = m; oy = 0; ox = 0;
+      } else if (small_m) {
+        n = fast_div(m, HWout, inv_hw);
+        const int rem = m - n * HWout;
+        oy = fast_div(rem, p.Wout, inv_w);
+        ox = rem - oy * p.Wout;
+      } else {
+        n = m / HWout;
+        const int rem = m - n * HWout;
+        oy = rem / p.Wout; ox = rem - oy * p.Wout;
+      }
       iy0[i] = oy * p.stride - p.pad;
       ix0[i] = ox * p.stride - p.pad;
       nb[i] = n * p.Hsrc * p.Wsrc;
@@ -203,6 +225,13 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
     if (ks0 + s < ks1) issue_tile(ks0 + s, s);
 
   const int frow = lane & 15, fq = lane >> 4;
+  // the epilogue's bias is fetched here, behind the first tile's DMA: loading it after the K loop put one more HBM
+  // round trip (~1 us) on the critical path of every launch
+  f32x4 bias[FN];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+    bias[i] = (bsel && p.splitk == 1) ? *(const f32x4*)(bsel + tile_n * BN + wn * (BN / 2) + fq * 4 + i * 16)
+                                      : f32x4{0.f, 0.f, 0.f, 0.f};
   int stage = 0, istage = STAGES - 1;
 #if ES_ABLATE & 4
   typename Traits<T>::vec8 xa0[FM], wa0[FN], xa1[FM], wa1[FN];
@@ -322,13 +351,27 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
   const int Cstore = geglu ? p.Cout / 2 : p.Cout;
   float scale = p.out_scale;
   if (p.out_scale_dev) scale *= *p.out_scale_dev;
-  f32x4 bias[FN];
-#pragma unroll
-  for (int i = 0; i < FN; ++i)
-    bias[i] = bsel ? *(const f32x4*)(bsel + tile_n * BN + pcol + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
   char* et = smem;
   T* outp = (T*)p.out;
   const T* resp = (const T*)p.residual;
+  // residual rows are requested before the LDS transposition, so their round trip overlaps phase A
+  constexpr int RPF = NPASS == 1 ? (BM * (BN / 8) + NT - 1) / NT : 0;     // 16-byte residual chunks per thread
+  u32x4 rpre[RPF > 0 ? RPF : 1];
+  const bool vec_store = (Cstore & 7) == 0;
+  if constexpr (RPF > 0) {
+    if (resp && vec_store) {
+      const int CH = (geglu ? BN / 2 : BN) / 8;
+      const int c_tile = tile_n * (geglu ? BN / 2 : BN);
+#pragma unroll
+      for (int k = 0; k < RPF; ++k) {
+        const int idx = tid + k * NT;
+        const int row = idx / CH, ch = idx - row * CH;
+        const int m = tile_m * BM + row, c = c_tile + ch * 8;
+        rpre[k] = u32x4{0u, 0u, 0u, 0u};
+        if (idx < BM * CH && m < M && c < Cstore) rpre[k] = *(const u32x4*)(resp + (size_t)m * Cstore + c);
+      }
+    }
+  }
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
     __syncthreads();                                      // stage buffers / previous pass's tile no longer read
@@ -382,19 +425,37 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
     // ---------------- epilogue phase B: coalesced residual add + store along the channel dim ----------------
     const int BNo = geglu ? BN / 2 : BNP;                 // tile width in stored channels (this pass)
     const int c_tile = tile_n * (geglu ? BN / 2 : BN) + pass * BNP;
-    if ((Cstore & 7) == 0) {
+    if (vec_store) {
       const int CH = BNo / 8;
-      for (int idx = tid; idx < BM * CH; idx += NT) {
-        const int row = idx / CH, ch = idx - row * CH;
-        const int m = tile_m * BM + row, c = c_tile + ch * 8;
-        if (m < M && c < Cstore) {
-          auto v = as_vec8<T>(*(const u32x4*)(et + row * EROW + ch * 16));
-          if (resp) {
-            const auto rv = as_vec8<T>(*(const u32x4*)(resp + (size_t)m * Cstore + c));
+      if constexpr (RPF > 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(rv[e]));
+        for (int k = 0; k < RPF; ++k) {
+          const int idx = tid + k * NT;
+          const int row = idx / CH, ch = idx - row * CH;
+          const int m = tile_m * BM + row, c = c_tile + ch * 8;
+          if (idx < BM * CH && m < M && c < Cstore) {
+            auto v = as_vec8<T>(*(const u32x4*)(et + row * EROW + ch * 16));
+            if (resp) {
+              const auto rv = as_vec8<T>(rpre[k]);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(rv[e]));
+            }
+            *(typename Traits<T>::vec8*)(outp + (size_t)m * Cstore + c) = v;
           }
-          *(typename Traits<T>::vec8*)(outp + (size_t)m * Cstore + c) = v;
+        }
+      } else {
+        for (int idx = tid; idx < BM * CH; idx += NT) {
+          const int row = idx / CH, ch = idx - row * CH;
+          const int m = tile_m * BM + row, c = c_tile + ch * 8;
+          if (m < M && c < Cstore) {
+            auto v = as_vec8<T>(*(const u32x4*)(et + row * EROW + ch * 16));
+            if (resp) {
+              const auto rv = as_vec8<T>(*(const u32x4*)(resp + (size_t)m * Cstore + c));
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(rv[e]));
+            }
+            *(typename Traits<T>::vec8*)(outp + (size_t)m * Cstore + c) = v;
+          }
         }
       }
     } else {
@@ -415,40 +476,77 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
 
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const es_gemm_desc p, const int M) {
-  // one thread = 8 consecutive channels of one pixel: sum the fp32 partials, then the same epilogue
+  // one thread = 8 consecutive channels of one pixel: sum the fp32 partials, then the same epilogue.  Every global
+  // load of the epilogue (bias, time embedding, residual) is issued before the slab loop: one round trip, not four.
   const int oct = p.rows_padded / 8;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long long)M * oct) return;
   const int m = (int)(idx / oct);
   const int c0 = (int)(idx - (long long)m * oct) * 8;
   if (c0 >= p.Cout) return;
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-  for (int z = 0; z < p.splitk; ++z) {
-    const float* w = p.workspace + ((size_t)z * M + m) * p.rows_padded + c0;
-    s0 += *(const f32x4*)w;
-    s1 += *(const f32x4*)(w + 4);
-  }
-  float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-  float scale = p.out_scale;
-  if (p.out_scale_dev) scale *= *p.out_scale_dev;
-  const int n = m / (p.Hout * p.Wout);
   const int nv = p.Cout - c0 < 8 ? p.Cout - c0 : 8;
+  const bool full = nv == 8 && (p.Cout & 7) == 0;        // 16-byte aligned rows of 8 valid channels
+  const int n = m / (p.Hout * p.Wout);
   const float* bsel = p.bias;
   if (p.ngroups > 1) {
     const int tm = m >> 7;
     bsel = p.bias_g[(tm >= p.mt_end[0]) + (tm >= p.mt_end[1]) + (tm >= p.mt_end[2])];
   }
-  for (int r = 0; r < nv; ++r) {
-    float x = v[r];
-    if (bsel) x += bsel[c0 + r];
-    if (p.temb) x += to_f32(((const T*)p.temb)[(size_t)n * p.temb_stride + c0 + r]);
+  float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, tv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (bsel) {                                             // bias is padded to rows_padded: always 8 readable values
+    const f32x4 b0 = *(const f32x4*)(bsel + c0), b1 = *(const f32x4*)(bsel + c0 + 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { bv[r] = b0[r]; bv[4 + r] = b1[r]; }
+  }
+  if (p.temb) {
+    const T* tp = (const T*)p.temb + (size_t)n * p.temb_stride + c0;
+    if (full && (p.temb_stride & 7) == 0 && (((size_t)p.temb) & 15) == 0) {
+      const auto t8 = as_vec8<T>(*(const u32x4*)tp);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) tv[r] = to_f32(t8[r]);
+    } else {
+      for (int r = 0; r < nv; ++r) tv[r] = to_f32(tp[r]);
+    }
+  }
+  if (p.residual) {
+    const T* rp = (const T*)p.residual + (size_t)m * p.Cout + c0;
+    if (full) {
+      const auto r8 = as_vec8<T>(*(const u32x4*)rp);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) rv[r] = to_f32(r8[r]);
+    } else {
+      for (int r = 0; r < nv; ++r) rv[r] = to_f32(rp[r]);
+    }
+  }
+  float scale = p.out_scale;
+  if (p.out_scale_dev) scale *= *p.out_scale_dev;
+  // slabs are summed in slice order (deterministic), four slices' loads in flight at a time
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  const size_t zstride = (size_t)M * p.rows_padded;
+  const float* w = p.workspace + (size_t)m * p.rows_padded + c0;
+  int z = 0;
+  for (; z + 4 <= p.splitk; z += 4) {
+    f32x4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[u] = *(const f32x4*)(w + (z + u) * zstride); b[u] = *(const f32x4*)(w + (z + u) * zstride + 4); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s0 += a[u]; s1 += b[u]; }
+  }
+  for (; z < p.splitk; ++z) {
+    s0 += *(const f32x4*)(w + z * zstride);
+    s1 += *(const f32x4*)(w + z * zstride + 4);
+  }
+  float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    float x = v[r] + bv[r] + tv[r];
     if (p.act == ES_ACT_SILU) x = silu_f(x);
     x = to_f32(from_f32<T>(x * scale));                   // same rounding point as the fused epilogue
-    if (p.residual) x += to_f32(((const T*)p.residual)[(size_t)m * p.Cout + c0 + r]);
-    v[r] = x;
+    v[r] = x + rv[r];
   }
   T* o = (T*)p.out + (size_t)m * p.Cout + c0;
-  if (nv == 8 && (p.Cout & 7) == 0) {
+  if (full) {
     typename Traits<T>::vec8 pk;
 #pragma unroll
     for (int r = 0; r < 8; ++r) pk[r] = from_f32<T>(v[r]);

@@ -44,7 +44,21 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const es_gn_desc p) {
     float s[8], ss[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
-    for (int px = p0 + ps; px < p1; px += PS) {
+    // four pixels' loads in flight per thread (a one-load-per-iteration loop pays one memory round trip each);
+    // the accumulation order over pixels is unchanged
+    int px = p0 + ps;
+    for (; px + 3 * PS < p1; px += 4 * PS) {
+      u32x4 raw[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) raw[u] = *(const u32x4*)(src + ((size_t)n * p.HW + px + u * PS) * cs + cc);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const auto v = as_vec8<T>(raw[u]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = to_f32(v[e]); s[e] += f; ss[e] += f * f; }
+      }
+    }
+    for (; px < p1; px += PS) {
       const auto v = as_vec8<T>(*(const u32x4*)(src + ((size_t)n * p.HW + px) * cs + cc));
 #pragma unroll
       for (int e = 0; e < 8; ++e) { const float f = to_f32(v[e]); s[e] += f; ss[e] += f * f; }
@@ -82,6 +96,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const es_gn_desc p, const
   float* shift = scale + C;            // [C]
   float* gstat = shift + C;            // [groups*2] mean, rstd
   float* red = gstat + 2 * p.groups;   // [slices][groups*2] partial sums of the partials
+  // gamma / beta go into the tables first (raw): their HBM round trip overlaps the partials' one
+  {
+    const float* gam = p.gamma;
+    const float* bet = p.beta;
+    if (p.ngroups > 1) {
+      const int g = (n >= p.n_end[0]) + (n >= p.n_end[1]) + (n >= p.n_end[2]);
+      gam = p.gamma_g[g];
+      bet = p.beta_g[g];
+    }
+    for (int c = threadIdx.x; c < C; c += 256) { scale[c] = gam[c]; shift[c] = bet[c]; }
+  }
   {
     // all 256 threads reduce the [nchunk][groups*2] partials: column = (group, stat), rows split into slices;
     // independent loads per thread (no serial latency chain), fixed summation order (bitwise reproducible)
@@ -107,37 +132,50 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const es_gn_desc p, const
     }
   }
   __syncthreads();
-  const float* gam = p.gamma;
-  const float* bet = p.beta;
-  if (p.ngroups > 1) {
-    const int g = (n >= p.n_end[0]) + (n >= p.n_end[1]) + (n >= p.n_end[2]);
-    gam = p.gamma_g[g];
-    bet = p.beta_g[g];
-  }
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = threadIdx.x; c < C; c += 256) {           // same thread wrote scale[c] / shift[c] above
     const int gi = c / cpg;
-    const float sc = gam[c] * gstat[gi * 2 + 1];
+    const float sc = scale[c] * gstat[gi * 2 + 1];
     scale[c] = sc;
-    shift[c] = bet[c] - gstat[gi * 2] * sc;
+    shift[c] = shift[c] - gstat[gi * 2] * sc;
   }
   __syncthreads();
   const long long total = (long long)p.HW * CH8;
   T* out = (T*)p.out + (size_t)n * p.HW * C;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int px = (int)(i / CH8);
-    const int c = (int)(i - (long long)px * CH8) * 8;
-    const bool second = c >= p.C1;
-    const T* src = second ? (const T*)p.x2 : (const T*)p.x;
-    const int cs = second ? p.C2 : p.C1, cc = second ? c - p.C1 : c;
-    const auto v = as_vec8<T>(*(const u32x4*)(src + ((size_t)n * p.HW + px) * cs + cc));
-    typename Traits<T>::vec8 r;
+  // grid-stride loop, four items' loads in flight per thread
+  const long long gstride = (long long)gridDim.x * 256;
+  for (long long i0 = (long long)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += 4 * gstride) {
+    u32x4 raw[4];
+    int pxs[4], cs_[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float f = to_f32(v[e]) * scale[c + e] + shift[c + e];
-      if (p.silu) f = silu_f(f);
-      r[e] = from_f32<T>(f);
+    for (int u = 0; u < 4; ++u) {
+      const long long i = i0 + u * gstride;
+      raw[u] = u32x4{0u, 0u, 0u, 0u};
+      pxs[u] = -1; cs_[u] = 0;
+      if (i < total) {
+        const int px = (int)(i / CH8);
+        const int c = (int)(i - (long long)px * CH8) * 8;
+        const bool second = c >= p.C1;
+        const T* src = second ? (const T*)p.x2 : (const T*)p.x;
+        const int cs = second ? p.C2 : p.C1, cc = second ? c - p.C1 : c;
+        raw[u] = *(const u32x4*)(src + ((size_t)n * p.HW + px) * cs + cc);
+        pxs[u] = px; cs_[u] = c;
+      }
     }
-    *(typename Traits<T>::vec8*)(out + (size_t)px * C + c) = r;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (pxs[u] >= 0) {
+        const auto v = as_vec8<T>(raw[u]);
+        const int c = cs_[u];
+        typename Traits<T>::vec8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float f = to_f32(v[e]) * scale[c + e] + shift[c + e];
+          if (p.silu) f = silu_f(f);
+          r[e] = from_f32<T>(f);
+        }
+        *(typename Traits<T>::vec8*)(out + (size_t)pxs[u] * C + c) = r;
+      }
+    }
   }
 }
 
