@@ -9,6 +9,7 @@
 //      element with no integer division.  Two sources (UNet skip concat) are read in place and written as one
 //      concatenated, normalised tensor.
 // LayerNorm: one wave per row, values held in registers, exact two-pass mean/variance via wave shuffles.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/edgestyle_hip.h"
 
@@ -179,6 +180,127 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const es_gn_desc p, const
   }
 }
 
+// One-launch GroupNorm for slabs that fit a workgroup's registers (the deeper UNet levels): block = (sample, gpb
+// consecutive groups); every thread owns one fixed 16-byte channel chunk and up to CPT pixels of it, read ONCE.
+// Statistics go through the same deterministic LDS reduction as gn_stats_kernel; the normalised values are written
+// straight from the registers.  Saves the second launch and the second read (small tensors are launch-latency bound:
+// ~7 us per launch at any size).
+template <typename T, int CPT>
+__global__ __launch_bounds__(256) void gn_slab_kernel(const es_gn_desc p, const int gpb) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n = blockIdx.y, gb = blockIdx.x;
+  const int C = p.C1 + p.C2, cpg = C / p.groups;
+  const int W = gpb * cpg, W8 = W / 8, PS = 256 / W8;
+  float* csum = (float*)smem;            // [PS][W]
+  float* csq = csum + PS * W;            // [PS][W]
+  float* gstat = csq + PS * W;           // [gpb][2] mean, rstd
+  const int t = threadIdx.x;
+  const int ps = t / W8, cq = t - ps * W8;
+  const bool active = ps < PS;
+  const int c = gb * W + cq * 8;         // first channel of this thread's chunk
+  const bool second = c >= p.C1;
+  const T* src = second ? (const T*)p.x2 : (const T*)p.x;
+  const int cs = second ? p.C2 : p.C1, cc = second ? c - p.C1 : c;
+  const float* gam = p.gamma;
+  const float* bet = p.beta;
+  if (p.ngroups > 1) {
+    const int g = (n >= p.n_end[0]) + (n >= p.n_end[1]) + (n >= p.n_end[2]);
+    gam = p.gamma_g[g];
+    bet = p.beta_g[g];
+  }
+  u32x4 raw[CPT];
+  f32x4 ga[2], be[2];
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      const int px = ps + k * PS;
+      raw[k] = u32x4{0u, 0u, 0u, 0u};
+      if (px < p.HW) raw[k] = *(const u32x4*)(src + ((size_t)n * p.HW + px) * cs + cc);
+    }
+    ga[0] = *(const f32x4*)(gam + c); ga[1] = *(const f32x4*)(gam + c + 4);
+    be[0] = *(const f32x4*)(bet + c); be[1] = *(const f32x4*)(bet + c + 4);
+    float s[8], ss[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {      // pad pixels hold zeros: they add nothing
+      const auto v = as_vec8<T>(raw[k]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float f = to_f32(v[e]); s[e] += f; ss[e] += f * f; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { csum[ps * W + cq * 8 + e] = s[e]; csq[ps * W + cq * 8 + e] = ss[e]; }
+  }
+  __syncthreads();
+  {
+    // two fixed-order steps: (1) one thread per channel folds the PS pixel slots (conflict-free LDS columns, no
+    // integer division), (2) one wave per local group folds its cpg channel sums with an xor tree
+    for (int ch = t; ch < W; ch += 256) {
+      float s = 0.f, ss = 0.f;
+      for (int q = 0; q < PS; ++q) { s += csum[q * W + ch]; ss += csq[q * W + ch]; }
+      csum[ch] = s;                      // row 0 is only read by this same thread above
+      csq[ch] = ss;
+    }
+    __syncthreads();
+    const int lg = t >> 6, l = t & 63;
+    float s = 0.f, ss = 0.f;
+    if (lg < gpb)
+      for (int i = l; i < cpg; i += 64) { s += csum[lg * cpg + i]; ss += csq[lg * cpg + i]; }
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    if (lg < gpb && l == 0) {
+      const float cnt = (float)cpg * (float)p.HW;
+      const float mean = s / cnt;
+      float var = ss / cnt - mean * mean;
+      var = var < 0.f ? 0.f : var;
+      gstat[lg * 2] = mean;
+      gstat[lg * 2 + 1] = rsqrtf(var + p.eps);
+    }
+  }
+  __syncthreads();
+  if (active) {
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int lg = (cq * 8 + e) / cpg;
+      const float g = e < 4 ? ga[0][e & 3] : ga[1][e & 3], b = e < 4 ? be[0][e & 3] : be[1][e & 3];
+      sc[e] = g * gstat[lg * 2 + 1];
+      sh[e] = b - gstat[lg * 2] * sc[e];
+    }
+    T* out = (T*)p.out + (size_t)n * p.HW * C + c;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      const int px = ps + k * PS;
+      if (px < p.HW) {
+        const auto v = as_vec8<T>(raw[k]);
+        typename Traits<T>::vec8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float f = to_f32(v[e]) * sc[e] + sh[e];
+          if (p.silu) f = silu_f(f);
+          r[e] = from_f32<T>(f);
+        }
+        *(typename Traits<T>::vec8*)(out + (size_t)px * C) = r;
+      }
+    }
+  }
+}
+
+// groups per block for the slab kernel (0 = not eligible).  Depends on (HW, C, groups) only, never on N: batched and
+// per-net launches of the same layer must take the same path to stay bitwise equal.
+int gn_slab_gpb(const es_gn_desc& d, int& cpt) {
+  const int C = d.C1 + d.C2, cpg = C / d.groups;
+  for (int gpb = 1; gpb <= 4; gpb *= 2) {
+    if (d.groups % gpb || (gpb * cpg) % 8) continue;
+    const int W8 = gpb * cpg / 8;
+    if (W8 > 256) return 0;
+    const int PS = 256 / W8;
+    cpt = (d.HW + PS - 1) / PS;
+    return cpt <= 24 ? gpb : 0;
+  }
+  return 0;
+}
+
 struct LnGroups {
   const float* gamma[4];
   const float* beta[4];
@@ -240,6 +362,18 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const T* __restrict__ x
 template <typename T>
 int launch_gn(const es_gn_desc& d, hipStream_t st) {
   const int C = d.C1 + d.C2;
+  int cpt = 0;
+  static const bool slab_on = !(getenv("ES_GN_SLAB") && getenv("ES_GN_SLAB")[0] == '0');   // tuning switch
+  const int gpb = slab_on ? gn_slab_gpb(d, cpt) : 0;
+  if (gpb) {
+    const int W = gpb * (C / d.groups);
+    const size_t lds = (size_t)(2 * (256 / (W / 8)) * W + 2 * gpb) * sizeof(float);
+    dim3 grid(d.groups / gpb, d.N);
+    if (cpt <= 8) hipLaunchKernelGGL((gn_slab_kernel<T, 8>), grid, dim3(256), lds, st, d, gpb);
+    else if (cpt <= 16) hipLaunchKernelGGL((gn_slab_kernel<T, 16>), grid, dim3(256), lds, st, d, gpb);
+    else hipLaunchKernelGGL((gn_slab_kernel<T, 24>), grid, dim3(256), lds, st, d, gpb);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  }
   int ppb = d.HW / GN_MAX_CHUNK;
   if (ppb < 16) ppb = 16;
   const int nchunk = (d.HW + ppb - 1) / ppb;
