@@ -37,6 +37,17 @@ ES_DEVICE float to_f32(f16 x) { return (float)x; }
 ES_DEVICE float to_f32(bf16 x) { return (float)x; }
 template <typename T> ES_DEVICE T from_f32(float x) { return (T)x; }
 
+// a / d for 0 <= a < 2^24, d >= 1, inv = 1.0f / d: the float quotient is off by at most one, fixed by one
+// correction step.  (Integer division is ~40 VALU instructions for 32 bits and >100 for 64 bits: index math of the
+// streaming kernels goes through this, with the exact division as the fallback for larger ranges.)
+ES_DEVICE int fast_div(int a, int d, float inv) {
+  int q = (int)((float)a * inv);
+  const int r = a - q * d;
+  q += (r >= d) - (r < 0);
+  return q;
+}
+ES_DEVICE int div_any(int a, int d, float inv, bool small) { return small ? fast_div(a, d, inv) : a / d; }
+
 ES_DEVICE float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // exact (erf) GELU, as torch.nn.functional.gelu default used by diffusers GEGLU.  erf by Abramowitz-Stegun 7.1.26
 // (|abs err| <= 1.5e-7, far below fp16/bf16 resolution): one rcp + one exp + 5 FMA instead of libm erff's ~40 ops.

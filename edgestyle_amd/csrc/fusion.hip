@@ -88,10 +88,12 @@ template <typename T>
 ES_DEVICE void fusion_a_body(const es_fusion_desc& p, const int bx, const int nb, const int n) {
   __shared__ float red[4];
   const int CH8 = p.C / 8;
-  const long long items = (long long)p.HW * CH8;
+  const int items = p.HW * CH8;
+  const bool small = items < (1 << 24);
+  const float inv_ch8 = 1.0f / (float)CH8;
   float s = 0.f, ss = 0.f;
-  for (long long i = (long long)bx * 256 + threadIdx.x; i < items; i += (long long)nb * 256) {
-    const int c = (int)(i % CH8) * 8;
+  for (int i = bx * 256 + threadIdx.x; i < items; i += nb * 256) {
+    const int c = (i - div_any(i, CH8, inv_ch8, small) * CH8) * 8;
     float z[3][8];
     load_z<T>(p, n, (size_t)i * 8, c, z);
 #pragma unroll
@@ -111,14 +113,16 @@ template <typename T>
 ES_DEVICE void fusion_b_body(const es_fusion_desc& p, const int bx, const int nchunk, const int n) {
   __shared__ float red[4];
   const int CH8 = p.C / 8;
-  const long long items = (long long)p.HW * CH8;
+  const int items = p.HW * CH8;
+  const bool small = items < (1 << 24);
+  const float inv_ch8 = 1.0f / (float)CH8;
   float mean1, rstd1;
   reduce_partials(p.scratch + ((size_t)n * 2 + 0) * FU_MAX_CHUNK * 2, nchunk, 3.f * (float)p.C * (float)p.HW,
                   p.eps, mean1, rstd1, red);
   float s = 0.f, ss = 0.f;
   T* U = (T*)p.u + (size_t)n * p.HW * p.C;
-  for (long long i = (long long)bx * 256 + threadIdx.x; i < items; i += (long long)nchunk * 256) {
-    const int c = (int)(i % CH8) * 8;
+  for (int i = bx * 256 + threadIdx.x; i < items; i += nchunk * 256) {
+    const int c = (i - div_any(i, CH8, inv_ch8, small) * CH8) * 8;
     float z[3][8];
     load_z<T>(p, n, (size_t)i * 8, c, z);
     // affine planes: [(pix*C + c)*3 + q], 24 contiguous values for this thread
@@ -158,15 +162,17 @@ ES_DEVICE void fusion_b_body(const es_fusion_desc& p, const int bx, const int nc
 template <typename T>
 ES_DEVICE void fusion_c_body(const es_fusion_desc& p, const int bx, const int nb, const int nchunk, const int n) {
   const int CH8 = p.C / 8;
-  const long long items = (long long)p.HW * CH8;
+  const int items = p.HW * CH8;
+  const bool small = items < (1 << 24);
+  const float inv_ch8 = 1.0f / (float)CH8;
   float mean2, rstd2;
   __shared__ float red[4];
   reduce_partials(p.scratch + ((size_t)n * 2 + 1) * FU_MAX_CHUNK * 2, nchunk, (float)p.C * (float)p.HW, p.eps,
                   mean2, rstd2, red);
   const T* U = (const T*)p.u + (size_t)n * p.HW * p.C;
   T* O = (T*)p.out + (size_t)n * p.HW * p.C;
-  for (long long i = (long long)bx * 256 + threadIdx.x; i < items; i += (long long)nb * 256) {
-    const int c = (int)(i % CH8) * 8;
+  for (int i = bx * 256 + threadIdx.x; i < items; i += nb * 256) {
+    const int c = (i - div_any(i, CH8, inv_ch8, small) * CH8) * 8;
     const auto u = as_vec8<T>(*(const u32x4*)(U + (size_t)i * 8));
     const auto g = as_vec8<T>(*(const u32x4*)((const T*)p.g2 + (size_t)i * 8));
     const auto b = as_vec8<T>(*(const u32x4*)((const T*)p.be2 + (size_t)i * 8));
@@ -259,6 +265,7 @@ static int fusion_check(const es_fusion_desc* d) {
   if (!d->w1 || !d->b1 || !d->g1 || !d->be1 || !d->w2 || !d->b2 || !d->g2 || !d->be2 || !d->w3 || !d->b3 ||
       !d->scratch || !d->u || !d->out) { es_set_error("es_fusion_block: null pointer"); return -1; }
   if (d->C % 8 || d->N < 1 || d->HW < 1) { es_set_error("es_fusion_block: C must be a multiple of 8"); return -1; }
+  if ((long long)d->HW * (d->C / 8) >= (1ll << 30)) { es_set_error("es_fusion_block: sample too large for 32-bit chunk indices"); return -1; }
   return 0;
 }
 

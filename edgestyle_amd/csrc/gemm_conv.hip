@@ -36,14 +36,6 @@ constexpr int BK = 64;
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// a / d for 0 <= a < 2^24, d >= 1, inv = 1.0f / d: the float quotient is off by at most one
-ES_DEVICE int fast_div(int a, int d, float inv) {
-  int q = (int)((float)a * inv);
-  const int r = a - q * d;
-  q += (r >= d) - (r < 0);
-  return q;
-}
-
 template <typename T>
 ES_DEVICE void store_elems(T* o, const float* v, int n) {
   for (int r = 0; r < n; ++r) o[r] = from_f32<T>(v[r]);
@@ -479,14 +471,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const es_gemm_desc p
   // one thread = 8 consecutive channels of one pixel: sum the fp32 partials, then the same epilogue.  Every global
   // load of the epilogue (bias, time embedding, residual) is issued before the slab loop: one round trip, not four.
   const int oct = p.rows_padded / 8;
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long long)M * oct) return;
-  const int m = (int)(idx / oct);
-  const int c0 = (int)(idx - (long long)m * oct) * 8;
+  const int idx = blockIdx.x * 256 + threadIdx.x;         // M * oct < 2^31 (entry-point check)
+  if (idx >= M * oct) return;
+  const bool small = M * oct < (1 << 24);
+  const int m = div_any(idx, oct, 1.0f / (float)oct, small);
+  const int c0 = (idx - m * oct) * 8;
   if (c0 >= p.Cout) return;
   const int nv = p.Cout - c0 < 8 ? p.Cout - c0 : 8;
   const bool full = nv == 8 && (p.Cout & 7) == 0;        // 16-byte aligned rows of 8 valid channels
-  const int n = m / (p.Hout * p.Wout);
+  const int n = div_any(m, p.Hout * p.Wout, 1.0f / (float)(p.Hout * p.Wout), small);
   const float* bsel = p.bias;
   if (p.ngroups > 1) {
     const int tm = m >> 7;
@@ -636,6 +629,7 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
   if (d->ksize != 1 && d->ksize != 3) { es_set_error("es_conv_gemm: ksize must be 1 or 3"); return -1; }
   if (d->splitk < 1 || d->splitk > d->Kpad / BK) { es_set_error("es_conv_gemm: bad splitk"); return -1; }
   if (d->splitk > 1 && (!d->workspace || d->act == ES_ACT_GEGLU)) { es_set_error("es_conv_gemm: splitk needs workspace and no GEGLU"); return -1; }
+  if (d->splitk > 1 && (long long)d->N * d->Hout * d->Wout * (d->rows_padded / 8) >= (1ll << 31)) { es_set_error("es_conv_gemm: split-K output too large for 32-bit indices"); return -1; }
   if (d->act == ES_ACT_GEGLU && (d->bn != 128 || d->Cout % 32)) { es_set_error("es_conv_gemm: GEGLU needs bn=128, Cout%32==0"); return -1; }
   if (d->N < 1 || d->Hout < 1 || d->Wout < 1) { es_set_error("es_conv_gemm: empty problem"); return -1; }
   if (d->bm != 0 && d->bm != 128 && d->bm != 256) { es_set_error("es_conv_gemm: bm must be 0 (auto), 128 or 256"); return -1; }

@@ -140,21 +140,23 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const es_gn_desc p, const
     shift[c] = shift[c] - gstat[gi * 2] * sc;
   }
   __syncthreads();
-  const long long total = (long long)p.HW * CH8;
+  const int total = p.HW * CH8;                       // chunks per sample (< 2^31 by the entry-point check)
+  const bool small = total < (1 << 24);
+  const float inv_ch8 = 1.0f / (float)CH8;
   T* out = (T*)p.out + (size_t)n * p.HW * C;
   // grid-stride loop, four items' loads in flight per thread
-  const long long gstride = (long long)gridDim.x * 256;
-  for (long long i0 = (long long)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += 4 * gstride) {
+  const int gstride = gridDim.x * 256;
+  for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += 4 * gstride) {
     u32x4 raw[4];
     int pxs[4], cs_[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const long long i = i0 + u * gstride;
+      const int i = i0 + u * gstride;
       raw[u] = u32x4{0u, 0u, 0u, 0u};
       pxs[u] = -1; cs_[u] = 0;
       if (i < total) {
-        const int px = (int)(i / CH8);
-        const int c = (int)(i - (long long)px * CH8) * 8;
+        const int px = div_any(i, CH8, inv_ch8, small);
+        const int c = (i - px * CH8) * 8;
         const bool second = c >= p.C1;
         const T* src = second ? (const T*)p.x2 : (const T*)p.x;
         const int cs = second ? p.C2 : p.C1, cc = second ? c - p.C1 : c;
@@ -426,6 +428,7 @@ extern "C" int es_group_norm(const es_gn_desc* d, void* stream) {
   if (d->groups < 1 || d->groups > GN_MAX_GROUPS || C % d->groups) { es_set_error("es_group_norm: bad group count"); return -1; }
   if (C > 8192) { es_set_error("es_group_norm: C too large for the LDS tables"); return -1; }
   if (d->N < 1 || d->HW < 1) { es_set_error("es_group_norm: empty problem"); return -1; }
+  if ((long long)d->HW * (C / 8) >= (1ll << 30)) { es_set_error("es_group_norm: sample too large for 32-bit chunk indices"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   int rc = d->dtype == ES_F16 ? launch_gn<f16>(*d, st) : launch_gn<bf16>(*d, st);
   if (rc) es_set_error("es_group_norm: launch failed");
