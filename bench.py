@@ -124,14 +124,19 @@ def gemm_roofline(pipe):
     traffic = None
     tp = os.path.join(ROOT, "profiles", "r01_gemm_pmc_traffic_b1.json")
     if os.path.exists(tp):   # HBM-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
-        try:                  # gfx950 corrections applied) over the same 494 launches replayed stand-alone; see DESIGN.md §7
-            traffic = json.load(open(tp)).get("conv_gemm_kernel", {}).get("hbm_bytes_per_launch")
+        try:                  # gfx950 corrections applied) over the same launch list replayed stand-alone; see DESIGN.md §7
+            prof = json.load(open(tp)).get("conv_gemm_kernel", {})
+            alg_now = sum(m[3].get("algorithmic_bytes", 0) for m, _ in res) / max(n, 1)
+            # only valid for the workload it was collected on (same launch list: count and algorithmic bytes)
+            if prof.get("launches") == n and abs(prof.get("algorithmic_bytes_per_launch", 0) - alg_now) <= 0.01 * alg_now:
+                traffic = prof.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     return {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv3x3/1x1/linear)", "achieved": round(ach, 2),
             "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
             "launches_per_step": n, "avg_launch_us": round(tot_t * 1e6 / max(n, 1), 2),
             "algorithmic_gflop_per_launch": round(tot_f / max(n, 1) / 1e9, 3),
+            "algorithmic_bytes_per_launch": int(sum(m[3].get("algorithmic_bytes", 0) for m, _ in res) / max(n, 1)),
             "gemm_time_per_step_ms": round(tot_t * 1e3, 3),
             "conv3x3_only": {"achieved": round(f3 / t3 / 1e12, 2) if t3 else None,
                              "frac": round(f3 / t3 / 1e12 / MFMA_PEAK_TFLOPS, 4) if t3 else None},

@@ -317,9 +317,21 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
                                (M, pw.cout, k * k * (C1 + C2), stride, splitk, bn),
                                dict(N=N, H=H, W=W, C1=C1, C2=C2, cout=pw.cout, k=k, stride=stride, pad=pad,
                                     upsample=bool(upsample), geglu=pw.geglu, splitk=splitk, Hout=Hout, Wout=Wout,
-                                    residual=residual is not None, temb=temb is not None)))
+                                    residual=residual is not None, temb=temb is not None, bn=bn,
+                                    stages=int(d.stages), group_n=list(group_n) if pws is not None else None,
+                                    algorithmic_bytes=_algorithmic_bytes(x, x2, pw, pws, out, residual))))
     L.check(L.load().es_conv_gemm(C.byref(d), _stream()), "es_conv_gemm")
     return out
+
+
+def _algorithmic_bytes(x, x2, pw, pws, out, residual) -> int:
+    """HBM bytes a launch must move at least once: activations in, every weight set, output out, residual in."""
+    n = x.numel() * x.element_size() + (x2.numel() * x2.element_size() if x2 is not None else 0)
+    n += sum(q.w.numel() * q.w.element_size() for q in (pws if pws is not None else [pw]))
+    n += out.numel() * out.element_size()
+    if residual is not None:
+        n += residual.numel() * residual.element_size()
+    return int(n)
 
 
 def linear(x: torch.Tensor, pw: PackedWeight, **kw) -> torch.Tensor:

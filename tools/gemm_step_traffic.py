@@ -26,15 +26,20 @@ def main(path):
         q = L["geom"]
         x = torch.randn(q["N"], q["H"], q["W"], q["C1"], generator=g, device=dev).half()
         x2 = torch.randn(q["N"], q["H"], q["W"], q["C2"], generator=g, device=dev).half() if q["C2"] else None
-        pw = ops.pack_weight(torch.randn(q["cout"], q["C1"] + q["C2"], q["k"], q["k"], generator=g, device=dev) * 0.02,
-                             torch.zeros(q["cout"], device=dev), torch.float16, dev, geglu=q["geglu"])
+        ng = len(q["group_n"]) if q.get("group_n") else 1
+        pw = [ops.pack_weight(torch.randn(q["cout"], q["C1"] + q["C2"], q["k"], q["k"], generator=g, device=dev) * 0.02,
+                              torch.zeros(q["cout"], device=dev), torch.float16, dev, geglu=q["geglu"]) for _ in range(ng)]
+        pw = pw if ng > 1 else pw[0]
         cs = q["cout"] // 2 if q["geglu"] else q["cout"]
         res = torch.randn(q["N"], q["Hout"], q["Wout"], cs, generator=g, device=dev).half() if q["residual"] else None
         work.append((x, x2, pw, res, q))
     torch.cuda.synchronize()
     for x, x2, pw, res, q in work:
+        ops.FORCE_BN = q.get("bn", 0)
         ops.conv_gemm(x, pw, x2=x2, stride=q["stride"], pad=q["pad"], upsample=q["upsample"], residual=res,
-                      splitk=q["splitk"], out_hw=(q["Hout"], q["Wout"]))
+                      splitk=q["splitk"], stages=q.get("stages", 0), out_hw=(q["Hout"], q["Wout"]),
+                      group_n=q.get("group_n"))
+    ops.FORCE_BN = 0
     torch.cuda.synchronize()
     print(f"replayed {len(work)} launches")
 
