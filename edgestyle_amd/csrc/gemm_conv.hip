@@ -30,6 +30,7 @@ constexpr int BK = 64;
 // Tool-only ablation builds (tools/gemm_ablate.sh): time the K loop with one ingredient removed.  Results are wrong
 // by construction; the product library is always built with ES_ABLATE == 0.
 //   1: no MFMA   2: no LDS-DMA inside the loop   4: no fragment reads inside the loop   8: no barrier / DMA wait
+//   16: no activation DMAs   32: no weight DMAs   64: every DMA out of range (issued, zero-filled, no memory traffic)
 #ifndef ES_ABLATE
 #define ES_ABLATE 0
 #endif
@@ -170,9 +171,12 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
     const int soff_w = ks * (BK * 2);
 #pragma unroll
     for (int i = 0; i < WI; ++i)
-      if (wave * WI + i < WP)                         // wave-uniform
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(ws + (wave * WI + i) * 1024), 16, (int)woff[i], soff_w, 0, 0);
-    if constexpr (ALIGNED) {
+      if (!(ES_ABLATE & 32) && wave * WI + i < WP)    // wave-uniform
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(ws + (wave * WI + i) * 1024), 16,
+                                                 (ES_ABLATE & 64) ? (int)OOB : (int)woff[i], soff_w, 0, 0);
+    if constexpr ((ES_ABLATE & 16) != 0) {
+      // ablation: no activation DMAs
+    } else if constexpr (ALIGNED) {
       const int second = cpos >= p.C1 ? 1 : 0;            // wave-uniform: a K-step never straddles taps or sources
       const int cs = second ? p.C2 : p.C1;
       const int cc = second ? cpos - p.C1 : cpos;
@@ -180,6 +184,10 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
         row_offsets(tap, cs, kc * 8);
         cur_tap = tap; cur_second = second;
       }
+#if ES_ABLATE & 64
+#pragma unroll
+      for (int i = 0; i < 4; ++i) voff[i] = OOB;
+#endif
       if (second) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
