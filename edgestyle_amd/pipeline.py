@@ -181,6 +181,68 @@ class StableDiffusionControlNetPipeline:
             emb = image                                                 # already embedded [N,C0,h,w]
         return _as_nhwc(emb, self.dtype, self.device)
 
+    def prepare_images(self, images, batch_size, do_cfg, cond_noise=None, generator=None):
+        """The six one-time condition embeddings (PL:352-377, 629-664) with the redundant work removed: the reference
+        embeds the CFG-duplicated batch net by net, so every deterministic encoder runs twice on identical pixels
+        (both CFG halves) and the nets that share an encoder (3 x VAE, 3 x openpose stack) run it separately.  Here
+        each shared encoder runs ONCE on the un-duplicated images of all its nets; only the VAE sampling noise is
+        per CFG half, drawn in net order for the duplicated batch exactly as before.  Falls back to per-net
+        prepare_image for anything that is not an RGB image tensor handled by the known net classes."""
+        from .models import ControlLoRAModel
+        nets = self.controlnet.nets
+        rgb = []
+        for img in images:
+            if not torch.is_tensor(img):
+                rgb = None
+                break
+            rgb.append(img.dim() == 4 and img.shape[1] == 3 and img.shape[0] in (1, batch_size))
+        if rgb is None or not all(rgb):
+            return [self.prepare_image(img, batch_size, do_cfg, net, noise=None if cond_noise is None else cond_noise[i],
+                                       generator=generator) for i, (img, net) in enumerate(zip(images, nets))]
+        rep = 2 if do_cfg else 1
+        N = batch_size * rep
+        imgs = [img.to(torch.float32).repeat_interleave(batch_size, dim=0) if img.shape[0] == 1 else img.to(torch.float32)
+                for img in images]
+        out = [None] * len(nets)
+        groups = {}                                  # shared encoder -> net indices
+        for i, net in enumerate(nets):
+            if isinstance(net, ControlLoRAModel) and net.config.uses_vae:
+                if net._vae is None:
+                    raise ValueError("vae must be provided if any of the controlnets uses a vae")     # MC:388-391
+                groups.setdefault(("vae", id(net._vae)), []).append(i)
+            else:
+                groups.setdefault(("stack", id(net)), []).append(i)
+        noise = {}
+        for i, net in enumerate(nets):               # sampling noise in net order, for the CFG-duplicated batch (CL:39)
+            if isinstance(net, ControlLoRAModel) and net.config.uses_vae:
+                vae = net._vae
+                hh, ww = imgs[i].shape[2] // vae.cfg.scale, imgs[i].shape[3] // vae.cfg.scale
+                nz = None if cond_noise is None else cond_noise[i]
+                if nz is None:
+                    nz = torch.randn((N, vae.cfg.latent_channels, hh, ww), generator=generator, dtype=torch.float32)
+                noise[i] = nz
+        for (kind, _), idx in groups.items():
+            batch = torch.cat([imgs[i] for i in idx]).to(self.device)
+            if kind == "vae":
+                vae = nets[idx[0]]._vae
+                if vae.device != self.device:
+                    vae.to(self.device)
+                dist = vae.encode(batch).latent_dist                    # one encoder pass for all its nets, no CFG copy
+                for k, i in enumerate(idx):
+                    net = nets[i]
+                    mom = dist.moments[k * batch_size:(k + 1) * batch_size]
+                    mom = torch.cat([mom] * rep) if rep > 1 else mom
+                    z = ops.vae_sample(mom.contiguous(), noise[i].to(self.device), vae.cfg.latent_channels,
+                                       net.engine.in_pad, vae.cfg.scaling_factor)
+                    out[i] = net.engine.embed_latent(z)
+            else:
+                net = nets[idx[0]]
+                emb = _as_nhwc(net.preprocess_image(batch), self.dtype, self.device)
+                for k, i in enumerate(idx):
+                    e = emb[k * batch_size:(k + 1) * batch_size]
+                    out[i] = torch.cat([e] * rep) if rep > 1 else e
+        return out                                   # NHWC [N,h,w,C0], compute dtype, on device
+
     def prepare_latents(self, batch_size, channels, h, w, generator, latents=None):
         """PL:585-627 (latents drawn on the CPU generator so results do not depend on the device RNG stream)."""
         shape = (batch_size, channels, h, w)
@@ -244,10 +306,7 @@ class StableDiffusionControlNetPipeline:
             self._runner = StepRunner(self.unet, self.controlnet)
 
         # PL:352-377 — condition images, embedded ONCE
-        conds = []
-        for i, (img, net) in enumerate(zip(image, self.controlnet.nets)):
-            nz = None if cond_noise is None else cond_noise[i]
-            conds.append(self.prepare_image(img, B, do_cfg, net, noise=nz, generator=generator))
+        conds = self.prepare_images(image, B, do_cfg, cond_noise, generator)
         h, w = conds[0].shape[1:3]
 
         # PL:382-398
