@@ -8,6 +8,7 @@
 //
 // Block = 4 waves; each wave owns QF x 16 queries (QF = 2 -> 128 queries per block), K/V tiles of KVT keys are
 // shared by the 4 waves through LDS; the next tile's global loads are in flight behind the current tile's MFMAs.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/edgestyle_hip.h"
 
@@ -327,7 +328,8 @@ int launch_attn(const es_attn_desc& d, hipStream_t st) {
 template <typename T>
 int dispatch(const es_attn_desc& d, hipStream_t st) {
   // 32 queries per wave (128 per block) only when that still yields >= 2 blocks per CU; else 16 per wave
-  const bool big = (long long)((d.Sq + 127) / 128) * d.heads * d.N >= 512;
+  static const long long big_thr = getenv("ES_ATTN_BIG") ? atoll(getenv("ES_ATTN_BIG")) : 512;
+  const bool big = (long long)((d.Sq + 127) / 128) * d.heads * d.N >= big_thr;
   // (64 queries per wave was measured slower: 309 registers -> one wave per SIMD)
   switch (d.d) {
     case 8: return launch_attn<T, 1, 1, 2, 64, true>(d, st);

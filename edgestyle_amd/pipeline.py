@@ -15,6 +15,8 @@ from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import Any, Callable, Dict, List, Optional, Sequence, Union
 
+import os
+
 import numpy as np
 import torch
 
@@ -64,7 +66,8 @@ class _Loop:
         """Everything between PL:435 and PL:522 for the step selected by the device counter."""
         ops.gather_row(self.t_table, self.step_idx, self.t_rows)
         ops.gather_row(self.scale_table, self.step_idx, self.scales_cur)
-        self.runner.step(self.model_in, self.t_rows, self.conds, [1.0] * 6, self.scales_cur, out=self.noise)
+        self.runner.step(self.model_in, self.t_rows, self.conds, [1.0] * 6, self.scales_cur, out=self.noise,
+                         step_idx=self.step_idx)
         if self.unipc:
             ops.cfg_unipc_step(self.noise, self.latents, self.hist[0], self.hist[1], self.hist[2], self.model_in,
                                self.coef, self.step_idx, float(self.guidance_scale), self.cfg_on)
@@ -351,6 +354,11 @@ class StableDiffusionControlNetPipeline:
             dst.copy_(src)
         loop.ehs.copy_(ehs.to(dev, self.dtype))
         self._runner.set_context(loop.ehs)
+        if self._runner.mode == "grouped" and os.environ.get("ES_TIME_TABLE", "1") == "1":
+            had = self._runner.tproj_table
+            self._runner.set_time_table(ts.float().to(dev), N)           # every step's time projections, once per call
+            if self._runner.tproj_table is not had:
+                regraph = True                                            # buffers were (re)allocated
 
         # PL:435-543 — the denoising loop
         if callback_on_step_end is not None or not self.use_graph:
