@@ -176,11 +176,15 @@ ES_DEVICE void fusion_c_body(const es_fusion_desc& p, const int bx, const int nb
     const auto u = as_vec8<T>(*(const u32x4*)(U + (size_t)i * 8));
     const auto g = as_vec8<T>(*(const u32x4*)((const T*)p.g2 + (size_t)i * 8));
     const auto b = as_vec8<T>(*(const u32x4*)((const T*)p.be2 + (size_t)i * 8));
+    u32x4 araw = {0u, 0u, 0u, 0u};
+    if (p.addend) araw = *(const u32x4*)((const T*)p.addend + ((size_t)n * p.HW * p.C) + (size_t)i * 8);
+    const auto a = as_vec8<T>(araw);
     typename Traits<T>::vec8 r;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float v = silu_f((to_f32(u[e]) - mean2) * rstd2 * to_f32(g[e]) + to_f32(b[e]));
       r[e] = from_f32<T>(p.w3[c + e] * v + p.b3[c + e]);
+      if (p.addend) r[e] = from_f32<T>(to_f32(r[e]) + to_f32(a[e]));      // == es_add(out, addend)
     }
     *(typename Traits<T>::vec8*)(O + (size_t)i * 8) = r;
   }

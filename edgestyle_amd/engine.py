@@ -223,14 +223,20 @@ class UNet(Encoder):
         h = ops.conv_gemm(x, self.conv_in)
         return self.run(h, tproj, ctx)
 
-    def forward(self, x, tproj, ctx, down_res: Optional[Sequence] = None, mid_res=None, out=None, encoded=None):
-        """x: [N,H,W,in_pad] -> noise prediction [N,H,W,out_channels] (PL:500-510)."""
+    def forward(self, x, tproj, ctx, down_res: Optional[Sequence] = None, mid_res=None, out=None, encoded=None,
+                presummed: bool = False):
+        """x: [N,H,W,in_pad] -> noise prediction [N,H,W,out_channels] (PL:500-510).  presummed: down_res / mid_res
+        already hold skip + residual (the fusion kernel added the encoder outputs)."""
         skips, h = encoded if encoded is not None else self.encode(x, tproj, ctx)
         skips = list(skips)
-        if down_res is not None:
-            skips = [ops.add(s, r.reshape(s.shape)) for s, r in zip(skips, down_res)]
-        if mid_res is not None:
-            h = ops.add(h, mid_res.reshape(h.shape))
+        if presummed:
+            skips = [r.reshape(s.shape) for s, r in zip(skips, down_res)]
+            h = mid_res.reshape(h.shape)
+        else:
+            if down_res is not None:
+                skips = [ops.add(s, r.reshape(s.shape)) for s, r in zip(skips, down_res)]
+            if mid_res is not None:
+                h = ops.add(h, mid_res.reshape(h.shape))
         ci = len(super().transformers())
         cfg = self.cfg
         for i, blk in enumerate(self.up):
@@ -302,11 +308,12 @@ class Fusion:
             self.params.append(ops.pack_fusion_params(sd, p, dtype, device))
 
     def forward(self, res_per_net: Sequence[Sequence[torch.Tensor]], bs: Sequence[Sequence[int]], N: int,
-                scales: Sequence[float], scales_dev=None):
-        """res_per_net[i][lvl]: tensor view whose data_ptr is sample 0 of net i at level lvl."""
+                scales: Sequence[float], scales_dev=None, addends=None):
+        """res_per_net[i][lvl]: tensor view whose data_ptr is sample 0 of net i at level lvl.  addends: optional 13
+        UNet skip / mid tensors; the outputs are then already `skip + residual` (PL:500-510)."""
         blocks = [([res_per_net[i][lvl] for i in range(6)], [bs[i][lvl] for i in range(6)], self.params[lvl], s * s, c)
                   for lvl, (c, s) in enumerate(self.table)]
-        outs = ops.fusion_blocks(blocks, N, scales, scales_dev)       # 3 launches for all 13 blocks
+        outs = ops.fusion_blocks(blocks, N, scales, scales_dev, addends=addends)   # 3 launches for all 13 blocks
         return [o.reshape(N, s, s, c) for o, (c, s) in zip(outs, self.table)]
 
 

@@ -64,7 +64,7 @@ class FusionDesc(C.Structure):
         ("w2", C.c_void_p), ("b2", C.c_void_p), ("g2", C.c_void_p), ("be2", C.c_void_p),
         ("w3", C.c_void_p), ("b3", C.c_void_p),
         ("scratch", C.c_void_p), ("u", C.c_void_p), ("out", C.c_void_p),
-        ("res_scale_dev", C.c_void_p),
+        ("res_scale_dev", C.c_void_p), ("addend", C.c_void_p),
         ("res_scale", C.c_float * 6),
         ("N", C.c_int32), ("HW", C.c_int32), ("C", C.c_int32),
         ("eps", C.c_float), ("dtype", C.c_int32),

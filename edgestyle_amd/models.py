@@ -780,9 +780,10 @@ class StepRunner:
                 res_per_net[p] = [r[a:] for r in res]
                 bs[p] = [r.stride(0) for r in res]
                 a += N
-        fused = self.controlnet.engine.forward(res_per_net, bs, N, scales, scales_dev)
         enc = ([s[ncn:] for s in skips], h[ncn:])
-        return ue.forward(x, tproj[ncn:], self.ctx_unet, fused[:-1], fused[-1], out=out, encoded=enc)
+        # the fusion kernel adds the UNet's own skip / mid tensors: its outputs ARE the decoder's inputs
+        fused = self.controlnet.engine.forward(res_per_net, bs, N, scales, scales_dev, addends=enc[0] + [enc[1]])
+        return ue.forward(x, tproj[ncn:], self.ctx_unet, fused[:-1], fused[-1], out=out, encoded=enc, presummed=True)
 
     def step_nchw(self, sample, timestep, ehs, conds, scales):
         """Convenience for tests: NCHW fp32 in / NCHW out."""

@@ -509,7 +509,8 @@ def gather_row(table: torch.Tensor, idx: torch.Tensor, out: torch.Tensor):
 _fusion_scratch = {}
 
 
-def _fusion_desc(res, res_bs, params: dict, N: int, HW: int, Cc: int, scales, scales_dev, out, eps, slot: int):
+def _fusion_desc(res, res_bs, params: dict, N: int, HW: int, Cc: int, scales, scales_dev, out, eps, slot: int,
+                 addend: Optional[torch.Tensor] = None):
     t0 = res[0]
     key = (t0.device, N, slot)
     sc = _fusion_scratch.get(key)
@@ -529,6 +530,10 @@ def _fusion_desc(res, res_bs, params: dict, N: int, HW: int, Cc: int, scales, sc
         setattr(d, name, params[name].data_ptr())
     d.scratch, d.u, d.out = sc.data_ptr(), u.data_ptr(), out.data_ptr()
     d.N, d.HW, d.C, d.eps, d.dtype = N, HW, Cc, eps, _dt(t0)
+    if addend is not None:
+        if addend.numel() != N * HW * Cc or not addend.is_contiguous() or addend.dtype != t0.dtype:
+            raise L.EdgeStyleHipError("fusion addend must be a contiguous [N,HW,C] tensor of the compute dtype")
+        d.addend = addend.data_ptr()
     return d, u, out
 
 
@@ -540,15 +545,17 @@ def fusion_block(res, res_bs, params: dict, N: int, HW: int, Cc: int, scales, sc
     return out
 
 
-def fusion_blocks(blocks, N: int, scales, scales_dev=None, eps: float = 1e-5):
+def fusion_blocks(blocks, N: int, scales, scales_dev=None, eps: float = 1e-5, addends=None):
     """All fusion blocks of a step in three launches.  blocks: list of (res, res_bs, params, HW, Cc) as for
-    fusion_block; returns the list of [N,HW,Cc] outputs."""
+    fusion_block; returns the list of [N,HW,Cc] outputs.  addends: optional list of [N,HW,Cc] tensors added to the
+    outputs (the UNet skip tensors: saves the 13 separate adds of PL:500-510)."""
     keep, outs = [], []
     for k0 in range(0, len(blocks), L.FUSION_MAX_BATCH):
         part = blocks[k0:k0 + L.FUSION_MAX_BATCH]
         arr = (L.FusionDesc * len(part))()
         for k, (res, res_bs, params, HW, Cc) in enumerate(part):
-            d, u, out = _fusion_desc(res, res_bs, params, N, HW, Cc, scales, scales_dev, None, eps, k0 + k)
+            d, u, out = _fusion_desc(res, res_bs, params, N, HW, Cc, scales, scales_dev, None, eps, k0 + k,
+                                     None if addends is None else addends[k0 + k])
             arr[k] = d
             keep.append(u)
             outs.append(out)

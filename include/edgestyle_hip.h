@@ -135,6 +135,8 @@ typedef struct {
   const float* w3; const float* b3;
   float* scratch; void* u; void* out;
   const float* res_scale_dev;  /* optional device float[6]: per-net conditioning_scale (CL:266-270), graph-updatable */
+  const void* addend;          /* optional [N,HW,C] dtype: the UNet skip / mid tensor this residual is added to
+                                * (PL:500-510): out = round(block) + addend, rounded like the separate add */
   float res_scale[6];          /* per-net conditioning_scale applied to res[i] on load (multiplied with the above) */
   int32_t N, HW, C;
   float eps;

@@ -254,6 +254,11 @@ def test_fusion_blocks_batched_equals_per_block():
     batched = ops.fusion_blocks(blocks, N, scales)
     for a, b in zip(single, batched):
         assert torch.equal(a, b)
+    # addend = the UNet skip tensor: one fused pass == block output followed by es_add
+    adds = [torch.randn(N, hw, c, generator=g).to(DEV, torch.float16) for _, _, _, hw, c in blocks]
+    summed = ops.fusion_blocks(blocks, N, scales, addends=adds)
+    for a, b, d in zip(single, summed, adds):
+        assert torch.equal(ops.add(a, d), b)
 
 
 def test_timestep_embedding():
