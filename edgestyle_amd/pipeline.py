@@ -354,6 +354,11 @@ class StableDiffusionControlNetPipeline:
             dst.copy_(src)
         loop.ehs.copy_(ehs.to(dev, self.dtype))
         self._runner.set_context(loop.ehs)
+        if self._runner.mode == "grouped":
+            had = self._runner.cond_cat
+            self._runner.set_conds(loop.conds)                            # conv_in + cond of all nets as one launch
+            if self._runner.cond_cat is not had:
+                regraph = True
         if self._runner.mode == "grouped" and os.environ.get("ES_TIME_TABLE", "1") == "1":
             had = self._runner.tproj_table
             self._runner.set_time_table(ts.float().to(dev), N)           # every step's time projections, once per call
