@@ -281,7 +281,7 @@ class ControlNet(Encoder):
         return ops.conv_gemm(z, self.conv_in)
 
     def forward(self, x, tproj, ctx, conds: Sequence[torch.Tensor], out_scale: float = 1.0,
-                out_scale_dev=None):
+                out_scale_dev=None, level_scales: Optional[Sequence[float]] = None):
         """x: [N,H,W,in_pad]; conds: k pre-embedded [N,H,W,C0] tensors -> the pass runs at batch k*N with shared
         weights (tproj/ctx must already be k*N rows).  Returns (13 residual tensors [k*N,HW,C])."""
         k = len(conds)
@@ -291,9 +291,10 @@ class ControlNet(Encoder):
         for i, c in enumerate(conds):                       # sample = conv_in(sample) + cond   (CL:197-203)
             ops.conv_gemm(x, self.conv_in, residual=c, out=h0[i * N:(i + 1) * N])
         skips, h = self.run(h0, tproj, ctx)
-        res = [ops.conv_gemm(s, z, out_scale=out_scale, out_scale_dev=out_scale_dev)
-               for s, z in zip(skips, self.zero)]
-        res.append(ops.conv_gemm(h, self.zero_mid, out_scale=out_scale, out_scale_dev=out_scale_dev))
+        ls = list(level_scales) if level_scales is not None else [1.0] * (len(self.zero) + 1)   # guess_mode: CL:256-264
+        res = [ops.conv_gemm(s, z, out_scale=out_scale * ls[i], out_scale_dev=out_scale_dev)
+               for i, (s, z) in enumerate(zip(skips, self.zero))]
+        res.append(ops.conv_gemm(h, self.zero_mid, out_scale=out_scale * ls[-1], out_scale_dev=out_scale_dev))
         return res
 
 

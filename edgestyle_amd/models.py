@@ -90,6 +90,11 @@ def _as_nchw_view(x: torch.Tensor) -> torch.Tensor:
     return x.permute(0, 3, 1, 2)
 
 
+def _guess_level_scales(n: int) -> List[float]:
+    """guess_mode: torch.logspace(-1, 0, 13) over the 12 down + 1 mid residuals (CL:256-264)."""
+    return torch.logspace(-1, 0, n).tolist()
+
+
 def _timestep_tensor(timestep, n: int, device) -> torch.Tensor:
     """CL:134-148: scalar / 0-d / [n] timestep -> fp32 [n] device tensor."""
     if not torch.is_tensor(timestep):
@@ -239,8 +244,6 @@ class ControlNetModel(_HipModel):
             controlnet_cond = torch.flip(controlnet_cond, dims=[1])
         elif order != "rgb":
             raise ValueError(f"unknown `controlnet_conditioning_channel_order`: {order}")   # CL:124-126
-        if guess_mode:
-            raise NotImplementedError("guess_mode is outside the EdgeStyle hot path (SURVEY.md §8f rank 3)")
         eng = self.engine
         N = sample.shape[0]
         x = _as_nhwc(sample, self.dtype, self.device, eng.in_pad)
@@ -249,7 +252,8 @@ class ControlNetModel(_HipModel):
         cond = _as_nhwc(controlnet_cond, self.dtype, self.device)
         tproj = eng.time_proj(_timestep_tensor(timestep, N, self.device))
         ctx = eng.context(encoder_hidden_states.to(self.device, self.dtype).contiguous())
-        res = eng.forward(x, tproj, ctx, [cond], out_scale=float(conditioning_scale))
+        ls = _guess_level_scales(len(eng.zero) + 1) if guess_mode else None           # CL:256-264
+        res = eng.forward(x, tproj, ctx, [cond], out_scale=float(conditioning_scale), level_scales=ls)
         down = [_as_nchw_view(r) for r in res[:-1]]
         mid = _as_nchw_view(res[-1])
         if not return_dict:
@@ -567,9 +571,7 @@ class EdgeStyleMultiControlNetModel(_HipModel):
 
     def __call__(self, sample, timestep, encoder_hidden_states, controlnet_cond: List[torch.Tensor],
                  conditioning_scale: List[float], guess_mode: bool = False, return_dict: bool = True, **unused):
-        """MC:116-171.  Returns (12 tensors, 1 tensor), NCHW-shaped."""
-        if guess_mode:
-            raise NotImplementedError("guess_mode is outside the EdgeStyle hot path")
+        """MC:116-171.  Returns (12 tensors, 1 tensor), NCHW-shaped.  guess_mode is handed to every net (MC:136-149)."""
         if len(controlnet_cond) != len(self.nets) or len(conditioning_scale) != len(self.nets):
             raise ValueError("controlnet_cond and conditioning_scale must have one entry per ControlNet")
         N = sample.shape[0]
@@ -588,7 +590,8 @@ class EdgeStyleMultiControlNetModel(_HipModel):
                 conds.append(_as_nhwc(c, dt, dev))
             tproj = eng.time_proj(_timestep_tensor(timestep, N, dev).repeat(k))
             ctx = eng.context(ehs.repeat(k, 1, 1) if k > 1 else ehs)
-            res = eng.forward(x, tproj, ctx, conds)
+            res = eng.forward(x, tproj, ctx, conds,
+                              level_scales=_guess_level_scales(len(eng.zero) + 1) if guess_mode else None)
             for j, p in enumerate(pos):
                 res_per_net[p] = [r[j * N:] for r in res]
                 bs[p] = [r.stride(0) for r in res]
@@ -624,6 +627,7 @@ class StepRunner:
         self._grouped = None
         self.ctx_grouped = None
         self._streams = None
+        self.ctx_guess = None
         # grouped mode: the time-embedding MLP + every ResnetBlock time projection depend on the timestep only, so
         # they are computed for ALL steps of a call at once (set_time_table) and one row is gathered per step
         self.tproj_table = None          # [T, ntot, width] compute dtype (the buffers of the current call)
@@ -652,9 +656,15 @@ class StepRunner:
         mc.to(device)
         return cls(unet, mc)
 
-    def set_context(self, ehs: torch.Tensor):
-        """ehs: [N,77,D] device dtype. Computes every cross-attention K/V projection once (constant over the loop)."""
+    def set_context(self, ehs: torch.Tensor, guess_mode: bool = False, n_cn: Optional[int] = None):
+        """ehs: [N,77,D] device dtype. Computes every cross-attention K/V projection once (constant over the loop).
+        guess_mode: the ControlNets see the last n_cn rows of ehs — under CFG only the conditional half (PL:453-459)."""
         self.ctx_unet = self.unet.engine.context(ehs, self.ctx_unet)
+        if guess_mode:
+            ehs_c = ehs[ehs.shape[0] - (n_cn or ehs.shape[0]):]
+            self.ctx_guess = [net.engine.context(ehs_c.repeat(len(pos), 1, 1) if len(pos) > 1 else ehs_c)
+                              for net, pos in self.groups]
+            return
         old = self.ctx_nets or [None] * len(self.groups)
         self.ctx_nets = []
         for (net, pos), o in zip(self.groups, old):
@@ -712,9 +722,36 @@ class StepRunner:
     def clear_time_table(self):
         self.tproj_table = self.tproj_cur = None
 
+    def _step_guess(self, x, t_rows, conds, scales, scales_dev, out):
+        """guess_mode (CL:256-264): the 13 residual levels are scaled 0.1..1 log-spaced.  Under CFG (PL:453-459,
+        487-497) the ControlNets additionally run on the conditional half only (conds then hold B samples) and the
+        unconditional half of the UNet gets no residuals."""
+        N = x.shape[0]
+        Bc = conds[0].shape[0]
+        B = N - Bc                                       # first row of the ControlNet batch inside x (0 without CFG)
+        ue = self.unet.engine
+        nn = len(self.controlnet.nets)
+        res_per_net, bs = [None] * nn, [None] * nn
+        xc = x[B:]
+        ls = _guess_level_scales(len(ue.cfg.residual_table()))
+        for gi, (net, pos) in enumerate(self.groups):
+            eng = net.engine
+            tproj = eng.time_proj(t_rows[: len(pos) * Bc])
+            res = eng.forward(xc, tproj, self.ctx_guess[gi], [conds[p] for p in pos], level_scales=ls)
+            for j, p in enumerate(pos):
+                res_per_net[p] = [r[j * Bc:] for r in res]
+                bs[p] = [r.stride(0) for r in res]
+        fused = self.controlnet.engine.forward(res_per_net, bs, Bc, scales, scales_dev)
+        tproj = ue.time_proj(t_rows[:N])
+        skips, h = ue.encode(x, tproj, self.ctx_unet)
+        for s_, f in zip(skips, fused[:-1]):              # torch.cat([zeros, d]) + skip == add into the cond half
+            ops.add(s_[B:], f.reshape(s_[B:].shape), out=s_[B:])
+        ops.add(h[B:], fused[-1].reshape(h[B:].shape), out=h[B:])
+        return ue.forward(x, tproj, self.ctx_unet, out=out, encoded=(skips, h))
+
     def step(self, x: torch.Tensor, t_rows: torch.Tensor, conds: Sequence[torch.Tensor], scales: Sequence[float],
              scales_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-             step_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+             step_idx: Optional[torch.Tensor] = None, guess_mode: bool = False) -> torch.Tensor:
         """x: [N,h,w,8] NHWC; t_rows: fp32 device [kmax*N] (all equal to the timestep); conds: 6 x [N,h,w,C0] NHWC.
 
         The three batched ControlNet passes and the UNet's own down+mid path do not depend on each other (the
@@ -722,6 +759,8 @@ class StepRunner:
         separate HIP streams (forked from / joined into the current stream, hence capturable as parallel hipGraph
         branches): at batch 1 a single chain's kernels cannot fill 256 CUs."""
         N = x.shape[0]
+        if guess_mode:
+            return self._step_guess(x, t_rows, conds, scales, scales_dev, out)
         nn = len(self.controlnet.nets)
         res_per_net, bs = [None] * nn, [None] * nn
         ue = self.unet.engine

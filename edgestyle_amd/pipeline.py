@@ -36,10 +36,11 @@ class StableDiffusionPipelineOutput:
 class _Loop:
     """Static device buffers + the captured step graph for one (B, cfg) shape."""
 
-    def __init__(self, pipe, B: int, cfg_on: bool, h: int, w: int):
+    def __init__(self, pipe, B: int, cfg_on: bool, h: int, w: int, guess: bool = False):
         dev, dt = pipe.device, pipe.dtype
         unet = pipe.unet
         self.B, self.cfg_on, self.h, self.w = B, cfg_on, h, w
+        self.guess = guess               # guess_mode: log-spaced level scales; under CFG ControlNets see the cond half only
         self.N = N = 2 * B if cfg_on else B
         Lc, Lp = unet.cfg.in_channels, unet.engine.in_pad
         c0 = unet.cfg.block_out_channels[0]
@@ -48,7 +49,7 @@ class _Loop:
         self.latents = torch.zeros((B, h, w, Lc), dtype=torch.float32, device=dev)
         self.model_in = torch.zeros((N, h, w, Lp), dtype=dt, device=dev)
         self.noise = torch.zeros((N, h, w, unet.cfg.out_channels), dtype=dt, device=dev)
-        self.conds = [torch.zeros((N, h, w, c0), dtype=dt, device=dev) for _ in range(6)]
+        self.conds = [torch.zeros((B if (guess and cfg_on) else N, h, w, c0), dtype=dt, device=dev) for _ in range(6)]
         self.ehs = torch.zeros((N, 77, unet.cfg.cross_attention_dim), dtype=dt, device=dev)
         self.step_idx = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.t_rows = torch.zeros((k * N,), dtype=torch.float32, device=dev)
@@ -67,7 +68,7 @@ class _Loop:
         ops.gather_row(self.t_table, self.step_idx, self.t_rows)
         ops.gather_row(self.scale_table, self.step_idx, self.scales_cur)
         self.runner.step(self.model_in, self.t_rows, self.conds, [1.0] * 6, self.scales_cur, out=self.noise,
-                         step_idx=self.step_idx)
+                         step_idx=self.step_idx, guess_mode=self.guess)
         if self.unipc:
             ops.cfg_unipc_step(self.noise, self.latents, self.hist[0], self.hist[1], self.hist[2], self.model_in,
                                self.coef, self.step_idx, float(self.guidance_scale), self.cfg_on)
@@ -274,8 +275,6 @@ class StableDiffusionControlNetPipeline:
                  guess_mode: bool = False, control_guidance_start: Union[float, List[float]] = 0.0,
                  control_guidance_end: Union[float, List[float]] = 1.0,
                  callback_on_step_end: Optional[Callable] = None, cond_noise: Optional[Sequence] = None, **kwargs):
-        if guess_mode:
-            raise NotImplementedError("guess_mode is outside the EdgeStyle hot path (SURVEY.md §8f)")
         if eta != 0.0:
             raise NotImplementedError("only the deterministic DDIM update (eta = 0) is implemented")
         if timesteps is not None:
@@ -309,7 +308,8 @@ class StableDiffusionControlNetPipeline:
             self._runner = StepRunner(self.unet, self.controlnet)
 
         # PL:352-377 — condition images, embedded ONCE
-        conds = self.prepare_images(image, B, do_cfg, cond_noise, generator)
+        guess = bool(guess_mode)
+        conds = self.prepare_images(image, B, do_cfg and not guess, cond_noise, generator)      # PL:352-377, 657-658
         h, w = conds[0].shape[1:3]
 
         # PL:382-398
@@ -317,10 +317,10 @@ class StableDiffusionControlNetPipeline:
         T = len(ts)
         lat = self.prepare_latents(B, self.unet.cfg.in_channels, h, w, generator, latents)
 
-        key = (B, do_cfg, h, w)
+        key = (B, do_cfg, h, w, guess)
         loop = self._loops.get(key)
         if loop is None:
-            loop = self._loops[key] = _Loop(self, B, do_cfg, h, w)
+            loop = self._loops[key] = _Loop(self, B, do_cfg, h, w, guess)
         N, k = loop.N, self._runner.kmax
         # PL:419-427 controlnet_keep folded into a per-step scale table
         keep = [[1.0 - float(i / T < s or (i + 1) / T > e)
@@ -353,13 +353,13 @@ class StableDiffusionControlNetPipeline:
         for dst, src in zip(loop.conds, conds):
             dst.copy_(src)
         loop.ehs.copy_(ehs.to(dev, self.dtype))
-        self._runner.set_context(loop.ehs)
-        if self._runner.mode == "grouped":
+        self._runner.set_context(loop.ehs, guess, loop.conds[0].shape[0])
+        if self._runner.mode == "grouped" and not guess:
             had = self._runner.cond_cat
             self._runner.set_conds(loop.conds)                            # conv_in + cond of all nets as one launch
             if self._runner.cond_cat is not had:
                 regraph = True
-        if self._runner.mode == "grouped" and os.environ.get("ES_TIME_TABLE", "1") == "1":
+        if self._runner.mode == "grouped" and not guess and os.environ.get("ES_TIME_TABLE", "1") == "1":
             had = self._runner.tproj_table
             self._runner.set_time_table(ts.float().to(dev), N)           # every step's time projections, once per call
             if self._runner.tproj_table is not had:

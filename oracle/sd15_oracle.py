@@ -194,7 +194,7 @@ def vae_cond_embedding(sd_cn: SD, vae_sd: SD, vae_cfg, cond, noise):
     return conv(sd_cn, "conv_in", z)
 
 
-def controlnet_forward(sd: SD, cfg, sample, t, ehs, cond, conditioning_scale=1.0, embed_fn=None):
+def controlnet_forward(sd: SD, cfg, sample, t, ehs, cond, conditioning_scale=1.0, embed_fn=None, guess_mode=False):
     """CachedControlNetModel.forward.  `cond` with latent spatial size is used as-is (CL:199-203)."""
     emb = time_embedding(sd, t, cfg, sample.shape[0])
     h = conv(sd, "conv_in", sample)
@@ -204,8 +204,13 @@ def controlnet_forward(sd: SD, cfg, sample, t, ehs, cond, conditioning_scale=1.0
     skips, h = encoder_forward(sd, cfg, h, emb, ehs)
     down = [conv(sd, f"controlnet_down_blocks.{i}", s, padding=0) for i, s in enumerate(skips)]
     mid = conv(sd, "controlnet_mid_block", h, padding=0)
-    down = [d * conditioning_scale for d in down]          # CL:266-270 (guess_mode=False)
-    mid = mid * conditioning_scale
+    if guess_mode:                                         # CL:256-264 (global_pool_conditions is False)
+        ls = torch.logspace(-1, 0, len(down) + 1) * conditioning_scale
+        down = [d * s for d, s in zip(down, ls)]
+        mid = mid * ls[-1]
+    else:
+        down = [d * conditioning_scale for d in down]      # CL:266-270
+        mid = mid * conditioning_scale
     return down, mid
 
 
@@ -254,11 +259,11 @@ def controlnet_block(sd: SD, p: str, x):
 
 
 def multicontrolnet_forward(fusion_sd: SD, nets: Sequence[Tuple[SD, object]], sample, t, ehs,
-                            conds: Sequence[torch.Tensor], scales: Sequence[float]):
+                            conds: Sequence[torch.Tensor], scales: Sequence[float], guess_mode=False):
     """EdgeStyleMultiControlNetModel.forward (MC:116-171). `nets` = 6 x (state_dict, cfg); conds pre-embedded."""
     downs, mids = [], []
     for (sd, cfg), cond, scale in zip(nets, conds, scales):
-        d, m = controlnet_forward(sd, cfg, sample, t, ehs, cond, scale)
+        d, m = controlnet_forward(sd, cfg, sample, t, ehs, cond, scale, guess_mode=guess_mode)      # MC:136-149
         downs.append(d)
         mids.append(m)
     down = [interleave_tensors(level) for level in zip(*downs)]
@@ -356,18 +361,25 @@ class DDIM:
 # ----------------------------------------------------------------------------------------------------------------
 # the pipeline (PL:91-582), with pre-embedded conditions (the cached semantics, PL:660-662)
 # ----------------------------------------------------------------------------------------------------------------
-def denoise_step(unet_sd, unet_cfg, fusion_sd, nets, sample, t, ehs, conds, scales):
-    """One controlnet->unet evaluation == OnnxUNetAndControlnets.forward (export_onnx.py:43-74)."""
-    down, mid = multicontrolnet_forward(fusion_sd, nets, sample, t, ehs, conds, scales)
+def denoise_step(unet_sd, unet_cfg, fusion_sd, nets, sample, t, ehs, conds, scales, guess_mode=False, cfg_on=True):
+    """One controlnet->unet evaluation == OnnxUNetAndControlnets.forward (export_onnx.py:43-74).
+    guess_mode with CFG (PL:453-459, 487-497): the ControlNets see only the conditional half (conds are then [B]
+    tensors) and the unconditional half of the UNet gets zero residuals."""
+    if guess_mode and cfg_on:
+        down, mid = multicontrolnet_forward(fusion_sd, nets, sample.chunk(2)[1], t, ehs.chunk(2)[1], conds, scales, True)
+        down = [torch.cat([torch.zeros_like(d), d]) for d in down]
+        mid = torch.cat([torch.zeros_like(mid), mid])
+    else:
+        down, mid = multicontrolnet_forward(fusion_sd, nets, sample, t, ehs, conds, scales, guess_mode)
     return unet_forward(unet_sd, unet_cfg, sample, t, ehs, down, mid)
 
 
 def pipeline(unet_sd, unet_cfg, fusion_sd, nets, vae_sd, vae_cfg, latents, prompt_embeds, negative_prompt_embeds,
              conds, num_inference_steps=50, guidance_scale=7.5, scales=None, control_guidance_start=0.0,
-             control_guidance_end=1.0, decode=True, on_step=None):
+             control_guidance_end=1.0, decode=True, on_step=None, guess_mode=False):
     """EdgeStyleStableDiffusionControlNetPipeline.__call__ (PL:91-582) for pre-embedded `conds`
     (6 x [B,C0,h,w]; duplicated for CFG here exactly like PL:657-658 does before embedding... the caller passes
-    already-embedded tensors of batch 2B when CFG is on, B otherwise)."""
+    already-embedded tensors of batch 2B when CFG is on and guess_mode is off, B otherwise)."""
     n_nets = len(nets)
     scales = list(scales) if scales is not None else [1.0] * n_nets
     cfg_on = guidance_scale > 1.0                              # do_classifier_free_guidance
@@ -382,7 +394,7 @@ def pipeline(unet_sd, unet_cfg, fusion_sd, nets, vae_sd, vae_cfg, latents, promp
         keep = [1.0 - float(i / T < s or (i + 1) / T > e) for s, e in zip(starts, ends)]   # PL:419-427
         x = torch.cat([latents] * 2) if cfg_on else latents     # PL:443-447
         cond_scale = [c * k for c, k in zip(scales, keep)]      # PL:464-470
-        eps = denoise_step(unet_sd, unet_cfg, fusion_sd, nets, x, t, ehs, conds, cond_scale)
+        eps = denoise_step(unet_sd, unet_cfg, fusion_sd, nets, x, t, ehs, conds, cond_scale, guess_mode, cfg_on)
         if cfg_on:
             e_u, e_t = eps.chunk(2)
             eps = e_u + guidance_scale * (e_t - e_u)            # PL:513-517

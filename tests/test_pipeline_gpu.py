@@ -136,6 +136,34 @@ def test_multicontrolnet_and_unet_call_surface(built):
     assert tuple(noise.shape) == (2, 4, s, s) and rel_err(noise, ref) < 2e-2
 
 
+@pytest.mark.parametrize("gs", [5.0, 1.0])
+def test_pipeline_guess_mode_vs_oracle(built, gs):
+    """guess_mode (CL:256-264 log-spaced level scales; under CFG the ControlNets run on the conditional half only and
+    the unconditional half gets zero residuals, PL:453-459, 487-497)."""
+    from oracle import sd15_oracle as O
+    pipe, ws, ucfg, vcfg = built
+    B, steps = 1, 3
+    lat, pe, ne, conds = _inputs(ucfg, B, seed=7)
+    ref = O.pipeline(ws["unet"], ucfg, ws["fusion"], oracle_nets(ws, ucfg), ws["vae"], vcfg, lat, pe, ne,
+                     [c.repeat(B, 1, 1, 1) for c in conds], num_inference_steps=steps, guidance_scale=gs, guess_mode=True)
+    out = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, latents=lat, guidance_scale=gs,
+               num_inference_steps=steps, output_type="pt", guess_mode=True).images
+    assert psnr(out, ref) >= 40.0
+    plain = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, latents=lat, guidance_scale=gs,
+                 num_inference_steps=steps, output_type="pt").images
+    assert not torch.equal(out, plain)                      # the mode does change the result
+    # the multi-ControlNet call surface hands guess_mode to every net (MC:136-149)
+    g = torch.Generator().manual_seed(3)
+    s = ucfg.sample_size
+    x = torch.randn(2, 4, s, s, generator=g).half().float()
+    ehs = torch.cat([ne, pe]).repeat(1, 1, 1)[:2]
+    cc = [c.repeat(2, 1, 1, 1) for c in conds]
+    down, mid = pipe.controlnet(x, 500, ehs, cc, [1.0] * 6, guess_mode=True, return_dict=False)
+    rd, rm = O.multicontrolnet_forward(ws["fusion"], oracle_nets(ws, ucfg), x, 500, ehs, cc, [1.0] * 6, guess_mode=True)
+    assert (mid.float().cpu() - rm).abs().max() < 2e-2 * max(1.0, float(rm.abs().max()))
+    assert (down[0].float().cpu() - rd[0]).abs().max() < 2e-2 * max(1.0, float(rd[0].abs().max()))
+
+
 def test_errors_match_reference_behaviour(built):
     pipe, ws, ucfg, vcfg = built
     lat, pe, ne, conds = _inputs(ucfg, 1)
