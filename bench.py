@@ -186,13 +186,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # rehearsal knobs (a 1-GPU box cannot host two RCCL ranks): ES_DIST_BACKEND=gloo ES_FORCE_DEVICE=0 runs the
+    # multi-rank control flow of this script with every rank on one GPU; the driver's runs use neither
+    dev_index = int(os.environ.get("ES_FORCE_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")          # RCCL over xGMI
+        dist.init_process_group(os.environ.get("ES_DIST_BACKEND", "nccl"))          # nccl == RCCL over xGMI
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", dev_index)
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
 
     import faulthandler

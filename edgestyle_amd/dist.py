@@ -35,6 +35,8 @@ def gather_images(images: torch.Tensor, world: Optional[int] = None, dst: int = 
     if world == 1:
         return images
     images = images.contiguous()
+    if dist.get_backend() == "gloo" and images.is_cuda:
+        images = images.cpu()            # CPU rehearsal of the multi-rank flow: gloo has no CUDA gather
     rank = dist.get_rank()
     bufs: Optional[List[torch.Tensor]] = [torch.empty_like(images) for _ in range(world)] if rank == dst else None
     dist.gather(images, bufs, dst=dst)
