@@ -42,13 +42,17 @@ ES_DEVICE void store_elems(T* o, const float* v, int n) {
   for (int r = 0; r < n; ++r) o[r] = from_f32<T>(v[r]);
 }
 
-template <typename T, int BM, int BN, bool ALIGNED, int STAGES>
-__global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void conv_gemm_kernel(const es_gemm_desc p,
-                                                                                              const int M,
-                                                                                              const int nk) {
-  constexpr int NW = BM / 32;        // waves: (BM/64) along pixels x 2 along couts; each owns 64 px x BN/2 couts
+template <typename T, int BM, int BN, bool ALIGNED, int STAGES, int FM = 4 /* pixel fragments per wave */>
+__global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? 2 : 1) void conv_gemm_kernel(const es_gemm_desc p,
+                                                                                                   const int M,
+                                                                                                   const int nk) {
+  // waves: WM along pixels x 2 along couts; each owns 16*FM px x BN/2 couts.  FM = 4: 4 waves per 128-pixel tile.
+  // FM = 2: the same tile on 8 waves (two per SIMD) for launches that leave a workgroup alone on its CU, where one
+  // wave per SIMD serialises DMA issue, fragment reads and MFMAs (measured 0.7 us per K-step vs 0.21 us of MFMA).
+  constexpr int WM = BM / (16 * FM);
+  constexpr int NW = WM * 2;
   constexpr int NT = NW * 64;
-  constexpr int FM = 4;              // pixel fragments per wave (64 pixels)
+  constexpr int XI = (BM / 8) / NW;  // activation DMA pieces (8 rows each) per wave per K-step
   constexpr int FN = BN / 32;        // cout fragments per wave (BN/2 couts)
   constexpr int WP = BN / 8;         // weight DMA pieces per K-step (8 rows each), dealt round-robin-by-block to waves
   constexpr int WI = (WP + NW - 1) / NW;
@@ -57,13 +61,13 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
   constexpr int NPASS = ((size_t)BM * (BN * 2 + 16) > (size_t)STAGES * (BM + BN) * BK * 2) ? 2 : 1;   // epilogue passes
   constexpr int BNP = BN / NPASS;    // couts staged per epilogue pass
   constexpr int EROW = BNP * 2 + 16; // epilogue tile row stride (bytes), padded against bank conflicts
-  constexpr int NI = 4 + WI;         // LDS-DMA instructions per wave per K-step
+  constexpr int NI = XI + WI;        // LDS-DMA instructions per wave per K-step
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave % (BM / 64), wn = wave / (BM / 64);
+  const int wm = wave % WM, wn = wave / WM;
   // XCD-aware tile mapping.  Workgroups are dealt round-robin to the 8 XCDs (private L2 each), so linear block id b
   // runs on XCD b % 8.  Give every XCD one CONTIGUOUS chunk of the tile list, ordered so that consecutive tiles share
   // the larger operand: weights larger than activations (small M, deep layers) -> tile_m fastest, an XCD owns whole
@@ -99,12 +103,12 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
   constexpr unsigned OOB = 0xFFFFFF00u;
   // (integer division costs ~40 VALU instructions and sits on every launch's critical path: linear layers skip it,
   // convs use a float reciprocal + one correction step, exact below 2^24)
-  int iy0[4], ix0[4], nb[4];
+  int iy0[XI], ix0[XI], nb[XI];
   const bool small_m = M < (1 << 24);
   const float inv_hw = 1.0f / (float)HWout, inv_w = 1.0f / (float)p.Wout;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = tile_m * BM + 32 * wave + 8 * i + lrow;
+  for (int i = 0; i < XI; ++i) {
+    const int m = tile_m * BM + 8 * (wave * XI + i) + lrow;
     iy0[i] = -(1 << 20); ix0[i] = -(1 << 20); nb[i] = 0;
     if (m < M) {
       int n, oy, ox;
@@ -151,13 +155,15 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
     tap = kg / Ctot;
     cpos = kg - tap * Ctot;
   }
-  unsigned voff[4] = {OOB, OOB, OOB, OOB};
+  unsigned voff[XI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) voff[i] = OOB;
   int cur_tap = -1, cur_second = -1;
   auto row_offsets = [&](int tp, int cs, int chan) {      // byte offset of (row i, tap tp, channel chan) or OOB
     int ky = 0, kx = 0;
     if (p.ksize == 3) { ky = (tp * 11) >> 5; kx = tp - ky * 3; }       // tp in [0,9): tp/3 without a divide
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < XI; ++i) {
       const int iy = iy0[i] + ky, ix = ix0[i] + kx;
       const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
       const int pix = nb[i] + (iy >> p.upsample) * p.Wsrc + (ix >> p.upsample);
@@ -186,16 +192,16 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
       }
 #if ES_ABLATE & 64
 #pragma unroll
-      for (int i = 0; i < 4; ++i) voff[i] = OOB;
+      for (int i = 0; i < XI; ++i) voff[i] = OOB;
 #endif
       if (second) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, (lptr_t)(xs + (32 * wave + 8 * i) * 128), 16, (int)voff[i], cc * 2, 0, 0);
+        for (int i = 0; i < XI; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, (lptr_t)(xs + 8 * (wave * XI + i) * 128), 16, (int)voff[i], cc * 2, 0, 0);
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rX1, (lptr_t)(xs + (32 * wave + 8 * i) * 128), 16, (int)voff[i], cc * 2, 0, 0);
+        for (int i = 0; i < XI; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rX1, (lptr_t)(xs + 8 * (wave * XI + i) * 128), 16, (int)voff[i], cc * 2, 0, 0);
       }
     } else {
       // small-Cin layers (conv_in, cond embedding): tap and channel differ per lane, single source
@@ -203,11 +209,11 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
         row_offsets(tap, p.C1, cpos);
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) voff[i] = OOB;
+        for (int i = 0; i < XI; ++i) voff[i] = OOB;
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rX1, (lptr_t)(xs + (32 * wave + 8 * i) * 128), 16, (int)voff[i], 0, 0, 0);
+      for (int i = 0; i < XI; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rX1, (lptr_t)(xs + 8 * (wave * XI + i) * 128), 16, (int)voff[i], 0, 0, 0);
     }
     cpos += BK;
     while (cpos >= Ctot) { cpos -= Ctot; ++tap; }
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
         typename Traits<T>::vec8 xa[FM];
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
-          const int row = wm * 64 + j * 16 + frow;
+          const int row = wm * (16 * FM) + j * 16 + frow;
           xa[j] = as_vec8<T>(*(const u32x4*)(xs + row * 128 + (((4 * h + fq) ^ (row & 7)) << 4)));
         }
         auto wfrag = [&](int i) {
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
     if (!(ES_ABLATE & 4) || ks == ks0) {
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
-      const int row = wm * 64 + j * 16 + frow;
+      const int row = wm * (16 * FM) + j * 16 + frow;
       xa0[j] = as_vec8<T>(*(const u32x4*)(xs + row * 128 + (((0 + fq) ^ (row & 7)) << 4)));
     }
 #pragma unroll
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
     if (!(ES_ABLATE & 4) || ks == ks0) {
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
-      const int row = wm * 64 + j * 16 + frow;
+      const int row = wm * (16 * FM) + j * 16 + frow;
       xa1[j] = as_vec8<T>(*(const u32x4*)(xs + row * 128 + (((4 + fq) ^ (row & 7)) << 4)));
     }
 #pragma unroll
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 2 && BM == 128) ? 2 : 1) void co
   }
 
   // ---------------- split-K: raw fp32 partials (16 B per lane) ----------------
-  const int prow = wm * 64 + frow;                        // + j*16 : pixel row inside the tile
+  const int prow = wm * (16 * FM) + frow;                 // + j*16 : pixel row inside the tile
   const int pcol = wn * (BN / 2) + fq * 4;                // + i*16 : cout column inside the tile
   if (p.splitk > 1) {
     float* wsp = p.workspace + (size_t)z * M * p.rows_padded;
@@ -571,20 +577,23 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
   dim3 grid(((M + bm - 1) / bm) * tn * d.splitk);
   int stages = d.stages;
   if (stages == 0) stages = 2;   // measured (tools/gemm_bench.py): 2 stages x 2 workgroups/CU beats a 3-4 deep ring at 1/CU
-#define ES_LAUNCH(BMV, BNV, AL, ST)                                                                         \
+#define ES_LAUNCH_F(BMV, BNV, AL, ST, FMV)                                                                  \
   do {                                                                                                      \
-    auto kfn = conv_gemm_kernel<T, BMV, BNV, AL, ST>;                                                       \
+    auto kfn = conv_gemm_kernel<T, BMV, BNV, AL, ST, FMV>;                                                  \
     const size_t lds = (size_t)ST * (BMV + BNV) * BK * 2;                                                   \
     static bool attr_set = false;                                                                           \
     if (!attr_set) {                                                                                        \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
       attr_set = true;                                                                                      \
     }                                                                                                       \
-    hipLaunchKernelGGL(kfn, grid, dim3(BMV * 2), lds, st, d, M, nk);                                        \
+    hipLaunchKernelGGL(kfn, grid, dim3(BMV * 8 / FMV), lds, st, d, M, nk);                                  \
   } while (0)
+#define ES_LAUNCH(BMV, BNV, AL, ST) ES_LAUNCH_F(BMV, BNV, AL, ST, 4)
 #define ES_LAUNCH_ST(BNV)                                                                                   \
   do {                                                                                                      \
-    if (bm == 256 && stages == 3) ES_LAUNCH(256, BNV, true, 3);                                             \
+    if (d.waves == 8 && stages == 4 && BNV == 128) ES_LAUNCH_F(128, 128, true, 4, 2);                       \
+    else if (d.waves == 8) ES_LAUNCH_F(128, BNV, true, 2, 2);                                               \
+    else if (bm == 256 && stages == 3) ES_LAUNCH(256, BNV, true, 3);                                        \
     else if (bm == 256) ES_LAUNCH(256, BNV, true, 2);                                                       \
     else if (stages == 2) ES_LAUNCH(128, BNV, true, 2);                                                     \
     else if (stages == 3) ES_LAUNCH(128, BNV, true, 3);                                                     \
@@ -595,6 +604,7 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
   else                  { if (aligned) ES_LAUNCH_ST(160); else ES_LAUNCH(128, 160, false, 2); }
 #undef ES_LAUNCH_ST
 #undef ES_LAUNCH
+#undef ES_LAUNCH_F
   if (d.splitk > 1) {
     const long long total = (long long)M * (d.rows_padded / 8);
     hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, M);
@@ -643,6 +653,10 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
   if (d->bm != 0 && d->bm != 128 && d->bm != 256) { es_set_error("es_conv_gemm: bm must be 0 (auto), 128 or 256"); return -1; }
   if (d->bm == 256 && (d->C1 % BK || d->C2 % BK)) { es_set_error("es_conv_gemm: bm=256 needs 64-aligned channels"); return -1; }
   if (d->stages != 0 && (d->stages < 2 || d->stages > 4)) { es_set_error("es_conv_gemm: stages must be 0 (auto), 2, 3 or 4"); return -1; }
+  if (d->waves != 0 && d->waves != 4 && d->waves != 8) { es_set_error("es_conv_gemm: waves must be 0 (auto), 4 or 8"); return -1; }
+  if (d->waves == 8 && (d->bm == 256 || d->bn == 320 || d->C1 % BK || d->C2 % BK || d->stages == 3 ||
+                        (d->stages == 4 && d->bn != 128))) {
+    es_set_error("es_conv_gemm: waves=8 is the 128-pixel tile on 8 waves: 64-aligned channels, 2 stages (4 with bn=128)"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   int rc = d->dtype == ES_F16 ? launch<f16>(*d, st) : launch<bf16>(*d, st);
   if (rc) es_set_error("es_conv_gemm: launch failed");

@@ -38,6 +38,8 @@ DEEP_RING = _os.environ.get("ES_DEEP_RING", "1") == "1"     # 4-stage LDS ring f
 FORCE_BN = 0        # tuning knob: 0 = per-launch choice between the legal N tiles
 FORCE_BM = 0        # tuning knob: 0 = kernel picks the pixel tile (128 / 256)
 FORCE_STAGES = 0    # tuning knob (tools/gemm_bench.py): 0 = kernel picks the LDS ring depth
+FORCE_WAVES = 0     # tuning knob: 0 = planner picks 4 or 8 waves per 128-pixel workgroup
+EIGHT_WAVES = _os.environ.get("ES_EIGHT_WAVES", "1") == "1"
 PROFILE = None      # set to a Profiler by bench.py: every es_conv_gemm launch gets an in-kernel timing slot
 
 
@@ -295,6 +297,14 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     d.xcd_m_fastest = (1 if (pws is None and splitk == 1 and M <= 2048 and pw.w.numel() > x.numel() + (x2.numel() if x2 is not None else 0)) else 0) \
         if XCD_ORDER < 0 else XCD_ORDER
     d.bm = FORCE_BM
+    if FORCE_WAVES:
+        d.waves = FORCE_WAVES
+    elif EIGHT_WAVES and k == 1 and M <= 65536 and C1 % BK == 0 and C2 % BK == 0 and bn != 320 and FORCE_BM != 256 \
+            and not (int(d.stages) == 4 and bn != 128) and int(d.stages) != 3:
+        # 1x1 convs / linears are short-K, latency-bound launches: two waves per SIMD on the same 128-pixel tile overlap
+        # DMA issue, fragment reads and MFMAs (tools/gemm_tune.py: 3-15 % on every 1x1 shape of a batch-1 step, none on 3x3 or on the
+        # memory-bound 1x1 launches of large batches)
+        d.waves = 8
     if splitk > 1:
         ws = _get_workspace(splitk * M * pw.rows_padded * 4, x.device)
         d.workspace = ws.data_ptr()

@@ -332,6 +332,42 @@ def test_errors_are_loud():
                       torch.zeros(1, 8, 36, dtype=torch.float16, device=DEV), heads=1)   # d=36 unsupported
 
 
+def test_conv_gemm_eight_wave_tile_equals_four_wave_tile():
+    """waves=8 (the 128-pixel tile on two waves per SIMD) reproduces the 4-wave kernel bit for bit: 3x3 with concat +
+    temb + residual + SiLU and split-K, 1x1 linear, GEGLU, 2- and 4-stage rings, both N tiles, bf16."""
+    from edgestyle_amd import ops, lib
+    g = torch.Generator().manual_seed(33)
+
+    def both(fn):
+        ops.FORCE_WAVES = 8
+        try:
+            a = fn()
+        finally:
+            ops.FORCE_WAVES = 0
+        return a, fn()
+
+    for dtype in (torch.float16, torch.bfloat16):
+        N, C1, C2, H = 3, 128, 64, 12                    # M = 432 (ragged)
+        for Cout in (256, 320):                          # bn = 128 / 160
+            x1 = torch.randn(N, H, H, C1, generator=g).to(DEV, dtype)
+            x2 = torch.randn(N, H, H, C2, generator=g).to(DEV, dtype)
+            pw = ops.pack_weight(torch.randn(Cout, C1 + C2, 3, 3, generator=g) / 40, torch.randn(Cout, generator=g) * 0.1, dtype, DEV)
+            temb = torch.randn(N, Cout, generator=g).to(DEV, dtype)
+            res = torch.randn(N, H, H, Cout, generator=g).to(DEV, dtype)
+            for splitk, stages in ((1, 2), (3, 2), (1, 4)):
+                if stages == 4 and Cout == 320:
+                    continue
+                a, b = both(lambda: ops.conv_gemm(x1, pw, x2=x2, temb=temb, residual=res, act=lib.ACT_SILU, splitk=splitk, stages=stages))
+                assert torch.equal(a, b), (dtype, Cout, splitk, stages)
+    xl = torch.randn(300, 320, generator=g).to(DEV, torch.float16)
+    pl = ops.pack_weight(torch.randn(1280, 320, generator=g) / 18, torch.randn(1280, generator=g) * 0.1, torch.float16, DEV)
+    a, b = both(lambda: ops.linear(xl, pl))
+    assert torch.equal(a, b)
+    pg = ops.pack_weight(torch.randn(2560, 320, generator=g) / 18, torch.randn(2560, generator=g) * 0.1, torch.float16, DEV, geglu=True)
+    a, b = both(lambda: ops.linear(xl, pg))
+    assert torch.equal(a, b)
+
+
 def test_grouped_launches_equal_separate_launches():
     """One grouped launch over the batch-concatenated activations == per-net launches (bit for bit): conv/linear with
     temb + residual, GroupNorm, LayerNorm."""

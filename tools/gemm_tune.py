@@ -32,8 +32,9 @@ B8 = [(112, 64, 320, 320, 3), (112, 64, 320, 320, 1), (112, 64, 1280, 320, 1), (
       (16, 32, 640, 640, 3), (16, 32, 1280, 640, 3), (16, 16, 1280, 1280, 3), (16, 16, 2560, 1280, 3)]
 
 
-def time_cfg(x, pws, outs, bn, splitk, stages, R):
+def time_cfg(x, pws, outs, bn, splitk, stages, R, waves=0):
     ops.FORCE_BN = bn
+    ops.FORCE_WAVES = waves
     try:
         for i in range(R):
             ops.conv_gemm(x, pws[i], out=outs[i], splitk=splitk, stages=stages)
@@ -50,6 +51,7 @@ def time_cfg(x, pws, outs, bn, splitk, stages, R):
         return best * 1e3
     finally:
         ops.FORCE_BN = 0
+        ops.FORCE_WAVES = 0
 
 
 def main():
@@ -85,18 +87,21 @@ def main():
                 for st in (2, 4):
                     if st == 4 and (tiles * sk > 256 or bn == 320):
                         continue
-                    try:
-                        res[(bn, sk, st)] = time_cfg(x, pws, outs, bn, sk, st, R)
-                    except Exception as e:  # noqa: BLE001
-                        print("   skip", (bn, sk, st), str(e)[:60], flush=True)
-        if (hbn, hsk, hst) not in res:
-            res[(hbn, hsk, hst)] = time_cfg(x, pws, outs, hbn, hsk, hst, R)
-        h = res[(hbn, hsk, hst)]
+                    for wv in (4, 8):
+                        if wv == 8 and (bn == 320 or (st == 4 and bn != 128) or Cin % 64):
+                            continue
+                        try:
+                            res[(bn, sk, st, wv)] = time_cfg(x, pws, outs, bn, sk, st, R, wv)
+                        except Exception as e:  # noqa: BLE001
+                            print("   skip", (bn, sk, st, wv), str(e)[:60], flush=True)
+        if (hbn, hsk, hst, 4) not in res:
+            res[(hbn, hsk, hst, 4)] = time_cfg(x, pws, outs, hbn, hsk, hst, R, 4)
+        h = res[(hbn, hsk, hst, 4)]
         top = sorted(res, key=res.get)[:4]
         bk = top[0]
         print(f"{shp} {M} | {(hbn, hsk, hst)} {h:.1f} | {bk} {res[bk]:.1f} | {h / res[bk]:.2f}x | "
               + " ".join(f"{c}:{res[c]:.1f}" for c in top[1:]), flush=True)
-        cells.append(dict(shape=shp, M=M, heuristic=[hbn, hsk, hst], cells={f"{b},{s},{t}": round(v, 2) for (b, s, t), v in res.items()}))
+        cells.append(dict(shape=shp, M=M, heuristic=[hbn, hsk, hst], cells={f"{b},{s},{t},{w}": round(v, 2) for (b, s, t, w), v in res.items()}))
     if a.json:
         os.makedirs(os.path.dirname(a.json), exist_ok=True)
         json.dump(cells, open(a.json, "w"))
