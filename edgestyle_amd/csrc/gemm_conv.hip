@@ -6,6 +6,8 @@
 // 64 pixels x BN/2 couts = 4 x (4|5) MFMA fragments.  Large launches use the big tile BM=256 x BN=320 (512 threads =
 // 8 waves as 4(M) x 2(N), 64 px x 160 couts per wave, one workgroup per CU): it moves half the L2->LDS bytes per
 // FLOP, which is what bounds the 128-pixel tile (tools/gemm_ablate.sh: its DMA stream alone takes longer than its MFMAs).
+// Tiny launches (a few dozen 128x128 tiles: the deep UNet levels at batch 1) use BM=64 x BN=64: they are bound by
+// weight bytes in flight x HBM latency, and four times as many workgroups keep four times as many DMA rings busy.
 //
 // Staging is LDS-DMA (`buffer_load_dwordx4 ... lds`): every wave-instruction copies 8 tile rows x 128 B straight from
 // global memory into LDS — no VGPR round trip and no ds_write traffic (ds_write_b128 tops out at ~79 B/clk/CU, which
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? 2 : 1) vo
   }
   int grp = 0;
   if (p.ngroups > 1) {
-    const int t128 = tile_m * (BM / 128);              // group table is in 128-pixel units
+    const int t128 = (tile_m * BM) / 128;               // group table is in 128-pixel units
     grp = (t128 >= p.mt_end[0]) + (t128 >= p.mt_end[1]) + (t128 >= p.mt_end[2]);
   }
   const void* wsel = p.ngroups > 1 ? p.w_g[grp] : p.w;
@@ -573,6 +575,7 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
   const int tn = d.rows_padded / d.bn;
   int bm = d.bm;
   if (d.bn == 320) bm = 256;
+  if (d.bn == 64) bm = 64;
   if (bm == 0) bm = 128;
   dim3 grid(((M + bm - 1) / bm) * tn * d.splitk);
   int stages = d.stages;
@@ -599,7 +602,8 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
     else if (stages == 3) ES_LAUNCH(128, BNV, true, 3);                                                     \
     else ES_LAUNCH(128, BNV, true, 4);                                                                      \
   } while (0)
-  if (d.bn == 320)      { ES_LAUNCH(256, 320, true, 2); }
+  if (d.bn == 64)       { if (stages == 4) ES_LAUNCH_F(64, 64, true, 4, 2); else ES_LAUNCH_F(64, 64, true, 2, 2); }
+  else if (d.bn == 320) { ES_LAUNCH(256, 320, true, 2); }
   else if (d.bn == 128) { if (aligned) ES_LAUNCH_ST(128); else ES_LAUNCH(128, 128, false, 2); }
   else                  { if (aligned) ES_LAUNCH_ST(160); else ES_LAUNCH(128, 160, false, 2); }
 #undef ES_LAUNCH_ST
@@ -635,7 +639,10 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
       for (int g = 0; g < d->ngroups; ++g)
         if (d->mt_end[g] & 1) { es_set_error("es_conv_gemm: 256-pixel tiles need groups of whole 256-pixel tiles"); return -1; }
   }
-  if (d->bn != 128 && d->bn != 160 && d->bn != 320) { es_set_error("es_conv_gemm: bn must be 128, 160 or 320"); return -1; }
+  if (d->bn != 64 && d->bn != 128 && d->bn != 160 && d->bn != 320) { es_set_error("es_conv_gemm: bn must be 64, 128, 160 or 320"); return -1; }
+  if (d->bn == 64 && ((d->bm != 0 && d->bm != 64) || d->C1 % BK || d->C2 % BK || d->stages == 3 || d->waves == 8 || d->act == ES_ACT_GEGLU)) {
+    es_set_error("es_conv_gemm: bn=64 is the 64x64 tile: 64-aligned channels, 2 or 4 stages, no GEGLU"); return -1; }
+  if (d->bm == 64 && d->bn != 64) { es_set_error("es_conv_gemm: bm=64 goes with bn=64"); return -1; }
   if (d->bn == 320 && (d->bm == 128 || d->C1 % BK || d->C2 % BK || (d->stages != 0 && d->stages != 2) || d->act == ES_ACT_GEGLU)) {
     es_set_error("es_conv_gemm: bn=320 is the 256-pixel tile: 64-aligned channels, 2 stages, no GEGLU"); return -1; }
   if (d->rows_padded % d->bn || d->rows_padded < d->Cout) { es_set_error("es_conv_gemm: bad rows_padded"); return -1; }
@@ -650,7 +657,7 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
   if (d->splitk > 1 && (long long)d->N * d->Hout * d->Wout * (d->rows_padded / 8) >= (1ll << 31)) { es_set_error("es_conv_gemm: split-K output too large for 32-bit indices"); return -1; }
   if (d->act == ES_ACT_GEGLU && (d->bn != 128 || d->Cout % 32)) { es_set_error("es_conv_gemm: GEGLU needs bn=128, Cout%32==0"); return -1; }
   if (d->N < 1 || d->Hout < 1 || d->Wout < 1) { es_set_error("es_conv_gemm: empty problem"); return -1; }
-  if (d->bm != 0 && d->bm != 128 && d->bm != 256) { es_set_error("es_conv_gemm: bm must be 0 (auto), 128 or 256"); return -1; }
+  if (d->bm != 0 && d->bm != 64 && d->bm != 128 && d->bm != 256) { es_set_error("es_conv_gemm: bm must be 0 (auto), 64, 128 or 256"); return -1; }
   if (d->bm == 256 && (d->C1 % BK || d->C2 % BK)) { es_set_error("es_conv_gemm: bm=256 needs 64-aligned channels"); return -1; }
   if (d->stages != 0 && (d->stages < 2 || d->stages > 4)) { es_set_error("es_conv_gemm: stages must be 0 (auto), 2, 3 or 4"); return -1; }
   if (d->waves != 0 && d->waves != 4 && d->waves != 8) { es_set_error("es_conv_gemm: waves must be 0 (auto), 4 or 8"); return -1; }

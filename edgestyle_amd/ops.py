@@ -40,6 +40,7 @@ FORCE_BM = 0        # tuning knob: 0 = kernel picks the pixel tile (128 / 256)
 FORCE_STAGES = 0    # tuning knob (tools/gemm_bench.py): 0 = kernel picks the LDS ring depth
 FORCE_WAVES = 0     # tuning knob: 0 = planner picks 4 or 8 waves per 128-pixel workgroup
 EIGHT_WAVES = _os.environ.get("ES_EIGHT_WAVES", "1") == "1"
+SMALL_TILE = _os.environ.get("ES_SMALL_TILE", "1") == "1"    # 64x64 tile for tiny launches
 PROFILE = None      # set to a Profiler by bench.py: every es_conv_gemm launch gets an in-kernel timing slot
 
 
@@ -182,13 +183,17 @@ def _get_workspace(nbytes: int, device) -> torch.Tensor:
 #     time (half the L2->LDS bytes); it only pays on launches of many rounds, so it is offered from 32k pixels up.
 PLAN_T160, PLAN_ALONE, PLAN_TFIX, PLAN_RED_FIX, PLAN_SLAB_BYTES_PER_UNIT = 1.25, 0.9, 2.0, 12.0, 4.0e6
 PLAN_T320, PLAN_BIG_MIN_M = 2.4, 32768
+#   * the 64x64 tile (tiny launches): a K-step costs 0.5 units with the CU to itself, 0.6 when several share it
+#     (0.9 for K > 2560, where MFMA throughput starts to matter and the small tile reads LDS twice as often per FLOP);
+#     1024 resident workgroups (32 KB of LDS each); offered up to 16k pixels.
+PLAN_T64_ALONE, PLAN_T64, PLAN_T64_LONG, PLAN_SMALL_MAX_M = 0.5, 0.6, 0.9, 16384
 BIG_TILE = _os.environ.get("ES_BIG_TILE", "0") == "1"      # opt-in: measured no end-to-end gain at batch 1 or 8
 PLAN_SLAB_BYTES_PER_UNIT = float(_os.environ.get("ES_PLAN_SLAB", PLAN_SLAB_BYTES_PER_UNIT))
 PLAN_RED_FIX = float(_os.environ.get("ES_PLAN_REDFIX", PLAN_RED_FIX))
 PLAN_MIN_SLICE, PLAN_NK_NOSPLIT, PLAN_RESIDENT = 12, 10, 512
 
 
-def plan_gemm(M: int, rows_padded: int, kpad: int, geglu: bool = False, bns=(160, 128), allow_split: bool = True):
+def plan_gemm(M: int, rows_padded: int, kpad: int, geglu: bool = False, bns=(160, 128, 64), allow_split: bool = True):
     """(bn, splitk, stages) with the lowest modelled time among the legal N tiles (ties go to the wider tile)."""
     if geglu:
         return 128, 1, 2
@@ -199,27 +204,39 @@ def plan_gemm(M: int, rows_padded: int, kpad: int, geglu: bool = False, bns=(160
             continue
         if bn == 320 and M < PLAN_BIG_MIN_M and len(bns) > 1:
             continue
-        bm = 256 if bn == 320 else BM
-        resident = PLAN_RESIDENT // 2 if bn == 320 else PLAN_RESIDENT
+        if bn == 64 and M > PLAN_SMALL_MAX_M and len(bns) > 1:
+            continue
+        bm = {320: 256, 64: 64}.get(bn, BM)
+        resident = {320: PLAN_RESIDENT // 2, 64: 2 * PLAN_RESIDENT}.get(bn, PLAN_RESIDENT)
         tiles = ((M + bm - 1) // bm) * (rows_padded // bn)
         cands = [1]
-        if allow_split and tiles < PLAN_RESIDENT // 2 and nk > PLAN_NK_NOSPLIT:
+        if allow_split and tiles < resident // 2 and nk > PLAN_NK_NOSPLIT:
             cands += list(range(2, min(nk // PLAN_MIN_SLICE, 32) + 1))
         for sk in cands:
             wgs = tiles * sk
-            tk = PLAN_T320 if bn == 320 else (PLAN_T160 if bn == 160 else 1.0) * (PLAN_ALONE if wgs <= PLAN_RESIDENT // 2 else 1.0)
+            if bn == 320:
+                tk = PLAN_T320
+            elif bn == 64:
+                if sk > 1 and wgs > PLAN_RESIDENT:
+                    continue
+                tk = PLAN_T64_ALONE if wgs <= PLAN_RESIDENT // 2 else (PLAN_T64 if nk <= 40 else PLAN_T64_LONG)
+            else:
+                tk = (PLAN_T160 if bn == 160 else 1.0) * (PLAN_ALONE if wgs <= PLAN_RESIDENT // 2 else 1.0)
             t = -(-wgs // resident) * ((nk / sk) * tk + PLAN_TFIX)
             if sk > 1:
                 t += PLAN_RED_FIX + sk * M * rows_padded * 8.0 / PLAN_SLAB_BYTES_PER_UNIT
             if best is None or t < best[0]:
                 best = (t, bn, sk, wgs)
     if best is None:
-        raise L.EdgeStyleHipError(f"plan_gemm: rows_padded {rows_padded} fits neither N tile")
+        raise L.EdgeStyleHipError(f"plan_gemm: rows_padded {rows_padded} fits no N tile")
     _, bn, sk, wgs = best
-    # one workgroup per CU at most: a 4-deep LDS ring (3 K-steps of DMA in flight) hides the HBM round trip that the
+    # at most one workgroup per CU: a 4-deep LDS ring (3 K-steps of DMA in flight) hides the HBM round trip that the
     # 2-stage ring leaves exposed when no second workgroup shares the CU.  Not inside concurrent chains (LANE > 0,
     # ES_CHAIN_MODE=streams): there 2 stages = 72 KB LDS let workgroups of different chains share a CU.
-    stages = 4 if (bn != 320 and DEEP_RING and LANE == 0 and wgs <= PLAN_RESIDENT // 2 and nk // sk >= 6) else 2
+    if bn == 64:
+        stages = 4 if (DEEP_RING and LANE == 0 and wgs <= PLAN_RESIDENT and nk // sk >= 6) else 2
+    else:
+        stages = 4 if (bn != 320 and DEEP_RING and LANE == 0 and wgs <= PLAN_RESIDENT // 2 and nk // sk >= 6) else 2
     return bn, sk, stages
 
 
@@ -273,8 +290,10 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     M = N * Hout * Wout
     big_ok = BIG_TILE and C1 % BK == 0 and C2 % BK == 0 and not pw.geglu and \
         (group_n is None or all((n * Hout * Wout) % 256 == 0 for n in group_n))
+    small_ok = SMALL_TILE and C1 % BK == 0 and C2 % BK == 0 and not pw.geglu and FORCE_WAVES != 8 and FORCE_BM in (0, 64)
+    cand = ((320,) if big_ok else ()) + (160, 128) + ((64,) if small_ok else ())
     bn, auto_splitk, auto_stages = plan_gemm(M, pw.rows_padded, pw.kpad, pw.geglu,
-                                             bns=((320, 160, 128) if big_ok else (160, 128)) if FORCE_BN == 0 else (FORCE_BN,))
+                                             bns=cand if FORCE_BN == 0 else (FORCE_BN,))
     if splitk is None:
         splitk = auto_splitk
         stages = stages or auto_stages
@@ -299,7 +318,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     d.bm = FORCE_BM
     if FORCE_WAVES:
         d.waves = FORCE_WAVES
-    elif EIGHT_WAVES and k == 1 and M <= 65536 and C1 % BK == 0 and C2 % BK == 0 and bn != 320 and FORCE_BM != 256 \
+    elif EIGHT_WAVES and k == 1 and M <= 65536 and C1 % BK == 0 and C2 % BK == 0 and bn not in (64, 320) and FORCE_BM != 256 \
             and not (int(d.stages) == 4 and bn != 128) and int(d.stages) != 3:
         # 1x1 convs / linears are short-K, latency-bound launches: two waves per SIMD on the same 128-pixel tile overlap
         # DMA issue, fragment reads and MFMAs (tools/gemm_tune.py: 3-15 % on every 1x1 shape of a batch-1 step, none on 3x3 or on the

@@ -70,7 +70,7 @@ typedef struct {
   const float* bias_g[4];
   int32_t stages;             /* LDS ring depth: 0 = auto, 2 (2 workgroups/CU), 3 or 4 (1 workgroup/CU) */
   int32_t xcd_m_fastest;      /* tile order inside an XCD's chunk: 1 = tile_m fastest (weights are the larger operand) */
-  int32_t bm;                 /* pixel tile: 0 = auto, 128 (4 waves) or 256 (8 waves, large M only) */
+  int32_t bm;                 /* pixel tile: 0 = auto, 64 (with bn = 64), 128 (4 waves) or 256 (8 waves, large M only) */
   int32_t waves;              /* waves per 128-pixel workgroup: 0 / 4 = default, 8 = two per SIMD (launches that leave
                                * a workgroup alone on its CU: one wave per SIMD cannot overlap DMA issue, LDS reads and
                                * MFMAs with itself) */

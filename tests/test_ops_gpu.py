@@ -332,6 +332,41 @@ def test_errors_are_loud():
                       torch.zeros(1, 8, 36, dtype=torch.float16, device=DEV), heads=1)   # d=36 unsupported
 
 
+def test_conv_gemm_small_tile_equals_default_tile():
+    """bn=64 (64x64 tile for tiny launches) reproduces the 128-pixel tile bit for bit: concat + temb + residual + SiLU,
+    ragged M, split-K, 2/4-stage rings, grouped weights, 1x1."""
+    from edgestyle_amd import ops, lib
+    g = torch.Generator().manual_seed(44)
+
+    def both(fn):
+        ops.FORCE_BN = 64
+        try:
+            a = fn()
+        finally:
+            ops.FORCE_BN = 0
+        return a, fn()
+
+    N, C1, C2, Cout, H = 3, 128, 64, 320, 10             # M = 300
+    x1 = torch.randn(N, H, H, C1, generator=g).to(DEV, torch.float16)
+    x2 = torch.randn(N, H, H, C2, generator=g).to(DEV, torch.float16)
+    pw = ops.pack_weight(torch.randn(Cout, C1 + C2, 3, 3, generator=g) / 40, torch.randn(Cout, generator=g) * 0.1, torch.float16, DEV)
+    temb = torch.randn(N, Cout, generator=g).to(DEV, torch.float16)
+    res = torch.randn(N, H, H, Cout, generator=g).to(DEV, torch.float16)
+    for splitk, stages in ((1, 2), (3, 2), (1, 4), (2, 4)):
+        a, b = both(lambda: ops.conv_gemm(x1, pw, x2=x2, temb=temb, residual=res, act=lib.ACT_SILU, splitk=splitk, stages=stages))
+        assert torch.equal(a, b), (splitk, stages)
+    xl = torch.randn(200, 1280, generator=g).to(DEV, torch.bfloat16)
+    pl = ops.pack_weight(torch.randn(1280, 1280, generator=g) / 36, torch.randn(1280, generator=g) * 0.1, torch.bfloat16, DEV)
+    a, b = both(lambda: ops.linear(xl, pl))
+    assert torch.equal(a, b)
+    counts, Hg = [2, 4, 2], 8                             # 64-pixel samples: groups of 128 / 256 / 128 pixels
+    xg = torch.randn(sum(counts), Hg, Hg, C1, generator=g).to(DEV, torch.float16)
+    pws = [ops.pack_weight(torch.randn(320, C1, 3, 3, generator=g) / 34, torch.randn(320, generator=g) * 0.1,
+                           torch.float16, DEV) for _ in counts]
+    a, b = both(lambda: ops.conv_gemm(xg, pws, group_n=counts))
+    assert torch.equal(a, b)
+
+
 def test_conv_gemm_eight_wave_tile_equals_four_wave_tile():
     """waves=8 (the 128-pixel tile on two waves per SIMD) reproduces the 4-wave kernel bit for bit: 3x3 with concat +
     temb + residual + SiLU and split-K, 1x1 linear, GEGLU, 2- and 4-stage rings, both N tiles, bf16."""

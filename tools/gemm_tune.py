@@ -77,18 +77,20 @@ def main():
         ops.LANE = 0
         hsk, hst = ops.plan_launch(M, pw, hbn)
         res = {}
-        for bn in (128, 160, 320):
+        for bn in (64, 128, 160, 320):
             if pw.rows_padded % bn:
                 continue
-            tiles = -(-M // (256 if bn == 320 else ops.BM)) * (pw.rows_padded // bn)
+            tiles = -(-M // {320: 256, 64: 64}.get(bn, ops.BM)) * (pw.rows_padded // bn)
             for sk in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32):
+                if bn == 64 and (Cin % 64 or M > 16384):
+                    continue
                 if sk > 1 and (nk // sk < 3 or tiles * sk > 1536):
                     continue
                 for st in (2, 4):
-                    if st == 4 and (tiles * sk > 256 or bn == 320):
+                    if st == 4 and (tiles * sk > (1024 if bn == 64 else 256) or bn == 320):
                         continue
                     for wv in (4, 8):
-                        if wv == 8 and (bn == 320 or (st == 4 and bn != 128) or Cin % 64):
+                        if wv == 8 and (bn in (64, 320) or (st == 4 and bn != 128) or Cin % 64):
                             continue
                         try:
                             res[(bn, sk, st, wv)] = time_cfg(x, pws, outs, bn, sk, st, R, wv)
