@@ -183,10 +183,11 @@ def _get_workspace(nbytes: int, device) -> torch.Tensor:
 #     time (half the L2->LDS bytes); it only pays on launches of many rounds, so it is offered from 32k pixels up.
 PLAN_T160, PLAN_ALONE, PLAN_TFIX, PLAN_RED_FIX, PLAN_SLAB_BYTES_PER_UNIT = 1.25, 0.9, 2.0, 12.0, 4.0e6
 PLAN_T320, PLAN_BIG_MIN_M = 2.4, 32768
-#   * the 64x64 tile (tiny launches): a K-step costs 0.5 units with the CU to itself, 0.6 when several share it
-#     (0.9 for K > 2560, where MFMA throughput starts to matter and the small tile reads LDS twice as often per FLOP);
+#   * the 64x64 tile (tiny launches): a K-step costs 0.5 units with the CU to itself and 0.5 + 0.16 (w - 1)^2 with w
+#     workgroups per CU (measured 0.87 at w = 2.5, 2.0 at w = 3.75); x1.5 for K > 2560, where MFMA throughput starts to
+#     matter and the small tile reads LDS twice as often per FLOP;
 #     1024 resident workgroups (32 KB of LDS each); offered up to 16k pixels.
-PLAN_T64_ALONE, PLAN_T64, PLAN_T64_LONG, PLAN_SMALL_MAX_M = 0.5, 0.6, 0.9, 16384
+PLAN_T64_ALONE, PLAN_T64, PLAN_T64_LONG, PLAN_SMALL_MAX_M = 0.5, 0.16, 1.5, 16384
 BIG_TILE = _os.environ.get("ES_BIG_TILE", "0") == "1"      # opt-in: measured no end-to-end gain at batch 1 or 8
 PLAN_SLAB_BYTES_PER_UNIT = float(_os.environ.get("ES_PLAN_SLAB", PLAN_SLAB_BYTES_PER_UNIT))
 PLAN_RED_FIX = float(_os.environ.get("ES_PLAN_REDFIX", PLAN_RED_FIX))
@@ -219,7 +220,8 @@ def plan_gemm(M: int, rows_padded: int, kpad: int, geglu: bool = False, bns=(160
             elif bn == 64:
                 if sk > 1 and wgs > PLAN_RESIDENT:
                     continue
-                tk = PLAN_T64_ALONE if wgs <= PLAN_RESIDENT // 2 else (PLAN_T64 if nk <= 40 else PLAN_T64_LONG)
+                w = wgs / (PLAN_RESIDENT // 2)                 # workgroups per CU
+                tk = (PLAN_T64_ALONE + PLAN_T64 * max(0.0, w - 1.0) ** 2) * (1.0 if nk <= 40 else PLAN_T64_LONG)
             else:
                 tk = (PLAN_T160 if bn == 160 else 1.0) * (PLAN_ALONE if wgs <= PLAN_RESIDENT // 2 else 1.0)
             t = -(-wgs // resident) * ((nk / sk) * tk + PLAN_TFIX)
