@@ -174,8 +174,9 @@ def test_attention_forced_rescale_and_strided_qkv():
                                                 (2, 320, 0, 32, True, 1e-5), (2, 640, 0, 16, True, 1e-5),
                                                 (3, 960, 0, 16, True, 1e-5), (2, 1280, 1280, 16, True, 1e-5),
                                                 (2, 320, 320, 12, False, 1e-5),
-                                                # two-launch path: slab too large for the registers
-                                                (2, 320, 0, 64, True, 1e-5), (2, 640, 320, 32, True, 1e-5)])
+                                                # 1024-thread slab blocks (level 0), and the two-launch path
+                                                (2, 320, 0, 64, True, 1e-5), (2, 320, 320, 64, True, 1e-5),
+                                                (2, 640, 320, 32, True, 1e-5), (1, 640, 320, 64, True, 1e-5)])
 def test_group_norm(N, C1, C2, H, silu, eps):
     from edgestyle_amd import ops
     g = torch.Generator().manual_seed(C1 + C2)
