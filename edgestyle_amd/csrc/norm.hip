@@ -17,6 +17,10 @@ namespace {
 
 constexpr int GN_MAX_CHUNK = 64;
 constexpr int GN_MAX_GROUPS = 64;
+#ifndef GN_UNROLL
+#define GN_UNROLL 4
+#endif
+constexpr int GNU = GN_UNROLL;          // independent 16-byte loads in flight per thread in the streaming loops
 
 ES_DEVICE int gn_pixels_per_block(int HW) {
   int ppb = HW / GN_MAX_CHUNK;
@@ -48,12 +52,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const es_gn_desc p) {
     // four pixels' loads in flight per thread (a one-load-per-iteration loop pays one memory round trip each);
     // the accumulation order over pixels is unchanged
     int px = p0 + ps;
-    for (; px + 3 * PS < p1; px += 4 * PS) {
-      u32x4 raw[4];
+    for (; px + (GNU - 1) * PS < p1; px += GNU * PS) {
+      u32x4 raw[GNU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) raw[u] = *(const u32x4*)(src + ((size_t)n * p.HW + px + u * PS) * cs + cc);
+      for (int u = 0; u < GNU; ++u) raw[u] = *(const u32x4*)(src + ((size_t)n * p.HW + px + u * PS) * cs + cc);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < GNU; ++u) {
         const auto v = as_vec8<T>(raw[u]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float f = to_f32(v[e]); s[e] += f; ss[e] += f * f; }
@@ -146,11 +150,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const es_gn_desc p, const
   T* out = (T*)p.out + (size_t)n * p.HW * C;
   // grid-stride loop, four items' loads in flight per thread
   const int gstride = gridDim.x * 256;
-  for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += 4 * gstride) {
-    u32x4 raw[4];
-    int pxs[4], cs_[4];
+  for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += GNU * gstride) {
+    u32x4 raw[GNU];
+    int pxs[GNU], cs_[GNU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < GNU; ++u) {
       const int i = i0 + u * gstride;
       raw[u] = u32x4{0u, 0u, 0u, 0u};
       pxs[u] = -1; cs_[u] = 0;
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const es_gn_desc p, const
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < GNU; ++u) {
       if (pxs[u] >= 0) {
         const auto v = as_vec8<T>(raw[u]);
         const int c = cs_[u];
@@ -384,7 +388,7 @@ int launch_gn(const es_gn_desc& d, hipStream_t st) {
   const size_t lds_stats = (size_t)2 * PS * C * sizeof(float);
   hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(nchunk, d.N), dim3(256), lds_stats, st, d);
   const long long total = (long long)d.HW * (C / 8);
-  int blocks = (int)((total + 256 * 4 - 1) / (256 * 4));
+  int blocks = (int)((total + 256 * GNU - 1) / (256 * GNU));
   if (blocks < 1) blocks = 1;
   if (blocks > 1024) blocks = 1024;
   const size_t lds = (size_t)(2 * C + 2 * d.groups + 256) * sizeof(float);
