@@ -191,23 +191,26 @@ __global__ __launch_bounds__(256, (QF == 1 && KS <= 3) ? 3 : ((KS <= 5 && QF <= 
     // v_max3 and half a packed convert; key masking only on the ragged last tile.
     const bool ragged = kv0 + KVT > p.Skv;
     typename Traits<T>::vec8 pb[QF][KF / 2];
+    if (__builtin_expect(ragged, 0)) {     // one cold block for all fragments: never if-converted into the hot loop
 #pragma unroll
-    for (int f = 0; f < QF; ++f) {
-      if (ragged) {
+      for (int f = 0; f < QF; ++f)
 #pragma unroll
         for (int kf = 0; kf < KF; ++kf)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             s[f][kf][r] = (kv0 + kf * 16 + g * 4 + r >= p.Skv) ? -3.0e38f : s[f][kf][r];
-      }
+    }
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
       float mx = s[f][0][0];
 #pragma unroll
       for (int kf = 0; kf < KF; ++kf) {
         mx = fmaxf(fmaxf(mx, s[f][kf][0]), s[f][kf][1]);
         mx = fmaxf(fmaxf(mx, s[f][kf][2]), s[f][kf][3]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      // lanes l, l^16, l^32, l^48 hold the four key groups of one query: two VALU half-swaps (no LDS round trip)
+      mx = xor16_max(mx);
+      mx = xor32_max(mx);
       if (kv0 == 0 || !__all(mx <= LAZY)) {                 // wave-uniform: raise the reference of this wave's queries
         const float dlt = kv0 == 0 ? mx : fmaxf(mx, 0.f);   // key 0 is always valid, so the first-tile max is finite
         const float nm = negm[f][0] - dlt;
@@ -292,8 +295,7 @@ __global__ __launch_bounds__(256, (QF == 1 && KS <= 3) ? 3 : ((KS <= 5 && QF <= 
       l = __shfl(o[f][DF - 1][0], 32 + col, 64);            // row d of O^T = fragment DF-1, lane group 2, register 0
     } else {
       l = lrun[f];
-      l += __shfl_xor(l, 16, 64);
-      l += __shfl_xor(l, 32, 64);
+      l = xor32_sum(xor16_sum(l));
     }
     const float inv = 1.0f / l;
     if (qi < p.Sq) {

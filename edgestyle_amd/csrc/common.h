@@ -48,6 +48,53 @@ ES_DEVICE int fast_div(int a, int d, float inv) {
 }
 ES_DEVICE int div_any(int a, int d, float inv, bool small) { return small ? fast_div(a, d, inv) : a / d; }
 
+// max over the lane pairs (l, l^16) / (l, l^32) with gfx950's v_permlane16/32_swap: swapping two copies of a register
+// leaves {own, partner} in the two results in either half, so a symmetric op needs no select and no LDS round trip.
+// Inline asm: hipcc folds the builtin on two equal inputs (and the max after it) away; `s_nop 1` covers the two wait
+// states between a VALU write of an operand and the swap reading it.
+ES_DEVICE float xor16_max(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
+ES_DEVICE float xor32_max(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
+
+ES_DEVICE float xor16_sum(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+ES_DEVICE float xor32_sum(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+// Whole-wave reductions without LDS (`__shfl_xor` compiles to ds_bpermute, ~120 cycles of latency per step): DPP
+// inside a 16-lane row (xor 1, xor 2, then the half-row and row mirrors: after the quad steps every lane of a quad holds
+// the quad's value, so mirrors pair the right quads), permlane swaps across rows.  Fixed order: deterministic.
+template <int CTRL>
+ES_DEVICE float dpp_mov(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+ES_DEVICE float wave_sum(float v) {
+  v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);    // row_half_mirror
+  v += dpp_mov<0x140>(v);    // row_mirror
+  return xor32_sum(xor16_sum(v));
+}
+ES_DEVICE float wave_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  return xor32_max(xor16_max(v));
+}
+
 ES_DEVICE float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // exact (erf) GELU, as torch.nn.functional.gelu default used by diffusers GEGLU.  erf by Abramowitz-Stegun 7.1.26
 // (|abs err| <= 1.5e-7, far below fp16/bf16 resolution): one rcp + one exp + 5 FMA instead of libm erff's ~40 ops.
@@ -70,15 +117,5 @@ template <typename T> ES_DEVICE typename Traits<T>::vec8 as_vec8(u32x4 v) {
   return __builtin_bit_cast(typename Traits<T>::vec8, v);
 }
 
-ES_DEVICE float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-ES_DEVICE float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
 
 #define ES_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : -2)
