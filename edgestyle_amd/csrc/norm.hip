@@ -85,7 +85,10 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const es_gn_desc p) {
       ss += csq[ps * C + c];
     }
   }
-  for (int o = 1; o < L; o <<= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+  // fold the L (4 or 8) lanes of a group: DPP quad steps, then the half-row mirror pairs the two quads (no LDS)
+  s += dpp_mov<0xB1>(s); ss += dpp_mov<0xB1>(ss);
+  s += dpp_mov<0x4E>(s); ss += dpp_mov<0x4E>(ss);
+  if (L == 8) { s += dpp_mov<0x141>(s); ss += dpp_mov<0x141>(ss); }
   if (gi < p.groups && l == 0) {
     float* o = p.partials + ((size_t)n * nchunk + chunk) * p.groups * 2 + gi * 2;
     o[0] = s; o[1] = ss;
