@@ -44,23 +44,30 @@ ES_DEVICE void store_elems(T* o, const float* v, int n) {
   for (int r = 0; r < n; ++r) o[r] = from_f32<T>(v[r]);
 }
 
-template <typename T, int BM, int BN, bool ALIGNED, int STAGES, int FM = 4 /* pixel fragments per wave */>
-__global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? 2 : 1) void conv_gemm_kernel(const es_gemm_desc p,
-                                                                                                   const int M,
-                                                                                                   const int nk) {
+template <typename T, int BM, int BN, bool ALIGNED, int STAGES, int FM = 4 /* pixel fragments per wave */,
+          int BKT = 64 /* K depth of a stage */>
+__global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM == 128) ? 2 : 1)) void conv_gemm_kernel(
+    const es_gemm_desc p, const int M, const int nk) {
+  // BKT = 32: half-depth stages.  The ring shrinks to 2 x 18 KB, the epilogue tile (43 KB) becomes the LDS high-water
+  // mark and THREE workgroups fit a CU: short-K launches (K = 320..1280, a handful of K-steps per tile) are bound by
+  // workgroup turnover - first-tile latency + epilogue drain - and residency is what hides it (2 vs 1 workgroups per
+  // CU: 1.5-1.6x on these launches).  Rows are 64 B; slot p of row r holds chunk p ^ (((r >> 2) & 1) << 1).
+  constexpr int RB = BKT * 2;        // bytes per tile row
+  constexpr int CPR = BKT / 8;       // 16-byte chunks per row
+  constexpr int RPP = 1024 / RB;     // rows per 1 KB LDS-DMA piece
   // waves: WM along pixels x 2 along couts; each owns 16*FM px x BN/2 couts.  FM = 4: 4 waves per 128-pixel tile.
   // FM = 2: the same tile on 8 waves (two per SIMD) for launches that leave a workgroup alone on its CU, where one
   // wave per SIMD serialises DMA issue, fragment reads and MFMAs (measured 0.7 us per K-step vs 0.21 us of MFMA).
   constexpr int WM = BM / (16 * FM);
   constexpr int NW = WM * 2;
   constexpr int NT = NW * 64;
-  constexpr int XI = (BM / 8) / NW;  // activation DMA pieces (8 rows each) per wave per K-step
+  constexpr int XI = (BM / RPP) / NW; // activation DMA pieces (1 KB each) per wave per K-step
   constexpr int FN = BN / 32;        // cout fragments per wave (BN/2 couts)
-  constexpr int WP = BN / 8;         // weight DMA pieces per K-step (8 rows each), dealt round-robin-by-block to waves
+  constexpr int WP = BN / RPP;       // weight DMA pieces per K-step (1 KB each), dealt block-wise to waves
   constexpr int WI = (WP + NW - 1) / NW;
-  constexpr int XT = BM * BK * 2;    // bytes per stage
-  constexpr int WT = BN * BK * 2;
-  constexpr int NPASS = ((size_t)BM * (BN * 2 + 16) > (size_t)STAGES * (BM + BN) * BK * 2) ? 2 : 1;   // epilogue passes
+  constexpr int XT = BM * RB;        // bytes per stage
+  constexpr int WT = BN * RB;
+  constexpr int NPASS = (BKT == 64 && (size_t)BM * (BN * 2 + 16) > (size_t)STAGES * (BM + BN) * RB) ? 2 : 1;   // epilogue passes
   constexpr int BNP = BN / NPASS;    // couts staged per epilogue pass
   constexpr int EROW = BNP * 2 + 16; // epilogue tile row stride (bytes), padded against bank conflicts
   constexpr int NI = XI + WI;        // LDS-DMA instructions per wave per K-step
@@ -89,8 +96,10 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? 2 : 1) vo
   const int ks1 = (int)(((long long)nk * (z + 1)) / p.splitk);
 
   // ---------------- loader state ----------------
-  const int lrow = lane >> 3;                      // row inside an 8-row DMA group
-  const int kc = (lane & 7) ^ (lrow & 7);          // global chunk that lands in LDS slot (lane & 7) of that row
+  const int lrow = lane / CPR;                     // row inside an RPP-row DMA piece
+  const int lslot = lane % CPR;                    // LDS slot the DMA writes for this lane
+  // global chunk that lands in that slot: the XOR swizzle is applied on the SOURCE side (lane-linear destination)
+  const int kc = BKT == 64 ? (lslot ^ (lrow & 7)) : (lslot ^ (((lrow >> 2) & 1) << 1));
   const int Ctot = p.C1 + p.C2;
   const int Ktrue = p.ksize * p.ksize * Ctot;
   const int Hin = p.Hsrc << p.upsample, Win = p.Wsrc << p.upsample;
@@ -110,7 +119,7 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? 2 : 1) vo
   const float inv_hw = 1.0f / (float)HWout, inv_w = 1.0f / (float)p.Wout;
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
-    const int m = tile_m * BM + 8 * (wave * XI + i) + lrow;
+    const int m = tile_m * BM + RPP * (wave * XI + i) + lrow;
     iy0[i] = -(1 << 20); ix0[i] = -(1 << 20); nb[i] = 0;
     if (m < M) {
       int n, oy, ox;
@@ -148,12 +157,12 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? 2 : 1) vo
 #pragma unroll
   for (int i = 0; i < WI; ++i) {
     const int piece = wave * WI + i;               // 8 weight rows; pieces beyond the tile read out of range (zeros)
-    woff[i] = piece < WP ? (unsigned)(((size_t)(tile_n * BN + 8 * piece + lrow) * p.Kpad + kc * 8) * 2) : OOB;
+    woff[i] = piece < WP ? (unsigned)(((size_t)(tile_n * BN + RPP * piece + lrow) * p.Kpad + kc * 8) * 2) : OOB;
   }
 
   int tap, cpos;
   {
-    const int kg = ks0 * BK + (ALIGNED ? 0 : kc * 8);
+    const int kg = ks0 * BKT + (ALIGNED ? 0 : kc * 8);
     tap = kg / Ctot;
     cpos = kg - tap * Ctot;
   }
@@ -176,7 +185,7 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? 2 : 1) vo
   auto issue_tile = [&](int ks, int stage) {
     char* xs = smem + stage * (XT + WT);
     char* ws = xs + XT;
-    const int soff_w = ks * (BK * 2);
+    const int soff_w = ks * RB;
 #pragma unroll
     for (int i = 0; i < WI; ++i)
       if (!(ES_ABLATE & 32) && wave * WI + i < WP)    // wave-uniform
@@ -199,15 +208,15 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? 2 : 1) vo
       if (second) {
 #pragma unroll
         for (int i = 0; i < XI; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, (lptr_t)(xs + 8 * (wave * XI + i) * 128), 16, (int)voff[i], cc * 2, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, (lptr_t)(xs + (wave * XI + i) * 1024), 16, (int)voff[i], cc * 2, 0, 0);
       } else {
 #pragma unroll
         for (int i = 0; i < XI; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rX1, (lptr_t)(xs + 8 * (wave * XI + i) * 128), 16, (int)voff[i], cc * 2, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rX1, (lptr_t)(xs + (wave * XI + i) * 1024), 16, (int)voff[i], cc * 2, 0, 0);
       }
     } else {
       // small-Cin layers (conv_in, cond embedding): tap and channel differ per lane, single source
-      if (ks * BK + kc * 8 < Ktrue) {
+      if (ks * BKT + kc * 8 < Ktrue) {
         row_offsets(tap, p.C1, cpos);
       } else {
 #pragma unroll
@@ -215,9 +224,9 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? 2 : 1) vo
       }
 #pragma unroll
       for (int i = 0; i < XI; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rX1, (lptr_t)(xs + 8 * (wave * XI + i) * 128), 16, (int)voff[i], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rX1, (lptr_t)(xs + (wave * XI + i) * 1024), 16, (int)voff[i], 0, 0, 0);
     }
-    cpos += BK;
+    cpos += BKT;
     while (cpos >= Ctot) { cpos -= Ctot; ++tap; }
   };
 
@@ -286,6 +295,24 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? 2 : 1) vo
           wcur = wnxt;
         }
       }
+    } else if constexpr (BKT == 32) {
+      // half-depth stage: one 32-deep fragment set per K-step, 64-byte rows
+      typename Traits<T>::vec8 xa[FM], wa[FN];
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const int row = wm * (16 * FM) + j * 16 + frow;
+        xa[j] = as_vec8<T>(*(const u32x4*)(xs + row * 64 + ((fq ^ (((row >> 2) & 1) << 1)) << 4)));
+      }
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const int row = wn * (BN / 2) + i * 16 + frow;
+        wa[i] = as_vec8<T>(*(const u32x4*)(ws + row * 64 + ((fq ^ (((row >> 2) & 1) << 1)) << 4)));
+      }
+      if (ks + STAGES - 1 < ks1) issue_tile(ks + STAGES - 1, istage);
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(wa[i], xa[j], acc[i][j]);
     } else {
 #if !(ES_ABLATE & 4)
     typename Traits<T>::vec8 xa0[FM], wa0[FN], xa1[FM], wa1[FN];
@@ -568,7 +595,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const es_gemm_desc p
 template <typename T>
 int launch(const es_gemm_desc& d, hipStream_t st) {
   const int M = d.N * d.Hout * d.Wout;
-  const int nk = d.Kpad / BK;
+  const int bk = d.bk == 32 ? 32 : BK;
+  const int nk = d.Kpad / bk;
   const int Ctot = d.C1 + d.C2;
   const bool aligned = (Ctot % BK == 0) && (d.C1 % BK == 0);
   // Pixel tile: 128 rows x 4 waves (2 workgroups/CU) by default; 256 rows x 8 waves (1 workgroup/CU) selectable (bm).
@@ -580,6 +608,18 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
   dim3 grid(((M + bm - 1) / bm) * tn * d.splitk);
   int stages = d.stages;
   if (stages == 0) stages = 2;   // measured (tools/gemm_bench.py): 2 stages x 2 workgroups/CU beats a 3-4 deep ring at 1/CU
+#define ES_LAUNCH_K(BMV, BNV, AL, ST, FMV, BKV)                                                             \
+  do {                                                                                                      \
+    auto kfn = conv_gemm_kernel<T, BMV, BNV, AL, ST, FMV, BKV>;                                             \
+    const size_t ring = (size_t)ST * (BMV + BNV) * BKV * 2, epi = (size_t)BMV * (BNV * 2 + 16);             \
+    const size_t lds = BKV == 64 ? ring : (ring > epi ? ring : epi);                                        \
+    static bool attr_set = false;                                                                           \
+    if (!attr_set) {                                                                                        \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+      attr_set = true;                                                                                      \
+    }                                                                                                       \
+    hipLaunchKernelGGL(kfn, grid, dim3(BMV * 8 / FMV), lds, st, d, M, nk);                                  \
+  } while (0)
 #define ES_LAUNCH_F(BMV, BNV, AL, ST, FMV)                                                                  \
   do {                                                                                                      \
     auto kfn = conv_gemm_kernel<T, BMV, BNV, AL, ST, FMV>;                                                  \
@@ -594,7 +634,8 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
 #define ES_LAUNCH(BMV, BNV, AL, ST) ES_LAUNCH_F(BMV, BNV, AL, ST, 4)
 #define ES_LAUNCH_ST(BNV)                                                                                   \
   do {                                                                                                      \
-    if (d.waves == 8 && stages == 4 && BNV == 128) ES_LAUNCH_F(128, 128, true, 4, 2);                       \
+    if (d.bk == 32) ES_LAUNCH_K(128, BNV, true, 2, 4, 32);                                                  \
+    else if (d.waves == 8 && stages == 4 && BNV == 128) ES_LAUNCH_F(128, 128, true, 4, 2);                  \
     else if (d.waves == 8) ES_LAUNCH_F(128, BNV, true, 2, 2);                                               \
     else if (bm == 256 && stages == 3) ES_LAUNCH(256, BNV, true, 3);                                        \
     else if (bm == 256) ES_LAUNCH(256, BNV, true, 2);                                                       \
@@ -609,6 +650,7 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
 #undef ES_LAUNCH_ST
 #undef ES_LAUNCH
 #undef ES_LAUNCH_F
+#undef ES_LAUNCH_K
   if (d.splitk > 1) {
     const long long total = (long long)M * (d.rows_padded / 8);
     hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, M);
@@ -661,6 +703,10 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
   if (d->bm == 256 && (d->C1 % BK || d->C2 % BK)) { es_set_error("es_conv_gemm: bm=256 needs 64-aligned channels"); return -1; }
   if (d->stages != 0 && (d->stages < 2 || d->stages > 4)) { es_set_error("es_conv_gemm: stages must be 0 (auto), 2, 3 or 4"); return -1; }
   if (d->waves != 0 && d->waves != 4 && d->waves != 8) { es_set_error("es_conv_gemm: waves must be 0 (auto), 4 or 8"); return -1; }
+  if (d->bk != 0 && d->bk != 64 && d->bk != 32) { es_set_error("es_conv_gemm: bk must be 0 (auto), 64 or 32"); return -1; }
+  if (d->bk == 32 && ((d->bn != 128 && d->bn != 160) || d->bm == 256 || d->bm == 64 || d->waves == 8 || d->C1 % BK || d->C2 % BK ||
+                      (d->stages != 0 && d->stages != 2))) {
+    es_set_error("es_conv_gemm: bk=32 is the 128-pixel tile with half-depth stages: bn 128|160, 4 waves, 2 stages, 64-aligned channels"); return -1; }
   if (d->waves == 8 && (d->bm == 256 || d->bn == 320 || d->C1 % BK || d->C2 % BK || d->stages == 3 ||
                         (d->stages == 4 && d->bn != 128))) {
     es_set_error("es_conv_gemm: waves=8 is the 128-pixel tile on 8 waves: 64-aligned channels, 2 stages (4 with bn=128)"); return -1; }

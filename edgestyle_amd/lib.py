@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
         ("bn", C.c_int32), ("dtype", C.c_int32),
         ("ngroups", C.c_int32), ("mt_end", C.c_int32 * 4), ("w_g", C.c_void_p * 4), ("bias_g", C.c_void_p * 4),
         ("stages", C.c_int32), ("xcd_m_fastest", C.c_int32), ("bm", C.c_int32), ("waves", C.c_int32),
-        ("out_scale", C.c_float),
+        ("bk", C.c_int32), ("out_scale", C.c_float),
     ]
 
 

@@ -39,6 +39,7 @@ FORCE_BN = 0        # tuning knob: 0 = per-launch choice between the legal N til
 FORCE_BM = 0        # tuning knob: 0 = kernel picks the pixel tile (128 / 256)
 FORCE_STAGES = 0    # tuning knob (tools/gemm_bench.py): 0 = kernel picks the LDS ring depth
 FORCE_WAVES = 0     # tuning knob: 0 = planner picks 4 or 8 waves per 128-pixel workgroup
+FORCE_BK = 0        # tuning knob: 32 = half-depth LDS stages (three workgroups per CU)
 EIGHT_WAVES = _os.environ.get("ES_EIGHT_WAVES", "1") == "1"
 SMALL_TILE = _os.environ.get("ES_SMALL_TILE", "1") == "1"    # 64x64 tile for tiny launches
 PROFILE = None      # set to a Profiler by bench.py: every es_conv_gemm launch gets an in-kernel timing slot
@@ -292,7 +293,8 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     M = N * Hout * Wout
     big_ok = BIG_TILE and C1 % BK == 0 and C2 % BK == 0 and not pw.geglu and \
         (group_n is None or all((n * Hout * Wout) % 256 == 0 for n in group_n))
-    small_ok = SMALL_TILE and C1 % BK == 0 and C2 % BK == 0 and not pw.geglu and FORCE_WAVES != 8 and FORCE_BM in (0, 64)
+    small_ok = SMALL_TILE and C1 % BK == 0 and C2 % BK == 0 and not pw.geglu and FORCE_WAVES != 8 and FORCE_BM in (0, 64) \
+        and FORCE_BK != 32
     cand = ((320,) if big_ok else ()) + (160, 128) + ((64,) if small_ok else ())
     bn, auto_splitk, auto_stages = plan_gemm(M, pw.rows_padded, pw.kpad, pw.geglu,
                                              bns=cand if FORCE_BN == 0 else (FORCE_BN,))
@@ -318,9 +320,10 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     d.xcd_m_fastest = (1 if (pws is None and splitk == 1 and M <= 2048 and pw.w.numel() > x.numel() + (x2.numel() if x2 is not None else 0)) else 0) \
         if XCD_ORDER < 0 else XCD_ORDER
     d.bm = FORCE_BM
+    d.bk = FORCE_BK
     if FORCE_WAVES:
         d.waves = FORCE_WAVES
-    elif EIGHT_WAVES and k == 1 and M <= 65536 and C1 % BK == 0 and C2 % BK == 0 and bn not in (64, 320) and FORCE_BM != 256 \
+    elif EIGHT_WAVES and FORCE_BK != 32 and k == 1 and M <= 65536 and C1 % BK == 0 and C2 % BK == 0 and bn not in (64, 320) and FORCE_BM != 256 \
             and not (int(d.stages) == 4 and bn != 128) and int(d.stages) != 3:
         # 1x1 convs / linears are short-K, latency-bound launches: two waves per SIMD on the same 128-pixel tile overlap
         # DMA issue, fragment reads and MFMAs (tools/gemm_tune.py: 3-15 % on every 1x1 shape of a batch-1 step, none on 3x3 or on the

@@ -74,6 +74,8 @@ typedef struct {
   int32_t waves;              /* waves per 128-pixel workgroup: 0 / 4 = default, 8 = two per SIMD (launches that leave
                                * a workgroup alone on its CU: one wave per SIMD cannot overlap DMA issue, LDS reads and
                                * MFMAs with itself) */
+  int32_t bk;                 /* K depth of an LDS stage: 0 / 64 = default, 32 = half-depth stages, three workgroups per CU
+                               * (short-K launches of many tiles: workgroup turnover bound) */
   float out_scale;
 } es_gemm_desc;
 int es_conv_gemm(const es_gemm_desc* d, void* stream);

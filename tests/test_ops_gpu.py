@@ -368,6 +368,48 @@ def test_conv_gemm_small_tile_equals_default_tile():
     assert torch.equal(a, b)
 
 
+def test_conv_gemm_half_depth_stages_equal_default():
+    """bk=32 (half-depth LDS stages, 64-byte rows with their own swizzle, three workgroups per CU) reproduces the
+    default kernel bit for bit: same K order per accumulator."""
+    from edgestyle_amd import ops, lib
+    g = torch.Generator().manual_seed(55)
+
+    def both(fn):
+        ops.FORCE_BK = 32
+        try:
+            a = fn()
+        finally:
+            ops.FORCE_BK = 0
+        return a, fn()
+
+    for dtype in (torch.float16, torch.bfloat16):
+        N, C1, C2, H = 3, 128, 64, 12                    # M = 432 (ragged)
+        for Cout in (256, 320):                          # bn = 128 / 160
+            x1 = torch.randn(N, H, H, C1, generator=g).to(DEV, dtype)
+            x2 = torch.randn(N, H, H, C2, generator=g).to(DEV, dtype)
+            pw = ops.pack_weight(torch.randn(Cout, C1 + C2, 3, 3, generator=g) / 40, torch.randn(Cout, generator=g) * 0.1, dtype, DEV)
+            temb = torch.randn(N, Cout, generator=g).to(DEV, dtype)
+            res = torch.randn(N, H, H, Cout, generator=g).to(DEV, dtype)
+            for splitk in (1, 3):
+                a, b = both(lambda: ops.conv_gemm(x1, pw, x2=x2, temb=temb, residual=res, act=lib.ACT_SILU, splitk=splitk, stages=2))
+                assert torch.equal(a, b), (dtype, Cout, splitk)
+            a, b = both(lambda: ops.conv_gemm(x1, ops.pack_weight(torch.ones(Cout, C1, 3, 3) / 40, None, dtype, DEV), stride=2, stages=2))
+            assert torch.equal(a, b)
+    xl = torch.randn(300, 320, generator=g).to(DEV, torch.float16)
+    pl = ops.pack_weight(torch.randn(1280, 320, generator=g) / 18, torch.randn(1280, generator=g) * 0.1, torch.float16, DEV)
+    a, b = both(lambda: ops.linear(xl, pl, stages=2))
+    assert torch.equal(a, b)
+    pg = ops.pack_weight(torch.randn(2560, 320, generator=g) / 18, torch.randn(2560, generator=g) * 0.1, torch.float16, DEV, geglu=True)
+    a, b = both(lambda: ops.linear(xl, pg))
+    assert torch.equal(a, b)
+    counts = [2, 4, 2]
+    xg = torch.randn(sum(counts), 16, 16, C1, generator=g).to(DEV, torch.float16)
+    pws = [ops.pack_weight(torch.randn(320, C1, 3, 3, generator=g) / 34, torch.randn(320, generator=g) * 0.1,
+                           torch.float16, DEV) for _ in counts]
+    a, b = both(lambda: ops.conv_gemm(xg, pws, group_n=counts, stages=2))
+    assert torch.equal(a, b)
+
+
 def test_conv_gemm_eight_wave_tile_equals_four_wave_tile():
     """waves=8 (the 128-pixel tile on two waves per SIMD) reproduces the 4-wave kernel bit for bit: 3x3 with concat +
     temb + residual + SiLU and split-K, 1x1 linear, GEGLU, 2- and 4-stage rings, both N tiles, bf16."""
