@@ -147,6 +147,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
   }
   const void* wsel = p.ngroups > 1 ? p.w_g[grp] : p.w;
   const float* bsel = p.ngroups > 1 ? p.bias_g[grp] : p.bias;
+  const float* lnsel = p.ln_colsum ? (p.ngroups > 1 ? p.ln_colsum_g[grp] : p.ln_colsum) : nullptr;   // LayerNorm fold
   const auto rW = __builtin_amdgcn_make_buffer_rsrc(
       (void*)wsel, (short)0, (int)((size_t)p.rows_padded * p.Kpad * 2), 0x00020000);
   const auto rX1 = __builtin_amdgcn_make_buffer_rsrc(
@@ -249,6 +250,16 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
   for (int i = 0; i < FN; ++i)
     bias[i] = (bsel && p.splitk == 1) ? *(const f32x4*)(bsel + tile_n * BN + wn * (BN / 2) + fq * 4 + i * 16)
                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+  // LayerNorm fold: column sums of the (gamma-folded) weights for this lane's couts, and this thread's share of the
+  // row statistics: TPR threads per tile row, each summing 8/TPR of the 8 chunks of every staged K-step
+  constexpr int TPR = NT / BM;
+  constexpr int LNC = 8 / TPR;
+  f32x4 lncs[FN];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+    lncs[i] = lnsel ? *(const f32x4*)(lnsel + tile_n * BN + wn * (BN / 2) + fq * 4 + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+  float ln_s = 0.f, ln_q = 0.f;
+  const int ln_row = tid / TPR, ln_part = tid % TPR;
   int stage = 0, istage = STAGES - 1;
 #if ES_ABLATE & 4
   typename Traits<T>::vec8 xa0[FM], wa0[FN], xa1[FM], wa1[FN];
@@ -265,6 +276,15 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
     }
     const char* xs = smem + stage * (XT + WT);
     const char* ws = xs + XT;
+    if constexpr (BKT == 64 && FN <= 5) {
+      if (lnsel) {                                       // LayerNorm fold: this thread's chunks of its row of the tile
+#pragma unroll
+        for (int c = 0; c < LNC; ++c) {
+          const int ch = ln_part * LNC + c;
+          chunk_moments(as_vec8<T>(*(const u32x4*)(xs + ln_row * 128 + ((ch ^ (ln_row & 7)) << 4))), ln_s, ln_q);
+        }
+      }
+    }
     // Fragment reads are software-pipelined against the MFMAs: the reads of the second 32-deep half are in flight
     // behind the first half's MFMAs, and the next tile's DMA issue (address math + 9 LDS-DMA instructions) sits
     // between the two read groups where it covers the first group's LDS latency.
@@ -407,14 +427,32 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
       }
     }
   }
+  float* rowstat = (float*)(smem + (size_t)STAGES * (XT + WT) - BM * 8);    // [BM][2] mean, rstd: beyond the epilogue tile
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
     __syncthreads();                                      // stage buffers / previous pass's tile no longer read
+    if (NPASS == 1 && lnsel) {
+      // fold the TPR partials of a row (adjacent lanes) and publish mean / rstd of the row
+      float s_ = ln_s, q_ = ln_q;
+      s_ += dpp_mov<0xB1>(s_); q_ += dpp_mov<0xB1>(q_);
+      if (TPR == 4) { s_ += dpp_mov<0x4E>(s_); q_ += dpp_mov<0x4E>(q_); }
+      if (ln_part == 0) {
+        const float inv_c = 1.0f / (float)p.C1;
+        const float mean = s_ * inv_c;
+        float var = q_ * inv_c - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        rowstat[ln_row * 2] = mean;
+        rowstat[ln_row * 2 + 1] = rsqrtf(var + p.ln_eps);
+      }
+      __syncthreads();
+    }
     if (NPASS == 1 || wn == pass) {
 #pragma unroll
       for (int j = 0; j < FM; ++j) {
         const int m = tile_m * BM + prow + j * 16;
         const int n = (m < M ? m : M - 1) / HWout;
+        float ln_mean = 0.f, ln_rstd = 1.f;
+        if (lnsel) { ln_mean = rowstat[(prow + j * 16) * 2]; ln_rstd = rowstat[(prow + j * 16) * 2 + 1]; }
         if (geglu) {
           if constexpr (FN % 2 == 0 && NPASS == 1) {
 #pragma unroll
@@ -422,7 +460,12 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
               typename Traits<T>::vec4 pk;
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const float hv = acc[i][j][r] + bias[i][r], gv = acc[i + 1][j][r] + bias[i + 1][r];
+                float ah = acc[i][j][r], ag = acc[i + 1][j][r];
+                if (lnsel) {
+                  ah = ln_rstd * (ah - ln_mean * lncs[i][r]);
+                  ag = ln_rstd * (ag - ln_mean * lncs[i + 1][r]);
+                }
+                const float hv = ah + bias[i][r], gv = ag + bias[i + 1][r];
                 pk[r] = from_f32<T>(hv * gelu_f(gv) * scale);
               }
               *(typename Traits<T>::vec4*)(et + (prow + j * 16) * EROW + ((wn * (BN / 2) + i * 16) / 2 + fq * 4) * 2) = pk;
@@ -446,7 +489,9 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
             typename Traits<T>::vec4 pk;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float x = acc[i][j][r] + bias[i][r] + tv[r];
+              float a = acc[i][j][r];
+              if (lnsel) a = ln_rstd * (a - ln_mean * lncs[i][r]);
+              float x = a + bias[i][r] + tv[r];
               if (p.act == ES_ACT_SILU) x = silu_f(x);
               pk[r] = from_f32<T>(x * scale);
             }
@@ -703,6 +748,12 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
   if (d->bm == 256 && (d->C1 % BK || d->C2 % BK)) { es_set_error("es_conv_gemm: bm=256 needs 64-aligned channels"); return -1; }
   if (d->stages != 0 && (d->stages < 2 || d->stages > 4)) { es_set_error("es_conv_gemm: stages must be 0 (auto), 2, 3 or 4"); return -1; }
   if (d->waves != 0 && d->waves != 4 && d->waves != 8) { es_set_error("es_conv_gemm: waves must be 0 (auto), 4 or 8"); return -1; }
+  if (d->ln_colsum && (d->ksize != 1 || d->stride != 1 || d->C2 || d->C1 % BK || d->Kpad != d->C1 || d->splitk != 1 || d->bk == 32 ||
+                       d->bn == 320 || d->bm == 256 || d->upsample || d->temb)) {
+    es_set_error("es_conv_gemm: LayerNorm fold needs a plain linear layer: ksize 1, one source, K = C1 (multiple of 64), splitk 1, bn 64|128|160"); return -1; }
+  if (d->ln_colsum && d->ngroups > 1)
+    for (int g = 0; g < d->ngroups; ++g)
+      if (!d->ln_colsum_g[g]) { es_set_error("es_conv_gemm: grouped LayerNorm fold needs ln_colsum_g for every group"); return -1; }
   if (d->bk != 0 && d->bk != 64 && d->bk != 32) { es_set_error("es_conv_gemm: bk must be 0 (auto), 64 or 32"); return -1; }
   if (d->bk == 32 && ((d->bn != 128 && d->bn != 160) || d->bm == 256 || d->bm == 64 || d->waves == 8 || d->C1 % BK || d->C2 % BK ||
                       (d->stages != 0 && d->stages != 2))) {

@@ -10,6 +10,7 @@ Module trees and forward order follow diffusers==0.26.3 (UNet2DConditionModel, C
 called from model/controllora.py:150-254 and model/edgestyle_pipeline.py:477-557; key names are the diffusers
 state-dict names (edgestyle_amd/weights.py).
 """
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -55,6 +56,16 @@ class _Packer:
     def norm(self, p: str) -> Tuple[torch.Tensor, torch.Tensor]:
         return self.t(p + ".weight").contiguous(), self.t(p + ".bias").contiguous()
 
+    def cat_ln(self, ps: Sequence[str], bias: bool, ln: str, geglu: bool = False) -> ops.PackedWeight:
+        """Linear layer(s) `ps` with the LayerNorm `ln` in front of them folded in (ops.pack_weight_ln)."""
+        w = torch.cat([self.t(p + ".weight") for p in ps], 0)
+        b = torch.cat([self.t(p + ".bias") for p in ps], 0) if bias else None
+        return ops.pack_weight_ln(w, b, self.t(ln + ".weight"), self.t(ln + ".bias"), 1e-5, self.dtype, self.device,
+                                  geglu=geglu)
+
+
+LN_FOLD = os.environ.get("ES_LN_FOLD", "1") == "1"     # LayerNorm folded into the Linear it feeds (es_gemm_desc.ln_colsum)
+
 
 class Resnet:
     def __init__(self, pk: _Packer, p: str, groups: int, eps: float, temb_off: Optional[int]):
@@ -90,6 +101,13 @@ class Transformer:
         self.ff2 = pk.conv(tb + ".ff.net.2")
         self.heads, self.groups = heads, groups
         self.c = self.proj_in.cout
+        # norm1 / norm2 / norm3 each feed exactly one Linear: folded into it, the three LayerNorm launches (and the
+        # write + re-read of the normalised tokens) disappear; needs 64-aligned channels (ops.pack_weight_ln)
+        self.ln_fold = LN_FOLD and self.c % 64 == 0
+        if self.ln_fold:
+            self.qkv_ln = pk.cat_ln([tb + ".attn1.to_q", tb + ".attn1.to_k", tb + ".attn1.to_v"], False, tb + ".norm1")
+            self.q2_ln = pk.cat_ln([tb + ".attn2.to_q"], False, tb + ".norm2")
+            self.ff1_ln = pk.cat_ln([tb + ".ff.net.0.proj"], True, tb + ".norm3", geglu=True)
 
     def context(self, ehs, out=None):
         """K/V projection of the text states [N,77,D] -> [N,77,2C]; constant over the denoising loop."""
@@ -99,16 +117,14 @@ class Transformer:
         N, H, W, C = x.shape
         h = ops.group_norm(x, self.norm[0], self.norm[1], self.groups, 1e-6, False)
         tok = ops.conv_gemm(h, self.proj_in).reshape(N, H * W, C)
-        n = ops.layer_norm(tok, *self.ln1)
-        qkv = ops.linear(n, self.qkv)
+        fold = self.ln_fold
+        qkv = ops.linear(tok, self.qkv_ln) if fold else ops.linear(ops.layer_norm(tok, *self.ln1), self.qkv)
         a = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], self.heads)
         tok = ops.linear(a, self.o1, residual=tok)
-        n = ops.layer_norm(tok, *self.ln2)
-        q = ops.linear(n, self.q2)
+        q = ops.linear(tok, self.q2_ln) if fold else ops.linear(ops.layer_norm(tok, *self.ln2), self.q2)
         a = ops.attention(q, kv[:, :, :C], kv[:, :, C:], self.heads)
         tok = ops.linear(a, self.o2, residual=tok)
-        n = ops.layer_norm(tok, *self.ln3)
-        f = ops.linear(n, self.ff1)
+        f = ops.linear(tok, self.ff1_ln) if fold else ops.linear(ops.layer_norm(tok, *self.ln3), self.ff1)
         tok = ops.linear(f, self.ff2, residual=tok)
         return ops.conv_gemm(tok.reshape(N, H, W, C), self.proj_out, residual=x)
 
@@ -449,16 +465,20 @@ class GroupedEncoder:
         rows = [n * H * W for n in c]
         h = ops.group_norm(x, [t.norm[0] for t in ts], [t.norm[1] for t in ts], t0.groups, 1e-6, False, group_n=c)
         tok = ops.conv_gemm(h, [t.proj_in for t in ts], group_n=c).reshape(N, H * W, C)
-        n = ops.layer_norm(tok, [t.ln1[0] for t in ts], [t.ln1[1] for t in ts], group_rows=rows)
-        qkv = ops.linear(n, [t.qkv for t in ts], group_n=rows)
+        fold = all(t.ln_fold for t in ts)
+
+        def ln_linear(k, plain, folded):
+            if fold:
+                return ops.linear(tok, [getattr(t, folded) for t in ts], group_n=rows)
+            n = ops.layer_norm(tok, [getattr(t, k)[0] for t in ts], [getattr(t, k)[1] for t in ts], group_rows=rows)
+            return ops.linear(n, [getattr(t, plain) for t in ts], group_n=rows)
+        qkv = ln_linear("ln1", "qkv", "qkv_ln")
         a = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], t0.heads)
         tok = ops.linear(a, [t.o1 for t in ts], residual=tok, group_n=rows)
-        n = ops.layer_norm(tok, [t.ln2[0] for t in ts], [t.ln2[1] for t in ts], group_rows=rows)
-        q = ops.linear(n, [t.q2 for t in ts], group_n=rows)
+        q = ln_linear("ln2", "q2", "q2_ln")
         a = ops.attention(q, kv[:, :, :C], kv[:, :, C:], t0.heads)
         tok = ops.linear(a, [t.o2 for t in ts], residual=tok, group_n=rows)
-        n = ops.layer_norm(tok, [t.ln3[0] for t in ts], [t.ln3[1] for t in ts], group_rows=rows)
-        f = ops.linear(n, [t.ff1 for t in ts], group_n=rows)
+        f = ln_linear("ln3", "ff1", "ff1_ln")
         tok = ops.linear(f, [t.ff2 for t in ts], residual=tok, group_n=rows)
         return ops.conv_gemm(tok.reshape(N, H, W, C), [t.proj_out for t in ts], residual=x, group_n=c)
 

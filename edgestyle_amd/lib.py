@@ -27,6 +27,7 @@ class GemmDesc(C.Structure):
         ("ngroups", C.c_int32), ("mt_end", C.c_int32 * 4), ("w_g", C.c_void_p * 4), ("bias_g", C.c_void_p * 4),
         ("stages", C.c_int32), ("xcd_m_fastest", C.c_int32), ("bm", C.c_int32), ("waves", C.c_int32),
         ("bk", C.c_int32), ("out_scale", C.c_float),
+        ("ln_colsum", C.c_void_p), ("ln_colsum_g", C.c_void_p * 4), ("ln_eps", C.c_float),
     ]
 
 

@@ -100,6 +100,8 @@ class PackedWeight:
     ksize: int
     bn: int
     geglu: bool = False
+    ln_colsum: Optional[torch.Tensor] = None   # fp32 [rows_padded]: LayerNorm folded into this linear layer (pack_weight_ln)
+    ln_eps: float = 1e-5
 
     @property
     def rows_padded(self):
@@ -153,6 +155,25 @@ def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype, devic
         bp = torch.zeros(rows, dtype=torch.float32, device=device)
         bp[:cout] = b
     return PackedWeight(wp, bp, cout_eff, cp, k, bn, geglu)
+
+
+def pack_weight_ln(weight: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
+                   eps: float, dtype, device, geglu: bool = False) -> PackedWeight:
+    """Linear(LayerNorm(x)) as ONE launch on the raw x (es_gemm_desc.ln_colsum):
+        LN(x) W^T + b = rstd (x (W*gamma)^T - mean colsum(W*gamma)) + (W beta + b)
+    The kernel gathers every row's mean / rstd from the activation tiles it stages anyway.  weight: [Cout, Cin]."""
+    w = weight.to(device=device, dtype=torch.float32)
+    if w.dim() == 4:
+        w = w[:, :, 0, 0]
+    g = gamma.to(device=device, dtype=torch.float32)
+    b = beta.to(device=device, dtype=torch.float32)
+    fb = w @ b
+    if bias is not None:
+        fb = fb + bias.to(device=device, dtype=torch.float32)
+    pw = pack_weight(w * g[None, :], fb, dtype, device, geglu=geglu)
+    pw.ln_colsum = pw.w.float().sum(dim=1).contiguous()          # of the ROUNDED weights the MFMAs multiply
+    pw.ln_eps = float(eps)
+    return pw
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -297,7 +318,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         and FORCE_BK != 32
     cand = ((320,) if big_ok else ()) + (160, 128) + ((64,) if small_ok else ())
     bn, auto_splitk, auto_stages = plan_gemm(M, pw.rows_padded, pw.kpad, pw.geglu,
-                                             bns=cand if FORCE_BN == 0 else (FORCE_BN,))
+                                             bns=cand if FORCE_BN == 0 else (FORCE_BN,), allow_split=pw.ln_colsum is None)
     if splitk is None:
         splitk = auto_splitk
         stages = stages or auto_stages
@@ -332,6 +353,10 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     if splitk > 1:
         ws = _get_workspace(splitk * M * pw.rows_padded * 4, x.device)
         d.workspace = ws.data_ptr()
+    if pw.ln_colsum is not None:
+        if (pws is not None and any(q.ln_colsum is None for q in pws)) or x2 is not None or k != 1:
+            raise L.EdgeStyleHipError("LayerNorm-folded weights need a plain linear launch (all groups folded)")
+        d.ln_colsum, d.ln_eps = pw.ln_colsum.data_ptr(), pw.ln_eps
     if pws is not None:
         hw = Hout * Wout
         gran = 256 if bn == 320 else BM
@@ -346,6 +371,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
             d.mt_end[g] = acc
             d.w_g[g] = q.w.data_ptr()
             d.bias_g[g] = q.bias.data_ptr() if q.bias is not None else None
+            d.ln_colsum_g[g] = q.ln_colsum.data_ptr() if q.ln_colsum is not None else None
     if PROFILE is not None:           # bench.py roofline leg: in-kernel s_memrealtime stamps for this launch
         d.prof = PROFILE.next((2.0 * M * pw.cout * k * k * (C1 + C2), k,
                                (M, pw.cout, k * k * (C1 + C2), stride, splitk, bn),

@@ -77,6 +77,15 @@ typedef struct {
   int32_t bk;                 /* K depth of an LDS stage: 0 / 64 = default, 32 = half-depth stages, three workgroups per CU
                                * (short-K launches of many tiles: workgroup turnover bound) */
   float out_scale;
+  /* LayerNorm folded into a linear layer (the three LayerNorms of a BasicTransformerBlock feed exactly one Linear
+   * each): x is the RAW residual stream, w holds W * gamma (per input channel), bias holds W beta + b, and
+   * ln_colsum[j] = sum_k w[j][k] (fp32, of the rounded packed weights).  The kernel accumulates every row's sum and
+   * sum of squares from the activation tiles it stages anyway and applies
+   *   out[m][j] = rstd_m * (acc[m][j] - mean_m * ln_colsum[j]) + bias[j]
+   * in the epilogue.  Needs ksize 1, one source, K == C1 (a multiple of 64), splitk 1, bn 64|128|160, bk 64. */
+  const float* ln_colsum;     /* NULL: plain launch */
+  const float* ln_colsum_g[4];
+  float ln_eps;
 } es_gemm_desc;
 int es_conv_gemm(const es_gemm_desc* d, void* stream);
 size_t es_conv_gemm_workspace_bytes(const es_gemm_desc* d);

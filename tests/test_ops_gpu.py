@@ -368,6 +368,50 @@ def test_conv_gemm_small_tile_equals_default_tile():
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_linear_with_folded_layer_norm(dtype):
+    """Linear(LayerNorm(x)) as one launch on the raw x (es_gemm_desc.ln_colsum) vs F.layer_norm + F.linear, on every
+    tile variant that can run it (128x128|160, 8 waves, 64x64), plain / GEGLU, grouped, ragged M, x with a large mean."""
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(66)
+    tol = 4e-3 if dtype == torch.float16 else 2.5e-2
+    for M, C, Cout, geglu in [(300, 320, 960, False), (200, 640, 640, False), (257, 320, 2560, True), (130, 1280, 1280, False)]:
+        x = q16(torch.randn(M, C, generator=g) * 1.5 + 0.7 + torch.randn(M, 1, generator=g), dtype)
+        gamma = 1 + 0.2 * torch.randn(C, generator=g)
+        beta = 0.1 * torch.randn(C, generator=g)
+        w = torch.randn(Cout, C, generator=g) / math.sqrt(C)
+        b = torch.randn(Cout, generator=g) * 0.1
+        y = F.linear(F.layer_norm(x, (C,), gamma, beta, 1e-5), w, b)
+        if geglu:
+            h, gate = y.chunk(2, dim=-1)
+            y = h * F.gelu(gate)
+        pw = ops.pack_weight_ln(w, b, gamma, beta, 1e-5, dtype, DEV, geglu=geglu)
+        xd = x.to(DEV, dtype)
+        outs = [ops.linear(xd, pw)]
+        for knob, val in (("FORCE_WAVES", 8), ("FORCE_BN", 64)):
+            if knob == "FORCE_BN" and geglu:
+                continue
+            setattr(ops, knob, val)
+            try:
+                outs.append(ops.linear(xd, pw))
+            finally:
+                setattr(ops, knob, 0)
+        for o in outs:
+            assert rel_err(o, y) < tol, (M, C, Cout, geglu)
+    # grouped: three weight sets with their own LayerNorm parameters over 2 + 4 + 2 samples of 64 tokens... 128-row groups
+    C, Cout, counts = 320, 960, [256, 512, 256]
+    xg = q16(torch.randn(sum(counts), C, generator=g) * 2 + 0.3, dtype)
+    pws, refs, a = [], [], 0
+    for n in counts:
+        gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+        w, b = torch.randn(Cout, C, generator=g) / math.sqrt(C), torch.randn(Cout, generator=g) * 0.1
+        pws.append(ops.pack_weight_ln(w, b, gamma, beta, 1e-5, dtype, DEV))
+        refs.append(F.linear(F.layer_norm(xg[a:a + n], (C,), gamma, beta, 1e-5), w, b))
+        a += n
+    yg = ops.linear(xg.to(DEV, dtype), pws, group_n=counts)
+    assert rel_err(yg, torch.cat(refs)) < tol
+
+
 def test_conv_gemm_half_depth_stages_equal_default():
     """bk=32 (half-depth LDS stages, 64-byte rows with their own swizzle, three workgroups per CU) reproduces the
     default kernel bit for bit: same K order per accumulator."""
