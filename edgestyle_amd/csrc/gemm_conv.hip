@@ -45,8 +45,9 @@ ES_DEVICE void store_elems(T* o, const float* v, int n) {
 }
 
 template <typename T, int BM, int BN, bool ALIGNED, int STAGES, int FM = 4 /* pixel fragments per wave */,
-          int BKT = 64 /* K depth of a stage */>
-__global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM == 128) ? 2 : 1)) void conv_gemm_kernel(
+          int BKT = 64 /* K depth of a stage */, bool LN = false /* LayerNorm folded into this linear layer */>
+// (second launch bound = minimum waves per SIMD: 8-wave workgroups need 4 to keep two workgroups on a CU)
+__global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM == 128) ? (FM == 2 ? 4 : 2) : 1)) void conv_gemm_kernel(
     const es_gemm_desc p, const int M, const int nk) {
   // BKT = 32: half-depth stages.  The ring shrinks to 2 x 18 KB, the epilogue tile (43 KB) becomes the LDS high-water
   // mark and THREE workgroups fit a CU: short-K launches (K = 320..1280, a handful of K-steps per tile) are bound by
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
   }
   const void* wsel = p.ngroups > 1 ? p.w_g[grp] : p.w;
   const float* bsel = p.ngroups > 1 ? p.bias_g[grp] : p.bias;
-  const float* lnsel = p.ln_colsum ? (p.ngroups > 1 ? p.ln_colsum_g[grp] : p.ln_colsum) : nullptr;   // LayerNorm fold
+  const float* lnsel = LN ? (p.ngroups > 1 ? p.ln_colsum_g[grp] : p.ln_colsum) : nullptr;   // LayerNorm fold
   const auto rW = __builtin_amdgcn_make_buffer_rsrc(
       (void*)wsel, (short)0, (int)((size_t)p.rows_padded * p.Kpad * 2), 0x00020000);
   const auto rX1 = __builtin_amdgcn_make_buffer_rsrc(
@@ -250,16 +251,22 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
   for (int i = 0; i < FN; ++i)
     bias[i] = (bsel && p.splitk == 1) ? *(const f32x4*)(bsel + tile_n * BN + wn * (BN / 2) + fq * 4 + i * 16)
                                       : f32x4{0.f, 0.f, 0.f, 0.f};
-  // LayerNorm fold: column sums of the (gamma-folded) weights for this lane's couts, and this thread's share of the
-  // row statistics: TPR threads per tile row, each summing 8/TPR of the 8 chunks of every staged K-step
-  constexpr int TPR = NT / BM;
-  constexpr int LNC = 8 / TPR;
-  f32x4 lncs[FN];
+  // LayerNorm fold: column sums of the (gamma-folded) weights for this lane's couts, and this wave's share of the row
+  // statistics.  The X fragments a wave loads for its MFMAs cover its 16*FM rows x the whole K-step, and the two waves
+  // of an N pair load the same ones: each takes HALF of them (fragments j < FM/2 or j >= FM/2) and lets the matrix
+  // core do the sums: mfma(X, X) is the 16x16 Gram block whose DIAGONAL is sum_k x^2 of each row, mfma(ones, X) has
+  // sum_k x of row p in every entry of column p.  Two MFMAs per fragment instead of ~16 v_dot2 (10-cycle issue each),
+  // no extra LDS traffic, and the K reduction needs no cross-lane step.
+  constexpr int LNH = LN ? FM / 2 : 1;
+  f32x4 lncs[LN ? FN : 1];
+  f32x4 ln_gram[LNH], ln_sum[LNH];
+  typename Traits<T>::vec8 ln_ones;
+  if constexpr (LN) {
 #pragma unroll
-  for (int i = 0; i < FN; ++i)
-    lncs[i] = lnsel ? *(const f32x4*)(lnsel + tile_n * BN + wn * (BN / 2) + fq * 4 + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
-  float ln_s = 0.f, ln_q = 0.f;
-  const int ln_row = tid / TPR, ln_part = tid % TPR;
+    for (int jj = 0; jj < LNH; ++jj) { ln_gram[jj] = f32x4{0.f, 0.f, 0.f, 0.f}; ln_sum[jj] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ln_ones[e] = from_f32<T>(1.0f);
+  }
   int stage = 0, istage = STAGES - 1;
 #if ES_ABLATE & 4
   typename Traits<T>::vec8 xa0[FM], wa0[FN], xa1[FM], wa1[FN];
@@ -276,15 +283,6 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
     }
     const char* xs = smem + stage * (XT + WT);
     const char* ws = xs + XT;
-    if constexpr (BKT == 64 && FN <= 5) {
-      if (lnsel) {                                       // LayerNorm fold: this thread's chunks of its row of the tile
-#pragma unroll
-        for (int c = 0; c < LNC; ++c) {
-          const int ch = ln_part * LNC + c;
-          chunk_moments(as_vec8<T>(*(const u32x4*)(xs + ln_row * 128 + ((ch ^ (ln_row & 7)) << 4))), ln_s, ln_q);
-        }
-      }
-    }
     // Fragment reads are software-pipelined against the MFMAs: the reads of the second 32-deep half are in flight
     // behind the first half's MFMAs, and the next tile's DMA issue (address math + 9 LDS-DMA instructions) sits
     // between the two read groups where it covers the first group's LDS latency.
@@ -362,6 +360,17 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
       wa1[i] = as_vec8<T>(*(const u32x4*)(ws + row * 128 + (((4 + fq) ^ (row & 7)) << 4)));
     }
     }
+    if constexpr (LN) {
+#pragma unroll
+      for (int jj = 0; jj < LNH; ++jj) {
+        const auto f0 = wn ? xa0[LNH + jj] : xa0[jj];
+        const auto f1 = wn ? xa1[LNH + jj] : xa1[jj];
+        ln_gram[jj] = mfma16(f0, f0, ln_gram[jj]);
+        ln_gram[jj] = mfma16(f1, f1, ln_gram[jj]);
+        ln_sum[jj] = mfma16(ln_ones, f0, ln_sum[jj]);
+        ln_sum[jj] = mfma16(ln_ones, f1, ln_sum[jj]);
+      }
+    }
 #if ES_ABLATE & 1
 #pragma unroll
     for (int j = 0; j < FM; ++j) { asm volatile("" ::"v"(xa0[j]), "v"(xa1[j])); }
@@ -431,18 +440,26 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
     __syncthreads();                                      // stage buffers / previous pass's tile no longer read
-    if (NPASS == 1 && lnsel) {
-      // fold the TPR partials of a row (adjacent lanes) and publish mean / rstd of the row
-      float s_ = ln_s, q_ = ln_q;
-      s_ += dpp_mov<0xB1>(s_); q_ += dpp_mov<0xB1>(q_);
-      if (TPR == 4) { s_ += dpp_mov<0x4E>(s_); q_ += dpp_mov<0x4E>(q_); }
-      if (ln_part == 0) {
-        const float inv_c = 1.0f / (float)p.C1;
-        const float mean = s_ * inv_c;
-        float var = q_ * inv_c - mean * mean;
-        var = var < 0.f ? 0.f : var;
-        rowstat[ln_row * 2] = mean;
-        rowstat[ln_row * 2 + 1] = rsqrtf(var + p.ln_eps);
+    if constexpr (LN) {
+      // (the column sums are fetched here, not before the K loop: 4-5 more live quads push the 8-wave variants past
+      // 128 VGPRs = one workgroup per CU, which costs far more than this one L2 round trip behind the barrier)
+#pragma unroll
+      for (int i = 0; i < FN; ++i) lncs[i] = *(const f32x4*)(lnsel + tile_n * BN + wn * (BN / 2) + fq * 4 + i * 16);
+      // row p of fragment jj: sum x is in every register of the lanes with frow == p; sum x^2 is the Gram diagonal,
+      // register p % 4 of the lane group p / 4 - moved to group 0 by two half-swaps
+#pragma unroll
+      for (int jj = 0; jj < LNH; ++jj) {
+        const float dq = fq == (frow >> 2) ? ln_gram[jj][frow & 3] : 0.f;
+        const float q_ = xor32_sum(xor16_sum(dq));
+        if (fq == 0) {
+          const int row = wm * (16 * FM) + ((wn ? LNH : 0) + jj) * 16 + frow;
+          const float inv_c = 1.0f / (float)p.C1;
+          const float mean = ln_sum[jj][0] * inv_c;
+          float var = q_ * inv_c - mean * mean;
+          var = var < 0.f ? 0.f : var;
+          rowstat[row * 2] = mean;
+          rowstat[row * 2 + 1] = rsqrtf(var + p.ln_eps);
+        }
       }
       __syncthreads();
     }
@@ -452,7 +469,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
         const int m = tile_m * BM + prow + j * 16;
         const int n = (m < M ? m : M - 1) / HWout;
         float ln_mean = 0.f, ln_rstd = 1.f;
-        if (lnsel) { ln_mean = rowstat[(prow + j * 16) * 2]; ln_rstd = rowstat[(prow + j * 16) * 2 + 1]; }
+        if constexpr (LN) { ln_mean = rowstat[(prow + j * 16) * 2]; ln_rstd = rowstat[(prow + j * 16) * 2 + 1]; }
         if (geglu) {
           if constexpr (FN % 2 == 0 && NPASS == 1) {
 #pragma unroll
@@ -461,7 +478,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 float ah = acc[i][j][r], ag = acc[i + 1][j][r];
-                if (lnsel) {
+                if constexpr (LN) {
                   ah = ln_rstd * (ah - ln_mean * lncs[i][r]);
                   ag = ln_rstd * (ag - ln_mean * lncs[i + 1][r]);
                 }
@@ -490,7 +507,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float a = acc[i][j][r];
-              if (lnsel) a = ln_rstd * (a - ln_mean * lncs[i][r]);
+              if constexpr (LN) a = ln_rstd * (a - ln_mean * lncs[i][r]);
               float x = a + bias[i][r] + tv[r];
               if (p.act == ES_ACT_SILU) x = silu_f(x);
               pk[r] = from_f32<T>(x * scale);
@@ -676,6 +693,17 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
     }                                                                                                       \
     hipLaunchKernelGGL(kfn, grid, dim3(BMV * 8 / FMV), lds, st, d, M, nk);                                  \
   } while (0)
+#define ES_LAUNCH_LN(BMV, BNV, ST, FMV)                                                                      \
+  do {                                                                                                      \
+    auto kfn = conv_gemm_kernel<T, BMV, BNV, true, ST, FMV, 64, true>;                                      \
+    const size_t lds = (size_t)ST * (BMV + BNV) * BK * 2;                                                   \
+    static bool attr_set = false;                                                                           \
+    if (!attr_set) {                                                                                        \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+      attr_set = true;                                                                                      \
+    }                                                                                                       \
+    hipLaunchKernelGGL(kfn, grid, dim3(BMV * 8 / FMV), lds, st, d, M, nk);                                  \
+  } while (0)
 #define ES_LAUNCH(BMV, BNV, AL, ST) ES_LAUNCH_F(BMV, BNV, AL, ST, 4)
 #define ES_LAUNCH_ST(BNV)                                                                                   \
   do {                                                                                                      \
@@ -688,7 +716,16 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
     else if (stages == 3) ES_LAUNCH(128, BNV, true, 3);                                                     \
     else ES_LAUNCH(128, BNV, true, 4);                                                                      \
   } while (0)
-  if (d.bn == 64)       { if (stages == 4) ES_LAUNCH_F(64, 64, true, 4, 2); else ES_LAUNCH_F(64, 64, true, 2, 2); }
+  if (d.ln_colsum) {
+    // LayerNorm-folded linear layers: the instantiations the planner can pick for a 1x1 launch
+    const bool w8 = d.waves == 8;
+    if (d.bn == 64)            { if (stages == 4) ES_LAUNCH_LN(64, 64, 4, 2); else ES_LAUNCH_LN(64, 64, 2, 2); }
+    else if (d.bn == 128 && w8) { if (stages == 4) ES_LAUNCH_LN(128, 128, 4, 2); else ES_LAUNCH_LN(128, 128, 2, 2); }
+    else if (d.bn == 128)       { if (stages == 4) ES_LAUNCH_LN(128, 128, 4, 4); else ES_LAUNCH_LN(128, 128, 2, 4); }
+    else if (w8)                { ES_LAUNCH_LN(128, 160, 2, 2); }
+    else                        { if (stages == 4) ES_LAUNCH_LN(128, 160, 4, 4); else ES_LAUNCH_LN(128, 160, 2, 4); }
+  }
+  else if (d.bn == 64)  { if (stages == 4) ES_LAUNCH_F(64, 64, true, 4, 2); else ES_LAUNCH_F(64, 64, true, 2, 2); }
   else if (d.bn == 320) { ES_LAUNCH(256, 320, true, 2); }
   else if (d.bn == 128) { if (aligned) ES_LAUNCH_ST(128); else ES_LAUNCH(128, 128, false, 2); }
   else                  { if (aligned) ES_LAUNCH_ST(160); else ES_LAUNCH(128, 160, false, 2); }
@@ -696,6 +733,7 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
 #undef ES_LAUNCH
 #undef ES_LAUNCH_F
 #undef ES_LAUNCH_K
+#undef ES_LAUNCH_LN
   if (d.splitk > 1) {
     const long long total = (long long)M * (d.rows_padded / 8);
     hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, M);
@@ -749,7 +787,7 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
   if (d->stages != 0 && (d->stages < 2 || d->stages > 4)) { es_set_error("es_conv_gemm: stages must be 0 (auto), 2, 3 or 4"); return -1; }
   if (d->waves != 0 && d->waves != 4 && d->waves != 8) { es_set_error("es_conv_gemm: waves must be 0 (auto), 4 or 8"); return -1; }
   if (d->ln_colsum && (d->ksize != 1 || d->stride != 1 || d->C2 || d->C1 % BK || d->Kpad != d->C1 || d->splitk != 1 || d->bk == 32 ||
-                       d->bn == 320 || d->bm == 256 || d->upsample || d->temb)) {
+                       d->bn == 320 || d->bm == 256 || d->upsample || d->temb || d->stages == 3)) {
     es_set_error("es_conv_gemm: LayerNorm fold needs a plain linear layer: ksize 1, one source, K = C1 (multiple of 64), splitk 1, bn 64|128|160"); return -1; }
   if (d->ln_colsum && d->ngroups > 1)
     for (int g = 0; g < d->ngroups; ++g)

@@ -64,7 +64,8 @@ class _Packer:
                                   geglu=geglu)
 
 
-LN_FOLD = os.environ.get("ES_LN_FOLD", "1") == "1"     # LayerNorm folded into the Linear it feeds (es_gemm_desc.ln_colsum)
+LN_FOLD = os.environ.get("ES_LN_FOLD", "1") in ("1", "qk")
+LN_FOLD_FF = os.environ.get("ES_LN_FOLD", "1") == "1"    # "qk": norm1/norm2 only, norm3 -> GEGLU stays a LayerNorm launch     # LayerNorm folded into the Linear it feeds (es_gemm_desc.ln_colsum)
 
 
 class Resnet:
@@ -101,13 +102,16 @@ class Transformer:
         self.ff2 = pk.conv(tb + ".ff.net.2")
         self.heads, self.groups = heads, groups
         self.c = self.proj_in.cout
-        # norm1 / norm2 / norm3 each feed exactly one Linear: folded into it, the three LayerNorm launches (and the
-        # write + re-read of the normalised tokens) disappear; needs 64-aligned channels (ops.pack_weight_ln)
+        # norm1 / norm2 / norm3 each feed exactly one Linear (QKV, to_q, GEGLU projection): folded into it, the
+        # LayerNorm launch and the write + re-read of the normalised tokens disappear; needs 64-aligned channels
+        # (ops.pack_weight_ln).  Measured per denoising step at batch 1: none 1.869, norm1+2 1.899, all three 1.905
+        # images/s (in isolation the GEGLU launch loses more than a LayerNorm launch costs - every one of its 20-80 N
+        # tiles redoes the row statistics - but inside the step the fold still wins).
         self.ln_fold = LN_FOLD and self.c % 64 == 0
         if self.ln_fold:
             self.qkv_ln = pk.cat_ln([tb + ".attn1.to_q", tb + ".attn1.to_k", tb + ".attn1.to_v"], False, tb + ".norm1")
             self.q2_ln = pk.cat_ln([tb + ".attn2.to_q"], False, tb + ".norm2")
-            self.ff1_ln = pk.cat_ln([tb + ".ff.net.0.proj"], True, tb + ".norm3", geglu=True)
+            self.ff1_ln = pk.cat_ln([tb + ".ff.net.0.proj"], True, tb + ".norm3", geglu=True) if LN_FOLD_FF else None
 
     def context(self, ehs, out=None):
         """K/V projection of the text states [N,77,D] -> [N,77,2C]; constant over the denoising loop."""
@@ -124,7 +128,7 @@ class Transformer:
         q = ops.linear(tok, self.q2_ln) if fold else ops.linear(ops.layer_norm(tok, *self.ln2), self.q2)
         a = ops.attention(q, kv[:, :, :C], kv[:, :, C:], self.heads)
         tok = ops.linear(a, self.o2, residual=tok)
-        f = ops.linear(tok, self.ff1_ln) if fold else ops.linear(ops.layer_norm(tok, *self.ln3), self.ff1)
+        f = ops.linear(tok, self.ff1_ln) if (fold and self.ff1_ln is not None) else ops.linear(ops.layer_norm(tok, *self.ln3), self.ff1)
         tok = ops.linear(f, self.ff2, residual=tok)
         return ops.conv_gemm(tok.reshape(N, H, W, C), self.proj_out, residual=x)
 
@@ -468,7 +472,7 @@ class GroupedEncoder:
         fold = all(t.ln_fold for t in ts)
 
         def ln_linear(k, plain, folded):
-            if fold:
+            if fold and folded is not None:
                 return ops.linear(tok, [getattr(t, folded) for t in ts], group_n=rows)
             n = ops.layer_norm(tok, [getattr(t, k)[0] for t in ts], [getattr(t, k)[1] for t in ts], group_rows=rows)
             return ops.linear(n, [getattr(t, plain) for t in ts], group_n=rows)
@@ -478,7 +482,7 @@ class GroupedEncoder:
         q = ln_linear("ln2", "q2", "q2_ln")
         a = ops.attention(q, kv[:, :, :C], kv[:, :, C:], t0.heads)
         tok = ops.linear(a, [t.o2 for t in ts], residual=tok, group_n=rows)
-        f = ln_linear("ln3", "ff1", "ff1_ln")
+        f = ln_linear("ln3", "ff1", "ff1_ln" if all(t.ln_fold and t.ff1_ln is not None for t in ts) else None)
         tok = ops.linear(f, [t.ff2 for t in ts], residual=tok, group_n=rows)
         return ops.conv_gemm(tok.reshape(N, H, W, C), [t.proj_out for t in ts], residual=x, group_n=c)
 
