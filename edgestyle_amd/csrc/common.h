@@ -37,22 +37,6 @@ ES_DEVICE float to_f32(f16 x) { return (float)x; }
 ES_DEVICE float to_f32(bf16 x) { return (float)x; }
 template <typename T> ES_DEVICE T from_f32(float x) { return (T)x; }
 
-// sum and sum of squares of the 8 values of a 16-byte chunk, accumulated in fp32 (v_dot2_f32_f16 for f16)
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-ES_DEVICE void chunk_moments(f16x8 v, float& s, float& q) {
-  const f16x2 one = {(_Float16)1.0f, (_Float16)1.0f};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const f16x2 a = {v[2 * e], v[2 * e + 1]};
-    s = __builtin_amdgcn_fdot2(a, one, s, false);
-    q = __builtin_amdgcn_fdot2(a, a, q, false);
-  }
-}
-ES_DEVICE void chunk_moments(bf16x8 v, float& s, float& q) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s += f; q = __builtin_fmaf(f, f, q); }
-}
-
 // a / d for 0 <= a < 2^24, d >= 1, inv = 1.0f / d: the float quotient is off by at most one, fixed by one
 // correction step.  (Integer division is ~40 VALU instructions for 32 bits and >100 for 64 bits: index math of the
 // streaming kernels goes through this, with the exact division as the fallback for larger ranges.)
