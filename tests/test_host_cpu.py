@@ -76,6 +76,42 @@ def test_splitk_heuristic_bounds():
         assert 1 <= s <= kpad // 64
 
 
+def test_plan_gemm_returns_legal_launches():
+    """Every (M, Cout, K) of the SD1.5 path gets a launch the C ABI accepts: bn divides rows_padded, split-K only where
+    it is allowed, 4-stage rings only with at most one workgroup per CU, the 64x64 tile only for small launches."""
+    for M in (2, 128, 512, 896, 2048, 3584, 8192, 14336, 57344, 458752):
+        for rows in (320, 640, 960, 1280, 1920, 2560, 3840):
+            for kpad in (320, 640, 1280, 2880, 5760, 11520, 23040):
+                for bns in ((160, 128, 64), (320, 160, 128), (128,)):
+                    if not any(rows % b == 0 for b in bns):
+                        continue
+                    bn, sk, st = ops.plan_gemm(M, rows, kpad, bns=bns)
+                    assert rows % bn == 0 and bn in bns
+                    assert 1 <= sk <= max(1, kpad // 64) and st in (2, 4)
+                    if bn == 64:
+                        assert M <= ops.PLAN_SMALL_MAX_M or len(bns) == 1
+                    if bn == 320:
+                        assert st == 2 and M >= ops.PLAN_BIG_MIN_M
+                    assert ops.plan_gemm(M, rows, kpad, bns=bns, allow_split=False)[1] == 1
+
+
+def test_layer_norm_fold_algebra():
+    """pack_weight_ln: Linear(LayerNorm(x)) == rstd (x (W gamma)^T - mean colsum) + (W beta + b), with the column sums
+    taken from the rounded packed weights (what the kernel's epilogue computes)."""
+    g = torch.Generator().manual_seed(5)
+    M, C, Cout = 37, 128, 192
+    x = torch.randn(M, C, generator=g) * 2 + 1
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    w, b = torch.randn(Cout, C, generator=g) / 11, torch.randn(Cout, generator=g) * 0.1
+    pw = ops.pack_weight_ln(w, b, gamma, beta, 1e-5, torch.float32, "cpu")
+    assert pw.ln_colsum is not None and pw.ln_colsum.shape[0] == pw.rows_padded
+    mean = x.mean(1, keepdim=True)
+    rstd = (x.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    y = rstd * (x @ pw.w[:Cout, :C].T - mean * pw.ln_colsum[None, :Cout]) + pw.bias[None, :Cout]
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x, (C,), gamma, beta, 1e-5), w, b)
+    assert float((y - ref).abs().max()) < 1e-4
+
+
 def test_controllora_state_dict_is_lora_plus_zero_convs_only():
     ucfg = C.tiny_unet()
     ws = make_weights(ucfg, C.tiny_vae())
