@@ -144,3 +144,71 @@ def test_full_step_chain_modes_match_oracle(mode):
         assert runner._grouped is not None and runner._grouped.groupable(64)
     err = float((out.float().cpu() - ref).abs().max())
     assert err < 2e-2, err
+
+
+def _rand_sd(shapes, seed, scale_fn):
+    g = torch.Generator().manual_seed(seed)
+    return {k: (scale_fn(k, shp) * torch.randn(shp, generator=g) + (1.0 if k.endswith("norm.weight") or ".norm" in k and k.endswith(".weight") else 0.0)).half().float()
+            for k, shp in shapes.items()}
+
+
+@pytest.mark.parametrize("C,heads,H", [(320, 8, 32), (1280, 8, 8)])
+def test_full_width_transformer_block_vs_oracle(C, heads, H):
+    """One Transformer2DModel at SD1.5 widths (head_dim 40 / 160; LayerNorms folded into their GEMMs, 8-wave and 64x64
+    tile launches, ones-column softmax) against the oracle block."""
+    from oracle import sd15_oracle as O
+    from edgestyle_amd import engine as E
+    p, tb = "attentions.0", "attentions.0.transformer_blocks.0"
+    D = 768
+    shapes = {f"{p}.norm.weight": (C,), f"{p}.norm.bias": (C,), f"{p}.proj_in.weight": (C, C, 1, 1), f"{p}.proj_in.bias": (C,),
+              f"{p}.proj_out.weight": (C, C, 1, 1), f"{p}.proj_out.bias": (C,)}
+    for i in (1, 2, 3):
+        shapes[f"{tb}.norm{i}.weight"] = (C,); shapes[f"{tb}.norm{i}.bias"] = (C,)
+    for a, kin in (("attn1", C), ("attn2", D)):
+        shapes[f"{tb}.{a}.to_q.weight"] = (C, C); shapes[f"{tb}.{a}.to_k.weight"] = (C, kin); shapes[f"{tb}.{a}.to_v.weight"] = (C, kin)
+        shapes[f"{tb}.{a}.to_out.0.weight"] = (C, C); shapes[f"{tb}.{a}.to_out.0.bias"] = (C,)
+    shapes[f"{tb}.ff.net.0.proj.weight"] = (8 * C, C); shapes[f"{tb}.ff.net.0.proj.bias"] = (8 * C,)
+    shapes[f"{tb}.ff.net.2.weight"] = (C, 4 * C); shapes[f"{tb}.ff.net.2.bias"] = (C,)
+    g = torch.Generator().manual_seed(C)
+    sd = {}
+    for k, shp in shapes.items():
+        if "norm" in k and k.endswith(".weight"):
+            sd[k] = (1 + 0.1 * torch.randn(shp, generator=g)).half().float()
+        elif k.endswith(".bias"):
+            sd[k] = (0.05 * torch.randn(shp, generator=g)).half().float()
+        else:
+            sd[k] = (torch.randn(shp, generator=g) / (shp[1] ** 0.5)).half().float()
+    x = (torch.randn(2, C, H, H, generator=g) * 1.5 + 0.3).half().float()
+    ehs = (torch.randn(2, 77, D, generator=g) * 0.5).half().float()
+    ref = O.transformer(sd, p, x, ehs, heads, 32)
+    pk = E._Packer(sd, torch.float16, DEV)
+    blk = E.Transformer(pk, p, heads, 32)
+    assert blk.ln_fold
+    kv = blk.context(ehs.to(DEV, torch.float16))
+    out = blk(to_nhwc(x, DEV), kv)
+    assert rel_err(out.permute(0, 3, 1, 2), ref) < 1e-2
+
+
+def test_full_width_resnet_block_vs_oracle():
+    """ResnetBlock2D 320 -> 640 with shortcut, time embedding and a concatenated skip input (decoder form)."""
+    from oracle import sd15_oracle as O
+    from edgestyle_amd import engine as E
+    g = torch.Generator().manual_seed(9)
+    C1, C2, Cout, H, p = 320, 320, 640, 32, "r"
+    sd = {f"{p}.norm1.weight": 1 + 0.1 * torch.randn(C1 + C2, generator=g), f"{p}.norm1.bias": 0.05 * torch.randn(C1 + C2, generator=g),
+          f"{p}.conv1.weight": torch.randn(Cout, C1 + C2, 3, 3, generator=g) / (9 * (C1 + C2)) ** 0.5, f"{p}.conv1.bias": 0.05 * torch.randn(Cout, generator=g),
+          f"{p}.time_emb_proj.weight": torch.randn(Cout, 1280, generator=g) / 36, f"{p}.time_emb_proj.bias": 0.05 * torch.randn(Cout, generator=g),
+          f"{p}.norm2.weight": 1 + 0.1 * torch.randn(Cout, generator=g), f"{p}.norm2.bias": 0.05 * torch.randn(Cout, generator=g),
+          f"{p}.conv2.weight": torch.randn(Cout, Cout, 3, 3, generator=g) / (9 * Cout) ** 0.5, f"{p}.conv2.bias": 0.05 * torch.randn(Cout, generator=g),
+          f"{p}.conv_shortcut.weight": torch.randn(Cout, C1 + C2, 1, 1, generator=g) / (C1 + C2) ** 0.5, f"{p}.conv_shortcut.bias": 0.05 * torch.randn(Cout, generator=g)}
+    sd = {k: v.half().float() for k, v in sd.items()}
+    x1 = torch.randn(2, C1, H, H, generator=g).half().float()
+    x2 = torch.randn(2, C2, H, H, generator=g).half().float()
+    temb = torch.randn(2, 1280, generator=g).half().float()
+    ref = O.resnet(sd, p, torch.cat([x1, x2], 1), temb, 32, 1e-5)
+    pk = E._Packer(sd, torch.float16, DEV)
+    blk = E.Resnet(pk, p, 32, 1e-5, 0)
+    from edgestyle_amd import ops
+    tproj = ops.linear(torch.nn.functional.silu(temb).to(DEV, torch.float16), pk.conv(f"{p}.time_emb_proj"))
+    out = blk(to_nhwc(x1, DEV), tproj, x2=to_nhwc(x2, DEV))
+    assert rel_err(out.permute(0, 3, 1, 2), ref) < 1e-2
