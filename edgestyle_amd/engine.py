@@ -79,6 +79,7 @@ class _Packer:
                                   geglu=geglu)
 
 
+FFO_FOLD = os.environ.get("ES_FFO_FOLD", "1") == "1"   # ff.net.2 + proj_out as one GEMM (Transformer.ffo)
 LN_FOLD = os.environ.get("ES_LN_FOLD", "1") in ("1", "qk")
 LN_FOLD_FF = os.environ.get("ES_LN_FOLD", "1") == "1"    # "qk": norm1/norm2 only, norm3 -> GEGLU stays a LayerNorm launch     # LayerNorm folded into the Linear it feeds (es_gemm_desc.ln_colsum)
 
@@ -117,6 +118,16 @@ class Transformer:
         self.ff2 = pk.conv(tb + ".ff.net.2")
         self.heads, self.groups = heads, groups
         self.c = self.proj_in.cout
+        # ff.net.2 -> (+ tokens) -> proj_out is linear end to end (SD1.5 has ONE transformer block per
+        # Transformer2DModel): proj_out(ff2(f) + tok) = (Wp Wf) f + Wp tok + (Wp bf + bp), i.e. one GEMM over the
+        # channel concat [f | tok] (K = 4C + C) with pre-multiplied weights (fp32 product, rounded once) - one launch
+        # and one write + re-read of the tokens less per transformer, same FLOPs.
+        self.ffo = None
+        if FFO_FOLD and self.c % 64 == 0:
+            wp = pk.t(p + ".proj_out.weight").reshape(self.c, self.c).double()
+            wf, bf = pk.t(tb + ".ff.net.2.weight").double(), pk.t(tb + ".ff.net.2.bias").double()
+            self.ffo = ops.pack_weight(torch.cat([wp @ wf, wp], 1).float(), (wp @ bf + pk.t(p + ".proj_out.bias").double()).float(),
+                                       pk.dtype, pk.device)
         # norm1 / norm2 / norm3 each feed exactly one Linear (QKV, to_q, GEGLU projection): folded into it, the
         # LayerNorm launch and the write + re-read of the normalised tokens disappear; needs 64-aligned channels
         # (ops.pack_weight_ln).  Measured per denoising step at batch 1: none 1.869, norm1+2 1.899, all three 1.905
@@ -144,6 +155,8 @@ class Transformer:
         a = ops.attention(q, kv[:, :, :C], kv[:, :, C:], self.heads)
         tok = ops.linear(a, self.o2, residual=tok)
         f = ops.linear(tok, self.ff1_ln) if (fold and self.ff1_ln is not None) else ops.linear(ops.layer_norm(tok, *self.ln3), self.ff1)
+        if self.ffo is not None:
+            return ops.conv_gemm(f.reshape(N, H, W, 4 * C), self.ffo, x2=tok.reshape(N, H, W, C), residual=x)
         tok = ops.linear(f, self.ff2, residual=tok)
         return ops.conv_gemm(tok.reshape(N, H, W, C), self.proj_out, residual=x)
 
@@ -498,6 +511,8 @@ class GroupedEncoder:
         a = ops.attention(q, kv[:, :, :C], kv[:, :, C:], t0.heads)
         tok = ops.linear(a, [t.o2 for t in ts], residual=tok, group_n=rows)
         f = ln_linear("ln3", "ff1", "ff1_ln" if all(t.ln_fold and t.ff1_ln is not None for t in ts) else None)
+        if all(t.ffo is not None for t in ts):
+            return ops.conv_gemm(f.reshape(N, H, W, 4 * C), [t.ffo for t in ts], x2=tok.reshape(N, H, W, C), residual=x, group_n=c)
         tok = ops.linear(f, [t.ff2 for t in ts], residual=tok, group_n=rows)
         return ops.conv_gemm(tok.reshape(N, H, W, C), [t.proj_out for t in ts], residual=x, group_n=c)
 
