@@ -313,6 +313,271 @@ __global__ __launch_bounds__(256, (QF == 1 && KS <= 3) ? 3 : ((KS <= 5 && QF <= 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 32x32 score tiles for the VALU-bound head dims (40, 80: UNet levels 0 and 1, where the softmax and not the matrix
+// core sets the pace).  S^T = K Q^T runs on mfma_f32_32x32x16: K-steps of 16 fit d = 40 / 80 as 48 / 80 (the 16x16x32
+// form pads them to 64 / 96), and a 32x32x16 MFMA blocks the SIMD's vector issue for 8 of its 32 cycles instead of 8
+// of 16, so the QK^T product costs 6 issue slots per 64 keys x 32 queries instead of 16.  A lane then owns ONE query
+// (lane & 31) and 16 keys per tile: the row max is 31 in-lane max + one permlane32 swap for 32 queries (was two
+// 16-query groups with two swaps each).  PV stays on 16x16x32 (d_v = 40 pads to 48, not 64): the exp'd scores are
+// packed to 16 bits in accumulator order and ONE v_permlane16_swap per register pair re-deals them into the B
+// operands of the two 16-query halves (X = registers 0..7, Y = registers 8..15 of a tile; after the swap X holds
+// queries 0..15 in all four lane groups, Y queries 16..31).  k index 8g+j of that operand is key
+// 16(g&1) + 4(g>>1) + 8(j>>2) + (j&3) of the tile; the V^T fragments are read with the same map.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+ES_DEVICE f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+ES_DEVICE f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+template <typename T> ES_DEVICE unsigned pack2(float a, float b) {
+  typedef T v2 __attribute__((ext_vector_type(2)));
+  v2 r;
+  r[0] = from_f32<T>(a); r[1] = from_f32<T>(b);
+  return __builtin_bit_cast(unsigned, r);
+}
+
+template <typename T, int KS /* QK k-steps of 16: DPAD = 16*KS */, int DF /* dv fragments of 16 */, bool ONES>
+__global__ __launch_bounds__(256, 2) void attention32_kernel(const es_attn_desc p) {
+  constexpr int KVT = 64;
+  constexpr int DPAD = 16 * KS;
+  constexpr int DVP = 16 * DF;
+  constexpr int KROW = DPAD * 2 + 16;   // bytes per K row in LDS (+16 B pad: 16 consecutive rows hit 16 distinct bank quads)
+  constexpr int VROW = DVP * 2 + 16;
+  constexpr int KCH = DPAD / 8;
+  constexpr int VCH = DVP / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TILE_BYTES = KVT * KROW + KVT * VROW;
+  char* ks_ = smem;
+  char* vs_ = smem + KVT * KROW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n32 = lane & 31, hi = lane >> 5;      // 32x32 layouts: query column / key half
+  const int col = lane & 15, g = lane >> 4;       // 16x16 layouts (PV product, epilogue)
+  const int h = blockIdx.y, n = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int d = p.d;
+  const int dch = d / 8;
+
+  const T* Q = (const T*)p.q + (size_t)n * p.bsq + (size_t)h * d;
+  const T* K = (const T*)p.k + (size_t)n * p.bsk + (size_t)h * d;
+  const T* V = (const T*)p.v + (size_t)n * p.bsv + (size_t)h * d;
+  T* O = (T*)p.o + (size_t)n * p.bso + (size_t)h * d;
+
+  const float sl2 = p.scale * 1.4426950408889634f;
+  // Q^T fragments (B operand of 32x32x16): lane holds Q[query = n32][16*ks + 8*hi .. +7], pre-scaled by scale*log2(e)
+  typename Traits<T>::vec8 qf[KS];
+  {
+    int qi = q0 + n32;
+    qi = qi < p.Sq ? qi : p.Sq - 1;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int ch = 2 * s + hi;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ch < dch) v = *(const u32x4*)(Q + (size_t)qi * p.ldq + ch * 8);
+      auto qv = as_vec8<T>(v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qv[e] = from_f32<T>(to_f32(qv[e]) * sl2);
+      qf[s] = qv;
+    }
+  }
+
+  for (int b = 0; b < 2; ++b) {
+    for (int i = tid; i < KVT * KCH; i += 256) {
+      const int r = i / KCH, c = i - r * KCH;
+      if (c >= dch) *(u32x4*)(ks_ + b * TILE_BYTES + r * KROW + c * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+    for (int i = tid; i < KVT * VCH; i += 256) {
+      const int r = i / VCH, c = i - r * VCH;
+      const unsigned one = (ONES && c == dch) ? (Traits<T>::is_bf16 ? 0x3F80u : 0x3C00u) : 0u;
+      if (c >= dch) *(u32x4*)(vs_ + b * TILE_BYTES + r * VROW + c * 16) = u32x4{one, 0u, 0u, 0u};
+    }
+  }
+
+  constexpr int KPT = (KVT * KCH + 255) / 256;
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  u32x4 kr[KPT], vr[KPT];
+  const int nch = KVT * dch;
+  const auto rK = __builtin_amdgcn_make_buffer_rsrc((void*)K, (short)0, (int)(((size_t)(p.Skv - 1) * p.ldk + d) * 2), 0x00020000);
+  const auto rV = __builtin_amdgcn_make_buffer_rsrc((void*)V, (short)0, (int)(((size_t)(p.Skv - 1) * p.ldv + d) * 2), 0x00020000);
+  unsigned koff[KPT], voffs[KPT];
+  int klds[KPT], vlds[KPT];
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) {
+    const int idx = tid + i * 256;
+    const bool own = idx < nch;
+    const int r = own ? idx / dch : 0;
+    const int c = own ? idx - r * dch : 0;
+    koff[i] = own ? (unsigned)((r * p.ldk + c * 8) * 2) : OOB;
+    voffs[i] = own ? (unsigned)((r * p.ldv + c * 8) * 2) : OOB;
+    klds[i] = own ? r * KROW + c * 16 : -1;
+    vlds[i] = own ? r * VROW + c * 16 : -1;
+  }
+  const unsigned kstep = (unsigned)(KVT * p.ldk * 2), vstep = (unsigned)(KVT * p.ldv * 2);
+  auto load_kv = [&]() {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      kr[i] = __builtin_amdgcn_raw_buffer_load_b128(rK, (int)koff[i], 0, 0);
+      vr[i] = __builtin_amdgcn_raw_buffer_load_b128(rV, (int)voffs[i], 0, 0);
+      koff[i] = koff[i] >= OOB ? OOB : koff[i] + kstep;
+      voffs[i] = voffs[i] >= OOB ? OOB : voffs[i] + vstep;
+    }
+  };
+  auto store_kv = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      if (klds[i] >= 0) {
+        *(u32x4*)(ks_ + buf * TILE_BYTES + klds[i]) = kr[i];
+        *(u32x4*)(vs_ + buf * TILE_BYTES + vlds[i]) = vr[i];
+      }
+    }
+  };
+
+  constexpr float LAZY = 8.0f;
+  f32x4 o[2][DF];                 // O^T of the two 16-query halves, 16x16 layout
+  f32x16 negm;                    // negated running reference of this lane's query, splatted: the S^T chains start from it
+  float lrun = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int j = 0; j < DF; ++j) o[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  load_kv();
+  store_kv(0);
+  if (KVT < p.Skv) load_kv();
+  int buf = 0;
+  // V^T fragment rows of this lane for the key map above: lanes 4q..4q+3 of a 16-lane group supply row q of a 4x16 block
+  const int vrow0 = 16 * (g & 1) + 4 * (g >> 1) + (col >> 2);
+  const int vcol0 = 4 * (col & 3);
+  for (int kv0 = 0; kv0 < p.Skv; kv0 += KVT) {
+    __syncthreads();
+    const char* kb = ks_ + buf * TILE_BYTES;
+    const char* vb = vs_ + buf * TILE_BYTES;
+
+    f32x16 s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ksx = 0; ksx < KS; ++ksx) {
+        const auto ka = as_vec8<T>(*(const u32x4*)(kb + (t * 32 + n32) * KROW + (2 * ksx + hi) * 16));
+        s[t] = mfma32(ka, qf[ksx], ksx == 0 ? negm : s[t]);
+      }
+    if (__builtin_expect(kv0 + KVT > p.Skv, 0)) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          s[t][r] = (kv0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.Skv) ? -3.0e38f : s[t][r];
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[t][r]), s[t][r + 1]);
+    mx = xor32_max(mx);
+    if (kv0 == 0 || !__all(mx <= LAZY)) {
+      const float dlt = kv0 == 0 ? mx : fmaxf(mx, 0.f);
+      const float nm = negm[0] - dlt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) negm[r] = nm;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] -= dlt;
+      if (kv0 != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(-dlt);
+        lrun *= alpha;
+        // alpha lives on the 32-query layout (query = lane & 31); O^T on the 16x16 one (query = 16 f + (lane & 15))
+        float a0 = alpha, a1 = alpha;
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a0), "+v"(a1));
+#pragma unroll
+        for (int j = 0; j < DF; ++j) { o[0][j] *= a0; o[1][j] *= a1; }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = __builtin_amdgcn_exp2f(s[t][r]);
+    if constexpr (!ONES) {
+      float rs = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rs += s[t][r];
+      lrun += rs;
+    }
+    typename Traits<T>::vec8 pb[2][2];     // [query half][tile]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      unsigned x[4], y[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        x[i] = pack2<T>(s[t][2 * i], s[t][2 * i + 1]);
+        y[i] = pack2<T>(s[t][8 + 2 * i], s[t][9 + 2 * i]);
+      }
+      asm volatile("s_nop 1\n\t"
+                   "v_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
+                   "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 1"
+                   : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+      pb[0][t] = as_vec8<T>(u32x4{x[0], x[1], x[2], x[3]});
+      pb[1][t] = as_vec8<T>(u32x4{y[0], y[1], y[2], y[3]});
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < DF; ++j) {
+        const char* base = vb + (32 * t + vrow0) * VROW + (j * 16 + vcol0) * 2;
+        const u32x2 lo = lds_read_tr16(base);
+        const u32x2 hi2 = lds_read_tr16(base + 8 * VROW);
+        const auto va = as_vec8<T>(u32x4{lo[0], lo[1], hi2[0], hi2[1]});
+        o[0][j] = mfma16(va, pb[0][t], o[0][j]);
+        o[1][j] = mfma16(va, pb[1][t], o[1][j]);
+      }
+    if (kv0 + KVT < p.Skv) {
+      store_kv(buf ^ 1);
+      if (kv0 + 2 * KVT < p.Skv) load_kv();
+    }
+    buf ^= 1;
+  }
+
+  // ---- epilogue: O[query][dv] = O^T / l ----
+  float l0, l1;
+  if constexpr (ONES) {
+    l0 = __shfl(o[0][DF - 1][0], 32 + col, 64);
+    l1 = __shfl(o[1][DF - 1][0], 32 + col, 64);
+  } else {
+    const float l = xor32_sum(lrun);                       // per query, 32-query layout
+    l0 = l; l1 = l;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(l0), "+v"(l1));
+  }
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int qi = q0 + f * 16 + col;
+    const float inv = 1.0f / (f ? l1 : l0);
+    if (qi < p.Sq) {
+#pragma unroll
+      for (int j = 0; j < DF; ++j) {
+        const int dv = j * 16 + g * 4;
+        if (dv < d) {
+          typename Traits<T>::vec4 pk;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pk[r] = from_f32<T>(o[f][j][r] * inv);
+          *(typename Traits<T>::vec4*)(O + (size_t)qi * p.ldo + dv) = pk;
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int KS, int DF, bool ONES>
+int launch_attn32(const es_attn_desc& d, hipStream_t st) {
+  constexpr int lds = 2 * (64 * (16 * KS * 2 + 16) + 64 * (16 * DF * 2 + 16));
+  auto kfn = attention32_kernel<T, KS, DF, ONES>;
+  dim3 grid((d.Sq + 127) / 128, d.heads, d.N);
+  hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, d);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 template <typename T, int KS, int DF, int QF, int KVT, bool ONES = false>
 int launch_attn(const es_attn_desc& d, hipStream_t st) {
   constexpr int lds = (KS <= 5 ? 2 : 1) * (KVT * (32 * KS * 2 + 16) + KVT * (16 * DF * 2 + 16));
@@ -332,6 +597,14 @@ int dispatch(const es_attn_desc& d, hipStream_t st) {
   // 32 queries per wave (128 per block) only when that still yields >= 2 blocks per CU; else 16 per wave
   static const long long big_thr = getenv("ES_ATTN_BIG") ? atoll(getenv("ES_ATTN_BIG")) : 512;
   const bool big = (long long)((d.Sq + 127) / 128) * d.heads * d.N >= big_thr;
+  static const bool tile32 = !(getenv("ES_ATTN32") && atoi(getenv("ES_ATTN32")) == 0);   // A/B switch (tools)
+  if (big && tile32) {
+    // measured (tools/attn_bench.py, 14 x 8 x 4096^2): head_dim 40 476 -> 449 us; head_dim 80 is no faster (189 VGPRs,
+    // two waves per SIMD instead of three) and stays on the 16x16 kernel unless asked for (ES_ATTN32=2, tests)
+    static const bool tile32_80 = getenv("ES_ATTN32") && atoi(getenv("ES_ATTN32")) == 2;
+    if (d.d == 40) return launch_attn32<T, 3, 3, true>(d, st);
+    if (d.d == 80 && tile32_80) return launch_attn32<T, 5, 5, false>(d, st);
+  }
   // (64 queries per wave was measured slower: 309 registers -> one wave per SIMD)
   switch (d.d) {
     case 8: return launch_attn<T, 1, 1, 2, 64, true>(d, st);

@@ -133,6 +133,11 @@ ATTN_CASES = [
     (1, 4, 16, 16, 64),
     (1, 1, 256, 256, 512),     # VAE mid-block attention
     (1, 8, 1024, 1024, 40),
+    # >= 512 blocks of 128 queries: the 32x32-score-tile kernel (head_dim 40 / 80)
+    (8, 8, 1024, 1024, 40),
+    (8, 8, 1000, 77, 40),      # ragged queries and keys
+    (8, 8, 1024, 200, 80),
+    (16, 8, 520, 136, 80),
 ]
 
 
@@ -158,6 +163,25 @@ def test_attention_forced_rescale_and_strided_qkv():
     C = heads * d
     qkv = torch.randn(N, S, 3 * C, generator=g)
     qkv[:, 150, C:2 * C] *= 8.0            # key 150 (third tile) spikes
+    qkv = q16(qkv)
+    q, k, v = qkv.split(C, dim=-1)
+    qh, kh, vh = (t.reshape(N, S, heads, d).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(N, S, C)
+    dq = qkv.to(DEV, torch.float16)
+    y = ops.attention(dq[:, :, :C], dq[:, :, C:2 * C], dq[:, :, 2 * C:], heads)
+    assert rel_err(y, ref) < 4e-3
+
+
+@pytest.mark.parametrize("d", [40, 80])
+def test_attention32_forced_rescale(d):
+    """32x32-tile kernel: a late key dominates some queries only (lazy rescale on the mixed 32-query / 16-query layouts)"""
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(d)
+    N, heads, S = 8, 8, 1024
+    C = heads * d
+    qkv = torch.randn(N, S, 3 * C, generator=g)
+    qkv[:, 700, C:2 * C] *= 6.0
+    qkv[:, 901, C:C + d] *= 10.0            # head 0 only, later tile
     qkv = q16(qkv)
     q, k, v = qkv.split(C, dim=-1)
     qh, kh, vh = (t.reshape(N, S, heads, d).transpose(1, 2) for t in (q, k, v))
