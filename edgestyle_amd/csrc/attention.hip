@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, (QF == 1 && KS <= 3) ? 3 : ((KS <= 5 && QF <= 
           typename Traits<T>::vec4 pk;
 #pragma unroll
           for (int r = 0; r < 4; ++r) pk[r] = from_f32<T>(o[f][j][r] * inv);
-          *(typename Traits<T>::vec4*)(O + (size_t)qi * p.ldo + dv) = pk;
+          store8(O + (size_t)qi * p.ldo + dv, __builtin_bit_cast(u32x2, pk));
         }
       }
     }
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void attention32_kernel(const es_attn_desc 
           typename Traits<T>::vec4 pk;
 #pragma unroll
           for (int r = 0; r < 4; ++r) pk[r] = from_f32<T>(o[f][j][r] * inv);
-          *(typename Traits<T>::vec4*)(O + (size_t)qi * p.ldo + dv) = pk;
+          store8(O + (size_t)qi * p.ldo + dv, __builtin_bit_cast(u32x2, pk));
         }
       }
     }

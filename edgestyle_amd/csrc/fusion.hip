@@ -149,7 +149,7 @@ ES_DEVICE void fusion_b_body(const es_fusion_desc& p, const int bx, const int nc
       const float ur = to_f32(uo[e]);      // statistics of the value pass C will actually read
       s += ur; ss += ur * ur;
     }
-    *(typename Traits<T>::vec8*)(U + (size_t)i * 8) = uo;
+    store16(U + (size_t)i * 8, __builtin_bit_cast(u32x4, uo));
   }
   s = block_sum(s, red);
   ss = block_sum(ss, red);
@@ -186,7 +186,7 @@ ES_DEVICE void fusion_c_body(const es_fusion_desc& p, const int bx, const int nb
       r[e] = from_f32<T>(p.w3[c + e] * v + p.b3[c + e]);
       if (p.addend) r[e] = from_f32<T>(to_f32(r[e]) + to_f32(a[e]));      // == es_add(out, addend)
     }
-    *(typename Traits<T>::vec8*)(O + (size_t)i * 8) = r;
+    store16(O + (size_t)i * 8, __builtin_bit_cast(u32x4, r));
   }
 }
 

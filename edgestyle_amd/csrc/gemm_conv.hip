@@ -22,6 +22,16 @@
 // Epilogue: bias / per-sample time-embedding add / SiLU / GEGLU / conditioning scale are applied in registers
 // (fp32), the tile is transposed through LDS, and the residual add + store run as full-line 16-byte accesses along
 // the NHWC channel dim (a lane-owns-4-channels direct store serialised on partial-line write round trips).
+// Output and split-K slab stores of THIS file are write-through (`sc1`): a GEMM that ends with its output dirty in the
+// XCDs' L2s pays the write-back at the kernel boundary; streamed out behind the remaining tiles it is free.  Measured
+// on the batch-1 pipeline (tools/per_image_times.py, 13 processes each): plain 527 ms per image in every process;
+// sc1 523 ms in about half of the processes and 496 ms in the others (constant inside a process, not tied to
+// allocation offsets or re-allocation: cause not found).  GroupNorm / attention / fusion outputs are re-read at once
+// by the next launch and measured better left in L2 (all-kernels sc1: 506 vs 491 ms on one box), `nt` and
+// `sc0 sc1` were no better than `sc1`.
+#ifndef ES_WT_STORES
+#define ES_WT_STORES 1
+#endif
 #include "common.h"
 #include "../../include/edgestyle_hip.h"
 
@@ -402,7 +412,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
       if (m < M) {
 #pragma unroll
         for (int i = 0; i < FN; ++i)
-          *(f32x4*)(wsp + (size_t)m * p.rows_padded + tile_n * BN + pcol + i * 16) = acc[i][j];
+          store16(wsp + (size_t)m * p.rows_padded + tile_n * BN + pcol + i * 16, __builtin_bit_cast(u32x4, acc[i][j]));
       }
     }
     if (p.prof && tid == 0) atomicMax(p.prof + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
@@ -537,7 +547,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(rv[e]));
             }
-            *(typename Traits<T>::vec8*)(outp + (size_t)m * Cstore + c) = v;
+            store16(outp + (size_t)m * Cstore + c, __builtin_bit_cast(u32x4, v));
           }
         }
       } else {
@@ -551,7 +561,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(rv[e]));
             }
-            *(typename Traits<T>::vec8*)(outp + (size_t)m * Cstore + c) = v;
+            store16(outp + (size_t)m * Cstore + c, __builtin_bit_cast(u32x4, v));
           }
         }
       }
@@ -648,7 +658,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const es_gemm_desc p
     typename Traits<T>::vec8 pk;
 #pragma unroll
     for (int r = 0; r < 8; ++r) pk[r] = from_f32<T>(v[r]);
-    *(typename Traits<T>::vec8*)o = pk;
+    store16(o, __builtin_bit_cast(u32x4, pk));
   } else {
     store_elems<T>(o, v, nv);
   }

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const es_gn_desc p, const
           if (p.silu) f = silu_f(f);
           r[e] = from_f32<T>(f);
         }
-        *(typename Traits<T>::vec8*)(out + (size_t)pxs[u] * C + c) = r;
+        store16(out + (size_t)pxs[u] * C + c, __builtin_bit_cast(u32x4, r));
       }
     }
   }
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void gn_slab_kernel(const es_gn_desc p, const 
           if (p.silu) f = silu_f(f);
           r[e] = from_f32<T>(f);
         }
-        *(typename Traits<T>::vec8*)(out + (size_t)px * C) = r;
+        store16(out + (size_t)px * C, __builtin_bit_cast(u32x4, r));
       }
     }
   }
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const T* __restrict__ x
 #pragma unroll
       for (int e = 0; e < 8; ++e)
         r[e] = from_f32<T>((to_f32(v[i][e]) - mean) * rstd * gamma[q * 8 + e] + beta[q * 8 + e]);
-      *(typename Traits<T>::vec8*)(orow + q * 8) = r;
+      store16(orow + q * 8, __builtin_bit_cast(u32x4, r));
     }
   }
 }
