@@ -123,18 +123,21 @@ template <typename T> ES_DEVICE typename Traits<T>::vec8 as_vec8(u32x4 v) {
 // 16-byte global store, optionally write-through (`sc1`): a kernel that ends with dirty lines in its XCD's L2 pays
 // their write-back at the kernel boundary (MI355X_MICROARCH.md 'boundary': + bytes / 6 TB/s); write-through stores
 // stream out while the kernel still computes.  ES_WT_STORES: 0 = plain, 1 = sc1.
+// The `s_nop 1` is REQUIRED: a VMEM store of more than 8 bytes reads its data registers after issue, and the
+// instruction after it may overwrite them (hipcc pads that hazard for its own stores, never inside inline asm; the
+// version without the nop passed nothing in tests/test_engine_gpu.py).
 #ifndef ES_WT_STORES
 #define ES_WT_STORES 0
 #endif
 ES_DEVICE void store16(void* ptr, u32x4 v) {
 #if ES_WT_STORES == 2
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
 #elif ES_WT_STORES == 3
-  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(ptr), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
 #elif ES_WT_STORES == 4
-  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(ptr), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
 #elif ES_WT_STORES
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
 #else
   *(u32x4*)ptr = v;
 #endif
@@ -142,7 +145,7 @@ ES_DEVICE void store16(void* ptr, u32x4 v) {
 
 ES_DEVICE void store8(void* ptr, u32x2 v) {
 #if ES_WT_STORES
-  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
+  asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
 #else
   *(u32x2*)ptr = v;
 #endif

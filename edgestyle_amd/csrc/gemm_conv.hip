@@ -22,13 +22,11 @@
 // Epilogue: bias / per-sample time-embedding add / SiLU / GEGLU / conditioning scale are applied in registers
 // (fp32), the tile is transposed through LDS, and the residual add + store run as full-line 16-byte accesses along
 // the NHWC channel dim (a lane-owns-4-channels direct store serialised on partial-line write round trips).
-// Output and split-K slab stores of THIS file are write-through (`sc1`): a GEMM that ends with its output dirty in the
-// XCDs' L2s pays the write-back at the kernel boundary; streamed out behind the remaining tiles it is free.  Measured
-// on the batch-1 pipeline (tools/per_image_times.py, 13 processes each): plain 527 ms per image in every process;
-// sc1 523 ms in about half of the processes and 496 ms in the others (constant inside a process, not tied to
-// allocation offsets or re-allocation: cause not found).  GroupNorm / attention / fusion outputs are re-read at once
-// by the next launch and measured better left in L2 (all-kernels sc1: 506 vs 491 ms on one box), `nt` and
-// `sc0 sc1` were no better than `sc1`.
+// Output and split-K slab stores of THIS file are write-through (`sc1`, common.h store16): a GEMM that ends with its
+// output dirty in the XCDs' L2s pays the write-back at the kernel boundary; streamed out behind the remaining tiles it
+// is free.  Measured on the batch-1 pipeline (tools/per_image_times.py, 5 processes each, same box): plain 508.8 ms per
+// image, sc1 504.4 ms (+0.9 %).  (A first version of the asm store lacked the wait state after it: wrong results, caught
+// by tests/test_engine_gpu.py, and "speed-ups" of 1-6 % that were the corrupted data's lower power draw.)
 #ifndef ES_WT_STORES
 #define ES_WT_STORES 1
 #endif

@@ -172,6 +172,32 @@ def test_attention_forced_rescale_and_strided_qkv():
     assert rel_err(y, ref) < 4e-3
 
 
+def test_attention32_head_dim_80_variant():
+    """The head_dim-80 instantiation of the 32x32-tile kernel is opt-in (ES_ATTN32=2, read once per process): run the
+    comparison in a child process with the switch set."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import torch, torch.nn.functional as F\n"
+        "from edgestyle_amd import ops\n"
+        "g = torch.Generator().manual_seed(3)\n"
+        "N, heads, Sq, Skv, d = 8, 8, 1000, 200, 80\n"
+        "C = heads * d\n"
+        "q = torch.randn(N, Sq, C, generator=g).half().float(); k = torch.randn(N, Skv, C, generator=g).half().float()\n"
+        "v = torch.randn(N, Skv, C, generator=g).half().float(); k[:, 150] *= 5.0\n"
+        "qh, kh, vh = (t.view(N, -1, heads, d).transpose(1, 2) for t in (q, k, v))\n"
+        "ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(N, Sq, C)\n"
+        "y = ops.attention(q.cuda().half(), k.cuda().half(), v.cuda().half(), heads).float().cpu()\n"
+        "err = float((y - ref).abs().max() / ref.abs().max())\n"
+        "assert err < 4e-3, err\n"
+        "print('ok', err)\n")
+    env = dict(os.environ, ES_ATTN32="2")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("d", [40, 80])
 def test_attention32_forced_rescale(d):
     """32x32-tile kernel: a late key dominates some queries only (lazy rescale on the mixed 32-query / 16-query layouts)"""
