@@ -240,3 +240,81 @@ def test_unipc_coefficient_table_reproduces_oracle_trajectory():
         x = o.step(nz, t, x)
     a, sg = o._alpha_sigma(o.sigmas[-1])
     assert float((x - (a * x0t + sg * nz).float()).abs().max()) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# serving loop (edgestyle_amd/serve.py): host logic with a stand-in pipeline
+class _FakePipe:
+    """Per-sample deterministic 'pipeline': image_i depends only on request i's own inputs."""
+
+    def __init__(self, fail_on_steps=None, delay=0.0):
+        self.calls = []
+        self.fail_on_steps, self.delay = fail_on_steps, delay
+
+    def __call__(self, prompt_embeds, negative_prompt_embeds, image, latents, guidance_scale, num_inference_steps,
+                 control_guidance_start, control_guidance_end, output_type):
+        import time
+        import types
+        assert output_type == "pt" and len(image) == 6
+        B = latents.shape[0]
+        assert all(t.shape[0] == B for t in (prompt_embeds, negative_prompt_embeds, *image))
+        self.calls.append((B, num_inference_steps, guidance_scale))
+        if self.fail_on_steps == num_inference_steps:
+            raise RuntimeError("boom")
+        time.sleep(self.delay)
+        per = latents.mean(dim=(1, 2, 3)) + prompt_embeds.mean(dim=(1, 2)) - negative_prompt_embeds.mean(dim=(1, 2)) \
+            + sum(im.mean(dim=(1, 2, 3)) * (k + 1) for k, im in enumerate(image)) + guidance_scale
+        return types.SimpleNamespace(images=per[:, None, None, None].expand(B, 3, 8, 8).clone())
+
+
+def _request(seed, steps=50, gs=7.5, hw=16):
+    from edgestyle_amd.serve import TryOnRequest
+    g = torch.Generator().manual_seed(1000 + seed)
+    return TryOnRequest([torch.randn(1, 3, hw, hw, generator=g) for _ in range(6)], torch.randn(1, 77, 32, generator=g),
+                        torch.randn(1, 77, 32, generator=g), gs, steps, seed)
+
+
+def test_service_batches_compatible_requests_and_results_do_not_depend_on_the_batch():
+    from edgestyle_amd.serve import TryOnService
+    solo_pipe = _FakePipe()
+    solo = TryOnService(solo_pipe, max_batch=1, max_wait_s=0.0)
+    want = [solo.submit(_request(s)).result(timeout=10) for s in range(5)]
+    solo.shutdown()
+    assert [c[0] for c in solo_pipe.calls] == [1] * 5
+
+    pipe = _FakePipe(delay=0.05)
+    svc = TryOnService(pipe, max_batch=8, max_wait_s=0.3, batch_sizes=(1, 2, 4, 8))
+    futs = [svc.submit(_request(s)) for s in range(5)]
+    got = [f.result(timeout=10) for f in futs]
+    svc.shutdown()
+    for a, b in zip(got, want):
+        assert a.shape == (1, 3, 8, 8) and torch.allclose(a, b, atol=1e-6)
+    # five compatible requests: captured batch sizes only -> 4 + 1, oldest first
+    assert sorted(c[0] for c in pipe.calls) == [1, 4] and pipe.calls[0][0] == 4
+    assert svc.stats["images"] == 5 and svc.stats["calls"] == 2
+
+
+def test_service_keeps_incompatible_requests_apart_and_survives_a_failing_batch():
+    from edgestyle_amd.serve import TryOnService
+    pipe = _FakePipe(fail_on_steps=7)
+    svc = TryOnService(pipe, max_batch=4, max_wait_s=0.2)
+    a = [svc.submit(_request(s, steps=50)) for s in range(2)]
+    b = [svc.submit(_request(s, steps=7)) for s in range(2)]          # this batch raises inside the pipeline
+    c = [svc.submit(_request(9, steps=50, gs=3.0))]
+    for f in a + c:
+        assert f.result(timeout=10).shape == (1, 3, 8, 8)
+    for f in b:
+        with pytest.raises(RuntimeError, match="boom"):
+            f.result(timeout=10)
+    svc.shutdown()
+    assert (2, 50, 7.5) in pipe.calls and (2, 7, 7.5) in pipe.calls and (1, 50, 3.0) in pipe.calls
+    with pytest.raises(RuntimeError):
+        svc.submit(_request(1))
+    with pytest.raises(ValueError):
+        TryOnService(pipe, batch_sizes=(2, 4))
+
+
+def test_service_latents_depend_on_the_request_seed_only():
+    from edgestyle_amd.serve import latents_for
+    a, b = latents_for(42, 4, 8, 8), latents_for(42, 4, 8, 8)
+    assert torch.equal(a, b) and not torch.equal(a, latents_for(43, 4, 8, 8)) and a.shape == (1, 4, 8, 8)

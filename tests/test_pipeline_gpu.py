@@ -264,3 +264,28 @@ def test_cli_counterpart_of_the_reference_test_script(tmp_path):
         "controlnet_0", "controlnet_1", "diffusion_pytorch_model.safetensors"]
     x = cli.load_image(str(tmp_path / "source" / "head" / "1.jpg"), 128, True)
     assert x.shape == (1, 3, 128, 128) and float(x.min()) >= -1 and float(x.max()) <= 1
+
+
+def test_try_on_service_batched_equals_individually_served(built):
+    """edgestyle_amd/serve.py over the real (tiny) pipeline: three concurrent requests run as one batch of 2 + one of 1;
+    each image matches the one the request gets when served alone (different tile plans per batch: PSNR, not bits)."""
+    from edgestyle_amd.serve import TryOnService, TryOnRequest
+    pipe, ws, ucfg, vcfg = built
+    s, c0 = ucfg.sample_size, ucfg.block_out_channels[0]
+
+    def req(seed):
+        g = torch.Generator().manual_seed(500 + seed)
+        return TryOnRequest([(torch.randn(1, c0, s, s, generator=g) * 0.3).half().float() for _ in range(6)],
+                            (torch.randn(1, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float(),
+                            (torch.randn(1, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float(),
+                            5.0, 4, seed)
+    solo = TryOnService(pipe, max_batch=1, max_wait_s=0.0, vae_scale=1)
+    want = [solo.submit(req(i)).result(timeout=300) for i in range(3)]
+    solo.shutdown()
+    svc = TryOnService(pipe, max_batch=2, max_wait_s=1.0, batch_sizes=(1, 2), vae_scale=1)
+    futs = [svc.submit(req(i)) for i in range(3)]
+    got = [f.result(timeout=300) for f in futs]
+    svc.shutdown()
+    assert svc.stats["calls"] == 2 and svc.stats["images"] == 3
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and psnr(a, b) >= 45.0
