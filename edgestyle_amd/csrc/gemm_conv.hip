@@ -52,11 +52,31 @@ ES_DEVICE void store_elems(T* o, const float* v, int n) {
   for (int r = 0; r < n; ++r) o[r] = from_f32<T>(v[r]);
 }
 
+// byte offset of (row i, tap tp, channel chan) of an activation source, or OOB (zero-filled by the buffer range check)
+template <int XI>
+ES_DEVICE void row_offsets_fn(unsigned (&voff)[XI], const int (&iy0)[XI], const int (&ix0)[XI], const int (&nb)[XI],
+                              const int tp, const int cs, const int chan, const int ksize, const int KK, const int pad,
+                              const int Hin, const int Win, const int upsample, const int Wsrc) {
+  int ky = 0, kx = 0;
+  if (ksize == 3) { ky = (tp * 11) >> 5; kx = tp - ky * 3; }         // tp in [0,9): tp/3 without a divide
+  if (tp >= KK) { ky = pad; kx = pad; }                              // tail tap: the output pixel (stride 1, no upsample)
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+    const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+    const int pix = nb[i] + (iy >> upsample) * Wsrc + (ix >> upsample);
+    voff[i] = ok ? (unsigned)(((size_t)pix * cs + chan) * 2) : 0xFFFFFF00u;
+  }
+}
+
 template <typename T, int BM, int BN, bool ALIGNED, int STAGES, int FM = 4 /* pixel fragments per wave */,
           int BKT = 64 /* K depth of a stage */, bool LN = false /* LayerNorm folded into this linear layer */>
 // (second launch bound = minimum waves per SIMD: 8-wave workgroups need 4 to keep two workgroups on a CU)
 __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM == 128) ? (FM == 2 ? 4 : 2) : 1)) void conv_gemm_kernel(
-    const es_gemm_desc p, const int M, const int nk) {
+    const es_gemm_desc p, const int M, const int nk, const void* const tail1, const void* const tail2, const int tailC1,
+    const int tailC2) {
+  // (the 1x1 tail sources travel as plain kernel arguments, not through `p`: any read of the descriptor's t1/t2/Ct1/Ct2
+  //  fields inside the K loop made hipcc keep the whole by-value descriptor in scratch memory - 3.4x slower kernels)
   // BKT = 32: half-depth stages.  The ring shrinks to 2 x 18 KB, the epilogue tile (43 KB) becomes the LDS high-water
   // mark and THREE workgroups fit a CU: short-K launches (K = 320..1280, a handful of K-steps per tile) are bound by
   // workgroup turnover - first-tile latency + epilogue drain - and residency is what hides it (2 vs 1 workgroups per
@@ -110,7 +130,13 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
   // global chunk that lands in that slot: the XOR swizzle is applied on the SOURCE side (lane-linear destination)
   const int kc = BKT == 64 ? (lslot ^ (lrow & 7)) : (lslot ^ (((lrow >> 2) & 1) << 1));
   const int Ctot = p.C1 + p.C2;
-  const int Ktrue = p.ksize * p.ksize * Ctot;
+  const int KK = p.ksize * p.ksize;
+  // (struct fields that meet in a select are copied to locals first: `c ? p.a : p.b` otherwise becomes a load through a
+  // selected ADDRESS, which pins the whole by-value descriptor in scratch memory - 700+ bytes per lane, 3.4x slower)
+  const int pC1 = p.C1, pC2 = p.C2, pCt1 = tailC1, pCt2 = tailC2;
+  const bool has_tail = tail1 != nullptr;
+  const int Ctail = has_tail ? pCt1 + pCt2 : 0;        // 1x1 tail sources (conv_shortcut folded into conv2): tap index KK
+  const int Ktrue = KK * Ctot + Ctail;
   const int Hin = p.Hsrc << p.upsample, Win = p.Wsrc << p.upsample;
   const int HWout = p.Hout * p.Wout;
 
@@ -163,6 +189,14 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
       (void*)p.x, (short)0, (int)((size_t)p.N * p.Hsrc * p.Wsrc * p.C1 * 2), 0x00020000);
   const auto rX2 = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.x2 ? p.x2 : p.x), (short)0, (int)((size_t)p.N * p.Hsrc * p.Wsrc * (p.x2 ? p.C2 : p.C1) * 2), 0x00020000);
+  const void* const pt1 = tail1 ? tail1 : p.x;
+  const void* const pt2 = tail2 ? tail2 : p.x;
+  const void* const px = p.x;
+  const void* const px2 = p.x2 ? p.x2 : p.x;
+  const int nX1 = (int)((size_t)p.N * p.Hsrc * p.Wsrc * pC1 * 2);
+  const int nX2 = (int)((size_t)p.N * p.Hsrc * p.Wsrc * (p.x2 ? pC2 : pC1) * 2);
+  const int nT1 = has_tail ? (int)((size_t)p.N * p.Hout * p.Wout * pCt1 * 2) : 0;
+  const int nT2 = tail2 ? (int)((size_t)p.N * p.Hout * p.Wout * pCt2 * 2) : 0;
   unsigned woff[WI];
 #pragma unroll
   for (int i = 0; i < WI; ++i) {
@@ -175,24 +209,19 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
     const int kg = ks0 * BKT + (ALIGNED ? 0 : kc * 8);
     tap = kg / Ctot;
     cpos = kg - tap * Ctot;
+    if (ALIGNED && tap >= KK) { tap = KK; cpos = kg - KK * Ctot; }      // a split-K slice that starts inside the tail
   }
   unsigned voff[XI];
 #pragma unroll
   for (int i = 0; i < XI; ++i) voff[i] = OOB;
   int cur_tap = -1, cur_second = -1;
-  auto row_offsets = [&](int tp, int cs, int chan) {      // byte offset of (row i, tap tp, channel chan) or OOB
-    int ky = 0, kx = 0;
-    if (p.ksize == 3) { ky = (tp * 11) >> 5; kx = tp - ky * 3; }       // tp in [0,9): tp/3 without a divide
-#pragma unroll
-    for (int i = 0; i < XI; ++i) {
-      const int iy = iy0[i] + ky, ix = ix0[i] + kx;
-      const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
-      const int pix = nb[i] + (iy >> p.upsample) * p.Wsrc + (ix >> p.upsample);
-      voff[i] = ok ? (unsigned)(((size_t)pix * cs + chan) * 2) : OOB;
-    }
-  };
-
-  auto issue_tile = [&](int ks, int stage) {
+  // (a free function, not a second lambda: with a closure nested inside issue_tile's closure hipcc stopped scalarising
+  //  the captures once the tail sources were added, and kept them - and the by-value descriptor - in scratch memory)
+  const int ks_tail = (KK * Ctot) / BKT;               // first K-step of the tail sources (aligned launches only)
+  const int pk_ksize = p.ksize, pk_pad = p.pad, pk_up = p.upsample, pk_wsrc = p.Wsrc;
+#define row_offsets(tp, cs, chan) \
+  row_offsets_fn<XI>(voff, iy0, ix0, nb, (tp), (cs), (chan), pk_ksize, KK, pk_pad, Hin, Win, pk_up, pk_wsrc)
+  auto issue_tile = [&, pt1, pt2, px, px2, nX1, nX2, nT1, nT2, pC1, pC2, pCt1, pCt2, KK, Ctot, Ktrue, Hin, Win, pk_ksize, pk_pad, pk_up, pk_wsrc, wave, kc, rW, ks_tail](int ks, int stage) __attribute__((always_inline)) {
     char* xs = smem + stage * (XT + WT);
     char* ws = xs + XT;
     const int soff_w = ks * RB;
@@ -204,9 +233,13 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
     if constexpr ((ES_ABLATE & 16) != 0) {
       // ablation: no activation DMAs
     } else if constexpr (ALIGNED) {
-      const int second = cpos >= p.C1 ? 1 : 0;            // wave-uniform: a K-step never straddles taps or sources
-      const int cs = second ? p.C2 : p.C1;
-      const int cc = second ? cpos - p.C1 : cpos;
+      const bool tail = ks >= ks_tail;                    // wave-uniform, like everything below (== tap >= KK)
+      int q0 = pC1, q1 = pC2, q2 = pCt1, q3 = pCt2;
+      asm("" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3));
+      const int c1 = tail ? q2 : q0;
+      const int second = cpos >= c1 ? 1 : 0;              // a K-step never straddles taps or sources
+      const int cs = second ? (tail ? q3 : q1) : c1;
+      const int cc = second ? cpos - c1 : cpos;
       if (tap != cur_tap || second != cur_second) {
         row_offsets(tap, cs, kc * 8);
         cur_tap = tap; cur_second = second;
@@ -215,15 +248,20 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
 #pragma unroll
       for (int i = 0; i < XI; ++i) voff[i] = OOB;
 #endif
-      if (second) {
+      // one load path; the descriptor is rebuilt from wave-uniform selects of (base, bytes) - a four-way branch over four
+      // ready-made descriptors made hipcc keep the by-value kernel descriptor in scratch memory (3.4x slower kernels)
+      // (the empty asm makes the eight candidates opaque values: hipcc otherwise rewrites "select of loads from the
+      //  closure" into "load from a selected closure ADDRESS", which pins the closure and every variable it captures in
+      //  scratch memory - 300-800 bytes per lane and 3.4x slower kernels)
+      const void *b0 = px, *b1 = px2, *b2 = pt1, *b3 = pt2;
+      int n0 = nX1, n1 = nX2, n2 = nT1, n3 = nT2;
+      asm("" : "+s"(b0), "+s"(b1), "+s"(b2), "+s"(b3), "+s"(n0), "+s"(n1), "+s"(n2), "+s"(n3));
+      const void* const base = tail ? (second ? b3 : b2) : (second ? b1 : b0);
+      const int nrec = tail ? (second ? n3 : n2) : (second ? n1 : n0);
+      const auto rS = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, nrec, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < XI; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, (lptr_t)(xs + (wave * XI + i) * 1024), 16, (int)voff[i], cc * 2, 0, 0);
-      } else {
-#pragma unroll
-        for (int i = 0; i < XI; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rX1, (lptr_t)(xs + (wave * XI + i) * 1024), 16, (int)voff[i], cc * 2, 0, 0);
-      }
+      for (int i = 0; i < XI; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, (lptr_t)(xs + (wave * XI + i) * 1024), 16, (int)voff[i], cc * 2, 0, 0);
     } else {
       // small-Cin layers (conv_in, cond embedding): tap and channel differ per lane, single source
       if (ks * BKT + kc * 8 < Ktrue) {
@@ -237,9 +275,10 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rX1, (lptr_t)(xs + (wave * XI + i) * 1024), 16, (int)voff[i], 0, 0, 0);
     }
     cpos += BKT;
-    while (cpos >= Ctot) { cpos -= Ctot; ++tap; }
+    if (tap < KK) { while (cpos >= Ctot) { cpos -= Ctot; ++tap; } }      // (the tail is the last tap: cpos just runs on)
   };
 
+#undef row_offsets
   f32x4 acc[FN][FM];
 #pragma unroll
   for (int i = 0; i < FN; ++i)
@@ -688,7 +727,7 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
       attr_set = true;                                                                                      \
     }                                                                                                       \
-    hipLaunchKernelGGL(kfn, grid, dim3(BMV * 8 / FMV), lds, st, d, M, nk);                                  \
+    hipLaunchKernelGGL(kfn, grid, dim3(BMV * 8 / FMV), lds, st, d, M, nk, d.t1, d.t2, d.Ct1, d.Ct2);                                  \
   } while (0)
 #define ES_LAUNCH_F(BMV, BNV, AL, ST, FMV)                                                                  \
   do {                                                                                                      \
@@ -699,7 +738,7 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
       attr_set = true;                                                                                      \
     }                                                                                                       \
-    hipLaunchKernelGGL(kfn, grid, dim3(BMV * 8 / FMV), lds, st, d, M, nk);                                  \
+    hipLaunchKernelGGL(kfn, grid, dim3(BMV * 8 / FMV), lds, st, d, M, nk, d.t1, d.t2, d.Ct1, d.Ct2);                                  \
   } while (0)
 #define ES_LAUNCH_LN(BMV, BNV, ST, FMV)                                                                      \
   do {                                                                                                      \
@@ -710,7 +749,7 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
       attr_set = true;                                                                                      \
     }                                                                                                       \
-    hipLaunchKernelGGL(kfn, grid, dim3(BMV * 8 / FMV), lds, st, d, M, nk);                                  \
+    hipLaunchKernelGGL(kfn, grid, dim3(BMV * 8 / FMV), lds, st, d, M, nk, d.t1, d.t2, d.Ct1, d.Ct2);                                  \
   } while (0)
 #define ES_LAUNCH(BMV, BNV, AL, ST) ES_LAUNCH_F(BMV, BNV, AL, ST, 4)
 #define ES_LAUNCH_ST(BNV)                                                                                   \
@@ -760,7 +799,7 @@ extern "C" size_t es_conv_gemm_workspace_bytes(const es_gemm_desc* d) {
 
 extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
   const int Ctot = d->C1 + d->C2;
-  const int Ktrue = d->ksize * d->ksize * Ctot;
+  const int Ktrue = d->ksize * d->ksize * Ctot + (d->t1 ? d->Ct1 + d->Ct2 : 0);
   if (!d->x || !d->out || (d->ngroups <= 1 && !d->w)) { es_set_error("es_conv_gemm: null pointer"); return -1; }
   if (d->ngroups > 4) { es_set_error("es_conv_gemm: at most 4 groups"); return -1; }
   if (d->ngroups > 1) {
@@ -785,6 +824,11 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
   if ((size_t)d->N * d->Hsrc * d->Wsrc * (d->C1 > d->C2 ? d->C1 : d->C2) * 2 >= 0x7FFFFFFFull ||
       (size_t)d->rows_padded * d->Kpad * 2 >= 0x7FFFFFFFull) { es_set_error("es_conv_gemm: operand larger than 2 GiB (32-bit buffer offsets)"); return -1; }
   if (d->ksize != 1 && d->ksize != 3) { es_set_error("es_conv_gemm: ksize must be 1 or 3"); return -1; }
+  if (d->t1 && (d->stride != 1 || d->upsample || d->C1 % BK || d->C2 % BK || d->Ct1 % BK || d->Ct2 % BK || d->Ct1 < BK ||
+                (d->Ct2 && !d->t2) || d->ln_colsum || d->Hout != d->Hsrc || d->Wout != d->Wsrc ||
+                (size_t)d->N * d->Hout * d->Wout * (d->Ct1 > d->Ct2 ? d->Ct1 : d->Ct2) * 2 >= 0x7FFFFFFFull)) {
+    es_set_error("es_conv_gemm: 1x1 tail sources need stride 1, no upsample, same-size output, 64-aligned channels"); return -1; }
+  if (!d->t1 && (d->t2 || d->Ct1 || d->Ct2)) { es_set_error("es_conv_gemm: tail fields set without t1"); return -1; }
   if (d->splitk < 1 || d->splitk > d->Kpad / BK) { es_set_error("es_conv_gemm: bad splitk"); return -1; }
   if (d->splitk > 1 && (!d->workspace || d->act == ES_ACT_GEGLU)) { es_set_error("es_conv_gemm: splitk needs workspace and no GEGLU"); return -1; }
   if (d->splitk > 1 && (long long)d->N * d->Hout * d->Wout * (d->rows_padded / 8) >= (1ll << 31)) { es_set_error("es_conv_gemm: split-K output too large for 32-bit indices"); return -1; }

@@ -63,6 +63,18 @@ class _Packer:
         _PACK_CACHE[key] = (weakref.ref(w), None if b is None else weakref.ref(b), pw)
         return pw
 
+    def conv_tail(self, p: str, pt: str) -> ops.PackedWeight:
+        """conv `p` with the 1x1 conv `pt` appended along K (ops.pack_weight_tail); cached per source tensors like conv()."""
+        w, wt = self.sd[p + ".weight"], self.sd[pt + ".weight"]
+        key = (id(w), id(wt), str(self.dtype), str(self.device), "tail")
+        hit = _PACK_CACHE.get(key)
+        if hit is not None and hit[0]() is w and hit[1]() is wt:
+            return hit[2]
+        pw = ops.pack_weight_tail(self.t(p + ".weight"), self.t(pt + ".weight"), self.t(p + ".bias") + self.t(pt + ".bias"),
+                                  self.dtype, self.device)
+        _PACK_CACHE[key] = (weakref.ref(w), weakref.ref(wt), pw)
+        return pw
+
     def cat(self, ps: Sequence[str], bias: bool) -> ops.PackedWeight:
         w = torch.cat([self.t(p + ".weight") for p in ps], 0)
         b = torch.cat([self.t(p + ".bias") for p in ps], 0) if bias else None
@@ -79,6 +91,7 @@ class _Packer:
                                   geglu=geglu)
 
 
+SHORTCUT_FOLD = os.environ.get("ES_SHORTCUT_FOLD", "1") == "1"   # conv_shortcut folded into conv2 (Resnet.conv2s)
 FFO_FOLD = os.environ.get("ES_FFO_FOLD", "1") == "1"   # ff.net.2 + proj_out as one GEMM (Transformer.ffo)
 LN_FOLD = os.environ.get("ES_LN_FOLD", "1") in ("1", "qk")
 LN_FOLD_FF = os.environ.get("ES_LN_FOLD", "1") == "1"    # "qk": norm1/norm2 only, norm3 -> GEGLU stays a LayerNorm launch     # LayerNorm folded into the Linear it feeds (es_gemm_desc.ln_colsum)
@@ -91,12 +104,22 @@ class Resnet:
         self.short = pk.conv(p + ".conv_shortcut") if (p + ".conv_shortcut.weight") in pk.sd else None
         self.groups, self.eps, self.temb_off = groups, eps, temb_off
         self.cout = self.conv1.cout
+        # conv2(h) + conv_shortcut(x) is one sum over K: the shortcut's 1x1 weights ride behind the 3x3 taps of conv2 as
+        # "tail" channels read from x (| x2) at the output pixel (es_gemm_desc.t1/t2, ops.pack_weight_tail) - one launch
+        # and one write + re-read of the shortcut tensor less per block, and the shortcut enters the fp32 accumulator
+        # instead of being rounded to 16 bits first.  Needs 64-aligned channels.
+        self.conv2s = None
+        w2, ws_ = pk.sd[p + ".conv2.weight"], pk.sd.get(p + ".conv_shortcut.weight")
+        if SHORTCUT_FOLD and ws_ is not None and w2.shape[1] % 64 == 0 and ws_.shape[1] % 64 == 0:
+            self.conv2s = pk.conv_tail(p + ".conv2", p + ".conv_shortcut")
 
     def __call__(self, x, tproj, x2=None):
         h = ops.group_norm(x, self.n1[0], self.n1[1], self.groups, self.eps, True, x2=x2)
         temb = None if self.temb_off is None else tproj[:, self.temb_off:]
         h = ops.conv_gemm(h, self.conv1, temb=temb)
         h = ops.group_norm(h, self.n2[0], self.n2[1], self.groups, self.eps, True)
+        if self.conv2s is not None and (x2 is None or (x.shape[3] % 64 == 0 and x2.shape[3] % 64 == 0)):
+            return ops.conv_gemm(h, self.conv2s, tail=(x, x2))
         xs = ops.conv_gemm(x, self.short, x2=x2) if self.short is not None else x
         return ops.conv_gemm(h, self.conv2, residual=xs)
 
@@ -487,6 +510,8 @@ class GroupedEncoder:
         h = ops.group_norm(x, [r.n1[0] for r in rs], [r.n1[1] for r in rs], r0.groups, r0.eps, True, group_n=c)
         h = ops.conv_gemm(h, [r.conv1 for r in rs], temb=tproj[:, r0.temb_off:], group_n=c)
         h = ops.group_norm(h, [r.n2[0] for r in rs], [r.n2[1] for r in rs], r0.groups, r0.eps, True, group_n=c)
+        if all(r.conv2s is not None for r in rs):
+            return ops.conv_gemm(h, [r.conv2s for r in rs], tail=(x,), group_n=c)
         xs = ops.conv_gemm(x, [r.short for r in rs], group_n=c) if r0.short is not None else x
         return ops.conv_gemm(h, [r.conv2 for r in rs], residual=xs, group_n=c)
 

@@ -28,6 +28,7 @@ class GemmDesc(C.Structure):
         ("stages", C.c_int32), ("xcd_m_fastest", C.c_int32), ("bm", C.c_int32), ("waves", C.c_int32),
         ("bk", C.c_int32), ("out_scale", C.c_float),
         ("ln_colsum", C.c_void_p), ("ln_colsum_g", C.c_void_p * 4), ("ln_eps", C.c_float),
+        ("t1", C.c_void_p), ("t2", C.c_void_p), ("Ct1", C.c_int32), ("Ct2", C.c_int32),
     ]
 
 

@@ -102,6 +102,7 @@ class PackedWeight:
     geglu: bool = False
     ln_colsum: Optional[torch.Tensor] = None   # fp32 [rows_padded]: LayerNorm folded into this linear layer (pack_weight_ln)
     ln_eps: float = 1e-5
+    ctail: int = 0                  # channels of the 1x1 tail sources appended along K (pack_weight_tail)
 
     @property
     def rows_padded(self):
@@ -155,6 +156,27 @@ def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype, devic
         bp = torch.zeros(rows, dtype=torch.float32, device=device)
         bp[:cout] = b
     return PackedWeight(wp, bp, cout_eff, cp, k, bn, geglu)
+
+
+def pack_weight_tail(weight: torch.Tensor, tail_weight: torch.Tensor, bias: Optional[torch.Tensor], dtype, device) -> PackedWeight:
+    """conv (weight [Cout,Cin,k,k]) and a 1x1 conv over OTHER tensors of the output's size (tail_weight [Cout,Ct] or
+    [Cout,Ct,1,1]) as one GEMM: K = (ky,kx,c) taps of the conv, then the tail channels (es_gemm_desc.t1/t2).
+    ResnetBlock2D: conv2(h) + conv_shortcut(x); `bias` is the SUM of the two biases.  64-aligned channels only."""
+    weight = weight.to(device=device, dtype=torch.float32)
+    tw = tail_weight.to(device=device, dtype=torch.float32).reshape(tail_weight.shape[0], -1)
+    cout, cin, k, _ = weight.shape
+    if cin % BK or tw.shape[1] % BK or tw.shape[0] != cout:
+        raise L.EdgeStyleHipError("pack_weight_tail: conv and tail channels must be multiples of 64, equal Cout")
+    w = torch.cat([weight.permute(0, 2, 3, 1).reshape(cout, k * k * cin), tw], 1)
+    bn = choose_bn(cout)
+    rows = (cout + bn - 1) // bn * bn
+    wp = torch.zeros(rows, w.shape[1], dtype=dtype, device=device)
+    wp[:cout] = w.to(dtype)
+    bp = None
+    if bias is not None:
+        bp = torch.zeros(rows, dtype=torch.float32, device=device)
+        bp[:cout] = bias.to(device=device, dtype=torch.float32)
+    return PackedWeight(wp, bp, cout, cin, k, bn, False, ctail=tw.shape[1])
 
 
 def pack_weight_ln(weight: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
@@ -283,7 +305,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
               residual: Optional[torch.Tensor] = None, act: int = L.ACT_NONE, out_scale: float = 1.0,
               out_scale_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
               out_hw=None, splitk: Optional[int] = None, stages: int = 0,
-              group_n: Optional[Sequence[int]] = None) -> torch.Tensor:
+              group_n: Optional[Sequence[int]] = None, tail: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
     """x: [N,H,W,C1] (+ x2 [N,H,W,C2]); returns [N,Hout,Wout,Cout] (Cout/2 for GEGLU).
 
     Grouped launch: `pw` is a list of PackedWeights of identical geometry and `group_n` the number of consecutive
@@ -298,6 +320,9 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     C2 = 0 if x2 is None else x2.shape[3]
     if C1 + C2 != pw.cin:
         raise L.EdgeStyleHipError(f"conv_gemm: input channels {C1}+{C2} != packed {pw.cin}")
+    tails = [t for t in (tail or ()) if t is not None]
+    if sum(t.shape[3] for t in tails) != pw.ctail or len(tails) > 2:
+        raise L.EdgeStyleHipError(f"conv_gemm: tail channels {[t.shape[3] for t in tails]} != packed {pw.ctail}")
     k = pw.ksize
     if pad is None:
         pad = 1 if k == 3 else 0
@@ -357,6 +382,12 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         if (pws is not None and any(q.ln_colsum is None for q in pws)) or x2 is not None or k != 1:
             raise L.EdgeStyleHipError("LayerNorm-folded weights need a plain linear launch (all groups folded)")
         d.ln_colsum, d.ln_eps = pw.ln_colsum.data_ptr(), pw.ln_eps
+    if tails:
+        if any(t.shape[:3] != (N, Hout, Wout) or not t.is_contiguous() for t in tails):
+            raise L.EdgeStyleHipError("conv_gemm: tail sources must be contiguous [N,Hout,Wout,C]")
+        d.t1, d.Ct1 = tails[0].data_ptr(), tails[0].shape[3]
+        if len(tails) == 2:
+            d.t2, d.Ct2 = tails[1].data_ptr(), tails[1].shape[3]
     if pws is not None:
         hw = Hout * Wout
         gran = 256 if bn == 320 else BM
@@ -365,7 +396,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         d.ngroups = len(pws)
         acc = 0
         for g, (q, n) in enumerate(zip(pws, group_n)):
-            if (q.rows_padded, q.kpad, q.cout, q.cin, q.ksize, q.geglu) != (pw.rows_padded, pw.kpad, pw.cout, pw.cin, pw.ksize, pw.geglu):
+            if (q.rows_padded, q.kpad, q.cout, q.cin, q.ksize, q.geglu, q.ctail) != (pw.rows_padded, pw.kpad, pw.cout, pw.cin, pw.ksize, pw.geglu, pw.ctail):
                 raise L.EdgeStyleHipError("grouped conv_gemm: weight geometry differs between groups")
             acc += n * hw // BM
             d.mt_end[g] = acc
@@ -373,13 +404,15 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
             d.bias_g[g] = q.bias.data_ptr() if q.bias is not None else None
             d.ln_colsum_g[g] = q.ln_colsum.data_ptr() if q.ln_colsum is not None else None
     if PROFILE is not None:           # bench.py roofline leg: in-kernel s_memrealtime stamps for this launch
-        d.prof = PROFILE.next((2.0 * M * pw.cout * k * k * (C1 + C2), k,
-                               (M, pw.cout, k * k * (C1 + C2), stride, splitk, bn),
+        d.prof = PROFILE.next((2.0 * M * pw.cout * (k * k * (C1 + C2) + pw.ctail), k,
+                               (M, pw.cout, k * k * (C1 + C2) + pw.ctail, stride, splitk, bn),
                                dict(N=N, H=H, W=W, C1=C1, C2=C2, cout=pw.cout, k=k, stride=stride, pad=pad,
                                     upsample=bool(upsample), geglu=pw.geglu, splitk=splitk, Hout=Hout, Wout=Wout,
                                     residual=residual is not None, temb=temb is not None, bn=bn,
                                     stages=int(d.stages), group_n=list(group_n) if pws is not None else None,
-                                    algorithmic_bytes=_algorithmic_bytes(x, x2, pw, pws, out, residual))))
+                                    ctail=pw.ctail,
+                                    algorithmic_bytes=_algorithmic_bytes(x, x2, pw, pws, out, residual)
+                                    + sum(t.numel() * t.element_size() for t in tails))))
     L.check(L.load().es_conv_gemm(C.byref(d), _stream()), "es_conv_gemm")
     return out
 

@@ -86,6 +86,13 @@ typedef struct {
   const float* ln_colsum;     /* NULL: plain launch */
   const float* ln_colsum_g[4];
   float ln_eps;
+  /* 1x1 tail sources (ResnetBlock2D: conv2(h) + conv_shortcut(x) as ONE launch): after the ksize*ksize taps over
+   * (x | x2) the K axis continues with ONE centre tap over the channel concat (t1 | t2), tensors of the OUTPUT's
+   * spatial size [N, Hout, Wout, Ct1|Ct2]; the packed weights are [W_conv | W_shortcut] along K, the bias is the sum.
+   * Needs stride 1, no upsample, 64-aligned C1, C2, Ct1, Ct2.  t1 == NULL: no tail. */
+  const void* t1;
+  const void* t2;
+  int32_t Ct1, Ct2;
 } es_gemm_desc;
 int es_conv_gemm(const es_gemm_desc* d, void* stream);
 size_t es_conv_gemm_workspace_bytes(const es_gemm_desc* d);
