@@ -852,7 +852,11 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
                         (d->stages == 4 && d->bn != 128))) {
     es_set_error("es_conv_gemm: waves=8 is the 128-pixel tile on 8 waves: 64-aligned channels, 2 stages (4 with bn=128)"); return -1; }
   hipStream_t st = (hipStream_t)stream;
-  int rc = d->dtype == ES_F16 ? launch<f16>(*d, st) : launch<bf16>(*d, st);
+  // the kernels find a tile's group as (t >= end[0]) + (t >= end[1]) + (t >= end[2]): unused entries must compare false
+  // (a caller's zero-initialised table sent every tile of a TWO-group launch to groups 1..3: null weights, GPU fault)
+  es_gemm_desc dd = *d;
+  for (int g = dd.ngroups > 1 ? dd.ngroups : 0; g < 4; ++g) dd.mt_end[g] = 0x7FFFFFFF;
+  int rc = dd.dtype == ES_F16 ? launch<f16>(dd, st) : launch<bf16>(dd, st);
   if (rc) es_set_error("es_conv_gemm: launch failed");
   return rc;
 }

@@ -437,7 +437,9 @@ extern "C" int es_group_norm(const es_gn_desc* d, void* stream) {
   if (d->N < 1 || d->HW < 1) { es_set_error("es_group_norm: empty problem"); return -1; }
   if ((long long)d->HW * (C / 8) >= (1ll << 30)) { es_set_error("es_group_norm: sample too large for 32-bit chunk indices"); return -1; }
   hipStream_t st = (hipStream_t)stream;
-  int rc = d->dtype == ES_F16 ? launch_gn<f16>(*d, st) : launch_gn<bf16>(*d, st);
+  es_gn_desc dd = *d;                                  // unused group-table entries must compare false (see es_conv_gemm)
+  for (int g = dd.ngroups > 1 ? dd.ngroups : 0; g < 4; ++g) dd.n_end[g] = 0x7FFFFFFF;
+  int rc = dd.dtype == ES_F16 ? launch_gn<f16>(dd, st) : launch_gn<bf16>(dd, st);
   if (rc) es_set_error("es_group_norm: launch failed");
   return rc;
 }

@@ -624,3 +624,65 @@ def test_conv_gemm_big_tile_equals_small_tile():
             ops.conv_gemm(xg[:, :8, :8].contiguous(), pws, group_n=counts)   # 64-pixel samples: groups of 128/256/128 px
         finally:
             ops.FORCE_BN = 0
+
+
+@pytest.mark.parametrize("N,H,C,Cout,Ct1,Ct2,splitk", [
+    (2, 16, 128, 256, 64, 0, None),       # planner's choice
+    (2, 16, 128, 256, 128, 64, None),     # two tail sources (decoder: shortcut over the skip concat)
+    (1, 8, 64, 128, 64, 64, 11),          # K = 9*64 + 128 = 11 K-steps, one per slice: the last two slices START in the tail
+    (2, 8, 256, 320, 192, 0, 5),          # slices that straddle the 3x3 taps / tail boundary, 160-wide N tile
+])
+def test_conv_gemm_tail_sources(N, H, C, Cout, Ct1, Ct2, splitk):
+    """conv3x3(h) + conv1x1(cat(t1, t2)) as ONE launch (ResnetBlock2D conv2 + conv_shortcut, es_gemm_desc.t1/t2)."""
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + C + Ct1 + Ct2)
+    h = q16(torch.randn(N, C, H, H, generator=g))
+    t1 = q16(torch.randn(N, Ct1, H, H, generator=g))
+    t2 = q16(torch.randn(N, Ct2, H, H, generator=g)) if Ct2 else None
+    w3 = q16(torch.randn(Cout, C, 3, 3, generator=g) / (9 * C) ** 0.5)
+    w1 = q16(torch.randn(Cout, Ct1 + Ct2, 1, 1, generator=g) / (Ct1 + Ct2) ** 0.5)
+    b = torch.randn(Cout, generator=g) * 0.1
+    tcat = t1 if t2 is None else torch.cat([t1, t2], 1)
+    ref = F.conv2d(h, w3, None, padding=1) + F.conv2d(tcat, w1, None) + b[None, :, None, None]
+    pw = ops.pack_weight_tail(w3, w1, b, torch.float16, DEV)
+    y = ops.conv_gemm(nhwc(h), pw, tail=(nhwc(t1), None if t2 is None else nhwc(t2)), splitk=splitk)
+    assert rel_err(y.permute(0, 3, 1, 2), ref) < 3e-3
+    with pytest.raises(Exception):
+        ops.conv_gemm(nhwc(h), pw, tail=(nhwc(t1)[..., :32],))
+
+
+def test_conv_gemm_tail_sources_grouped_matches_per_group():
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(77)
+    C, Cout, Ct, H = 64, 128, 64, 16
+    pws, hs, ts = [], [], []
+    for n in (2, 1):
+        pws.append(ops.pack_weight_tail(q16(torch.randn(Cout, C, 3, 3, generator=g) / 24), q16(torch.randn(Cout, Ct, generator=g) / 8),
+                                        torch.randn(Cout, generator=g) * 0.1, torch.float16, DEV))
+        hs.append(nhwc(q16(torch.randn(n, C, H, H, generator=g))))
+        ts.append(nhwc(q16(torch.randn(n, Ct, H, H, generator=g))))
+    sep = torch.cat([ops.conv_gemm(h, p, tail=(t,), splitk=1) for h, p, t in zip(hs, pws, ts)], 0)
+    grp = ops.conv_gemm(torch.cat(hs, 0), pws, tail=(torch.cat(ts, 0),), group_n=[2, 1], splitk=1)
+    assert torch.equal(sep, grp)
+
+
+def test_two_group_launches_group_norm_and_conv():
+    """ngroups == 2 (the group tables have four slots; unused ones must not catch any tile / sample)."""
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(5)
+    C, H, counts = 64, 16, [1, 2]
+    x = torch.randn(sum(counts), H, H, C, generator=g).to(DEV, torch.float16)
+    gam = [(1 + 0.1 * torch.randn(C, generator=g)).to(DEV) for _ in counts]
+    bet = [(0.1 * torch.randn(C, generator=g)).to(DEV) for _ in counts]
+    ng = ops.group_norm(x, gam, bet, 32, 1e-5, True, group_n=counts)
+    a = 0
+    for i, n in enumerate(counts):
+        assert torch.equal(ng[a:a + n], ops.group_norm(x[a:a + n].contiguous(), gam[i], bet[i], 32, 1e-5, True))
+        a += n
+    pws = [ops.pack_weight(torch.randn(128, C, 3, 3, generator=g) / 24, torch.randn(128, generator=g) * 0.1, torch.float16, DEV)
+           for _ in counts]
+    yg = ops.conv_gemm(x, pws, group_n=counts, splitk=1)
+    a = 0
+    for i, n in enumerate(counts):
+        assert torch.equal(yg[a:a + n], ops.conv_gemm(x[a:a + n].contiguous(), pws[i], splitk=1))
+        a += n
