@@ -187,8 +187,6 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
       (void*)wsel, (short)0, (int)((size_t)p.rows_padded * p.Kpad * 2), 0x00020000);
   const auto rX1 = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.x, (short)0, (int)((size_t)p.N * p.Hsrc * p.Wsrc * p.C1 * 2), 0x00020000);
-  const auto rX2 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.x2 ? p.x2 : p.x), (short)0, (int)((size_t)p.N * p.Hsrc * p.Wsrc * (p.x2 ? p.C2 : p.C1) * 2), 0x00020000);
   const void* const pt1 = tail1 ? tail1 : p.x;
   const void* const pt2 = tail2 ? tail2 : p.x;
   const void* const px = p.x;
@@ -221,7 +219,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
   const int pk_ksize = p.ksize, pk_pad = p.pad, pk_up = p.upsample, pk_wsrc = p.Wsrc;
 #define row_offsets(tp, cs, chan) \
   row_offsets_fn<XI>(voff, iy0, ix0, nb, (tp), (cs), (chan), pk_ksize, KK, pk_pad, Hin, Win, pk_up, pk_wsrc)
-  auto issue_tile = [&, pt1, pt2, px, px2, nX1, nX2, nT1, nT2, pC1, pC2, pCt1, pCt2, KK, Ctot, Ktrue, Hin, Win, pk_ksize, pk_pad, pk_up, pk_wsrc, wave, kc, rW, ks_tail](int ks, int stage) __attribute__((always_inline)) {
+  auto issue_tile = [&](int ks, int stage) __attribute__((always_inline)) {
     char* xs = smem + stage * (XT + WT);
     char* ws = xs + XT;
     const int soff_w = ks * RB;
