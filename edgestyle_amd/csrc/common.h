@@ -99,15 +99,23 @@ ES_DEVICE float wave_max(float v) {
 // the fusion passes and GEMM epilogues, whose outputs are rounded to 16 bits anyway.
 ES_DEVICE float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // exact (erf) GELU, as torch.nn.functional.gelu default used by diffusers GEGLU.  erf by Abramowitz-Stegun 7.1.26
-// (|abs err| <= 1.5e-7, far below fp16/bf16 resolution): one rcp + one exp + 5 FMA instead of libm erff's ~40 ops.
-ES_DEVICE float erf_as(float x) {
+// (|abs err| <= 5e-7 against torch's erf GELU over [-12, 12], far below fp16/bf16 resolution), arranged for the GEGLU epilogue:
+//   gelu(x) = x * Phi(x),  Phi(x) = x >= 0 ? 1 - h : h,  h = 0.5 * poly(t) * exp(-x^2 / 2),  t = 1 / (1 + p |x| / sqrt 2)
+// with the 0.5 folded into the polynomial, the 1/sqrt 2 into p, exp as exp2 of one pre-scaled product: one rcp, one
+// exp2, 5 FMA/mul for the polynomial, 6 more ops - 16 issue slots instead of 21 for 0.5 x (1 + erf(x / sqrt 2)).
+// (Measured: 505.5 vs 505.6 ms per image - the FF projections are not bound by this epilogue arithmetic.)
+ES_DEVICE float gelu_f(float x) {
   const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float r = 1.0f - poly * __expf(-ax * ax);
-  return copysignf(r, x);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(ax, 0.3275911f * 0.70710678118654752f, 1.0f));
+  const float u = x * 0.84932180028801904f;                       // sqrt(log2(e) / 2): exp(-x^2/2) = exp2(-u^2)
+  const float e = __builtin_amdgcn_exp2f(-(u * u));
+  float poly = __builtin_fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+  poly = __builtin_fmaf(t, poly, 0.5f * 1.421413741f);
+  poly = __builtin_fmaf(t, poly, 0.5f * -0.284496736f);
+  poly = __builtin_fmaf(t, poly, 0.5f * 0.254829592f);
+  const float h = poly * t * e;                                    // 0.5 * erfc(|x| / sqrt 2)
+  return x * (x >= 0.f ? 1.0f - h : h);
 }
-ES_DEVICE float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
 
 // transposed LDS read: 16-lane group reads a 4x16 block of 16-bit elements, lane i gets column i (4 rows)
 ES_DEVICE u32x2 lds_read_tr16(const void* lds_ptr) {
