@@ -45,7 +45,15 @@ def main():
             row.append(t)
         ops.FORCE_BN = 0
         ops.BIG_TILE = False
-        print(f"M={M} K={K} N={N}: planner {row[0]:.1f} us, 256x320 tile {row[1]:.1f} us", flush=True)
+        ops.FORCE_BK = 32                     # half-depth stages: three 4-wave workgroups per CU
+        ew = ops.EIGHT_WAVES
+        ops.EIGHT_WAVES = False
+        try:
+            row.append(timed(lambda: [ops.conv_gemm(x, pws[i], residual=res, out=outs[i]) for i in range(R)], R))
+        finally:
+            ops.FORCE_BK = 0
+            ops.EIGHT_WAVES = ew
+        print(f"M={M} K={K} N={N}: planner {row[0]:.1f} us, 256x320 tile {row[1]:.1f} us, BK=32 x 3 workgroups/CU {row[2]:.1f} us", flush=True)
 
 
 if __name__ == "__main__":
