@@ -112,6 +112,40 @@ def test_layer_norm_fold_algebra():
     assert float((y - ref).abs().max()) < 1e-4
 
 
+def test_tail_and_ffo_fold_algebra():
+    """The two weight folds of this path restated on the CPU from the packed tensors themselves.
+    (a) ops.pack_weight_tail: conv3x3(h) + conv1x1(t) == one GEMM over K = (ky,kx,c) taps of h followed by t's channels at
+        the output pixel (ResnetBlock2D conv2 + conv_shortcut);
+    (b) engine.Transformer.ffo: proj_out(ff2(f) + tok) + x == [Wp Wf | Wp] [f | tok] + (Wp bf + bp) + x."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(9)
+    N, C, Ct, Cout, H = 2, 64, 128, 96, 5
+    h, t = torch.randn(N, C, H, H, generator=g), torch.randn(N, Ct, H, H, generator=g)
+    w3, w1 = torch.randn(Cout, C, 3, 3, generator=g) / 24, torch.randn(Cout, Ct, 1, 1, generator=g) / 11
+    b = torch.randn(Cout, generator=g)
+    pw = ops.pack_weight_tail(w3, w1, b, torch.float32, "cpu")
+    assert pw.ctail == Ct and pw.cin == C and pw.ksize == 3 and pw.kpad == 9 * C + Ct
+    cols = F.unfold(h, 3, padding=1)                                  # [N, C*9, HW], index c*9 + tap
+    cols = cols.view(N, C, 9, H * H).permute(0, 3, 2, 1).reshape(N, H * H, 9 * C)      # tap-major (ky,kx,c), like the kernel's K
+    a = torch.cat([cols, t.permute(0, 2, 3, 1).reshape(N, H * H, Ct)], 2)
+    y = (a @ pw.w[:Cout].T + pw.bias[:Cout]).permute(0, 2, 1).reshape(N, Cout, H, H)
+    ref = F.conv2d(h, w3, None, padding=1) + F.conv2d(t, w1, None) + b[None, :, None, None]
+    assert float((y - ref).abs().max()) < 1e-4
+    with pytest.raises(Exception):
+        ops.pack_weight_tail(w3[:, :40], w1, b, torch.float32, "cpu")      # 40 input channels: not a multiple of 64
+
+    Cm, M = 64, 11
+    f, tok, x = torch.randn(M, 4 * Cm, generator=g), torch.randn(M, Cm, generator=g), torch.randn(M, Cm, generator=g)
+    wf, bf = torch.randn(Cm, 4 * Cm, generator=g) / 16, torch.randn(Cm, generator=g) * 0.1
+    wp, bp = torch.randn(Cm, Cm, generator=g) / 8, torch.randn(Cm, generator=g) * 0.1
+    ref = F.linear(F.linear(f, wf, bf) + tok, wp, bp) + x
+    wc = torch.cat([wp.double() @ wf.double(), wp.double()], 1).float()
+    bc = (wp.double() @ bf.double() + bp.double()).float()
+    pwc = ops.pack_weight(wc, bc, torch.float32, "cpu")
+    y = torch.cat([f, tok], 1) @ pwc.w[:Cm, : 5 * Cm].T + pwc.bias[:Cm] + x
+    assert float((y - ref).abs().max()) < 1e-4
+
+
 def test_controllora_state_dict_is_lora_plus_zero_convs_only():
     ucfg = C.tiny_unet()
     ws = make_weights(ucfg, C.tiny_vae())
