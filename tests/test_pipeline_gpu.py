@@ -289,3 +289,19 @@ def test_try_on_service_batched_equals_individually_served(built):
     assert svc.stats["calls"] == 2 and svc.stats["images"] == 3
     for a, b in zip(got, want):
         assert a.shape == b.shape and psnr(a, b) >= 45.0
+
+
+def test_pipeline_odd_batch_matches_single_images(built):
+    """B = 3 (not a captured serving size, not a multiple of anything): every image of the batch equals the image the same
+    inputs give alone (tile plans differ with the batch: PSNR, not bits)."""
+    pipe, ws, ucfg, vcfg = built
+    lat, pe, ne, conds = _inputs(ucfg, 3, seed=7)
+    conds3 = [c.repeat(3, 1, 1, 1) * torch.tensor([1.0, 0.5, -0.7])[:, None, None, None] for c in conds]
+    conds3 = [c.half().float() for c in conds3]
+    out = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds3, latents=lat, guidance_scale=6.0,
+               num_inference_steps=4, output_type="pt").images
+    assert out.shape[0] == 3 and bool(torch.isfinite(out).all())
+    for i in range(3):
+        one = pipe(prompt_embeds=pe[i:i + 1], negative_prompt_embeds=ne[i:i + 1], image=[c[i:i + 1] for c in conds3],
+                   latents=lat[i:i + 1], guidance_scale=6.0, num_inference_steps=4, output_type="pt").images
+        assert psnr(out[i:i + 1], one) >= 45.0, i
