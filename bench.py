@@ -10,7 +10,9 @@ DDIM] -> VAE decode -> [0,1] image, inputs already resident in HBM (SURVEY.md §
 random-init SD1.5-shaped tensors (no checkpoints exist offline), data is synthetic.
 
 Prints ONE JSON line on rank 0 with the contract fields plus `roofline` (implicit-GEMM conv/linear kernel, MFMA
-bound) and `cpu_baseline` (the CPU oracle timed on this host's cores on one denoising step).
+bound), `cpu_baseline` (the CPU oracle timed on this host's cores on a bounded sample of denoising steps), `parity` (the
+HIP step of the benchmarked configuration against that oracle on identical inputs), `throughput_mode` (BASELINE
+configs[2], batch 8, with its own roofline) and `stress_mode` (BASELINE configs[4], 768x768 bf16 batch 4).
 """
 import argparse
 import json
@@ -96,13 +98,27 @@ def make_inputs(ucfg, vcfg, B, device, seed=42):
     return lat, pe.to(device), ne.to(device), imgs, cond_noise
 
 
-def gemm_roofline(pipe):
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def gemm_roofline(pipe, traffic_profile="r02_gemm_pmc_traffic_b1.json", replay_iters=20):
     """Price the implicit-GEMM kernel against the dense fp16 MFMA peak with ALGORITHMIC flops (2*M*Cout*k*k*Cin) over
     the es_conv_gemm launches of one captured denoising step (the unit replayed 50x per image = 96 % of the image's
-    FLOPs).  Launch durations are in-kernel s_memrealtime stamps (min workgroup start .. max workgroup end) taken
-    while the step replays as a hipGraph: host-side HIP events cannot see inside a graph replay, and around eager
-    launches they mostly measure host enqueue gaps.  The rocprofv3 summary under profiles/ gives the same averages."""
-    res = pipe.profile_one_step()
+    FLOPs).  Two clocks, both reported:
+      * `avg_launch_us` / `achieved`: in-kernel s_memrealtime stamps (min workgroup start .. max workgroup end) taken
+        while the step replays as a hipGraph - per-launch resolution (conv3x3_only comes from it), but the stamp mode
+        adds two global atomics per workgroup, so it reads a little high;
+      * `replay`: the same launch list run by the production kernels (no stamps), GEMM launches only, captured as one
+        graph and timed by HIP events around `replay_iters` replays on the launching stream - what rocprofv3's
+        per-kernel average (profiles/) must agree with."""
+    res = pipe.profile_one_step(gemm_replay_iters=replay_iters)
     tot_f = sum(m[0] for m, _ in res)
     tot_t = sum(t for _, t in res)
     f3 = sum(m[0] for m, _ in res if m[1] == 3)
@@ -110,7 +126,7 @@ def gemm_roofline(pipe):
     shapes = {}
     if os.environ.get("ES_DUMP_GEMM"):
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "gemm_step_launches.json"), "w") as f:
+        with open(os.path.join(ROOT, "gpurun_out", os.environ.get("ES_DUMP_GEMM_NAME", "gemm_step_launches.json")), "w") as f:
             json.dump([dict(geom=m[3], seconds=t) for m, t in res], f)
     for (fl, k, shp, _g), t in res:
         a = shapes.setdefault(shp, [0, 0.0, 0.0])
@@ -121,8 +137,8 @@ def gemm_roofline(pipe):
             log(f"  {shp} {c} {t * 1e6:.0f} {t / c * 1e6:.1f} {fl / t / 1e12:.0f}")
     n = len(res)
     ach = tot_f / tot_t / 1e12
-    traffic = None
-    tp = os.path.join(ROOT, "profiles", "r01_gemm_pmc_traffic_b1.json")
+    traffic, traffic_src = None, None
+    tp = os.path.join(ROOT, "profiles", traffic_profile)
     if os.path.exists(tp):   # HBM-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
         try:                  # gfx950 corrections applied) over the same launch list replayed stand-alone; see DESIGN.md §7
             prof = json.load(open(tp)).get("conv_gemm_kernel", {})
@@ -130,42 +146,72 @@ def gemm_roofline(pipe):
             # only valid for the workload it was collected on (same launch list: count and algorithmic bytes)
             if prof.get("launches") == n and abs(prof.get("algorithmic_bytes_per_launch", 0) - alg_now) <= 0.01 * alg_now:
                 traffic = prof.get("hbm_bytes_per_launch")
+                traffic_src = f"profiles/{traffic_profile} (builder-collected rocprofv3 --pmc passes, not measured in this run)"
         except Exception:
             traffic = None
-    return {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv3x3/1x1/linear)", "achieved": round(ach, 2),
-            "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-            "launches_per_step": n, "avg_launch_us": round(tot_t * 1e6 / max(n, 1), 2),
-            "algorithmic_gflop_per_launch": round(tot_f / max(n, 1) / 1e9, 3),
-            "algorithmic_bytes_per_launch": int(sum(m[3].get("algorithmic_bytes", 0) for m, _ in res) / max(n, 1)),
-            "gemm_time_per_step_ms": round(tot_t * 1e3, 3),
-            "conv3x3_only": {"achieved": round(f3 / t3 / 1e12, 2) if t3 else None,
-                             "frac": round(f3 / t3 / 1e12 / MFMA_PEAK_TFLOPS, 4) if t3 else None},
-            "how": "in-kernel s_memrealtime stamps on every es_conv_gemm launch of one hipGraph-replayed denoising step"}
+    out = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv3x3/1x1/linear)", "achieved": round(ach, 2),
+           "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+           "traffic_source": traffic_src,
+           "launches_per_step": n, "avg_launch_us": round(tot_t * 1e6 / max(n, 1), 2),
+           "algorithmic_gflop_per_launch": round(tot_f / max(n, 1) / 1e9, 3),
+           "algorithmic_bytes_per_launch": int(sum(m[3].get("algorithmic_bytes", 0) for m, _ in res) / max(n, 1)),
+           "gemm_time_per_step_ms": round(tot_t * 1e3, 3),
+           "conv3x3_only": {"achieved": round(f3 / t3 / 1e12, 2) if t3 else None,
+                            "frac": round(f3 / t3 / 1e12 / MFMA_PEAK_TFLOPS, 4) if t3 else None,
+                            "launches": sum(1 for m, _ in res if m[1] == 3)},
+           "how": "in-kernel s_memrealtime stamps on every es_conv_gemm launch of one hipGraph-replayed denoising step"}
+    rp = getattr(pipe, "last_gemm_replay_ms", None)
+    if rp:
+        out["replay"] = {"ms_per_step": round(rp, 3), "avg_launch_us": round(rp * 1e3 / max(n, 1), 2),
+                         "achieved": round(tot_f / (rp * 1e-3) / 1e12, 2),
+                         "frac": round(tot_f / (rp * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                         "how": f"production kernels (no stamps): the {n} es_conv_gemm launches of the step + their split-K "
+                                f"reduces as one hipGraph, HIP events around {replay_iters} replays"}
+    return out
 
 
-def cpu_baseline(ws, ucfg, B, steps_total, tiny):
-    """The CPU oracle (plain PyTorch fp32 restatement of the reference diffusers pipeline) on this host's cores:
-    ONE full 6-cond denoising step at the benchmark batch, extrapolated to the 50-step loop."""
+def cpu_baseline_and_parity(pipe, ws, ucfg, B, steps_total, tiny):
+    """The CPU oracle (plain PyTorch fp32 restatement of the reference diffusers pipeline) on this host's cores: full
+    6-cond denoising steps at the benchmark batch (one untimed warm-up step, then the timed sample), extrapolated to the
+    50-step loop.  The FIRST oracle step doubles as the checker of the benchmarked configuration: the HIP step (same
+    grouped launches the timed region replays) runs on the same inputs and weights and its error is reported."""
     from oracle import sd15_oracle as O
     from tests.helpers import oracle_nets
     cores = host_cores()
     torch.set_num_threads(cores)
-    cws = {k: {kk: vv.float().cpu() for kk, vv in v.items()} for k, v in ws.items() if k != "vae"}
+    # fp16-rounded weights on both sides: the HIP path stores fp16, the oracle computes with the same values in fp32
+    cws = {k: {kk: vv.half().float().cpu() for kk, vv in v.items()} for k, v in ws.items() if k != "vae"}
     g = torch.Generator().manual_seed(1)
     N, s, c0 = 2 * B, ucfg.sample_size, ucfg.block_out_channels[0]
-    x = torch.randn(N, 4, s, s, generator=g)
-    ehs = torch.randn(N, 77, ucfg.cross_attention_dim, generator=g) * 0.5
-    conds = [torch.randn(N, c0, s, s, generator=g) * 0.3 for _ in range(6)]
+    x = torch.randn(N, 4, s, s, generator=g).half().float()
+    ehs = (torch.randn(N, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+    conds = [(torch.randn(N, c0, s, s, generator=g) * 0.3).half().float() for _ in range(6)]
     nets = oracle_nets(cws, ucfg)
-    n_sample = 1 if tiny else 2                 # ~13 s of CPU work on the GPU box's 16 host threads (first step also warms oneDNN)
-    t0 = time.time()
+    n_sample = 1 if tiny else 2
     with torch.no_grad():
+        ref = O.denoise_step(cws["unet"], ucfg, cws["fusion"], nets, x, 501, ehs, conds, [1.0] * 6)   # warm-up + checker
+        t0 = time.time()
         for i in range(n_sample):
-            O.denoise_step(cws["unet"], ucfg, cws["fusion"], nets, x, 501 - 20 * i, ehs, conds, [1.0] * 6)
-    dt = (time.time() - t0) / n_sample
-    return {"value": round(B / (dt * steps_total), 6), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{n_sample} of {steps_total} denoising steps (6 ControlNets + fusion + UNet, CFG batch {N}) = {dt:.1f} s each, "
-                      f"x{steps_total}; condition embedding and VAE decode excluded"}
+            O.denoise_step(cws["unet"], ucfg, cws["fusion"], nets, x, 481 - 20 * i, ehs, conds, [1.0] * 6)
+        dt = (time.time() - t0) / n_sample
+    dev = pipe.device
+    runner = pipe._runner
+    mode_ok = runner.mode == "grouped" and runner._grouped_encoder(N).groupable(
+        (s >> (len(ucfg.block_out_channels) - 1)) ** 2)
+    got = runner.step_nchw(x.to(dev), 501, ehs.to(dev), [c.to(dev) for c in conds], [1.0] * 6).float().cpu()
+    err = (got - ref).abs()
+    parity = {"what": f"one HIP denoising step (6 ControlNets + fusion + UNet, CFG batch {N}, "
+                      f"{'grouped lockstep launches' if mode_ok else 'per-net launches'}) vs the CPU oracle on identical "
+                      "inputs and fp16-rounded weights",
+              "max_abs": round(float(err.max()), 6), "rel_to_max": round(float(err.max() / ref.abs().max()), 6),
+              "rms_rel": round(float(err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()), 6),
+              "bar_max_abs": 2e-2, "ok": bool(float(err.max()) <= 2e-2)}
+    base = {"value": round(B / (dt * steps_total), 6), "unit": "images/s", "cores": cores, "kind": "port",
+            "cpu": cpu_model(),
+            "sample": f"{n_sample} of {steps_total} denoising steps after one untimed warm-up step (6 ControlNets + fusion "
+                      f"+ UNet, CFG batch {N}) = {dt:.1f} s each on {cores} threads, x{steps_total}; condition embedding "
+                      "and VAE decode excluded"}
+    return base, parity
 
 
 def main():
@@ -182,6 +228,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches (needed under rocprofv3 --pmc, which cannot "
                                                             "collect counters through a hipGraph replay)")
+    ap.add_argument("--no-stress-mode", action="store_true",
+                    help="skip the extra 768x768 bf16 batch-4 (BASELINE configs[4]) measurement")
     ap.add_argument("--no-throughput-mode", action="store_true",
                     help="skip the extra batch-8 (BASELINE configs[2]) measurement reported beside the headline value")
     args = ap.parse_args()
@@ -248,15 +296,20 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "bf16",
             "data": "synthetic (seeded random-init SD1.5-shaped weights, random conds/latents/prompt embeds, seed 42)",
-            "config": {"workload": ("TINY plumbing config" if args.tiny else
-                                    f"BASELINE configs[{1 if B == 1 else 2}]: full 6-cond edgestyle_multicontrolnet + controllora, "
-                                    f"{args.resolution}x{args.resolution}, {args.ddim_steps} DDIM steps, CFG 7.5, batch={B}/GPU, hipGraph-captured step, "
-                                    "cond embedding + VAE decode included"),
-                       "images_per_gpu": B, "ddim_steps": args.ddim_steps, "parallelism": f"dp{world} (independent images, one RCCL gather)"},
+            "config": {"workload": "", "images_per_gpu": B, "ddim_steps": args.ddim_steps, "parallelism": f"dp{world} (independent images, one RCCL gather)"},
         }
+        cfg_idx = 4 if args.resolution != 512 else (1 if B == 1 else 2)
+        line["config"]["workload"] = ("TINY plumbing config" if args.tiny else
+                                      f"BASELINE configs[{cfg_idx}]: full 6-cond edgestyle_multicontrolnet + controllora, "
+                                      f"{args.resolution}x{args.resolution}, {args.ddim_steps} DDIM steps, CFG 7.5, batch={B}/GPU, "
+                                      "hipGraph-captured step, cond embedding + VAE decode included")
         if not args.no_roofline:
             line["roofline"] = gemm_roofline(pipe)
             log("roofline leg done")
+        if not args.no_cpu_baseline and world == 1:
+            # before the batch-8 leg: the parity step must run the very configuration the timed region replayed
+            line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(pipe, ws, ucfg, B, args.ddim_steps, args.tiny)
+            log(f"cpu baseline + parity done: {line['parity']}")
         if not args.no_throughput_mode and world == 1 and B != 8 and not args.tiny and args.resolution == 512:
             # BASELINE configs[2]: same path, 8 images per step (hipGraph-captured, throughput mode); reported beside
             # the headline value, never instead of it
@@ -265,19 +318,49 @@ def main():
             def one8():
                 return pipe(prompt_embeds=pe8, negative_prompt_embeds=ne8, image=imgs8, latents=lat8, guidance_scale=7.5,
                             num_inference_steps=args.ddim_steps, output_type="pt", cond_noise=cn8).images
+            one8()                                         # capture + warm clocks on this shape
             one8()
             torch.cuda.synchronize()
+            n8 = 2
             t8 = time.perf_counter()
-            img8 = one8()
+            for _ in range(n8):
+                img8 = one8()
             torch.cuda.synchronize()
-            t8 = time.perf_counter() - t8
+            t8 = (time.perf_counter() - t8) / n8
             assert bool(torch.isfinite(img8).all())
             line["throughput_mode"] = {"workload": "BASELINE configs[2]: same path, batch=8 per step", "value": round(8 / t8, 4),
-                                       "unit": "images/s", "ms_per_step": round(t8 * 1e3, 1), "steps": 1}
+                                       "unit": "images/s", "ms_per_step": round(t8 * 1e3, 1), "steps": n8, "warmup": 2}
+            if not args.no_roofline:
+                r8 = gemm_roofline(pipe, traffic_profile="r02_gemm_pmc_traffic_b8.json", replay_iters=5)
+                line["throughput_mode"]["roofline"] = {k: r8[k] for k in (
+                    "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "launches_per_step",
+                    "avg_launch_us", "gemm_time_per_step_ms", "conv3x3_only", "replay") if k in r8}
             log(f"throughput mode (batch 8): {8 / t8:.3f} images/s")
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(ws, ucfg, B, args.ddim_steps, args.tiny)
-            log("cpu baseline done")
+            del lat8, pe8, ne8, imgs8, cn8, img8
+        if not args.no_stress_mode and world == 1 and not args.tiny and args.resolution == 512 and dtype == torch.float16:
+            # BASELINE configs[4]: bf16, 768x768, batch 4 (outside the reference's own domain): one warmed,
+            # timed pipeline call on a second pipeline object; the 512 one is released first
+            pipe._loops.clear()
+            pipe._runner = None
+            del pipe
+            torch.cuda.empty_cache()
+            pipe5, _ws5, ucfg5, vcfg5 = build_pipeline(device, torch.bfloat16, resolution=768)
+            lat5, pe5, ne5, imgs5, cn5 = make_inputs(ucfg5, vcfg5, 4, device, seed=42)
+
+            def one5():
+                return pipe5(prompt_embeds=pe5, negative_prompt_embeds=ne5, image=imgs5, latents=lat5, guidance_scale=7.5,
+                             num_inference_steps=args.ddim_steps, output_type="pt", cond_noise=cn5).images
+            one5()
+            torch.cuda.synchronize()
+            t5 = time.perf_counter()
+            img5 = one5()
+            torch.cuda.synchronize()
+            t5 = time.perf_counter() - t5
+            assert img5.shape == (4, 3, 768, 768) and bool(torch.isfinite(img5).all())
+            line["stress_mode"] = {"workload": "BASELINE configs[4]: bf16, 768x768, 50 DDIM steps, batch=4, VAE decode included",
+                                   "value": round(4 / t5, 4), "unit": "images/s", "ms_per_step": round(t5 * 1e3, 1),
+                                   "steps": 1, "warmup": 1, "dtype": "bf16"}
+            log(f"stress mode (768x768 bf16 batch 4): {4 / t5:.3f} images/s")
         faulthandler.cancel_dump_traceback_later()
         print(json.dumps(line), flush=True)
     if world > 1:

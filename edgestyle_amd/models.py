@@ -606,39 +606,74 @@ class EdgeStyleMultiControlNetModel(_HipModel):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+class StepState:
+    """Every device buffer a (captured) denoising step reads that outlives one pipeline call: the cross-attention K/V
+    projections of the text states, the batch-concatenated condition embeddings / replicated sample of the grouped
+    conv_in launch, and the per-call time-projection table.  One StepState belongs to ONE `pipeline._Loop` (one graph):
+    the buffers are allocated once, refilled in place, and `signature()` lists their addresses so the loop re-captures
+    its graph if any of them ever moves (a graph replays the pointers it was captured with)."""
+
+    def __init__(self):
+        self.ctx_unet: Optional[List[torch.Tensor]] = None
+        self.ctx_nets: Optional[List[List[torch.Tensor]]] = None
+        self.ctx_grouped: Optional[List[torch.Tensor]] = None
+        self.ctx_guess: Optional[List[List[torch.Tensor]]] = None
+        self.ctx_single: Optional[List[torch.Tensor]] = None
+        self.cond_cat = self.x_rep = None
+        self.cond_src = None
+        self.tproj_table = self.tproj_cur = None
+
+    def signature(self) -> Tuple[int, ...]:
+        sig = []
+
+        def walk(o):
+            if torch.is_tensor(o):
+                sig.append(o.data_ptr())
+            elif isinstance(o, (list, tuple)):
+                for x in o:
+                    walk(x)
+            else:
+                sig.append(0)
+        for name in ("ctx_unet", "ctx_nets", "ctx_grouped", "ctx_guess", "ctx_single", "cond_cat", "x_rep", "tproj_table",
+                     "tproj_cur"):
+            walk(getattr(self, name))
+        return tuple(sig)
+
+
+def _fill_context(engine, ehs, outs):
+    """engine.context into `outs` when they fit (in place: graph-stable), else fresh tensors."""
+    if outs is not None and outs[0].shape[0] == ehs.shape[0]:
+        return engine.context(ehs, outs)
+    return engine.context(ehs)
+
+
 class StepRunner:
     """controlnet -> unet for one timestep == OnnxUNetAndControlnets.forward (export_onnx.py:43-74), with all
-    per-image constants (text K/V projections, conditioning embeddings) hoisted out and static buffers so that the
-    call sequence is hipGraph-capturable.  Inputs/outputs NHWC."""
+    per-image constants (text K/V projections, conditioning embeddings) hoisted out and static buffers (StepState) so
+    that the call sequence is hipGraph-capturable.  Inputs/outputs NHWC.
 
-    def __init__(self, unet: UNet2DConditionModel, controlnet: EdgeStyleMultiControlNetModel):
+    `controlnet` is the reference's fused 6-net EdgeStyleMultiControlNetModel, or ONE plain ControlNetModel (PL:338-351:
+    its 13 residuals go to the UNet without fusion blocks - BASELINE configs[0])."""
+
+    def __init__(self, unet: UNet2DConditionModel, controlnet):
         self.unet, self.controlnet = unet, controlnet
         self.device, self.dtype = unet.device, unet.dtype
+        self.single = isinstance(controlnet, ControlNetModel)
         # nets sharing weights run as ONE batched chain (measured: 7 unbatched chains are 12 % slower at batch 1)
-        self.groups = controlnet.groups()
+        self.groups = [(controlnet, [0])] if self.single else controlnet.groups()
         self.kmax = max(len(p) for _, p in self.groups)
-        self.ctx_unet = None
-        self.ctx_nets = None
         # execution of the four independent encoder chains of a step:
         #   "grouped" — one lockstep pass of grouped launches over the batch-concatenated activations (default)
         #   "streams" — one HIP stream per chain (parallel hipGraph branches)
         #   "serial"  — one chain after the other (profiling)
         self.mode = os.environ.get("ES_CHAIN_MODE", "serial" if os.environ.get("ES_SERIAL") == "1" else "grouped")
         self._grouped = None
-        self.ctx_grouped = None
         self._streams = None
-        self.ctx_guess = None
-        # grouped mode: the time-embedding MLP + every ResnetBlock time projection depend on the timestep only, so
-        # they are computed for ALL steps of a call at once (set_time_table) and one row is gathered per step
-        self.tproj_table = None          # [T, ntot, width] compute dtype (the buffers of the current call)
-        self.tproj_cur = None            # [ntot, width]
-        self._tproj_bufs = {}            # shape -> (table, cur): one pair per loop geometry, never freed (graph pointers)
-        # grouped mode: conv_in(sample) + cond of all nets and the UNet as ONE grouped launch: the sample replicated
-        # per slot and the (per call constant) condition embeddings concatenated in group order, zeros for the UNet
-        self._convin_bufs = {}           # shape -> (x_rep, cond_cat)
-        self.cond_cat = None
-        self.x_rep = None
-        self._cond_src = None
+        # every buffer a step reads between calls lives in a StepState; `state` is the one the next step() uses
+        # (the pipeline switches it to the running loop's; stand-alone callers get this default one)
+        self.state = StepState()
+        self.keep_debug = False          # tests: keep the last step's decoder inputs (fused residuals) in self.debug
+        self.debug = None
 
     @classmethod
     def from_state_dicts(cls, ws: Dict[str, Dict[str, torch.Tensor]], ucfg: UNetConfig, dtype, device,
@@ -657,27 +692,30 @@ class StepRunner:
         return cls(unet, mc)
 
     def set_context(self, ehs: torch.Tensor, guess_mode: bool = False, n_cn: Optional[int] = None):
-        """ehs: [N,77,D] device dtype. Computes every cross-attention K/V projection once (constant over the loop).
+        """ehs: [N,77,D] device dtype. Computes every cross-attention K/V projection once (constant over the loop),
+        in place into the current StepState's buffers when they exist.
         guess_mode: the ControlNets see the last n_cn rows of ehs — under CFG only the conditional half (PL:453-459)."""
-        self.ctx_unet = self.unet.engine.context(ehs, self.ctx_unet)
+        st = self.state
+        st.ctx_unet = _fill_context(self.unet.engine, ehs, st.ctx_unet)
         if guess_mode:
             ehs_c = ehs[ehs.shape[0] - (n_cn or ehs.shape[0]):]
-            self.ctx_guess = [net.engine.context(ehs_c.repeat(len(pos), 1, 1) if len(pos) > 1 else ehs_c)
-                              for net, pos in self.groups]
+            old = st.ctx_guess or [None] * len(self.groups)
+            st.ctx_guess = [_fill_context(net.engine, ehs_c.repeat(len(pos), 1, 1) if len(pos) > 1 else ehs_c, o)
+                            for (net, pos), o in zip(self.groups, old)]
             return
-        old = self.ctx_nets or [None] * len(self.groups)
-        self.ctx_nets = []
+        old = st.ctx_nets or [None] * len(self.groups)
+        st.ctx_nets = []
         for (net, pos), o in zip(self.groups, old):
             k = len(pos)
-            self.ctx_nets.append(net.engine.context(ehs.repeat(k, 1, 1) if k > 1 else ehs, o))
+            st.ctx_nets.append(_fill_context(net.engine, ehs.repeat(k, 1, 1) if k > 1 else ehs, o))
         # batch-concatenated K/V projections for the grouped lockstep pass (static buffers: graph-stable pointers)
-        n_enc = len(self.ctx_nets[0])
-        cat = [torch.cat([c[i] for c in self.ctx_nets] + [self.ctx_unet[i]]) for i in range(n_enc)]
-        if self.ctx_grouped is not None and self.ctx_grouped[0].shape == cat[0].shape:
-            for dst, src in zip(self.ctx_grouped, cat):
+        n_enc = len(st.ctx_nets[0])
+        cat = [torch.cat([c[i] for c in st.ctx_nets] + [st.ctx_unet[i]]) for i in range(n_enc)]
+        if st.ctx_grouped is not None and st.ctx_grouped[0].shape == cat[0].shape:
+            for dst, src in zip(st.ctx_grouped, cat):
                 dst.copy_(src)
         else:
-            self.ctx_grouped = cat
+            st.ctx_grouped = cat
 
     def _grouped_encoder(self, N: int):
         ue = self.unet.engine
@@ -689,80 +727,101 @@ class StepRunner:
 
     def set_time_table(self, timesteps: torch.Tensor, N: int):
         """timesteps: fp32 device [T].  Fills tproj_table[s] = what GroupedEncoder.time_proj would produce at step s
-        (16 launches per call instead of ~20 per step); buffers are reused in place so captured graphs stay valid."""
+        (16 launches per call instead of ~20 per step); the StepState's buffers are reused in place while T is unchanged."""
         ge = self._grouped_encoder(N)
+        st = self.state
         T = int(timesteps.shape[0])
         shape = (T, ge.ntot, ge.width)
-        if shape not in self._tproj_bufs:
-            self._tproj_bufs[shape] = (torch.zeros(shape, dtype=self.dtype, device=self.device),
-                                       torch.zeros(shape[1:], dtype=self.dtype, device=self.device))
-        self.tproj_table, self.tproj_cur = self._tproj_bufs[shape]
+        if st.tproj_table is None or tuple(st.tproj_table.shape) != shape:
+            st.tproj_table = torch.zeros(shape, dtype=self.dtype, device=self.device)
+            st.tproj_cur = torch.zeros(shape[1:], dtype=self.dtype, device=self.device)
         a = 0
         for e, n in zip(ge.encs, ge.counts):
             proj = e.time_proj(timesteps)                                # [T, width_e]
-            self.tproj_table[:, a:a + n, : e.tproj_width] = proj[:, None, :]
+            st.tproj_table[:, a:a + n, : e.tproj_width] = proj[:, None, :]
             a += n
 
     def set_conds(self, conds: Sequence[torch.Tensor]):
-        """conds: the 6 embedded conditions [N,h,w,C0] of this call (constant over the loop)."""
+        """conds: the embedded conditions [N,h,w,C0] of this call (constant over the loop)."""
         N, H, W, C0 = conds[0].shape
         ge = self._grouped_encoder(N)
-        key = (ge.ntot, H, W, C0, self.unet.engine.in_pad)
-        if key not in self._convin_bufs:
-            self._convin_bufs[key] = (torch.zeros((ge.ntot, H, W, self.unet.engine.in_pad), dtype=self.dtype, device=self.device),
-                                      torch.zeros((ge.ntot, H, W, C0), dtype=self.dtype, device=self.device))
-        self.x_rep, self.cond_cat = self._convin_bufs[key]
-        self._cond_src = [c.data_ptr() for c in conds]   # the step only trusts cond_cat for these very buffers
+        st = self.state
+        if st.cond_cat is None or tuple(st.cond_cat.shape) != (ge.ntot, H, W, C0):
+            st.x_rep = torch.zeros((ge.ntot, H, W, self.unet.engine.in_pad), dtype=self.dtype, device=self.device)
+            st.cond_cat = torch.zeros((ge.ntot, H, W, C0), dtype=self.dtype, device=self.device)
+        st.cond_src = [c.data_ptr() for c in conds]      # the step only trusts cond_cat for these very buffers
         a = 0
         for _, pos in self.groups:
             for p in pos:
-                self.cond_cat[a:a + N].copy_(conds[p])
+                st.cond_cat[a:a + N].copy_(conds[p])
                 a += N                                   # the UNet's slot stays zero
 
     def clear_time_table(self):
-        self.tproj_table = self.tproj_cur = None
+        self.state.tproj_table = self.state.tproj_cur = None
+
+    @property
+    def n_nets(self) -> int:
+        return 1 if self.single else len(self.controlnet.nets)
+
+    def _fuse(self, results, N: int, scales, scales_dev, addends=None):
+        """Per-group ControlNet residuals -> the 13 tensors the UNet adds (MC:151-169).  Single ControlNet: they are the
+        net's own (already scaled) residuals."""
+        if self.single:
+            return results[0]
+        nn = self.n_nets
+        res_per_net, bs = [None] * nn, [None] * nn
+        for gi, (net, pos) in enumerate(self.groups):
+            res = results[gi]
+            for j, p in enumerate(pos):
+                res_per_net[p] = [r[j * N:] for r in res]
+                bs[p] = [r.stride(0) for r in res]
+        return self.controlnet.engine.forward(res_per_net, bs, N, scales, scales_dev, addends=addends)
+
+    def _cn_scale(self, scales, scales_dev):
+        """Single ControlNet: the conditioning scale rides on the zero-conv epilogues (CL:266-270)."""
+        if not self.single:
+            return {}
+        return dict(out_scale=float(scales[0]), out_scale_dev=None if scales_dev is None else scales_dev[0:1])
 
     def _step_guess(self, x, t_rows, conds, scales, scales_dev, out):
         """guess_mode (CL:256-264): the 13 residual levels are scaled 0.1..1 log-spaced.  Under CFG (PL:453-459,
         487-497) the ControlNets additionally run on the conditional half only (conds then hold B samples) and the
         unconditional half of the UNet gets no residuals."""
+        st = self.state
         N = x.shape[0]
         Bc = conds[0].shape[0]
         B = N - Bc                                       # first row of the ControlNet batch inside x (0 without CFG)
         ue = self.unet.engine
-        nn = len(self.controlnet.nets)
-        res_per_net, bs = [None] * nn, [None] * nn
         xc = x[B:]
         ls = _guess_level_scales(len(ue.cfg.residual_table()))
+        results = {}
         for gi, (net, pos) in enumerate(self.groups):
             eng = net.engine
             tproj = eng.time_proj(t_rows[: len(pos) * Bc])
-            res = eng.forward(xc, tproj, self.ctx_guess[gi], [conds[p] for p in pos], level_scales=ls)
-            for j, p in enumerate(pos):
-                res_per_net[p] = [r[j * Bc:] for r in res]
-                bs[p] = [r.stride(0) for r in res]
-        fused = self.controlnet.engine.forward(res_per_net, bs, Bc, scales, scales_dev)
+            results[gi] = eng.forward(xc, tproj, st.ctx_guess[gi], [conds[p] for p in pos], level_scales=ls,
+                                      **self._cn_scale(scales, scales_dev))
+        fused = self._fuse(results, Bc, scales, scales_dev)
         tproj = ue.time_proj(t_rows[:N])
-        skips, h = ue.encode(x, tproj, self.ctx_unet)
+        skips, h = ue.encode(x, tproj, st.ctx_unet)
         for s_, f in zip(skips, fused[:-1]):              # torch.cat([zeros, d]) + skip == add into the cond half
             ops.add(s_[B:], f.reshape(s_[B:].shape), out=s_[B:])
         ops.add(h[B:], fused[-1].reshape(h[B:].shape), out=h[B:])
-        return ue.forward(x, tproj, self.ctx_unet, out=out, encoded=(skips, h))
+        return ue.forward(x, tproj, st.ctx_unet, out=out, encoded=(skips, h))
 
     def step(self, x: torch.Tensor, t_rows: torch.Tensor, conds: Sequence[torch.Tensor], scales: Sequence[float],
              scales_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
              step_idx: Optional[torch.Tensor] = None, guess_mode: bool = False) -> torch.Tensor:
-        """x: [N,h,w,8] NHWC; t_rows: fp32 device [kmax*N] (all equal to the timestep); conds: 6 x [N,h,w,C0] NHWC.
+        """x: [N,h,w,8] NHWC; t_rows: fp32 device [kmax*N] (all equal to the timestep); conds: n_nets x [N,h,w,C0] NHWC.
 
         The three batched ControlNet passes and the UNet's own down+mid path do not depend on each other (the
-        residuals are only added after the UNet's down path, PL:500-510), so they run as four concurrent chains on
-        separate HIP streams (forked from / joined into the current stream, hence capturable as parallel hipGraph
-        branches): at batch 1 a single chain's kernels cannot fill 256 CUs."""
+        residuals are only added after the UNet's down path, PL:500-510): by default they run in lockstep as grouped
+        launches (_step_grouped); ES_CHAIN_MODE=streams runs them as four concurrent chains on separate HIP streams
+        (forked from / joined into the current stream, hence capturable as parallel hipGraph branches), =serial one
+        after the other."""
+        st = self.state
         N = x.shape[0]
         if guess_mode:
             return self._step_guess(x, t_rows, conds, scales, scales_dev, out)
-        nn = len(self.controlnet.nets)
-        res_per_net, bs = [None] * nn, [None] * nn
         ue = self.unet.engine
         results = {}
         if self.mode == "grouped":
@@ -774,37 +833,35 @@ class StepRunner:
             net, pos = self.groups[gi]
             eng = net.engine
             tproj = eng.time_proj(t_rows[: len(pos) * N])
-            results[gi] = eng.forward(x, tproj, self.ctx_nets[gi], [conds[p] for p in pos])
+            results[gi] = eng.forward(x, tproj, st.ctx_nets[gi], [conds[p] for p in pos], **self._cn_scale(scales, scales_dev))
 
         def unet_chain():
             tproj = ue.time_proj(t_rows[:N])
-            results["unet"] = (tproj, ue.encode(x, tproj, self.ctx_unet))
+            results["unet"] = (tproj, ue.encode(x, tproj, st.ctx_unet))
 
         chains = [lambda gi=gi: cn_chain(gi) for gi in range(len(self.groups))] + [unet_chain]
         if self.mode == "streams":
             main = torch.cuda.current_stream()
             if self._streams is None:
                 self._streams = [torch.cuda.Stream(device=self.device) for _ in chains]
-            for i, (fn, st) in enumerate(zip(chains, self._streams)):
-                st.wait_stream(main)
-                with torch.cuda.stream(st), ops.lane(i + 1):
+            for i, (fn, stream) in enumerate(zip(chains, self._streams)):
+                stream.wait_stream(main)
+                with torch.cuda.stream(stream), ops.lane(i + 1):
                     fn()
-            for st in self._streams:
-                main.wait_stream(st)
+            for stream in self._streams:
+                main.wait_stream(stream)
         else:
             for fn in chains:
                 fn()
-        for gi, (net, pos) in enumerate(self.groups):
-            res = results[gi]
-            for j, p in enumerate(pos):
-                res_per_net[p] = [r[j * N:] for r in res]
-                bs[p] = [r.stride(0) for r in res]
-        fused = self.controlnet.engine.forward(res_per_net, bs, N, scales, scales_dev)
+        fused = self._fuse(results, N, scales, scales_dev)
         tproj, enc = results["unet"]
-        return ue.forward(x, tproj, self.ctx_unet, fused[:-1], fused[-1], out=out, encoded=enc)
+        if self.keep_debug:
+            self.debug = dict(fused=[f.clone() for f in fused])
+        return ue.forward(x, tproj, st.ctx_unet, fused[:-1], fused[-1], out=out, encoded=enc)
 
     def _step_grouped(self, x, t_rows, conds, scales, scales_dev, out, step_idx=None):
         """The three batched ControlNet passes and the UNet encoder as ONE lockstep pass of grouped launches."""
+        st = self.state
         N = x.shape[0]
         ue = self.unet.engine
         ge = self._grouped_encoder(N)
@@ -815,11 +872,11 @@ class StepRunner:
         ncn = sum(counts[:-1])
         c0 = ue.conv_in.cout
         h0 = torch.empty((ge.ntot, x.shape[1], x.shape[2], c0), dtype=x.dtype, device=x.device)
-        if self.cond_cat is not None and self.cond_cat.shape == h0.shape and self.x_rep.shape[-1] == x.shape[-1] \
-                and [c.data_ptr() for c in conds] == self._cond_src:
+        if st.cond_cat is not None and st.cond_cat.shape == h0.shape and st.x_rep.shape[-1] == x.shape[-1] \
+                and [c.data_ptr() for c in conds] == st.cond_src:
             # sample = conv_in(sample) + cond (CL:197-203) for every net, and the UNet's conv_in, in one grouped launch
-            self.x_rep.view(ge.ntot // N, N, *x.shape[1:]).copy_(x.unsqueeze(0).expand(ge.ntot // N, *x.shape))
-            ops.conv_gemm(self.x_rep, [e.conv_in for e in encs], residual=self.cond_cat, group_n=counts, out=h0)
+            st.x_rep.view(ge.ntot // N, N, *x.shape[1:]).copy_(x.unsqueeze(0).expand(ge.ntot // N, *x.shape))
+            ops.conv_gemm(st.x_rep, [e.conv_in for e in encs], residual=st.cond_cat, group_n=counts, out=h0)
         else:
             a = 0
             for net, pos in self.groups:                  # sample = conv_in(sample) + cond   (CL:197-203)
@@ -827,19 +884,27 @@ class StepRunner:
                     ops.conv_gemm(x, net.engine.conv_in, residual=conds[p], out=h0[a:a + N])
                     a += N
             ops.conv_gemm(x, ue.conv_in, out=h0[a:a + N])
-        if step_idx is not None and self.tproj_table is not None and self.tproj_table.shape[1] == ge.ntot:
+        if step_idx is not None and st.tproj_table is not None and st.tproj_table.shape[1] == ge.ntot:
             # one gather instead of 4 x (sinusoid + 3 linears) per step; fp16/bf16 rows moved as fp32 words
-            T = self.tproj_table.shape[0]
-            ops.gather_row(self.tproj_table.view(T, -1).view(torch.float32), step_idx, self.tproj_cur.view(-1).view(torch.float32))
-            tproj = self.tproj_cur
+            T = st.tproj_table.shape[0]
+            ops.gather_row(st.tproj_table.view(T, -1).view(torch.float32), step_idx, st.tproj_cur.view(-1).view(torch.float32))
+            tproj = st.tproj_cur
         else:
             tproj = ge.time_proj(t_rows)
-        skips, h = ge.run(h0, tproj, self.ctx_grouped)
+        skips, h = ge.run(h0, tproj, st.ctx_grouped)
         cn_counts = counts[:-1]
         cn_engs = encs[:-1]
+        enc = ([s[ncn:] for s in skips], h[ncn:])
+        if self.single:
+            # one ControlNet: skip + scale * zero_conv(cn_skip) straight out of the zero-conv epilogue (PL:500-510)
+            kw = self._cn_scale(scales, scales_dev)
+            e = cn_engs[0]
+            fused = [ops.conv_gemm(s[:ncn], e.zero[i], residual=enc[0][i], **kw) for i, s in enumerate(skips)]
+            fused.append(ops.conv_gemm(h[:ncn], e.zero_mid, residual=enc[1], **kw))
+            return ue.forward(x, tproj[ncn:], st.ctx_unet, fused[:-1], fused[-1], out=out, encoded=enc, presummed=True)
         res = [ops.conv_gemm(s[:ncn], [e.zero[i] for e in cn_engs], group_n=cn_counts) for i, s in enumerate(skips)]
         res.append(ops.conv_gemm(h[:ncn], [e.zero_mid for e in cn_engs], group_n=cn_counts))
-        nn = len(self.controlnet.nets)
+        nn = self.n_nets
         res_per_net, bs = [None] * nn, [None] * nn
         a = 0
         for net, pos in self.groups:
@@ -847,13 +912,15 @@ class StepRunner:
                 res_per_net[p] = [r[a:] for r in res]
                 bs[p] = [r.stride(0) for r in res]
                 a += N
-        enc = ([s[ncn:] for s in skips], h[ncn:])
         # the fusion kernel adds the UNet's own skip / mid tensors: its outputs ARE the decoder's inputs
         fused = self.controlnet.engine.forward(res_per_net, bs, N, scales, scales_dev, addends=enc[0] + [enc[1]])
-        return ue.forward(x, tproj[ncn:], self.ctx_unet, fused[:-1], fused[-1], out=out, encoded=enc, presummed=True)
+        if self.keep_debug:
+            self.debug = dict(presummed=[f.clone() for f in fused], skips=[e.clone() for e in enc[0] + [enc[1]]])
+        return ue.forward(x, tproj[ncn:], st.ctx_unet, fused[:-1], fused[-1], out=out, encoded=enc, presummed=True)
 
     def step_nchw(self, sample, timestep, ehs, conds, scales):
-        """Convenience for tests: NCHW fp32 in / NCHW out."""
+        """Convenience for tests: NCHW fp32 in / NCHW out (on a StepState of its own: a pipeline loop's is left alone)."""
+        self.state = StepState()
         N = sample.shape[0]
         dev, dt = self.device, self.dtype
         self.set_context(ehs.to(dev, dt).contiguous())

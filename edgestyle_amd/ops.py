@@ -50,9 +50,11 @@ class Profiler:
     each workgroup of an instrumented launch atomically mins its start / maxes its end s_memrealtime stamp
     (100 MHz constant clock) into a device slot; duration = (max end - min start) * 10 ns."""
 
-    def __init__(self, device, capacity: int = 8192):
+    def __init__(self, device, capacity: int = 8192, stamps: bool = True):
         self.slots = torch.empty((capacity, 2), dtype=torch.int64, device=device)
         self.meta = []
+        self.stamps = stamps        # False: only record the descriptors (launch list), no in-kernel atomics
+        self.descs = []             # a copy of every es_gemm_desc launched while this profiler was active
         self.reset()
 
     def reset(self):
@@ -64,7 +66,14 @@ class Profiler:
         if i >= self.slots.shape[0]:
             raise L.EdgeStyleHipError("Profiler capacity exceeded")
         self.meta.append(meta)
-        return self.slots[i].data_ptr()
+        return self.slots[i].data_ptr() if self.stamps else 0
+
+    def replay_gemms(self):
+        """Launch the recorded es_conv_gemm descriptors again on the current stream, un-instrumented (the production
+        kernel: no stamp atomics).  The buffers they point at must still be alive (keep the graph that owns them)."""
+        lib = L.load()
+        for d in self.descs:
+            L.check(lib.es_conv_gemm(C.byref(d), _stream()), "es_conv_gemm(replay)")
 
     def results(self, first: int = 0):
         s = self.slots[first:len(self.meta)].cpu().tolist()
@@ -202,6 +211,7 @@ def pack_weight_ln(weight: torch.Tensor, bias: Optional[torch.Tensor], gamma: to
 # split-K workspace (grown outside graph capture by a warm-up pass)
 # ----------------------------------------------------------------------------------------------------------------
 _workspace = {}
+_workspace_retired = []
 
 
 def _get_workspace(nbytes: int, device) -> torch.Tensor:
@@ -210,6 +220,8 @@ def _get_workspace(nbytes: int, device) -> torch.Tensor:
     if ws is None or ws.numel() * 4 < nbytes:
         if torch.cuda.is_current_stream_capturing():
             raise L.EdgeStyleHipError("split-K workspace too small during graph capture; run one eager warm-up first")
+        if ws is not None:
+            _workspace_retired.append(ws)      # graphs captured earlier still write their slabs there: never freed
         ws = torch.empty(max(nbytes // 4, 1 << 22), dtype=torch.float32, device=device[0])
         _workspace[device] = ws
     return ws
@@ -413,6 +425,10 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
                                     ctail=pw.ctail,
                                     algorithmic_bytes=_algorithmic_bytes(x, x2, pw, pws, out, residual)
                                     + sum(t.numel() * t.element_size() for t in tails))))
+        dd = L.GemmDesc()
+        C.memmove(C.byref(dd), C.byref(d), C.sizeof(L.GemmDesc))
+        dd.prof = None
+        PROFILE.descs.append(dd)
     L.check(L.load().es_conv_gemm(C.byref(d), _stream()), "es_conv_gemm")
     return out
 

@@ -22,9 +22,29 @@ import torch
 
 from . import ops
 from .lib import EdgeStyleHipError
-from .models import (AutoencoderKL, ControlNetModel, EdgeStyleMultiControlNetModel, StepRunner,
+from .models import (AutoencoderKL, ControlNetModel, EdgeStyleMultiControlNetModel, StepRunner, StepState,
                      UNet2DConditionModel, _as_nhwc, _as_nchw_view)
 from .schedulers import DDIMScheduler, UniPCMultistepScheduler
+
+
+_HOST_GENS = {}
+
+
+def _host_generator(generator):
+    """torch.Generator on a device -> a CPU generator seeded with its initial_seed() (one per device generator object,
+    so successive draws advance like the original would); lists are mapped element-wise; CPU generators pass through."""
+    if generator is None:
+        return None
+    if isinstance(generator, (list, tuple)):
+        return [_host_generator(g) for g in generator]
+    if generator.device.type == "cpu":
+        return generator
+    key = id(generator)
+    hit = _HOST_GENS.get(key)
+    if hit is None or hit[0] is not generator or hit[1] != generator.initial_seed():
+        hit = (generator, generator.initial_seed(), torch.Generator().manual_seed(generator.initial_seed()))
+        _HOST_GENS[key] = hit
+    return hit[2]
 
 
 @dataclass
@@ -34,7 +54,9 @@ class StableDiffusionPipelineOutput:
 
 
 class _Loop:
-    """Static device buffers + the captured step graph for one (B, cfg) shape."""
+    """Static device buffers + the captured step graph for one (B, cfg, h, w, guess) shape.  Everything the graph reads
+    between calls is owned here (the StepState included) and refilled in place; `sig` records the addresses the graph
+    was captured with, and a call whose buffers differ re-captures (never replays stale pointers)."""
 
     def __init__(self, pipe, B: int, cfg_on: bool, h: int, w: int, guess: bool = False):
         dev, dt = pipe.device, pipe.dtype
@@ -45,29 +67,47 @@ class _Loop:
         Lc, Lp = unet.cfg.in_channels, unet.engine.in_pad
         c0 = unet.cfg.block_out_channels[0]
         self.runner = pipe._runner
+        self.state = StepState()
+        nn = self.nn = self.runner.n_nets
         k = self.runner.kmax
         self.latents = torch.zeros((B, h, w, Lc), dtype=torch.float32, device=dev)
         self.model_in = torch.zeros((N, h, w, Lp), dtype=dt, device=dev)
         self.noise = torch.zeros((N, h, w, unet.cfg.out_channels), dtype=dt, device=dev)
-        self.conds = [torch.zeros((B if (guess and cfg_on) else N, h, w, c0), dtype=dt, device=dev) for _ in range(6)]
+        self.conds = [torch.zeros((B if (guess and cfg_on) else N, h, w, c0), dtype=dt, device=dev) for _ in range(nn)]
         self.ehs = torch.zeros((N, 77, unet.cfg.cross_attention_dim), dtype=dt, device=dev)
         self.step_idx = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.t_rows = torch.zeros((k * N,), dtype=torch.float32, device=dev)
-        self.scales_cur = torch.ones((6,), dtype=torch.float32, device=dev)
+        self.scales_cur = torch.ones((nn,), dtype=torch.float32, device=dev)
         self.hist = [torch.zeros((B, h, w, Lc), dtype=torch.float32, device=dev) for _ in range(3)]   # UniPC state
         self.unipc = False
         self.t_table = None
         self.scale_table = None
         self.coef = None
         self.graph = None
+        self.sig = None
+        self.captures = 0                # how often this loop's graph was (re)captured (tests)
         self.guidance_scale = None
         self.steps = None
+
+    def signature(self):
+        return self.state.signature() + tuple(t.data_ptr() for t in (self.t_table, self.scale_table, self.coef)) + \
+            (ops.LANE,)
+
+    def set_model_in(self, lat_nchw: torch.Tensor):
+        """latents [B,L,h,w] (device) -> the networks' input: both CFG halves, compute dtype, channel-padded (PL:443-447)."""
+        mi = lat_nchw.permute(0, 2, 3, 1).to(self.model_in.dtype)
+        B = self.B
+        self.model_in.zero_()
+        self.model_in[:B, ..., : mi.shape[-1]] = mi
+        if self.cfg_on:
+            self.model_in[B:, ..., : mi.shape[-1]] = mi
 
     def one_step(self):
         """Everything between PL:435 and PL:522 for the step selected by the device counter."""
         ops.gather_row(self.t_table, self.step_idx, self.t_rows)
         ops.gather_row(self.scale_table, self.step_idx, self.scales_cur)
-        self.runner.step(self.model_in, self.t_rows, self.conds, [1.0] * 6, self.scales_cur, out=self.noise,
+        self.runner.state = self.state
+        self.runner.step(self.model_in, self.t_rows, self.conds, [1.0] * self.nn, self.scales_cur, out=self.noise,
                          step_idx=self.step_idx, guess_mode=self.guess)
         if self.unipc:
             ops.cfg_unipc_step(self.noise, self.latents, self.hist[0], self.hist[1], self.hist[2], self.model_in,
@@ -82,12 +122,14 @@ class StableDiffusionControlNetPipeline:
     """Keeps the constructor / from_pretrained / __call__ surface TT:263-275 and TT:326-359 use."""
 
     def __init__(self, vae: AutoencoderKL, text_encoder=None, tokenizer=None, unet: UNet2DConditionModel = None,
-                 controlnet: EdgeStyleMultiControlNetModel = None, scheduler=None, safety_checker=None,
-                 feature_extractor=None, image_encoder=None, requires_safety_checker: bool = False):
+                 controlnet: Union[EdgeStyleMultiControlNetModel, ControlNetModel] = None, scheduler=None,
+                 safety_checker=None, feature_extractor=None, image_encoder=None, requires_safety_checker: bool = False):
         if unet is None or controlnet is None or vae is None:
             raise ValueError("vae, unet and controlnet are required")
         if isinstance(controlnet, (list, tuple)):
-            raise ValueError("pass an EdgeStyleMultiControlNetModel (the reference's fused 6-net model)")
+            # the stock pipeline wraps a list into diffusers' MultiControlNetModel (plain sum of residuals); the reference
+            # never takes that path (TT:252-258 builds the fused EdgeStyleMultiControlNetModel), so it is not built here
+            raise ValueError("pass an EdgeStyleMultiControlNetModel (the reference's fused 6-net model) or one ControlNetModel")
         self.vae, self.text_encoder, self.tokenizer = vae, text_encoder, tokenizer
         self.unet, self.controlnet = unet, controlnet
         self.scheduler = scheduler or DDIMScheduler()
@@ -98,6 +140,7 @@ class StableDiffusionControlNetPipeline:
         self.use_graph = True
         self._runner = None
         self._loops: Dict[Any, _Loop] = {}
+        self._last_loop: Optional[_Loop] = None
 
     @classmethod
     def from_pretrained(cls, path=None, **components):
@@ -116,6 +159,7 @@ class StableDiffusionControlNetPipeline:
             self.text_encoder.to("cpu")          # CLIP text encode is outside the hot path
         self._runner = None
         self._loops.clear()
+        self._last_loop = None
         return self
 
     @property
@@ -145,13 +189,25 @@ class StableDiffusionControlNetPipeline:
         with torch.no_grad():
             return self.text_encoder(tok.input_ids)[0].float()
 
+    @property
+    def _single(self) -> bool:
+        """A plain ControlNetModel as `controlnet` (PL:338-351) instead of the fused multi-net model."""
+        return isinstance(self.controlnet, ControlNetModel)
+
+    @property
+    def _nets(self):
+        return [self.controlnet] if self._single else self.controlnet.nets
+
     def check_inputs(self, image, prompt, prompt_embeds, controlnet_conditioning_scale, starts, ends):
-        n = len(self.controlnet.nets)
+        n = len(self._nets)
         if prompt is None and prompt_embeds is None:
             raise ValueError("Provide either `prompt` or `prompt_embeds`.")
         if prompt is not None and prompt_embeds is not None:
             raise ValueError("Cannot forward both `prompt` and `prompt_embeds`.")
-        if not isinstance(image, (list, tuple)) or len(image) != n:
+        if self._single:
+            if isinstance(image, (list, tuple)) and not (len(image) == 1 or not torch.is_tensor(image[0])):
+                raise ValueError("a single ControlNet takes one conditioning image")
+        elif not isinstance(image, (list, tuple)) or len(image) != n:
             raise ValueError(f"For multiple controlnets: `image` must be a list of {n} conditioning images")
         if isinstance(controlnet_conditioning_scale, (list, tuple)) and len(controlnet_conditioning_scale) != n:
             raise ValueError("`controlnet_conditioning_scale` must have one entry per ControlNet")
@@ -163,7 +219,7 @@ class StableDiffusionControlNetPipeline:
             if s < 0.0 or e > 1.0:
                 raise ValueError("control guidance start/end must lie in [0, 1]")
 
-    def prepare_image(self, image, batch_size, do_cfg, net, noise=None, generator=None):
+    def prepare_image(self, image, batch_size, do_cfg, net, noise=None, generator=None, num_images_per_prompt: int = 1):
         """PL:629-664: -> fp32 [b,3,H,W] -> repeat -> CFG duplicate -> one-time embedding -> NHWC [N,h,w,C0]."""
         if not torch.is_tensor(image):
             arr = np.asarray(image, dtype=np.float32)
@@ -175,17 +231,19 @@ class StableDiffusionControlNetPipeline:
         image = image.to(torch.float32)
         if image.shape[0] == 1:
             image = image.repeat_interleave(batch_size, dim=0)          # PL:647-653
-        elif image.shape[0] != batch_size:
-            raise ValueError("condition image batch must be 1 or equal to the prompt batch")
+        else:                                                           # image batch == prompt batch: one per prompt
+            image = image.repeat_interleave(num_images_per_prompt, dim=0)
+            if image.shape[0] != batch_size:
+                raise ValueError("condition image batch must be 1 or equal to the prompt batch")
         if do_cfg:
             image = torch.cat([image] * 2)                              # PL:657-658
         if tuple(image.shape[1:2]) == (3,):
-            emb = net.preprocess_image(image.to(self.device), noise=noise, generator=generator)
+            emb = net.preprocess_image(image.to(self.device), noise=noise, generator=_host_generator(generator))
         else:
             emb = image                                                 # already embedded [N,C0,h,w]
         return _as_nhwc(emb, self.dtype, self.device)
 
-    def prepare_images(self, images, batch_size, do_cfg, cond_noise=None, generator=None):
+    def prepare_images(self, images, batch_size, do_cfg, cond_noise=None, generator=None, num_images_per_prompt: int = 1):
         """The six one-time condition embeddings (PL:352-377, 629-664) with the redundant work removed: the reference
         embeds the CFG-duplicated batch net by net, so every deterministic encoder runs twice on identical pixels
         (both CFG halves) and the nets that share an encoder (3 x VAE, 3 x openpose stack) run it separately.  Here
@@ -193,7 +251,8 @@ class StableDiffusionControlNetPipeline:
         per CFG half, drawn in net order for the duplicated batch exactly as before.  Falls back to per-net
         prepare_image for anything that is not an RGB image tensor handled by the known net classes."""
         from .models import ControlLoRAModel
-        nets = self.controlnet.nets
+        nets = self._nets
+        generator = _host_generator(generator)
         rgb = []
         for img in images:
             if not torch.is_tensor(img):
@@ -202,7 +261,8 @@ class StableDiffusionControlNetPipeline:
             rgb.append(img.dim() == 4 and img.shape[1] == 3 and img.shape[0] in (1, batch_size))
         if rgb is None or not all(rgb):
             return [self.prepare_image(img, batch_size, do_cfg, net, noise=None if cond_noise is None else cond_noise[i],
-                                       generator=generator) for i, (img, net) in enumerate(zip(images, nets))]
+                                       generator=generator, num_images_per_prompt=num_images_per_prompt)
+                    for i, (img, net) in enumerate(zip(images, nets))]
         rep = 2 if do_cfg else 1
         N = batch_size * rep
         imgs = [img.to(torch.float32).repeat_interleave(batch_size, dim=0) if img.shape[0] == 1 else img.to(torch.float32)
@@ -248,7 +308,10 @@ class StableDiffusionControlNetPipeline:
         return out                                   # NHWC [N,h,w,C0], compute dtype, on device
 
     def prepare_latents(self, batch_size, channels, h, w, generator, latents=None):
-        """PL:585-627 (latents drawn on the CPU generator so results do not depend on the device RNG stream)."""
+        """PL:585-627.  Latents are always drawn on the HOST RNG stream (results then do not depend on the device's
+        Philox stream, and the CPU oracle can reproduce them): a device generator, as TT:274 passes
+        (`torch.Generator(device).manual_seed(42)`), is re-seated as a CPU generator with the same initial seed."""
+        generator = _host_generator(generator)
         shape = (batch_size, channels, h, w)
         if isinstance(generator, list) and len(generator) != batch_size:
             raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an "
@@ -284,7 +347,7 @@ class StableDiffusionControlNetPipeline:
         if not isinstance(self.scheduler, (DDIMScheduler, UniPCMultistepScheduler)):
             raise EdgeStyleHipError("the fused step kernels implement DDIM (the BASELINE metric) and UniPC (TT:273); "
                                     "assign edgestyle_amd.schedulers.DDIMScheduler or UniPCMultistepScheduler")
-        nn = len(self.controlnet.nets)
+        nn = len(self._nets)
         # PL:243-265 broadcast guidance windows
         if not isinstance(control_guidance_start, list):
             control_guidance_start = [control_guidance_start] * nn
@@ -292,6 +355,8 @@ class StableDiffusionControlNetPipeline:
             control_guidance_end = [control_guidance_end] * nn
         self.check_inputs(image, prompt, prompt_embeds, controlnet_conditioning_scale, control_guidance_start,
                           control_guidance_end)
+        if self._single and not isinstance(image, (list, tuple)):
+            image = [image]
         if isinstance(controlnet_conditioning_scale, (int, float)):                 # PL:295-300
             controlnet_conditioning_scale = [float(controlnet_conditioning_scale)] * nn
         do_cfg = guidance_scale > 1.0
@@ -309,7 +374,8 @@ class StableDiffusionControlNetPipeline:
 
         # PL:352-377 — condition images, embedded ONCE
         guess = bool(guess_mode)
-        conds = self.prepare_images(image, B, do_cfg and not guess, cond_noise, generator)      # PL:352-377, 657-658
+        conds = self.prepare_images(image, B, do_cfg and not guess, cond_noise, generator,
+                                    num_images_per_prompt)                                      # PL:352-377, 657-658
         h, w = conds[0].shape[1:3]
 
         # PL:382-398
@@ -321,6 +387,7 @@ class StableDiffusionControlNetPipeline:
         loop = self._loops.get(key)
         if loop is None:
             loop = self._loops[key] = _Loop(self, B, do_cfg, h, w, guess)
+        self._last_loop = loop
         N, k = loop.N, self._runner.kmax
         # PL:419-427 controlnet_keep folded into a per-step scale table
         keep = [[1.0 - float(i / T < s or (i + 1) / T > e)
@@ -335,9 +402,8 @@ class StableDiffusionControlNetPipeline:
         cw = 12 if unipc else 4
         if loop.t_table is None or loop.t_table.shape[0] != T or loop.coef.shape[1] != cw:
             loop.t_table = torch.empty((T, k * N), dtype=torch.float32, device=dev)
-            loop.scale_table = torch.empty((T, 6), dtype=torch.float32, device=dev)
+            loop.scale_table = torch.empty((T, nn), dtype=torch.float32, device=dev)
             loop.coef = torch.empty((T, cw), dtype=torch.float32, device=dev)
-            regraph = True
         for hbuf in loop.hist:
             hbuf.zero_()
         loop.t_table.copy_(ts.float()[:, None].expand(T, k * N))
@@ -345,25 +411,21 @@ class StableDiffusionControlNetPipeline:
         loop.coef.copy_(self.scheduler.coef_table())
         loop.step_idx.zero_()
         loop.latents.copy_(lat.permute(0, 2, 3, 1))
-        mi = lat.permute(0, 2, 3, 1).to(self.dtype)
-        loop.model_in.zero_()
-        loop.model_in[:B, ..., : mi.shape[-1]] = mi.to(dev)                        # PL:443-447
-        if do_cfg:
-            loop.model_in[B:, ..., : mi.shape[-1]] = mi.to(dev)
+        loop.set_model_in(lat.to(dev))                                            # PL:443-447
         for dst, src in zip(loop.conds, conds):
             dst.copy_(src)
         loop.ehs.copy_(ehs.to(dev, self.dtype))
-        self._runner.set_context(loop.ehs, guess, loop.conds[0].shape[0])
-        if self._runner.mode == "grouped" and not guess:
-            had = self._runner.cond_cat
-            self._runner.set_conds(loop.conds)                            # conv_in + cond of all nets as one launch
-            if self._runner.cond_cat is not had:
-                regraph = True
-        if self._runner.mode == "grouped" and not guess and os.environ.get("ES_TIME_TABLE", "1") == "1":
-            had = self._runner.tproj_table
-            self._runner.set_time_table(ts.float().to(dev), N)           # every step's time projections, once per call
-            if self._runner.tproj_table is not had:
-                regraph = True                                            # buffers were (re)allocated
+        # every buffer the step reads between calls belongs to THIS loop (StepState): filled in place, and the graph
+        # is re-captured whenever one of them sits at another address than at capture time
+        runner = self._runner
+        runner.state = loop.state
+        runner.set_context(loop.ehs, guess, loop.conds[0].shape[0])
+        if runner.mode == "grouped" and not guess:
+            runner.set_conds(loop.conds)                                  # conv_in + cond of all nets as one launch
+            if os.environ.get("ES_TIME_TABLE", "1") == "1":
+                runner.set_time_table(ts.float().to(dev), N)              # every step's time projections, once per call
+        if loop.signature() != loop.sig:
+            regraph = True
 
         # PL:435-543 — the denoising loop
         if callback_on_step_end is not None or not self.use_graph:
@@ -372,7 +434,10 @@ class StableDiffusionControlNetPipeline:
                 if callback_on_step_end is not None:
                     out = callback_on_step_end(self, i, int(ts[i]), {"latents": _as_nchw_view(loop.latents)})
                     if out and "latents" in out:
+                        # PL:529-531: the returned latents are what the next step's networks, the scheduler and the
+                        # decode see
                         loop.latents.copy_(out["latents"].permute(0, 2, 3, 1))
+                        loop.set_model_in(out["latents"].to(dev))
         else:
             start = 0
             if regraph:
@@ -384,6 +449,8 @@ class StableDiffusionControlNetPipeline:
                 with torch.cuda.graph(g):
                     loop.one_step()
                 loop.graph = g
+                loop.sig = loop.signature()
+                loop.captures += 1
                 loop.step_idx.copy_(saved)            # capture does not execute; keep the counter where it was
             for _ in range(start, T):
                 loop.graph.replay()
@@ -409,12 +476,17 @@ class StableDiffusionControlNetPipeline:
         return StableDiffusionPipelineOutput(images=img, nsfw_content_detected=None)
 
 
-    def profile_one_step(self):
+    def profile_one_step(self, gemm_replay_iters: int = 0):
         """Re-capture the step graph of the most recent call with in-kernel timing stamps on every es_conv_gemm
-        launch, replay ONE step, and return [(meta, seconds)] (ops.Profiler).  Used by bench.py's roofline leg."""
+        launch, replay ONE step, and return [(meta, seconds)] (ops.Profiler).  Used by bench.py's roofline leg.
+
+        gemm_replay_iters > 0 additionally times the SAME launch list as the production kernels run it (no stamp
+        atomics): only the es_conv_gemm launches (with their split-K reduces), captured as one graph and replayed that
+        many times between two HIP events on the launching stream; the average per replay lands in
+        `self.last_gemm_replay_ms`."""
         if not self._loops:
             raise EdgeStyleHipError("run the pipeline once before profiling")
-        loop = list(self._loops.values())[-1]
+        loop = self._last_loop or list(self._loops.values())[-1]
         prof = ops.Profiler(self.device)
         torch.cuda.synchronize()
         ops.PROFILE = prof
@@ -425,6 +497,7 @@ class StableDiffusionControlNetPipeline:
             loop.step_idx.zero_()
             loop.one_step()                  # eager serial warm-up: sizes lane-0 scratch outside the capture
             prof.meta.clear()
+            prof.descs.clear()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -437,7 +510,27 @@ class StableDiffusionControlNetPipeline:
         torch.cuda.synchronize()
         g.replay()
         torch.cuda.synchronize()
-        return prof.results()
+        res = prof.results()
+        self.last_gemm_replay_ms = None
+        if gemm_replay_iters > 0:
+            prof.replay_gemms()              # eager once (same workspace sizes as the step: nothing grows)
+            torch.cuda.synchronize()
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2):
+                prof.replay_gemms()
+            for _ in range(3):
+                g2.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(gemm_replay_iters):
+                g2.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            self.last_gemm_replay_ms = e0.elapsed_time(e1) / gemm_replay_iters
+            del g2
+        loop.step_idx.zero_()
+        del g
+        return res
 
 
 class EdgeStyleStableDiffusionControlNetPipeline(StableDiffusionControlNetPipeline):

@@ -363,14 +363,27 @@ class DDIM:
 # ----------------------------------------------------------------------------------------------------------------
 def denoise_step(unet_sd, unet_cfg, fusion_sd, nets, sample, t, ehs, conds, scales, guess_mode=False, cfg_on=True):
     """One controlnet->unet evaluation == OnnxUNetAndControlnets.forward (export_onnx.py:43-74).
+    fusion_sd None = the single-ControlNet form of the pipeline (nets and conds hold one entry).
     guess_mode with CFG (PL:453-459, 487-497): the ControlNets see only the conditional half (conds are then [B]
     tensors) and the unconditional half of the UNet gets zero residuals."""
+    if fusion_sd is None:
+        # a plain ControlNetModel as `controlnet` (PL:338-351, PL:426, PL:464-470): one net, scalar scale, its 13
+        # residuals go to the UNet as they are (no fusion blocks) — BASELINE configs[0]
+        (sd, ncfg), = nets
+        cond, = conds
+        scale = scales[0] if isinstance(scales, (list, tuple)) else scales
+
+        def cn(x, e):
+            return controlnet_forward(sd, ncfg, x, t, e, cond, scale, guess_mode=guess_mode)
+    else:
+        def cn(x, e):
+            return multicontrolnet_forward(fusion_sd, nets, x, t, e, conds, scales, guess_mode)
     if guess_mode and cfg_on:
-        down, mid = multicontrolnet_forward(fusion_sd, nets, sample.chunk(2)[1], t, ehs.chunk(2)[1], conds, scales, True)
+        down, mid = cn(sample.chunk(2)[1], ehs.chunk(2)[1])
         down = [torch.cat([torch.zeros_like(d), d]) for d in down]
         mid = torch.cat([torch.zeros_like(mid), mid])
     else:
-        down, mid = multicontrolnet_forward(fusion_sd, nets, sample, t, ehs, conds, scales, guess_mode)
+        down, mid = cn(sample, ehs)
     return unet_forward(unet_sd, unet_cfg, sample, t, ehs, down, mid)
 
 

@@ -65,3 +65,71 @@ def tiny_step_check(device="cuda:0", seed=0):
     out = runner.step_nchw(x.to(device), t, ehs.to(device), [c.to(device) for c in conds], scales)
     torch.cuda.synchronize()
     return float((out.float().cpu() - ref).abs().max())
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# full-size (SD1.5 width, 64x64 latents = the benchmarked configuration) fixtures: inputs are regenerated from seeds
+# (torch's CPU generator), only the oracle's OUTPUTS are committed under tests/golden/ (make_golden_full.py)
+# ----------------------------------------------------------------------------------------------------------------
+FULL_RANK = 32          # LoRA rank of the reference's training default (TR:275)
+FULL_STEP_T = 501
+FULL_STEP_SCALES = [1.0, 0.8, 1.0, 1.0, 0.5, 1.0]
+
+
+def full_weights(seed=0, keys=("unet", "openpose", "lora0", "lora1", "fusion", "vae")):
+    """fp16-rounded fp32 CPU weights of the full SD1.5-shaped model set (about 6 GB)."""
+    ucfg, vcfg = C.sd15_unet(), C.sd15_vae()
+    shapes = dict(unet=(W.unet_shapes, (ucfg,), "unet."), openpose=(W.controlnet_shapes, (ucfg,), "openpose."),
+                  lora0=(W.controllora_saved_shapes, (ucfg, FULL_RANK), "controlnet_0."),
+                  lora1=(W.controllora_saved_shapes, (ucfg, FULL_RANK), "controlnet_1."),
+                  fusion=(W.fusion_shapes, (ucfg,), "fusion."), vae=(W.vae_shapes, (vcfg,), "vae."))
+    out = {}
+    for k in keys:
+        fn, a, prefix = shapes[k]
+        sd = W.random_state_dict(fn(*a), seed, prefix)
+        out[k] = {kk: vv.half().float() for kk, vv in sd.items()}
+        del sd
+    return ucfg, vcfg, out
+
+
+def full_step_inputs(seed=42):
+    """One 6-cond CFG step at the benchmarked geometry: N = 2 samples, 64x64 latents, 77 x 768 text states."""
+    ucfg = C.sd15_unet()
+    g = torch.Generator().manual_seed(seed)
+    N, s, c0 = 2, ucfg.sample_size, ucfg.block_out_channels[0]
+    x = torch.randn(N, 4, s, s, generator=g).half().float()
+    ehs = (torch.randn(N, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+    conds = [(torch.randn(N, c0, s, s, generator=g) * 0.3).half().float() for _ in range(6)]
+    return x, ehs, conds
+
+
+def full_pipeline_inputs(seed=43, B=1):
+    """4-step DDIM pipeline at 512x512 (BASELINE configs[1] geometry): latents, prompt / negative embeds, six
+    pre-embedded conditions [1,320,64,64]."""
+    ucfg = C.sd15_unet()
+    g = torch.Generator().manual_seed(seed)
+    s, c0 = ucfg.sample_size, ucfg.block_out_channels[0]
+    lat = torch.randn(B, 4, s, s, generator=g)
+    pe = (torch.randn(B, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+    ne = (torch.randn(B, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+    conds = [(torch.randn(1, c0, s, s, generator=g) * 0.3).half().float() for _ in range(6)]
+    return lat, pe, ne, conds
+
+
+def single_cn_inputs(seed=44):
+    """BASELINE configs[0]: UNet + ONE openpose ControlNet, 512x512, 4 DDIM steps; the pose image is a raw
+    [1,3,512,512] tensor in [0,1] (TT:29-48) that the net's own conv stack embeds."""
+    ucfg, vcfg = C.sd15_unet(), C.sd15_vae()
+    g = torch.Generator().manual_seed(seed)
+    s = ucfg.sample_size
+    lat = torch.randn(1, 4, s, s, generator=g)
+    pe = (torch.randn(1, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+    ne = (torch.randn(1, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+    pose = torch.rand(1, 3, s * vcfg.scale, s * vcfg.scale, generator=g).half().float()
+    return lat, pe, ne, pose
+
+
+def psnr(a, b, peak=1.0):
+    import math
+    mse = float(((a.float().cpu() - b.float().cpu()) ** 2).mean())
+    return 10 * math.log10(peak * peak / max(mse, 1e-20))

@@ -305,3 +305,189 @@ def test_pipeline_odd_batch_matches_single_images(built):
         one = pipe(prompt_embeds=pe[i:i + 1], negative_prompt_embeds=ne[i:i + 1], image=[c[i:i + 1] for c in conds3],
                    latents=lat[i:i + 1], guidance_scale=6.0, num_inference_steps=4, output_type="pt").images
         assert psnr(out[i:i + 1], one) >= 45.0, i
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# graph / static-buffer ownership (a captured graph replays the pointers it was captured with)
+# ----------------------------------------------------------------------------------------------------------------
+def _call(pipe, lat, pe, ne, conds, **kw):
+    a = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, latents=lat, guidance_scale=5.0,
+             num_inference_steps=3, output_type="pt")
+    a.update(kw)
+    return pipe(**a).images
+
+
+def test_guess_mode_second_call_with_other_prompt_reads_its_own_text_states(built):
+    """Two guess_mode calls of the same shape with different prompt embeddings: the replayed graph must see the second
+    call's text K/V projections (they are refilled in place in buffers the loop owns), i.e. equal the eager run."""
+    pipe, ws, ucfg, vcfg = built
+    lat, pe, ne, conds = _inputs(ucfg, 1, seed=31)
+    _, pe2, ne2, _ = _inputs(ucfg, 1, seed=32)
+    out1 = _call(pipe, lat, pe, ne, conds, guess_mode=True)
+    out2 = _call(pipe, lat, pe2, ne2, conds, guess_mode=True)
+    assert not torch.equal(out1, out2)
+    pipe.use_graph = False
+    try:
+        eager2 = _call(pipe, lat, pe2, ne2, conds, guess_mode=True)
+        eager1 = _call(pipe, lat, pe, ne, conds, guess_mode=True)
+    finally:
+        pipe.use_graph = True
+    assert torch.equal(out2, eager2) and torch.equal(out1, eager1)
+
+
+@pytest.mark.parametrize("mode", ["serial", "grouped"])
+def test_batch_switch_1_2_1_replays_cached_graphs_without_recapture(built, mode):
+    """B = 1, 2, 1 through one pipeline: every loop owns its buffers, so the second B = 1 call replays the graph captured
+    by the first (no re-capture), and every result equals the eager run."""
+    pipe, ws, ucfg, vcfg = built
+    pipe._runner = None
+    pipe._loops.clear()
+    lat1, pe1, ne1, conds = _inputs(ucfg, 1, seed=41)
+    lat2, pe2, ne2, _ = _inputs(ucfg, 2, seed=42)
+    lat3, pe3, ne3, _ = _inputs(ucfg, 1, seed=43)
+    first = _call(pipe, lat1, pe1, ne1, conds)
+    pipe._runner.mode = mode
+    pipe._loops.clear()
+    a = _call(pipe, lat1, pe1, ne1, conds)
+    loop1 = pipe._last_loop
+    assert loop1.captures == 1
+    b = _call(pipe, lat2, pe2, ne2, conds)
+    c = _call(pipe, lat3, pe3, ne3, conds)
+    a2 = _call(pipe, lat1, pe1, ne1, conds)
+    assert pipe._last_loop is loop1 and loop1.captures == 1, "the cached B=1 graph was re-captured"
+    assert torch.equal(a, a2) and torch.equal(a, first)
+    pipe.use_graph = False
+    try:
+        assert torch.equal(b, _call(pipe, lat2, pe2, ne2, conds))
+        assert torch.equal(c, _call(pipe, lat3, pe3, ne3, conds))
+    finally:
+        pipe.use_graph = True
+        pipe._runner = None
+        pipe._loops.clear()
+
+
+def test_callback_latents_feed_the_next_step_and_the_decode(built):
+    """PL:529-531: latents returned by callback_on_step_end replace the loop's latents — for the scheduler, for the
+    next step's networks and for the VAE decode.  Checked against the oracle loop with the same intervention."""
+    from oracle import sd15_oracle as O
+    pipe, ws, ucfg, vcfg = built
+    lat, pe, ne, conds = _inputs(ucfg, 1, seed=51)
+    steps, gs = 4, 5.0
+    nets = oracle_nets(ws, ucfg)
+    oconds = [c.repeat(2, 1, 1, 1) for c in conds]
+    sch = O.DDIM()
+    ts = sch.set_timesteps(steps)
+    x = lat.clone()
+    ehs = torch.cat([ne, pe])
+    for i, t in enumerate(ts.tolist()):
+        eps = O.denoise_step(ws["unet"], ucfg, ws["fusion"], nets, torch.cat([x] * 2), t, ehs, oconds, [1.0] * 6)
+        e_u, e_t = eps.chunk(2)
+        x = sch.step(e_u + gs * (e_t - e_u), t, x)
+        if i in (1, steps - 1):
+            x = x * 0.8 + 0.1
+    ref = (O.vae_decode(ws["vae"], vcfg, x / vcfg.scaling_factor) / 2 + 0.5).clamp(0, 1)
+
+    def cb(p, i, t, kw):
+        return {"latents": kw["latents"] * 0.8 + 0.1} if i in (1, steps - 1) else {}
+    out = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, latents=lat, guidance_scale=gs,
+               num_inference_steps=steps, output_type="pt", callback_on_step_end=cb).images
+    assert psnr(out, ref) >= 40.0
+    plain = _call(pipe, lat, pe, ne, conds, num_inference_steps=steps)
+    assert psnr(plain, ref) < 35.0                      # the intervention is visible
+
+
+def test_device_generator_like_the_reference_test_script(built):
+    """TT:274 hands `torch.Generator(device).manual_seed(42)` to the pipeline: accepted, and (documented) drawn on a
+    host generator with the same seed, so it equals a CPU generator seeded alike."""
+    pipe, ws, ucfg, vcfg = built
+    _, pe, ne, conds = _inputs(ucfg, 1, seed=61)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, guidance_scale=5.0, num_inference_steps=3,
+              output_type="pt")
+    with torch.autocast("cuda"):                            # TT:327
+        a = pipe(generator=torch.Generator(DEV).manual_seed(42), **kw).images
+    b = pipe(generator=torch.Generator().manual_seed(42), **kw).images
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+
+
+def test_num_images_per_prompt_repeats_a_per_prompt_image_batch(built):
+    """PL:647-653: an image batch equal to the prompt batch is repeated num_images_per_prompt times."""
+    pipe, ws, ucfg, vcfg = built
+    lat, pe, ne, conds = _inputs(ucfg, 2, seed=71)
+    conds2 = [(c.repeat(2, 1, 1, 1) * torch.tensor([1.0, -0.5])[:, None, None, None]).half().float() for c in conds]
+    lat4 = torch.cat([lat, lat + 0.1]).index_select(0, torch.tensor([0, 2, 1, 3]))
+    out = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds2, latents=lat4, guidance_scale=5.0,
+               num_inference_steps=3, output_type="pt", num_images_per_prompt=2).images
+    assert out.shape[0] == 4
+    one = pipe(prompt_embeds=pe[1:2], negative_prompt_embeds=ne[1:2], image=[c[1:2] for c in conds2], latents=lat4[3:4],
+               guidance_scale=5.0, num_inference_steps=3, output_type="pt").images
+    assert psnr(out[3:4], one) >= 45.0
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# one plain ControlNetModel as `controlnet` (PL:338-351) — BASELINE configs[0] at tiny width, vs the live oracle
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("guess,gs", [(False, 7.5), (False, 1.0), (True, 5.0)])
+def test_single_controlnet_pipeline_vs_oracle(built, guess, gs):
+    from oracle import sd15_oracle as O
+    from edgestyle_amd.pipeline import StableDiffusionControlNetPipeline
+    pipe, ws, ucfg, vcfg = built
+    pose = pipe.controlnet.nets[1]
+    p1 = StableDiffusionControlNetPipeline(vae=pipe.vae, unet=pipe.unet, controlnet=pose).to(DEV)
+    g = torch.Generator().manual_seed(81)
+    s = ucfg.sample_size
+    lat, pe, ne, _ = _inputs(ucfg, 1, seed=82)
+    img = torch.rand(1, 3, s * 8, s * 8, generator=g).half().float()
+    N = 2 if (gs > 1 and not guess) else 1
+    steps = 4
+    ref = O.pipeline(ws["unet"], ucfg, None, [(ws["openpose"], ucfg)], ws["vae"], vcfg, lat, pe, ne,
+                     [img.repeat(N, 1, 1, 1)], num_inference_steps=steps, guidance_scale=gs, scales=[0.8],
+                     control_guidance_end=0.75, guess_mode=guess)
+    out = p1(prompt_embeds=pe, negative_prompt_embeds=ne, image=img, latents=lat, guidance_scale=gs,
+             num_inference_steps=steps, output_type="pt", controlnet_conditioning_scale=0.8, control_guidance_end=0.75,
+             guess_mode=guess).images
+    assert psnr(out, ref) >= 40.0
+    with pytest.raises(ValueError):
+        p1(prompt_embeds=pe, negative_prompt_embeds=ne, image=[img, img], latents=lat)
+
+
+def test_string_prompts_through_a_random_init_clip_text_encoder(built, tmp_path):
+    """`prompt=` / `negative_prompt=` (TT:328-338): tokenizer + CLIPTextModel from transformers, built offline from a
+    config (random init) and a synthetic byte-level BPE vocabulary; the embeddings the pipeline derives equal the ones
+    computed by hand, and the image equals the prompt_embeds= call."""
+    import json
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTokenizer
+    pipe, ws, ucfg, vcfg = built
+    chars = [chr(c) for c in range(ord("a"), ord("z") + 1)] + [",", "."]
+    vocab = {}
+    for ch in chars:
+        vocab[ch] = len(vocab)
+    for ch in chars:
+        vocab[ch + "</w>"] = len(vocab)
+    vocab["<|startoftext|>"] = len(vocab)
+    vocab["<|endoftext|>"] = len(vocab)
+    (tmp_path / "vocab.json").write_text(json.dumps(vocab))
+    (tmp_path / "merges.txt").write_text("#version: 0.2\n")
+    tok = CLIPTokenizer(str(tmp_path / "vocab.json"), str(tmp_path / "merges.txt"), model_max_length=77)
+    torch.manual_seed(0)
+    enc = CLIPTextModel(CLIPTextConfig(vocab_size=len(vocab), hidden_size=ucfg.cross_attention_dim, intermediate_size=128,
+                                       num_hidden_layers=2, num_attention_heads=4, max_position_embeddings=77,
+                                       bos_token_id=vocab["<|startoftext|>"], eos_token_id=vocab["<|endoftext|>"],
+                                       pad_token_id=vocab["<|endoftext|>"])).eval()
+    from edgestyle_amd.pipeline import StableDiffusionControlNetPipeline
+    p2 = StableDiffusionControlNetPipeline(vae=pipe.vae, text_encoder=enc, tokenizer=tok, unet=pipe.unet,
+                                           controlnet=pipe.controlnet).to(DEV)
+    lat, _, _, conds = _inputs(ucfg, 1, seed=91)
+    prompt, neg = "edgestyle, red, dress some text", "blurry"
+    with torch.no_grad():
+        def emb(t):
+            ids = tok([t], padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+            return enc(ids)[0].float()
+        pe, ne = emb(prompt), emb(neg)
+    assert pe.shape == (1, 77, ucfg.cross_attention_dim) and not torch.equal(pe, ne)
+    a = p2(prompt=prompt, negative_prompt=neg, image=conds, latents=lat, guidance_scale=5.0, num_inference_steps=3,
+           output_type="pt").images
+    b = p2(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, latents=lat, guidance_scale=5.0,
+           num_inference_steps=3, output_type="pt").images
+    assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        p2(prompt=prompt, prompt_embeds=pe, image=conds, latents=lat)
