@@ -384,16 +384,17 @@ def test_callback_latents_feed_the_next_step_and_the_decode(built):
         e_u, e_t = eps.chunk(2)
         x = sch.step(e_u + gs * (e_t - e_u), t, x)
         if i in (1, steps - 1):
-            x = x * 0.8 + 0.1
+            x = x * 0.5 + 0.3
     ref = (O.vae_decode(ws["vae"], vcfg, x / vcfg.scaling_factor) / 2 + 0.5).clamp(0, 1)
 
     def cb(p, i, t, kw):
-        return {"latents": kw["latents"] * 0.8 + 0.1} if i in (1, steps - 1) else {}
+        return {"latents": kw["latents"] * 0.5 + 0.3} if i in (1, steps - 1) else {}
     out = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, latents=lat, guidance_scale=gs,
                num_inference_steps=steps, output_type="pt", callback_on_step_end=cb).images
-    assert psnr(out, ref) >= 40.0
+    got = psnr(out, ref)
+    assert got >= 40.0
     plain = _call(pipe, lat, pe, ne, conds, num_inference_steps=steps)
-    assert psnr(plain, ref) < 35.0                      # the intervention is visible
+    assert psnr(plain, ref) < got - 8.0                 # the intervention is visible
 
 
 def test_device_generator_like_the_reference_test_script(built):
