@@ -285,6 +285,7 @@ extern "C" size_t es_sizeof_desc(int which) {
     case 2: return sizeof(es_gn_desc);
     case 3: return sizeof(es_fusion_desc);
     case 4: return sizeof(es_ln_desc);
+    case 5: return sizeof(es_xs_desc);
     default: return 0;
   }
 }

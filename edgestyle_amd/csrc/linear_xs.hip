@@ -1,0 +1,344 @@
+// Row-stationary short-K linear layer for gfx950:  out[M, N] = epilogue( LN?(X[M, K]) W[N, K]^T + bias ),  K = 320 | 640.
+//
+// The transformer projections of the two shallow UNet levels (to_q|k|v: K = C -> 3C, GEGLU: K = C -> 8C, C = 320 | 640)
+// have few K-steps and many output columns.  The tiled kernel (gemm_conv.hip) re-stages the activation tile once per
+// N tile and pays its pipeline fill + epilogue drain per 5-10 K-steps: 300-500 TFLOP/s.  Here one workgroup of 8 waves
+// owns 256 rows for ALL of its output columns:
+//   * a wave keeps its 32 rows x K of activations IN REGISTERS as MFMA B operands (80 | 160 VGPRs), loaded once,
+//     LayerNorm-ed in registers (fp32 statistics; gamma / beta are folded into W / bias by ops.pack_weight_ln);
+//   * the weights stream through LDS in 40 KB stages (64 | 32 output columns x K) filled by LDS-DMA
+//     (`buffer_load_dwordx4 ... lds`, 5 per wave per stage, XOR swizzle on the source address) in a 3-deep ring: two
+//     stages are always in flight behind the MFMAs of the current one, one counted `s_waitcnt vmcnt` + one raw barrier
+//     per stage, and the stream never drains between "tiles" because there are none;
+//   * per stage a wave issues NF x K/32 x 2 MFMAs (16x16x32) against NF x K/32 ds_read_b128 weight fragments - the
+//     same LDS bytes per MFMA as the tiled kernel, with no activation reads at all;
+//   * epilogue per stage in registers (bias, exact-erf GEGLU), staged through a wave-private LDS tile so that global
+//     stores are full 128-byte lines (16 B per lane), write-through like the GEMM's.
+// Small M (the batch-1 UNet decoder): the N range is split over `nslices` workgroups per row block, each re-reading
+// its rows (cheap: they stay in L2) so the launch still fills the chip.
+//
+// Replaces (as called from model/controllora.py:205-238 through diffusers BasicTransformerBlock): norm1 -> attn1.to_q|k|v,
+// norm3 -> ff.net.0 (GEGLU) at the 64x64 and 32x32 levels.  Same math as es_conv_gemm with ln_colsum / ES_ACT_GEGLU;
+// results differ from it only by fp16 rounding of the normalised activations (tests/test_ops_gpu.py).
+#ifndef ES_WT_STORES
+#define ES_WT_STORES 1
+#endif
+#include "common.h"
+#include "../../include/edgestyle_hip.h"
+
+// Tool-only ablation builds (tools/xs_ablate.sh): time the kernel with one ingredient removed.  Results are wrong by
+// construction; the product library is always built with XS_ABLATE == 0.
+//   1: no MFMA   2: no GELU (hidden * gate)   4: no global stores   8: no DMA wait / barrier   16: no DMA inside the loop
+//   32: no weight fragment reads inside the K loop
+#ifndef XS_ABLATE
+#define XS_ABLATE 0
+#endif
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int XS_ROWS = 256;          // rows per workgroup (8 waves x 32)
+constexpr int XS_STAGES = 3;
+constexpr int XS_STAGE_W = 40960;     // weight bytes per stage
+constexpr int XS_STAGE = XS_STAGE_W + 256;   // + the stage's bias values (fp32)
+constexpr int XS_OROW = 144;          // wave-private output staging: 32 rows x (128 + 16 pad) bytes
+constexpr int XS_LDS = XS_STAGES * XS_STAGE + 8 * 32 * XS_OROW;
+
+template <int N> ES_DEVICE void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int KC /* K / 32 */, bool GEGLU, bool LN>
+__global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
+  constexpr int K = KC * 32;
+  constexpr int NF = KC == 10 ? 4 : 2;          // 16-column fragments per stage
+  constexpr int CH = NF * 16;                    // output columns (GEMM N) per stage
+  constexpr int SUB = CH * 128;                  // bytes of one 64-deep sub-tile [CH rows][128 B]
+  constexpr int PPS = CH / 8;                    // 1 KB DMA pieces per sub-tile
+  constexpr int OUTB = GEGLU ? CH : CH * 2;      // stored bytes per row per stage
+  constexpr int P = 128 / OUTB;                  // stages per full 128-byte output line
+  static_assert(KC == 10 || KC == 20, "K = 320 or 640");
+  static_assert(NF * 16 * K * 2 == XS_STAGE_W, "stage geometry");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 15, fq = lane >> 4;
+  const int slice = blockIdx.x % p.nslices, rb = blockIdx.x / p.nslices;
+  if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+
+  // this workgroup's stages: [c0, c1), whole groups of P
+  const int total = (p.Cout + CH - 1) / CH;
+  const int c0 = slice * p.chunks_per_slice;
+  int c1 = c0 + p.chunks_per_slice;
+  c1 = c1 < total ? c1 : total;
+  const int nch = c1 - c0;
+
+  int grp = 0;
+  if (p.ngroups > 1) {
+    const int t128 = rb * (XS_ROWS / 128);
+    grp = (t128 >= p.mt_end[0]) + (t128 >= p.mt_end[1]) + (t128 >= p.mt_end[2]);
+  }
+  const void* wsel = p.ngroups > 1 ? p.w_g[grp] : p.w;
+  const float* bsel = p.ngroups > 1 ? p.bias_g[grp] : p.bias;
+  const auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)wsel, (short)0, (int)((size_t)p.rows_padded * K * 2), 0x00020000);
+  const auto rB = __builtin_amdgcn_make_buffer_rsrc((void*)bsel, (short)0, (int)((size_t)p.rows_padded * 4), 0x00020000);
+  const auto rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, (short)0, (int)((size_t)p.M * K * 2), 0x00020000);
+
+  // ---------------- weight stream: DMA addressing ----------------
+  const int lrow = lane >> 3;                    // row inside an 8-row piece
+  const int kc8 = (lane & 7) ^ lrow;             // global 16-byte chunk landing in LDS slot (lane & 7): XOR swizzle on the source
+  const unsigned wvoff = (unsigned)((lrow * K + kc8 * 8) * 2);
+  auto issue = [&](int c, int stage) __attribute__((always_inline)) {
+    char* sb = smem + stage * XS_STAGE;
+    const int n0 = c * CH;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int piece = wave * 5 + i;            // 40 pieces per stage
+      const int st = piece / PPS, g = piece - st * PPS;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(sb + st * SUB + g * 1024), 16, (int)wvoff,
+                                               ((n0 + g * 8) * K + st * 64) * 2, 0, 0);
+    }
+    // the stage's bias values (every wave writes the same 256 bytes: keeps the per-wave DMA count uniform)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lptr_t)(sb + XS_STAGE_W), 4, lane * 4, n0 * 4, 0, 0);
+  };
+  constexpr int NDMA = 6;                        // VMEM instructions per wave per stage
+
+  // ---------------- activations: 32 rows x K per wave, straight into MFMA B-operand registers ----------------
+  const int r0 = rb * XS_ROWS + wave * 32;
+  typename Traits<T>::vec8 xr[2][KC];
+#pragma unroll
+  for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      const int row = r0 + rf * 16 + frow;
+      const unsigned off = row < p.M ? (unsigned)(((size_t)row * K + kc * 32 + fq * 8) * 2) : 0xFFFFFF00u;
+      xr[rf][kc] = as_vec8<T>(__builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)off, 0, 0)));
+    }
+  if (nch > 0) issue(c0, 0);
+  if (nch > 1) issue(c0 + 1, 1);
+
+  if constexpr (LN) {
+    // LayerNorm statistics of each row from the registers (a row's K values sit in the four lanes frow, frow+16,
+    // frow+32, frow+48), fp32 sums, then the normalised values replace the raw ones.  One fragment at a time and an
+    // opaque barrier on it in between: hipcc otherwise keeps fp32 copies of all 160 | 320 values alive across the two
+    // passes (K = 640: 750 bytes of scratch per lane).
+#pragma unroll
+    for (int rf = 0; rf < 2; ++rf) {
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float v = to_f32(xr[rf][kc][e]); s += v; ss = __builtin_fmaf(v, v, ss); }
+        asm volatile("" : "+v"(xr[rf][kc]));
+      }
+      s = xor32_sum(xor16_sum(s));
+      ss = xor32_sum(xor16_sum(ss));
+      const float mean = s * (1.0f / (float)K);
+      float var = ss * (1.0f / (float)K) - mean * mean;
+      var = var < 0.f ? 0.f : var;
+      const float rstd = rsqrtf(var + p.ln_eps);
+      const float shift = -mean * rstd;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xr[rf][kc][e] = from_f32<T>(__builtin_fmaf(to_f32(xr[rf][kc][e]), rstd, shift));
+        asm volatile("" : "+v"(xr[rf][kc]));
+      }
+    }
+  }
+
+  char* ostage = smem + XS_STAGES * XS_STAGE + wave * (32 * XS_OROW);
+  const auto rO = __builtin_amdgcn_make_buffer_rsrc(p.out, (short)0, (int)((size_t)p.M * p.ldo * 2), 0x00020000);
+
+  // The two waves that share a SIMD (w and w + 4) run the same program between the same barriers: left alone they do
+  // their MFMAs together and their epilogue arithmetic together, and the matrix pipe idles through every epilogue
+  // (measured: removing the MFMAs from this kernel saved exactly their stand-alone time).  Waves 4-7 therefore run
+  // half a stage out of phase: they defer the epilogue of stage c to the start of stage c + 1 (accumulators and bias
+  // kept in registers), so inside one barrier interval a SIMD sees [MFMA | epilogue] from one wave beside
+  // [epilogue | MFMA] from the other.
+  const bool late = wave >= 4;
+
+  // top of iteration ci: stage ci landed?  VMEM operations of this wave younger than its DMAs of stage ci (issued at the
+  // top of iteration ci-2): the next stage's NDMA, plus the 4 output stores of every finished line group in between.
+  // Early waves store the line of stage c at the end of iteration c, late waves at the start of iteration c + 1; the
+  // first iterations (no stores yet in the window) use the conservative count.
+  auto top = [&](int ci) __attribute__((always_inline)) {
+    const int cio = ci - (late ? 1 : 0);
+    if (XS_ABLATE & 8) {
+    } else if (ci + 1 >= nch) {
+      wait_vm<0>();
+    } else if (ci < (late ? 3 : 2)) {
+      wait_vm<NDMA>();
+    } else if constexpr (P == 1) {
+      wait_vm<NDMA + 8>();
+    } else if constexpr (P == 2) {
+      wait_vm<NDMA + 4>();
+    } else {
+      if ((cio & 3) < 2) wait_vm<NDMA + 4>(); else wait_vm<NDMA>();
+    }
+    if (!(XS_ABLATE & 8)) __builtin_amdgcn_s_barrier();   // everyone's pieces of stage ci landed; everyone is done with stage ci-1
+    if (!(XS_ABLATE & 16) && ci + 2 < nch) issue(c0 + ci + 2, (ci + 2) % XS_STAGES);
+  };
+
+  // MFMAs of stage ci into acc (+ the stage's bias values, which live in the LDS stage that is recycled two barriers on)
+  auto compute = [&](int ci, f32x4 (&acc)[NF][2], f32x4 (&bias)[NF]) __attribute__((always_inline)) {
+    const char* sb = smem + (ci % XS_STAGES) * XS_STAGE;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) { acc[nf][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[nf][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // weight fragments are read one K-chunk (NF x 16 bytes per lane) ahead of the MFMAs that consume them
+    typename Traits<T>::vec8 wf[2][NF];
+    auto wread = [&](int kc, typename Traits<T>::vec8 (&dst)[NF]) __attribute__((always_inline)) {
+      const int st = kc >> 1, h = kc & 1;
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const int row = nf * 16 + frow;
+        dst[nf] = as_vec8<T>(*(const u32x4*)(sb + st * SUB + row * 128 + (((4 * h + fq) ^ (row & 7)) << 4)));
+      }
+    };
+    wread(0, wf[0]);
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) bias[nf] = *(const f32x4*)(sb + XS_STAGE_W + (nf * 16 + fq * 4) * 4);
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      if (!(XS_ABLATE & 32) && kc + 1 < KC) wread(kc + 1, wf[(kc + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);          // (hipcc otherwise sinks every read to just before its first MFMA)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+#if XS_ABLATE & 1
+        asm volatile("" ::"v"(wf[(XS_ABLATE & 32) ? 0 : (kc & 1)][nf]), "v"(xr[0][kc]), "v"(xr[1][kc]));
+#else
+        acc[nf][0] = mfma16(wf[(XS_ABLATE & 32) ? 0 : (kc & 1)][nf], xr[0][kc], acc[nf][0]);
+        acc[nf][1] = mfma16(wf[(XS_ABLATE & 32) ? 0 : (kc & 1)][nf], xr[1][kc], acc[nf][1]);
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // epilogue of stage ci: registers -> wave-private LDS tile -> (every P stages) full-line global stores
+  auto epilogue = [&](int ci, const f32x4 (&acc)[NF][2], const f32x4 (&bias)[NF]) __attribute__((always_inline)) {
+    const int sub = ci % P;                       // position of this stage inside its 128-byte output line
+#pragma unroll
+    for (int nf = 0; nf < NF; nf += (GEGLU ? 2 : 1)) {
+#pragma unroll
+      for (int rf = 0; rf < 2; ++rf) {
+        typename Traits<T>::vec4 pk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if constexpr (GEGLU) {
+            const float gate = acc[nf + 1][rf][r] + bias[nf + 1][r];
+            pk[r] = from_f32<T>((acc[nf][rf][r] + bias[nf][r]) * ((XS_ABLATE & 2) ? gate : gelu_f(gate)));
+          } else {
+            pk[r] = from_f32<T>(acc[nf][rf][r] + bias[nf][r]);
+          }
+        }
+        const int chan = (GEGLU ? nf / 2 : nf) * 16 + fq * 4;
+        *(typename Traits<T>::vec4*)(ostage + (rf * 16 + frow) * XS_OROW + sub * OUTB + chan * 2) = pk;
+      }
+    }
+    if (sub == P - 1) {
+      // a full 128-byte line per row is staged: 4 coalesced 16-byte-per-lane stores (8 rows each)
+      const int line = (c0 + ci) / P;             // 64-channel group of the output row
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = i * 8 + (lane >> 3), col = lane & 7;
+        const u32x4 v = *(const u32x4*)(ostage + row * XS_OROW + col * 16);
+        // range-checked buffer store (rows >= M fall beyond num_records and are dropped by the hardware): the store
+        // is issued unconditionally, so every wave's VMEM count per iteration is the same - the counted waits above
+        // depend on it.  aux 16 = sc1 (write-through, like the GEMM's output stores)
+        const unsigned off = (unsigned)(((size_t)(r0 + row) * p.ldo + line * 64 + col * 8) * 2);
+        if (!(XS_ABLATE & 4)) __builtin_amdgcn_raw_buffer_store_b128(v, rO, (int)off, 0, ES_WT_STORES ? 16 : 0);
+        else asm volatile("" ::"v"(v), "v"(off));
+      }
+    }
+  };
+
+  f32x4 accA[NF][2], accB[NF][2], bA[NF], bB[NF];
+  if (!late) {
+    for (int ci = 0; ci < nch; ++ci) {
+      top(ci);
+      compute(ci, accA, bA);
+      epilogue(ci, accA, bA);
+    }
+  } else {
+    // unrolled by two so that the two accumulator sets keep static names
+    int ci = 0;
+    for (; ci + 1 < nch; ci += 2) {
+      top(ci);
+      if (ci > 0) epilogue(ci - 1, accB, bB);
+      compute(ci, accA, bA);
+      top(ci + 1);
+      epilogue(ci, accA, bA);
+      compute(ci + 1, accB, bB);
+    }
+    if (ci < nch) {
+      top(ci);
+      if (ci > 0) epilogue(ci - 1, accB, bB);
+      compute(ci, accA, bA);
+      epilogue(ci, accA, bA);
+    } else if (nch > 0) {
+      epilogue(nch - 1, accB, bB);
+    }
+  }
+  if (p.prof && tid == 0) atomicMax(p.prof + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+template <typename T, int KC, bool GEGLU, bool LN>
+int launch_one(const es_xs_desc& d, hipStream_t st) {
+  auto kfn = linear_xs_kernel<T, KC, GEGLU, LN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, XS_LDS);
+    attr_set = true;
+  }
+  const int rbs = (d.M + XS_ROWS - 1) / XS_ROWS;
+  hipLaunchKernelGGL(kfn, dim3(rbs * d.nslices), dim3(512), XS_LDS, st, d);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <typename T>
+int launch(const es_xs_desc& d, hipStream_t st) {
+  const bool g = d.geglu != 0, ln = d.ln != 0;
+  if (d.K == 320) {
+    if (g) return ln ? launch_one<T, 10, true, true>(d, st) : launch_one<T, 10, true, false>(d, st);
+    return ln ? launch_one<T, 10, false, true>(d, st) : launch_one<T, 10, false, false>(d, st);
+  }
+  if (g) return ln ? launch_one<T, 20, true, true>(d, st) : launch_one<T, 20, true, false>(d, st);
+  return ln ? launch_one<T, 20, false, true>(d, st) : launch_one<T, 20, false, false>(d, st);
+}
+
+}  // namespace
+
+extern "C" void es_set_error(const char* msg);
+
+extern "C" int es_linear_xs(const es_xs_desc* d, void* stream) {
+  if (!d->x || !d->out || (d->ngroups <= 1 && (!d->w || !d->bias))) { es_set_error("es_linear_xs: null pointer (bias is required: pass zeros)"); return -1; }
+  if (d->K != 320 && d->K != 640) { es_set_error("es_linear_xs: K must be 320 or 640"); return -1; }
+  const int CH = d->K == 320 ? 64 : 32;
+  const int P = 128 / (d->geglu ? CH : CH * 2);
+  if (d->M < 1 || d->Cout < CH || d->Cout % (CH * P) || d->rows_padded < d->Cout) {
+    es_set_error("es_linear_xs: Cout must be a multiple of the 128-byte output line (64 stored channels)"); return -1; }
+  const int total = d->Cout / CH;
+  if (d->nslices < 1 || d->chunks_per_slice < P || d->chunks_per_slice % P ||
+      (long long)d->nslices * d->chunks_per_slice < total || (long long)(d->nslices - 1) * d->chunks_per_slice >= total) {
+    es_set_error("es_linear_xs: slices must cover Cout in whole output lines, none empty"); return -1; }
+  const int cstore = d->geglu ? d->Cout / 2 : d->Cout;
+  if (d->ldo < cstore || d->ldo % 8) { es_set_error("es_linear_xs: bad output pitch"); return -1; }
+  if ((size_t)d->M * d->K * 2 >= 0x7FFFFFFFull || (size_t)d->rows_padded * d->K * 2 >= 0x7FFFFFFFull ||
+      ((size_t)d->M + 256) * d->ldo * 2 >= 0xFFFFFF00ull) {
+    es_set_error("es_linear_xs: operand larger than 2 GiB (32-bit buffer offsets)"); return -1; }
+  if (d->ngroups > 4) { es_set_error("es_linear_xs: at most 4 groups"); return -1; }
+  es_xs_desc dd = *d;
+  if (d->ngroups > 1) {
+    const int tm = (d->M + 127) / 128;
+    for (int g = 0; g < d->ngroups; ++g)
+      if (!d->w_g[g] || !d->bias_g[g] || d->mt_end[g] <= (g ? d->mt_end[g - 1] : 0) || (d->mt_end[g] & 1)) {
+        es_set_error("es_linear_xs: groups must be non-empty runs of whole 256-row blocks"); return -1; }
+    if (d->mt_end[d->ngroups - 1] != tm) { es_set_error("es_linear_xs: groups must cover M"); return -1; }
+  }
+  for (int g = dd.ngroups > 1 ? dd.ngroups : 0; g < 4; ++g) dd.mt_end[g] = 0x7FFFFFFF;
+  int rc = dd.dtype == ES_F16 ? launch<f16>(dd, (hipStream_t)stream) : launch<bf16>(dd, (hipStream_t)stream);
+  if (rc) es_set_error("es_linear_xs: launch failed");
+  return rc;
+}

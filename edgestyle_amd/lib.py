@@ -32,6 +32,17 @@ class GemmDesc(C.Structure):
     ]
 
 
+class XsDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("out", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p),
+        ("w_g", C.c_void_p * 4), ("bias_g", C.c_void_p * 4), ("prof", C.c_void_p),
+        ("mt_end", C.c_int32 * 4), ("ngroups", C.c_int32),
+        ("M", C.c_int32), ("K", C.c_int32), ("Cout", C.c_int32), ("rows_padded", C.c_int32),
+        ("ldo", C.c_int32), ("geglu", C.c_int32), ("ln", C.c_int32), ("ln_eps", C.c_float),
+        ("nslices", C.c_int32), ("chunks_per_slice", C.c_int32), ("dtype", C.c_int32),
+    ]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p),
@@ -82,6 +93,7 @@ SYMBOLS = {
     "es_sizeof_desc": (C.c_size_t, [_I]),
     "es_conv_gemm": (C.c_int, [C.POINTER(GemmDesc), _P]),
     "es_conv_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
+    "es_linear_xs": (C.c_int, [C.POINTER(XsDesc), _P]),
     "es_attention": (C.c_int, [C.POINTER(AttnDesc), _P]),
     "es_group_norm": (C.c_int, [C.POINTER(GnDesc), _P]),
     "es_group_norm_partials_bytes": (C.c_size_t, [_I, _I]),
@@ -127,7 +139,7 @@ def load():
         fn.argtypes = args
     if lib.es_abi_version() != 1:
         raise EdgeStyleHipError("libedgestyle_hip.so ABI version mismatch")
-    for i, st in enumerate((GemmDesc, AttnDesc, GnDesc, FusionDesc, LnDesc)):
+    for i, st in enumerate((GemmDesc, AttnDesc, GnDesc, FusionDesc, LnDesc, XsDesc)):
         if lib.es_sizeof_desc(i) != C.sizeof(st):
             raise EdgeStyleHipError(f"descriptor layout mismatch for {st.__name__}: C {lib.es_sizeof_desc(i)} "
                                     f"vs ctypes {C.sizeof(st)}")

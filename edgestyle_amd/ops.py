@@ -73,7 +73,8 @@ class Profiler:
         kernel: no stamp atomics).  The buffers they point at must still be alive (keep the graph that owns them)."""
         lib = L.load()
         for d in self.descs:
-            L.check(lib.es_conv_gemm(C.byref(d), _stream()), "es_conv_gemm(replay)")
+            fn = lib.es_linear_xs if isinstance(d, L.XsDesc) else lib.es_conv_gemm
+            L.check(fn(C.byref(d), _stream()), "GEMM replay")
 
     def results(self, first: int = 0):
         s = self.slots[first:len(self.meta)].cpu().tolist()
@@ -312,6 +313,87 @@ def plan_launch(M: int, pw: "PackedWeight", bn: int):
     return sk, st
 
 
+XS_ENABLED = _os.environ.get("ES_XS", "1") == "1"      # row-stationary short-K linear kernel (csrc/linear_xs.hip)
+XS_TARGET_WGS = 256
+XS_MIN_M = int(_os.environ.get("ES_XS_MIN_M", "8192"))   # 0: no size policy (tests exercise every shape)
+_zero_bias = {}
+
+
+def xs_eligible(M: int, pw: "PackedWeight", pws, group_n, hw: int) -> bool:
+    """K = 320 | 640 linear layers with an output width of whole 128-byte lines: the to_q|k|v and GEGLU projections of
+    the 64x64 and 32x32 levels."""
+    if not XS_ENABLED or pw.ksize != 1 or pw.kpad not in (320, 640) or pw.cin != pw.kpad or pw.ctail:
+        return False
+    ch = 64 if pw.kpad == 320 else 32
+    line = ch * (128 // (ch if pw.geglu else 2 * ch))        # GEMM columns per 128-byte output line
+    if pw.cout % line or pw.cout < 4 * line:
+        return False
+    if pws is not None:
+        if len(pws) > 4 or any((n * hw) % 256 for n in group_n) or any((q.ln_colsum is None) != (pw.ln_colsum is None) for q in pws):
+            return False
+    # where it wins (tools/xs_bench.py, batch-1 shapes): 1.4-1.6x on the 14-sample launches of both levels and 1.05-1.1x on
+    # the decoder's wide K = 320 projections; it loses where a workgroup's share of N is a few chunks (the activation
+    # rows are re-read per slice and the 40 KB stages no longer amortise): small M with K = 640, narrow N at small M
+    if XS_MIN_M and (M < XS_MIN_M or (M < 4 * XS_MIN_M and pw.cout < (960 if pw.kpad == 320 else 1920))):
+        return False
+    return True
+
+
+def linear_xs(x: torch.Tensor, pw, M: int, out: torch.Tensor, group_rows=None) -> torch.Tensor:
+    """x: [M, K] contiguous; pw (or list of pw for a grouped launch with `group_rows` rows each) -> out [M, cstore]."""
+    pws = None
+    if isinstance(pw, (list, tuple)):
+        pws = list(pw) if len(pw) > 1 else None
+        pw = pw[0]
+    K = pw.kpad
+    ch = 64 if K == 320 else 32
+    pline = 128 // (ch if pw.geglu else 2 * ch)             # chunks per 128-byte output line
+    total = pw.cout // ch
+    lines = total // pline
+    rbs = (M + 255) // 256
+    want = max(1, min(lines, XS_TARGET_WGS // rbs))
+    lps = -(-lines // want)                                  # lines per slice
+    nslices = -(-lines // lps)
+    d = L.XsDesc()
+    d.x, d.out = x.data_ptr(), out.data_ptr()
+
+    def bias_of(q):
+        if q.bias is not None:
+            return q.bias.data_ptr()
+        key = (x.device, q.rows_padded)
+        z = _zero_bias.get(key)
+        if z is None:
+            z = _zero_bias[key] = torch.zeros(q.rows_padded, dtype=torch.float32, device=x.device)
+        return z.data_ptr()
+    d.w, d.bias = pw.w.data_ptr(), bias_of(pw)
+    d.M, d.K, d.Cout, d.rows_padded = M, K, pw.cout, pw.rows_padded
+    d.ldo = out.shape[-1]
+    d.geglu, d.ln, d.ln_eps = int(pw.geglu), int(pw.ln_colsum is not None), pw.ln_eps
+    d.nslices, d.chunks_per_slice, d.dtype = nslices, lps * pline, _dt(x)
+    if pws is not None:
+        d.ngroups = len(pws)
+        acc = 0
+        for g, (q, n) in enumerate(zip(pws, group_rows)):
+            if (q.rows_padded, q.kpad, q.cout, q.geglu) != (pw.rows_padded, pw.kpad, pw.cout, pw.geglu):
+                raise L.EdgeStyleHipError("grouped linear_xs: weight geometry differs between groups")
+            acc += n // 128
+            d.mt_end[g] = acc
+            d.w_g[g] = q.w.data_ptr()
+            d.bias_g[g] = bias_of(q)
+    if PROFILE is not None:
+        d.prof = PROFILE.next((2.0 * M * pw.cout * K, 1, (M, pw.cout, K, 1, 1, 0),
+                               dict(N=M, H=1, W=1, C1=K, C2=0, cout=pw.cout, k=1, stride=1, pad=0, upsample=False,
+                                    geglu=pw.geglu, splitk=1, Hout=1, Wout=1, residual=False, temb=False, bn=0, stages=3,
+                                    group_n=list(group_rows) if pws is not None else None, ctail=0, kernel="linear_xs",
+                                    algorithmic_bytes=_algorithmic_bytes(x, None, pw, pws, out, None))))
+        dd = L.XsDesc()
+        C.memmove(C.byref(dd), C.byref(d), C.sizeof(L.XsDesc))
+        dd.prof = None
+        PROFILE.descs.append(dd)
+    L.check(L.load().es_linear_xs(C.byref(d), _stream()), "es_linear_xs")
+    return out
+
+
 def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Optional[int] = None,
               upsample: bool = False, x2: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None,
               residual: Optional[torch.Tensor] = None, act: int = L.ACT_NONE, out_scale: float = 1.0,
@@ -349,6 +431,13 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     if out is None:
         out = torch.empty((N, Hout, Wout, cstore), dtype=x.dtype, device=x.device)
     M = N * Hout * Wout
+    if (k == 1 and stride == 1 and not upsample and x2 is None and temb is None and residual is None and not tails
+            and act == L.ACT_NONE and out_scale == 1.0 and out_scale_dev is None and splitk is None and FORCE_BN == 0
+            and x.is_contiguous() and out.is_contiguous()
+            and xs_eligible(M, pw, pws, group_n, Hout * Wout)):
+        linear_xs(x.reshape(M, C1), pws if pws is not None else pw, M, out.reshape(M, cstore),
+                  None if pws is None else [n * Hout * Wout for n in group_n])
+        return out
     big_ok = BIG_TILE and C1 % BK == 0 and C2 % BK == 0 and not pw.geglu and \
         (group_n is None or all((n * Hout * Wout) % 256 == 0 for n in group_n))
     small_ok = SMALL_TILE and C1 % BK == 0 and C2 % BK == 0 and not pw.geglu and FORCE_WAVES != 8 and FORCE_BM in (0, 64) \

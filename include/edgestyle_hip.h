@@ -25,7 +25,7 @@ enum { ES_ACT_NONE = 0, ES_ACT_SILU = 1, ES_ACT_GEGLU = 2 };
 
 #define ES_ABI_VERSION 1
 int es_abi_version(void);
-/* sizeof the descriptor structs as compiled (0 gemm, 1 attn, 2 gn, 3 fusion, 4 ln): lets a binding verify its mirror */
+/* sizeof the descriptor structs as compiled (0 gemm, 1 attn, 2 gn, 3 fusion, 4 ln, 5 xs): lets a binding verify its mirror */
 size_t es_sizeof_desc(int which);
 const char* es_last_error(void);
 
@@ -96,6 +96,34 @@ typedef struct {
 } es_gemm_desc;
 int es_conv_gemm(const es_gemm_desc* d, void* stream);
 size_t es_conv_gemm_workspace_bytes(const es_gemm_desc* d);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * es_linear_xs — row-stationary short-K linear layer (K = 320 | 640): out = epilogue(LayerNorm?(x) W^T + bias).
+ * Replaces, at the 64x64 and 32x32 UNet / ControlNet levels: BasicTransformerBlock.norm1 -> attn1.to_q|k|v and
+ * norm3 -> ff.net.0 (GEGLU) (diffusers, called under model/controllora.py:205-238) - the same math as es_conv_gemm with
+ * ln_colsum / ES_ACT_GEGLU, organised for few K-steps and many output columns (csrc/linear_xs.hip).
+ * x [M, K] dtype, raw residual stream when ln != 0 (gamma / beta are folded into w / bias: ops.pack_weight_ln);
+ * w packed [rows_padded][K] (GEGLU: rows interleaved 16 hidden | 16 gate, as for es_conv_gemm); bias fp32
+ * [rows_padded] (required); out [M, ldo] dtype, Cout (or Cout / 2 for GEGLU) columns written.
+ * Workgroup = 256 rows x one slice of the output columns: grid = ceil(M / 256) * nslices, slice s covers the
+ * `chunks_per_slice` column chunks (64 columns at K = 320, 32 at K = 640) starting at s * chunks_per_slice.
+ * Grouped launch like es_conv_gemm: rows [mt_end[g-1], mt_end[g]) * 128 use w_g[g] / bias_g[g] (even mt_end only).
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x; void* out;
+  const void* w; const float* bias;
+  const void* w_g[4]; const float* bias_g[4];
+  unsigned long long* prof;   /* as es_gemm_desc.prof */
+  int32_t mt_end[4];
+  int32_t ngroups;
+  int32_t M, K, Cout, rows_padded;
+  int32_t ldo;                /* output row pitch in elements */
+  int32_t geglu, ln;
+  float ln_eps;
+  int32_t nslices, chunks_per_slice;
+  int32_t dtype;
+} es_xs_desc;
+int es_linear_xs(const es_xs_desc* d, void* stream);
 
 /* Fused attention softmax(Q K^T * scale) V (flash-style, online softmax, MFMA).
  * Replaces torch.nn.functional.scaled_dot_product_attention under diffusers Attention (attn1/attn2/VAE attn).

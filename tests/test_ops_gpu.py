@@ -456,6 +456,7 @@ def test_linear_with_folded_layer_norm(dtype):
     from edgestyle_amd import ops
     g = torch.Generator().manual_seed(66)
     tol = 4e-3 if dtype == torch.float16 else 2.5e-2
+    ops.XS_ENABLED = False                                # this test is about the tiled kernel's fold; linear_xs has its own
     for M, C, Cout, geglu in [(300, 320, 960, False), (200, 640, 640, False), (257, 320, 2560, True), (130, 1280, 1280, False)]:
         x = q16(torch.randn(M, C, generator=g) * 1.5 + 0.7 + torch.randn(M, 1, generator=g), dtype)
         gamma = 1 + 0.2 * torch.randn(C, generator=g)
@@ -490,6 +491,7 @@ def test_linear_with_folded_layer_norm(dtype):
         refs.append(F.linear(F.layer_norm(xg[a:a + n], (C,), gamma, beta, 1e-5), w, b))
         a += n
     yg = ops.linear(xg.to(DEV, dtype), pws, group_n=counts)
+    ops.XS_ENABLED = True
     assert rel_err(yg, torch.cat(refs)) < tol
 
 
@@ -717,3 +719,64 @@ def test_two_group_launches_group_norm_and_conv():
     for i, n in enumerate(counts):
         assert torch.equal(yg[a:a + n], ops.conv_gemm(x[a:a + n].contiguous(), pws[i], splitk=1))
         a += n
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_linear_xs_row_stationary_kernel(dtype):
+    """es_linear_xs (csrc/linear_xs.hip: activations in registers, weights streamed through an LDS ring) vs torch and vs
+    the tiled kernel, on every instantiation: K = 320 | 640, plain | GEGLU, LayerNorm | none, N split over slices
+    (small M), ragged M, grouped weights, a bias-free projection (to_q|k|v)."""
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(99)
+    tol = 4e-3 if dtype == torch.float16 else 2.5e-2
+    ops.XS_MIN_M = 0                                      # no size policy here: every instantiation must be exercised
+    cases = [  # M, C, Cout, geglu, ln, bias
+        (57344 // 8, 320, 960, False, True, False),      # to_q|k|v: 28 row blocks x 9 slices
+        (2048, 320, 2560, True, True, True),             # decoder GEGLU: 8 row blocks x 20 slices
+        (1000, 640, 1920, False, True, False),           # ragged M, K = 640
+        (512, 640, 5120, True, True, True),              # K = 640 GEGLU (4 stages per output line)
+        (300, 320, 320, False, False, True),             # proj_in-like plain layer, ragged
+        (256, 640, 640, False, False, True),
+        (40, 320, 1280, True, False, True),              # fewer rows than one wave pair
+    ]
+    for M, C, Cout, geglu, ln, bias in cases:
+        x = q16(torch.randn(M, C, generator=g) * 1.5 + 0.7 + torch.randn(M, 1, generator=g), dtype)
+        gamma = 1 + 0.2 * torch.randn(C, generator=g)
+        beta = 0.1 * torch.randn(C, generator=g)
+        w = torch.randn(Cout, C, generator=g) / math.sqrt(C)
+        b = torch.randn(Cout, generator=g) * 0.1 if bias else None
+        xin = F.layer_norm(x, (C,), gamma, beta, 1e-5) if ln else x
+        y = F.linear(xin, w, b)
+        if geglu:
+            h, gate = y.chunk(2, dim=-1)
+            y = h * F.gelu(gate)
+        if ln:
+            pw = ops.pack_weight_ln(w, b, gamma, beta, 1e-5, dtype, DEV, geglu=geglu)
+        else:
+            pw = ops.pack_weight(w, b, dtype, DEV, geglu=geglu)
+        xd = x.to(DEV, dtype)
+        assert ops.xs_eligible(M, pw, None, None, 1)
+        got = ops.linear(xd, pw)
+        ops.XS_ENABLED = False
+        try:
+            tiled = ops.linear(xd, pw)
+        finally:
+            ops.XS_ENABLED = True
+        assert rel_err(got, y) < tol, (M, C, Cout, geglu, ln, rel_err(got, y))
+        assert rel_err(got, tiled) < tol, (M, C, Cout, geglu, ln)
+    # grouped: four weight sets over [2, 6, 4, 2] x 256 rows (the lockstep encoder's group table), GEGLU
+    C, Cout, counts = 320, 2560, [512, 1536, 1024, 512]
+    xg = q16(torch.randn(sum(counts), C, generator=g) * 2 + 0.3, dtype)
+    pws, refs, a = [], [], 0
+    for n in counts:
+        gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+        w, b = torch.randn(Cout, C, generator=g) / math.sqrt(C), torch.randn(Cout, generator=g) * 0.1
+        pws.append(ops.pack_weight_ln(w, b, gamma, beta, 1e-5, dtype, DEV, geglu=True))
+        hh, gate = F.linear(F.layer_norm(xg[a:a + n], (C,), gamma, beta, 1e-5), w, b).chunk(2, dim=-1)
+        refs.append(hh * F.gelu(gate))
+        a += n
+    yg = ops.linear(xg.to(DEV, dtype), pws, group_n=counts)
+    assert rel_err(yg, torch.cat(refs)) < tol
+    # deterministic: same launch twice, bit for bit
+    assert torch.equal(yg, ops.linear(xg.to(DEV, dtype), pws, group_n=counts))
+    ops.XS_MIN_M = 8192
