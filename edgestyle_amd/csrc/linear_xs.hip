@@ -33,6 +33,11 @@
 #ifndef XS_ABLATE
 #define XS_ABLATE 0
 #endif
+// Tool-only diagnostic build (tools/xs_stamps.py): XS_STAMPS=1 writes s_memtime stamps of waves 0 and 4 of two workgroups
+// (after the barrier / after the MFMAs / after the epilogue of stages 4..11) into the buffer passed as `prof`.
+#ifndef XS_STAMPS
+#define XS_STAMPS 0
+#endif
 
 namespace {
 
@@ -65,7 +70,15 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 15, fq = lane >> 4;
   const int slice = blockIdx.x % p.nslices, rb = blockIdx.x / p.nslices;
+#if XS_STAMPS
+  const int sblk = blockIdx.x == 3 ? 0 : (blockIdx.x == 100 ? 1 : -1);
+  auto stamp = [&](int ci, int what) __attribute__((always_inline)) {
+    if (p.prof && sblk >= 0 && (wave & 3) == 0 && lane == 0 && ci >= 4 && ci < 12)
+      p.prof[((sblk * 2 + (wave >> 2)) * 8 + (ci - 4)) * 3 + what] = __builtin_amdgcn_s_memtime();
+  };
+#else
   if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 
   // this workgroup's stages: [c0, c1), whole groups of P
   const int total = (p.Cout + CH - 1) / CH;
@@ -158,6 +171,14 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
   // kept in registers), so inside one barrier interval a SIMD sees [MFMA | epilogue] from one wave beside
   // [epilogue | MFMA] from the other.
   const bool late = wave >= 4;
+  // ... and they are the younger half of the workgroup: at equal priority the SIMD's arbiter serves the older wave first
+  // (MI355X_MICROARCH.md, two waves per SIMD, items 2 and 4), so a late wave's epilogue crawled behind its partner's
+  // MFMAs AND epilogue (in-kernel stamps: 3700 cycles against 1300 for the same code in the older wave, which then sat
+  // idle at the barrier for half the stage).  One static s_setprio for the younger half, no per-phase flips.
+#ifndef XS_PRIO
+#define XS_PRIO 1
+#endif
+  if (XS_PRIO && late) __builtin_amdgcn_s_setprio(1);
 
   // top of iteration ci: stage ci landed?  VMEM operations of this wave younger than its DMAs of stage ci (issued at the
   // top of iteration ci-2): the next stage's NDMA, plus the 4 output stores of every finished line group in between.
@@ -184,8 +205,6 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
   // MFMAs of stage ci into acc (+ the stage's bias values, which live in the LDS stage that is recycled two barriers on)
   auto compute = [&](int ci, f32x4 (&acc)[NF][2], f32x4 (&bias)[NF]) __attribute__((always_inline)) {
     const char* sb = smem + (ci % XS_STAGES) * XS_STAGE;
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf) { acc[nf][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[nf][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     // weight fragments are read one K-chunk (NF x 16 bytes per lane) ahead of the MFMAs that consume them
     typename Traits<T>::vec8 wf[2][NF];
     auto wread = [&](int kc, typename Traits<T>::vec8 (&dst)[NF]) __attribute__((always_inline)) {
@@ -197,8 +216,13 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
       }
     };
     wread(0, wf[0]);
+    // the bias enters as the C operand of each accumulator's first MFMA: no add in the epilogue
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) bias[nf] = *(const f32x4*)(sb + XS_STAGE_W + (nf * 16 + fq * 4) * 4);
+    for (int nf = 0; nf < NF; ++nf) {
+      bias[nf] = *(const f32x4*)(sb + XS_STAGE_W + (nf * 16 + fq * 4) * 4);
+      acc[nf][0] = bias[nf];
+      acc[nf][1] = bias[nf];
+    }
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
       if (!(XS_ABLATE & 32) && kc + 1 < KC) wread(kc + 1, wf[(kc + 1) & 1]);
@@ -227,10 +251,10 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if constexpr (GEGLU) {
-            const float gate = acc[nf + 1][rf][r] + bias[nf + 1][r];
-            pk[r] = from_f32<T>((acc[nf][rf][r] + bias[nf][r]) * ((XS_ABLATE & 2) ? gate : gelu_f(gate)));
+            const float gate = acc[nf + 1][rf][r];
+            pk[r] = from_f32<T>(acc[nf][rf][r] * ((XS_ABLATE & 2) ? gate : gelu_f(gate)));
           } else {
-            pk[r] = from_f32<T>(acc[nf][rf][r] + bias[nf][r]);
+            pk[r] = from_f32<T>(acc[nf][rf][r]);
           }
         }
         const int chan = (GEGLU ? nf / 2 : nf) * 16 + fq * 4;
@@ -258,19 +282,46 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
   if (!late) {
     for (int ci = 0; ci < nch; ++ci) {
       top(ci);
+#if XS_STAMPS
+      stamp(ci, 0);
+#endif
       compute(ci, accA, bA);
+#if XS_STAMPS
+      stamp(ci, 1);
+#endif
       epilogue(ci, accA, bA);
+#if XS_STAMPS
+      stamp(ci, 2);
+#endif
     }
   } else {
     // unrolled by two so that the two accumulator sets keep static names
     int ci = 0;
     for (; ci + 1 < nch; ci += 2) {
       top(ci);
+#if XS_STAMPS
+      stamp(ci, 0);
+#endif
       if (ci > 0) epilogue(ci - 1, accB, bB);
+#if XS_STAMPS
+      stamp(ci, 1);
+#endif
       compute(ci, accA, bA);
+#if XS_STAMPS
+      stamp(ci, 2);
+#endif
       top(ci + 1);
+#if XS_STAMPS
+      stamp(ci + 1, 0);
+#endif
       epilogue(ci, accA, bA);
+#if XS_STAMPS
+      stamp(ci + 1, 1);
+#endif
       compute(ci + 1, accB, bB);
+#if XS_STAMPS
+      stamp(ci + 1, 2);
+#endif
     }
     if (ci < nch) {
       top(ci);
@@ -281,7 +332,9 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
       epilogue(nch - 1, accB, bB);
     }
   }
+#if !XS_STAMPS
   if (p.prof && tid == 0) atomicMax(p.prof + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 template <typename T, int KC, bool GEGLU, bool LN>
