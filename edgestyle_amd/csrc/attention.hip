@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "../../include/edgestyle_hip.h"
+#include "plan.h"
 
 // Tool-only build (-DES_ATTN_STAMPS): wave 0 of block (1,0,0) accumulates s_memtime deltas per loop phase into
 // es_attn_dbg (read back with es_attn_debug_read).  Perturbs the schedule; never compiled into the product library.
@@ -633,6 +634,7 @@ extern "C" int es_attn_debug_read(unsigned long long* host16) {
 #endif
 
 extern "C" int es_attention(const es_attn_desc* d, void* stream) {
+  ES_PLAN_RECORD(ES_OP_ATTENTION, d, sizeof(*d));
   if (!d->q || !d->k || !d->v || !d->o) { es_set_error("es_attention: null pointer"); return -1; }
   if (d->d % 8 || d->ldq % 8 || d->ldk % 8 || d->ldv % 8 || d->ldo % 4) { es_set_error("es_attention: d and strides must be multiples of 8"); return -1; }
   if (d->Sq < 1 || d->Skv < 1 || d->N < 1 || d->heads < 1) { es_set_error("es_attention: empty problem"); return -1; }

@@ -11,6 +11,7 @@
 // NHWC residual tensors in place, fp32 statistics, deterministic two-level reductions (no global atomics).
 #include "common.h"
 #include "../../include/edgestyle_hip.h"
+#include "plan.h"
 
 namespace {
 
@@ -275,6 +276,7 @@ static int fusion_check(const es_fusion_desc* d) {
 
 extern "C" int es_fusion_blocks(const es_fusion_desc* ds, int count, void* stream) {
   if (!ds || count < 1 || count > ES_FUSION_MAX_BATCH) { es_set_error("es_fusion_blocks: 1..13 blocks per call"); return -1; }
+  ES_PLAN_RECORD(ES_OP_FUSION_BLOCKS, ds, sizeof(*ds) * count);
   for (int k = 0; k < count; ++k) {
     if (fusion_check(ds + k)) return -1;
     if (ds[k].N != ds[0].N || ds[k].dtype != ds[0].dtype) { es_set_error("es_fusion_blocks: blocks must share N and dtype"); return -1; }
@@ -288,6 +290,7 @@ extern "C" int es_fusion_blocks(const es_fusion_desc* ds, int count, void* strea
 }
 
 extern "C" int es_fusion_block(const es_fusion_desc* d, void* stream) {
+  ES_PLAN_RECORD(ES_OP_FUSION_BLOCK, d, sizeof(*d));
   if (fusion_check(d)) return -1;
   hipStream_t st = (hipStream_t)stream;
   int rc = d->dtype == ES_F16 ? launch_fusion<f16>(*d, st) : launch_fusion<bf16>(*d, st);

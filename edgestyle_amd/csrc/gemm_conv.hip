@@ -32,6 +32,7 @@
 #endif
 #include "common.h"
 #include "../../include/edgestyle_hip.h"
+#include "plan.h"
 
 namespace {
 
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
       }
       iy0[i] = oy * p.stride - p.pad;
       ix0[i] = ox * p.stride - p.pad;
+      if (p.x_nmod) n -= (n / p.x_nmod) * p.x_nmod;      // several groups read the same source samples
       nb[i] = n * p.Hsrc * p.Wsrc;
     }
   }
@@ -185,14 +187,15 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
   const float* lnsel = LN ? (p.ngroups > 1 ? p.ln_colsum_g[grp] : p.ln_colsum) : nullptr;   // LayerNorm fold
   const auto rW = __builtin_amdgcn_make_buffer_rsrc(
       (void*)wsel, (short)0, (int)((size_t)p.rows_padded * p.Kpad * 2), 0x00020000);
+  const int Nsrc = p.x_nmod ? p.x_nmod : p.N;          // samples the source tensors hold
   const auto rX1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.x, (short)0, (int)((size_t)p.N * p.Hsrc * p.Wsrc * p.C1 * 2), 0x00020000);
+      (void*)p.x, (short)0, (int)((size_t)Nsrc * p.Hsrc * p.Wsrc * p.C1 * 2), 0x00020000);
   const void* const pt1 = tail1 ? tail1 : p.x;
   const void* const pt2 = tail2 ? tail2 : p.x;
   const void* const px = p.x;
   const void* const px2 = p.x2 ? p.x2 : p.x;
-  const int nX1 = (int)((size_t)p.N * p.Hsrc * p.Wsrc * pC1 * 2);
-  const int nX2 = (int)((size_t)p.N * p.Hsrc * p.Wsrc * (p.x2 ? pC2 : pC1) * 2);
+  const int nX1 = (int)((size_t)Nsrc * p.Hsrc * p.Wsrc * pC1 * 2);
+  const int nX2 = (int)((size_t)Nsrc * p.Hsrc * p.Wsrc * (p.x2 ? pC2 : pC1) * 2);
   const int nT1 = has_tail ? (int)((size_t)p.N * p.Hout * p.Wout * pCt1 * 2) : 0;
   const int nT2 = tail2 ? (int)((size_t)p.N * p.Hout * p.Wout * pCt2 * 2) : 0;
   unsigned woff[WI];
@@ -796,6 +799,7 @@ extern "C" size_t es_conv_gemm_workspace_bytes(const es_gemm_desc* d) {
 }
 
 extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
+  ES_PLAN_RECORD(ES_OP_CONV_GEMM, d, sizeof(*d));
   const int Ctot = d->C1 + d->C2;
   const int Ktrue = d->ksize * d->ksize * Ctot + (d->t1 ? d->Ct1 + d->Ct2 : 0);
   if (!d->x || !d->out || (d->ngroups <= 1 && !d->w)) { es_set_error("es_conv_gemm: null pointer"); return -1; }
@@ -827,6 +831,7 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
                 (size_t)d->N * d->Hout * d->Wout * (d->Ct1 > d->Ct2 ? d->Ct1 : d->Ct2) * 2 >= 0x7FFFFFFFull)) {
     es_set_error("es_conv_gemm: 1x1 tail sources need stride 1, no upsample, same-size output, 64-aligned channels"); return -1; }
   if (!d->t1 && (d->t2 || d->Ct1 || d->Ct2)) { es_set_error("es_conv_gemm: tail fields set without t1"); return -1; }
+  if (d->x_nmod < 0 || (d->x_nmod && (d->x2 || d->t1 || d->x_nmod > d->N))) { es_set_error("es_conv_gemm: x_nmod needs a single source and 0 < x_nmod <= N"); return -1; }
   if (d->splitk < 1 || d->splitk > d->Kpad / BK) { es_set_error("es_conv_gemm: bad splitk"); return -1; }
   if (d->splitk > 1 && (!d->workspace || d->act == ES_ACT_GEGLU)) { es_set_error("es_conv_gemm: splitk needs workspace and no GEGLU"); return -1; }
   if (d->splitk > 1 && (long long)d->N * d->Hout * d->Wout * (d->rows_padded / 8) >= (1ll << 31)) { es_set_error("es_conv_gemm: split-K output too large for 32-bit indices"); return -1; }

@@ -25,6 +25,7 @@
 #endif
 #include "common.h"
 #include "../../include/edgestyle_hip.h"
+#include "plan.h"
 
 // Tool-only ablation builds (tools/xs_ablate.sh): time the kernel with one ingredient removed.  Results are wrong by
 // construction; the product library is always built with XS_ABLATE == 0.
@@ -366,6 +367,7 @@ int launch(const es_xs_desc& d, hipStream_t st) {
 extern "C" void es_set_error(const char* msg);
 
 extern "C" int es_linear_xs(const es_xs_desc* d, void* stream) {
+  ES_PLAN_RECORD(ES_OP_LINEAR_XS, d, sizeof(*d));
   if (!d->x || !d->out || (d->ngroups <= 1 && (!d->w || !d->bias))) { es_set_error("es_linear_xs: null pointer (bias is required: pass zeros)"); return -1; }
   if (d->K != 320 && d->K != 640) { es_set_error("es_linear_xs: K must be 320 or 640"); return -1; }
   const int CH = d->K == 320 ? 64 : 32;

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "../../include/edgestyle_hip.h"
+#include "plan.h"
 
 namespace {
 
@@ -425,6 +426,7 @@ extern "C" size_t es_group_norm_partials_bytes(int N, int groups) {
 }
 
 extern "C" int es_group_norm(const es_gn_desc* d, void* stream) {
+  ES_PLAN_RECORD(ES_OP_GROUP_NORM, d, sizeof(*d));
   const int C = d->C1 + d->C2;
   if (!d->x || !d->out || !d->partials || (d->ngroups <= 1 && (!d->gamma || !d->beta))) { es_set_error("es_group_norm: null pointer"); return -1; }
   if (d->ngroups > 4) { es_set_error("es_group_norm: at most 4 groups"); return -1; }
@@ -446,6 +448,10 @@ extern "C" int es_group_norm(const es_gn_desc* d, void* stream) {
 
 extern "C" int es_layer_norm(const void* x, void* out, const float* gamma, const float* beta, int M, int C,
                              float eps, int dtype, void* stream) {
+  if (es_plan_recording()) {
+    const es_op_layer_norm a{x, out, gamma, beta, M, C, eps, dtype};
+    es_plan_record(ES_OP_LAYER_NORM, &a, sizeof(a));
+  }
   if (!x || !out || !gamma || !beta) { es_set_error("es_layer_norm: null pointer"); return -1; }
   if (C % 8 || M < 1) { es_set_error("es_layer_norm: C must be a multiple of 8"); return -1; }
   hipStream_t st = (hipStream_t)stream;
@@ -457,6 +463,7 @@ extern "C" int es_layer_norm(const void* x, void* out, const float* gamma, const
 }
 
 extern "C" int es_layer_norm_grouped(const es_ln_desc* d, void* stream) {
+  ES_PLAN_RECORD(ES_OP_LAYER_NORM_GROUPED, d, sizeof(*d));
   if (!d->x || !d->out || d->C % 8 || d->M < 1 || d->ngroups < 1 || d->ngroups > 4) { es_set_error("es_layer_norm_grouped: bad arguments"); return -1; }
   LnGroups grp;
   grp.ngroups = d->ngroups;

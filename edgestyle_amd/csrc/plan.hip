@@ -1,0 +1,317 @@
+// Native execution of the denoising path: recorded launch lists (es_plan) and the context that owns them (es_ctx).
+//
+// The reference's step function is OnnxUNetAndControlnets.forward (export_onnx.py:43-74) and its loop is
+// EdgeStyleStableDiffusionControlNetPipeline.__call__ (model/edgestyle_pipeline.py:435-557); both are Python.  Here the
+// host language only BUILDS a context (packs weights, allocates the static buffers and walks the model once while a
+// plan records every C-ABI launch of that walk).  After that es_denoise_step / es_denoise_loop / es_vae_decode run with
+// plain device pointers from any host: inputs are copied into the context's static buffers, the launch list is re-issued
+// on the caller's stream (or replayed as a hipGraph instantiated from it), outputs are copied out.  No interpreter, no
+// torch, no allocation in these calls.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/edgestyle_hip.h"
+#include "plan.h"
+
+extern "C" void es_set_error(const char* msg);
+
+struct es_plan {
+  struct Op { int kind; size_t off, bytes; };
+  std::vector<Op> ops;
+  std::vector<char> blob;
+};
+
+namespace {
+thread_local es_plan* g_rec = nullptr;
+thread_local bool g_replaying = false;
+
+int launch_op(const es_plan* p, const es_plan::Op& op, hipStream_t st, const float* guidance_override) {
+  const char* a = p->blob.data() + op.off;
+  void* s = (void*)st;
+  switch (op.kind) {
+    case ES_OP_CONV_GEMM: return es_conv_gemm((const es_gemm_desc*)a, s);
+    case ES_OP_LINEAR_XS: return es_linear_xs((const es_xs_desc*)a, s);
+    case ES_OP_ATTENTION: return es_attention((const es_attn_desc*)a, s);
+    case ES_OP_GROUP_NORM: return es_group_norm((const es_gn_desc*)a, s);
+    case ES_OP_LAYER_NORM: { auto* r = (const es_op_layer_norm*)a; return es_layer_norm(r->x, r->out, r->gamma, r->beta, r->M, r->C, r->eps, r->dtype, s); }
+    case ES_OP_LAYER_NORM_GROUPED: return es_layer_norm_grouped((const es_ln_desc*)a, s);
+    case ES_OP_FUSION_BLOCK: return es_fusion_block((const es_fusion_desc*)a, s);
+    case ES_OP_FUSION_BLOCKS: return es_fusion_blocks((const es_fusion_desc*)a, (int)(op.bytes / sizeof(es_fusion_desc)), s);
+    case ES_OP_TIMESTEP_EMBEDDING: { auto* r = (const es_op_timestep*)a; return es_timestep_embedding(r->t, r->out, r->N, r->dim, r->dtype, s); }
+    case ES_OP_CFG_DDIM: { auto* r = (const es_op_cfg_ddim*)a;
+      return es_cfg_ddim_step(r->noise, r->latents, r->model_in, r->coef, r->step_idx, guidance_override ? *guidance_override : r->guidance_scale,
+                              r->B, r->HW, r->L, r->Lstride, r->cfg, r->nsteps, r->dtype, s); }
+    case ES_OP_CFG_UNIPC: { auto* r = (const es_op_cfg_unipc*)a;
+      return es_cfg_unipc_step(r->noise, r->latents, r->last_sample, r->m0, r->m1, r->model_in, r->coef, r->step_idx,
+                               guidance_override ? *guidance_override : r->guidance_scale, r->B, r->HW, r->L, r->Lstride, r->cfg, r->nsteps, r->dtype, s); }
+    case ES_OP_NCHW_TO_NHWC: { auto* r = (const es_op_nchw_to_nhwc*)a; return es_nchw_f32_to_nhwc(r->in, r->out, r->N, r->C, r->HW, r->Cpad, r->dtype, s); }
+    case ES_OP_NHWC_TO_NCHW: { auto* r = (const es_op_nhwc_to_nchw*)a; return es_nhwc_to_nchw_f32(r->in, r->out, r->N, r->C, r->HW, r->Cstride, r->scale, r->shift, r->clamp01, r->dtype, s); }
+    case ES_OP_ADD: { auto* r = (const es_op_add*)a; return es_add(r->a, r->b, r->y, r->n, r->dtype, s); }
+    case ES_OP_VAE_SAMPLE: { auto* r = (const es_op_vae_sample*)a; return es_vae_sample(r->moments, r->noise, r->z, r->N, r->HW, r->L, r->Lpad, r->scaling, r->dtype, s); }
+    case ES_OP_INCR: { auto* r = (const es_op_incr*)a; return es_incr(r->ctr, s); }
+    case ES_OP_GATHER_ROW: { auto* r = (const es_op_gather_row*)a; return es_gather_row(r->table, r->idx, r->out, r->row_len, r->nrows, s); }
+    case ES_OP_MEMCPY: { auto* r = (const es_op_memcpy*)a; return es_memcpy(r->dst, r->src, r->bytes, s); }
+    case ES_OP_MEMCPY2D: { auto* r = (const es_op_memcpy2d*)a; return es_memcpy2d(r->dst, r->dpitch, r->src, r->spitch, r->width, r->height, s); }
+    case ES_OP_FILL_F32: { auto* r = (const es_op_fill_f32*)a; return es_fill_f32(r->dst, r->value, r->n, s); }
+    case ES_OP_LATENTS_TO_INPUT: { auto* r = (const es_op_latents_to_input*)a; return es_latents_to_input(r->latents, r->model_in, r->B, r->HW, r->L, r->Lstride, r->cfg, r->dtype, s); }
+    default: es_set_error("es_plan_launch: unknown op"); return -1;
+  }
+}
+
+int run_plan(const es_plan* p, hipStream_t st, const float* guidance_override) {
+  if (g_rec) { es_set_error("es_plan_launch: a plan is recording on this thread"); return -1; }
+  g_replaying = true;
+  int rc = 0;
+  for (const auto& op : p->ops)
+    if ((rc = launch_op(p, op, st, guidance_override)) != 0) break;
+  g_replaying = false;
+  return rc;
+}
+}  // namespace
+
+extern "C" int es_plan_recording(void) { return g_rec != nullptr && !g_replaying; }
+extern "C" void es_plan_record(int kind, const void* args, size_t bytes) {
+  es_plan* p = g_rec;
+  const size_t off = (p->blob.size() + 15) & ~(size_t)15;
+  p->blob.resize(off + bytes);
+  memcpy(p->blob.data() + off, args, bytes);
+  p->ops.push_back({kind, off, bytes});
+}
+
+extern "C" es_plan* es_plan_create(void) { return new es_plan(); }
+extern "C" void es_plan_destroy(es_plan* p) { if (g_rec == p) g_rec = nullptr; delete p; }
+extern "C" int es_plan_begin_record(es_plan* p) {
+  if (!p || g_rec) { es_set_error("es_plan_begin_record: null plan, or another plan is recording on this thread"); return -1; }
+  g_rec = p;
+  return 0;
+}
+extern "C" int es_plan_end_record(es_plan* p) {
+  if (!p || g_rec != p) { es_set_error("es_plan_end_record: this plan is not recording"); return -1; }
+  g_rec = nullptr;
+  return 0;
+}
+extern "C" int es_plan_size(const es_plan* p) { return p ? (int)p->ops.size() : -1; }
+extern "C" int es_plan_count(const es_plan* p, int kind) {
+  if (!p) return -1;
+  int n = 0;
+  for (const auto& op : p->ops) n += op.kind == kind;
+  return n;
+}
+extern "C" int es_plan_launch(const es_plan* p, void* stream) {
+  if (!p) { es_set_error("es_plan_launch: null plan"); return -1; }
+  return run_plan(p, (hipStream_t)stream, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct es_ctx {
+  int device = 0;
+  es_plan* plan[ES_PLAN_COUNT] = {};
+  hipGraphExec_t exec[ES_PLAN_COUNT] = {};
+  float exec_guidance[ES_PLAN_COUNT] = {};
+  void* buf[ES_BUF_COUNT] = {};
+  size_t bytes[ES_BUF_COUNT] = {};
+  es_ctx_geometry g = {};
+  float cond_scales[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+  float control_start = 0.f, control_end = 1.f;
+  int use_graphs = 1;
+  hipStream_t cap_stream = nullptr; // plans are captured into graphs on a stream of the context's own (the caller's may
+                                    // be the legacy default stream, which cannot capture); the graphs launch on the caller's
+  std::vector<float> host;          // staging for the per-call tables
+  std::vector<float> alphas_cumprod;   // the scheduler's schedule (es_ctx_set_alphas_cumprod; SD1.5 default otherwise)
+};
+
+namespace {
+int need(const es_ctx* c, int slot, const char* what) {
+  if (!c->buf[slot]) { es_set_error(what); return -1; }
+  return 0;
+}
+int d2d(void* dst, const void* src, size_t n, hipStream_t st) {
+  if (dst == src || !n) return 0;
+  if (hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, st) != hipSuccess) { es_set_error("es_ctx: device copy failed"); return -2; }
+  return 0;
+}
+int h2d(void* dst, const void* src, size_t n, hipStream_t st) {
+  if (hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, st) != hipSuccess) { es_set_error("es_ctx: host-to-device copy failed"); return -2; }
+  return 0;
+}
+
+// one plan: as a hipGraph captured from the launch list (re-captured when the guidance scale baked into its scheduler
+// node changes), or - use_graphs 0, or while the caller's stream is itself capturing - re-issued launch by launch
+int run(es_ctx* c, int which, hipStream_t st, const float* guidance) {
+  es_plan* p = c->plan[which];
+  if (!p) { es_set_error("es_ctx: plan not set"); return -1; }
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cs);
+  if (!c->use_graphs || cs != hipStreamCaptureStatusNone) return run_plan(p, st, guidance);
+  const float gs = guidance ? *guidance : 0.f;
+  if (c->exec[which] && c->exec_guidance[which] != gs) { (void)hipGraphExecDestroy(c->exec[which]); c->exec[which] = nullptr; }
+  if (!c->exec[which]) {
+    hipGraph_t graph = nullptr;
+    if (!c->cap_stream && hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking) != hipSuccess) { es_set_error("es_ctx: hipStreamCreate failed"); return -2; }
+    if (hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { es_set_error("es_ctx: hipStreamBeginCapture failed"); return -2; }
+    const int rc = run_plan(p, c->cap_stream, guidance);
+    const hipError_t e = hipStreamEndCapture(c->cap_stream, &graph);
+    if (rc || e != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); if (!rc) es_set_error("es_ctx: hipStreamEndCapture failed"); return rc ? rc : -2; }
+    const hipError_t ei = hipGraphInstantiate(&c->exec[which], graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) { c->exec[which] = nullptr; es_set_error("es_ctx: hipGraphInstantiate failed"); return -2; }
+    c->exec_guidance[which] = gs;
+  }
+  if (hipGraphLaunch(c->exec[which], st) != hipSuccess) { es_set_error("es_ctx: hipGraphLaunch failed"); return -2; }
+  return 0;
+}
+
+// DDIMScheduler of the SD1.5 checkpoints (diffusers scheduler_config: scaled_linear betas 0.00085..0.012, 1000 train
+// steps, set_alpha_to_one False, steps_offset 1, eta 0): {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)} per step,
+// a_prev = alphas_cumprod of the NEXT timestep of the list (t - 1000 / n), alphas_cumprod[0] after the last one
+void default_alphas(std::vector<float>& ac) {
+  ac.resize(1000);
+  const float b0 = sqrtf(0.00085f), b1 = sqrtf(0.012f);
+  float prod = 1.0f;
+  for (int i = 0; i < 1000; ++i) {
+    const float b = b0 + (b1 - b0) * (float)i / 999.0f;
+    prod *= 1.0f - b * b;
+    ac[i] = prod;
+  }
+}
+void ddim_coef(es_ctx* c, const float* ts, int n, float* out) {
+  if (c->alphas_cumprod.empty()) default_alphas(c->alphas_cumprod);
+  const std::vector<float>& ac = c->alphas_cumprod;
+  const int last = (int)ac.size() - 1;
+  auto at = [&](float t) { int i = (int)t; i = i < 0 ? 0 : (i > last ? last : i); return ac[i]; };
+  for (int i = 0; i < n; ++i) {
+    const float a_t = at(ts[i]);
+    const float a_p = i + 1 < n ? at(ts[i + 1]) : ac[0];
+    out[i * 4 + 0] = sqrtf(a_t); out[i * 4 + 1] = sqrtf(1.0f - a_t);
+    out[i * 4 + 2] = sqrtf(a_p); out[i * 4 + 3] = sqrtf(1.0f - a_p);
+  }
+}
+}  // namespace
+
+extern "C" int es_ctx_create(int device, es_ctx** out) {
+  if (!out) { es_set_error("es_ctx_create: null out"); return -1; }
+  es_ctx* c = new es_ctx();
+  c->device = device;
+  *out = c;
+  return 0;
+}
+extern "C" void es_ctx_destroy(es_ctx* c) {
+  if (!c) return;
+  for (int i = 0; i < ES_PLAN_COUNT; ++i) {
+    if (c->exec[i]) (void)hipGraphExecDestroy(c->exec[i]);
+    if (c->plan[i]) es_plan_destroy(c->plan[i]);
+  }
+  if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
+  delete c;
+}
+extern "C" int es_ctx_set_geometry(es_ctx* c, const es_ctx_geometry* g) {
+  if (!c || !g || g->B < 1 || g->h < 1 || g->w < 1 || g->n_steps < 1 || g->n_conds < 1 || g->n_conds > 6) { es_set_error("es_ctx_set_geometry: bad geometry"); return -1; }
+  c->g = *g;
+  return 0;
+}
+extern "C" int es_ctx_set_plan(es_ctx* c, int which, es_plan* p) {
+  if (!c || which < 0 || which >= ES_PLAN_COUNT || !p) { es_set_error("es_ctx_set_plan: bad arguments"); return -1; }
+  if (c->exec[which]) { (void)hipGraphExecDestroy(c->exec[which]); c->exec[which] = nullptr; }
+  if (c->plan[which] && c->plan[which] != p) es_plan_destroy(c->plan[which]);
+  c->plan[which] = p;
+  return 0;
+}
+extern "C" int es_ctx_bind(es_ctx* c, int slot, void* dev, size_t nbytes) {
+  if (!c || slot < 0 || slot >= ES_BUF_COUNT || !dev || !nbytes) { es_set_error("es_ctx_bind: bad arguments"); return -1; }
+  c->buf[slot] = dev;
+  c->bytes[slot] = nbytes;
+  return 0;
+}
+extern "C" int es_ctx_set_options(es_ctx* c, const float* cond_scales, float control_guidance_start, float control_guidance_end, int use_graphs) {
+  if (!c) { es_set_error("es_ctx_set_options: null ctx"); return -1; }
+  if (cond_scales) memcpy(c->cond_scales, cond_scales, sizeof(c->cond_scales));
+  c->control_start = control_guidance_start;
+  c->control_end = control_guidance_end;
+  c->use_graphs = use_graphs;
+  return 0;
+}
+extern "C" int es_ctx_set_alphas_cumprod(es_ctx* c, const float* alphas_cumprod, int n) {
+  if (!c || !alphas_cumprod || n < 1) { es_set_error("es_ctx_set_alphas_cumprod: bad arguments"); return -1; }
+  c->alphas_cumprod.assign(alphas_cumprod, alphas_cumprod + n);
+  return 0;
+}
+extern "C" int es_ctx_plan_size(const es_ctx* c, int which) {
+  return (c && which >= 0 && which < ES_PLAN_COUNT && c->plan[which]) ? es_plan_size(c->plan[which]) : -1;
+}
+
+// == OnnxUNetAndControlnets.forward (export_onnx.py:43-74): one ControlNets -> fusion -> UNet evaluation at timestep t
+extern "C" int es_denoise_step(es_ctx* c, const void* sample, float t, const void* ehs, const void* const* cond_embeds,
+                               const float* scales, void* out_noise, void* stream) {
+  if (!c || !sample || !ehs || !cond_embeds || !out_noise) { es_set_error("es_denoise_step: null argument"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  if (need(c, ES_BUF_SAMPLE, "es_denoise_step: ES_BUF_SAMPLE not bound") || need(c, ES_BUF_T_ROWS, "es_denoise_step: ES_BUF_T_ROWS not bound") ||
+      need(c, ES_BUF_EHS, "es_denoise_step: ES_BUF_EHS not bound") || need(c, ES_BUF_SCALES, "es_denoise_step: ES_BUF_SCALES not bound") ||
+      need(c, ES_BUF_NOISE, "es_denoise_step: ES_BUF_NOISE not bound")) return -1;
+  int rc;
+  if ((rc = d2d(c->buf[ES_BUF_SAMPLE], sample, c->bytes[ES_BUF_SAMPLE], st))) return rc;
+  if ((rc = d2d(c->buf[ES_BUF_EHS], ehs, c->bytes[ES_BUF_EHS], st))) return rc;
+  for (int i = 0; i < c->g.n_conds; ++i) {
+    if (!cond_embeds[i] || !c->buf[ES_BUF_COND0 + i]) { es_set_error("es_denoise_step: condition embedding missing / not bound"); return -1; }
+    if ((rc = d2d(c->buf[ES_BUF_COND0 + i], cond_embeds[i], c->bytes[ES_BUF_COND0 + i], st))) return rc;
+  }
+  if (hipMemsetD32Async((hipDeviceptr_t)c->buf[ES_BUF_T_ROWS], __builtin_bit_cast(int, t), c->bytes[ES_BUF_T_ROWS] / 4, st) != hipSuccess) { es_set_error("es_denoise_step: fill failed"); return -2; }
+  c->host.resize(8);
+  for (int i = 0; i < 6; ++i) c->host[i] = scales ? scales[i] : 1.f;
+  if ((rc = h2d(c->buf[ES_BUF_SCALES], c->host.data(), (size_t)c->g.n_conds * 4, st))) return rc;
+  if ((rc = run(c, ES_PLAN_STEP_GENERIC, st, nullptr))) return rc;
+  return d2d(out_noise, c->buf[ES_BUF_NOISE], c->bytes[ES_BUF_NOISE], st);
+}
+
+// == the denoising loop of EdgeStyleStableDiffusionControlNetPipeline.__call__ (model/edgestyle_pipeline.py:435-543),
+// DDIM eta 0: latents fp32 [B,h,w,L] NHWC in/out, ehs [N,77,D] dtype (negative prompt first under CFG, PL:329-330)
+extern "C" int es_denoise_loop(es_ctx* c, float* latents_inout, const void* ehs, float guidance_scale, const float* timesteps,
+                               int n_steps, void* stream) {
+  if (!c || !latents_inout || !ehs || !timesteps) { es_set_error("es_denoise_loop: null argument"); return -1; }
+  if (n_steps != c->g.n_steps) { es_set_error("es_denoise_loop: the context was built for another number of steps"); return -1; }
+  const int need_slots[] = {ES_BUF_LATENTS, ES_BUF_SAMPLE, ES_BUF_EHS, ES_BUF_STEP_IDX, ES_BUF_T_TABLE, ES_BUF_SCALE_TABLE, ES_BUF_COEF, ES_BUF_TIMESTEPS};
+  for (int s : need_slots) if (need(c, s, "es_denoise_loop: a static buffer is not bound")) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const es_ctx_geometry& g = c->g;
+  const int T = n_steps, nc = g.n_conds;
+  const size_t trow = c->bytes[ES_BUF_T_TABLE] / 4 / T;          // kmax * N timestep copies per step
+  c->host.resize((size_t)T * (trow + nc + 4 + 1));
+  float* tt = c->host.data();
+  float* sc = tt + (size_t)T * trow;
+  float* cf = sc + (size_t)T * nc;
+  float* tsd = cf + (size_t)T * 4;
+  for (int i = 0; i < T; ++i) {
+    for (size_t j = 0; j < trow; ++j) tt[i * trow + j] = timesteps[i];
+    const float keep = 1.0f - (float)(((float)i / T < c->control_start) || ((float)(i + 1) / T > c->control_end));   // PL:419-427
+    for (int k = 0; k < nc; ++k) sc[i * nc + k] = c->cond_scales[k] * keep;
+    tsd[i] = timesteps[i];
+  }
+  ddim_coef(c, timesteps, T, cf);
+  int rc;
+  if ((rc = h2d(c->buf[ES_BUF_T_TABLE], tt, (size_t)T * trow * 4, st))) return rc;
+  if ((rc = h2d(c->buf[ES_BUF_SCALE_TABLE], sc, (size_t)T * nc * 4, st))) return rc;
+  if ((rc = h2d(c->buf[ES_BUF_COEF], cf, (size_t)T * 16, st))) return rc;
+  if ((rc = h2d(c->buf[ES_BUF_TIMESTEPS], tsd, (size_t)T * 4, st))) return rc;
+  if (hipMemsetAsync(c->buf[ES_BUF_STEP_IDX], 0, 4, st) != hipSuccess) { es_set_error("es_denoise_loop: memset failed"); return -2; }
+  if ((rc = d2d(c->buf[ES_BUF_LATENTS], latents_inout, c->bytes[ES_BUF_LATENTS], st))) return rc;
+  if ((rc = d2d(c->buf[ES_BUF_EHS], ehs, c->bytes[ES_BUF_EHS], st))) return rc;
+  if ((rc = es_latents_to_input((const float*)c->buf[ES_BUF_LATENTS], c->buf[ES_BUF_SAMPLE], g.B, g.h * g.w, g.latent_channels,
+                                g.latent_pad, g.cfg, g.dtype, stream))) return rc;
+  if ((rc = run(c, ES_PLAN_PREP, st, nullptr))) return rc;        // text K/V projections, condition slots, time-projection table
+  for (int i = 0; i < T; ++i)
+    if ((rc = run(c, ES_PLAN_STEP, st, &guidance_scale))) return rc;
+  return d2d(latents_inout, c->buf[ES_BUF_LATENTS], c->bytes[ES_BUF_LATENTS], st);
+}
+
+// == vae.decode(latents / scaling_factor) + image_processor.postprocess(output_type "pt") (PL:552-572):
+// latents fp32 [B,h,w,L] NHWC -> image fp32 [B,3,8h,8w] NCHW in [0,1]
+extern "C" int es_vae_decode(es_ctx* c, const float* latents, float* out_img, void* stream) {
+  if (!c || !latents || !out_img) { es_set_error("es_vae_decode: null argument"); return -1; }
+  if (need(c, ES_BUF_SAMPLE, "es_vae_decode: ES_BUF_SAMPLE not bound") || need(c, ES_BUF_IMAGE, "es_vae_decode: ES_BUF_IMAGE not bound")) return -1;
+  const es_ctx_geometry& g = c->g;
+  int rc;
+  if ((rc = es_latents_to_input(latents, c->buf[ES_BUF_SAMPLE], g.B, g.h * g.w, g.latent_channels, g.latent_pad, g.cfg, g.dtype, stream))) return rc;
+  if ((rc = run(c, ES_PLAN_DECODE, (hipStream_t)stream, nullptr))) return rc;
+  return d2d(out_img, c->buf[ES_BUF_IMAGE], c->bytes[ES_BUF_IMAGE], (hipStream_t)stream);
+}

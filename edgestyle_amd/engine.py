@@ -162,9 +162,10 @@ class Transformer:
             self.q2_ln = pk.cat_ln([tb + ".attn2.to_q"], False, tb + ".norm2")
             self.ff1_ln = pk.cat_ln([tb + ".ff.net.0.proj"], True, tb + ".norm3", geglu=True) if LN_FOLD_FF else None
 
-    def context(self, ehs, out=None):
-        """K/V projection of the text states [N,77,D] -> [N,77,2C]; constant over the denoising loop."""
-        return ops.linear(ehs, self.kv2, out=out)
+    def context(self, ehs, out=None, rep: int = 1):
+        """K/V projection of the text states [N,77,D] -> [rep*N,77,2C] (rep copies: the nets of a weight-sharing group
+        see the same text states); constant over the denoising loop."""
+        return ops.linear(ehs, self.kv2, out=out, x_rep=rep)
 
     def __call__(self, x, kv):
         N, H, W, C = x.shape
@@ -495,12 +496,16 @@ class GroupedEncoder:
     def groupable(self, hw_min: int) -> bool:
         return len(self.encs) <= 4 and all((n * hw_min) % ops.BM == 0 for n in self.counts)
 
-    def time_proj(self, t_rows: torch.Tensor) -> torch.Tensor:
-        """[ntot, width]: each group's ResnetBlock time projections (offsets of down/mid blocks coincide)."""
-        out = torch.zeros((self.ntot, self.width), dtype=self.encs[0].dtype, device=t_rows.device)
+    def time_proj(self, t_rows: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[ntot, width]: each group's ResnetBlock time projections (offsets of down/mid blocks coincide).  `out`: a
+        zero-initialised buffer to fill (columns beyond a group's width are never written)."""
+        if out is None:
+            out = torch.zeros((self.ntot, self.width), dtype=self.encs[0].dtype, device=t_rows.device)
+        es = out.element_size()
         a = 0
         for e, n in zip(self.encs, self.counts):
-            out[a:a + n, : e.tproj_width].copy_(e.time_proj(t_rows[:n]))
+            proj = e.time_proj(t_rows[:n])
+            ops.memcpy2d(out[a].data_ptr(), self.width * es, proj.data_ptr(), e.tproj_width * es, e.tproj_width * es, n)
             a += n
         return out
 

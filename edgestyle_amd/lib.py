@@ -29,6 +29,7 @@ class GemmDesc(C.Structure):
         ("bk", C.c_int32), ("out_scale", C.c_float),
         ("ln_colsum", C.c_void_p), ("ln_colsum_g", C.c_void_p * 4), ("ln_eps", C.c_float),
         ("t1", C.c_void_p), ("t2", C.c_void_p), ("Ct1", C.c_int32), ("Ct2", C.c_int32),
+        ("x_nmod", C.c_int32),
     ]
 
 
@@ -41,6 +42,19 @@ class XsDesc(C.Structure):
         ("ldo", C.c_int32), ("geglu", C.c_int32), ("ln", C.c_int32), ("ln_eps", C.c_float),
         ("nslices", C.c_int32), ("chunks_per_slice", C.c_int32), ("dtype", C.c_int32),
     ]
+
+
+class CtxGeometry(C.Structure):
+    _fields_ = [("B", C.c_int32), ("cfg", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+                ("latent_channels", C.c_int32), ("latent_pad", C.c_int32), ("n_conds", C.c_int32),
+                ("n_steps", C.c_int32), ("dtype", C.c_int32)]
+
+
+# es_plan / es_ctx enums (include/edgestyle_hip.h)
+PLAN_STEP_GENERIC, PLAN_PREP, PLAN_STEP, PLAN_DECODE = 0, 1, 2, 3
+(BUF_SAMPLE, BUF_T_ROWS, BUF_EHS, BUF_COND0, BUF_COND1, BUF_COND2, BUF_COND3, BUF_COND4, BUF_COND5, BUF_SCALES, BUF_NOISE,
+ BUF_LATENTS, BUF_STEP_IDX, BUF_T_TABLE, BUF_SCALE_TABLE, BUF_COEF, BUF_TIMESTEPS, BUF_IMAGE) = range(18)
+OP_CONV_GEMM, OP_LINEAR_XS, OP_ATTENTION = 1, 2, 3      # csrc/plan.h es_op_kind (es_plan_count)
 
 
 class AttnDesc(C.Structure):
@@ -111,6 +125,28 @@ SYMBOLS = {
     "es_incr": (C.c_int, [_P, _P]),
     "es_gather_row": (C.c_int, [_P, _P, _P, _I, _I, _P]),
     "es_layer_norm_grouped": (C.c_int, [C.POINTER(LnDesc), _P]),
+    "es_latents_to_input": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "es_memcpy": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "es_memcpy2d": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_size_t, _P]),
+    "es_fill_f32": (C.c_int, [_P, _F, C.c_size_t, _P]),
+    "es_plan_create": (_P, []),
+    "es_plan_destroy": (None, [_P]),
+    "es_plan_begin_record": (C.c_int, [_P]),
+    "es_plan_end_record": (C.c_int, [_P]),
+    "es_plan_size": (C.c_int, [_P]),
+    "es_plan_count": (C.c_int, [_P, _I]),
+    "es_plan_launch": (C.c_int, [_P, _P]),
+    "es_ctx_create": (C.c_int, [_I, C.POINTER(_P)]),
+    "es_ctx_destroy": (None, [_P]),
+    "es_ctx_set_geometry": (C.c_int, [_P, C.POINTER(CtxGeometry)]),
+    "es_ctx_set_plan": (C.c_int, [_P, _I, _P]),
+    "es_ctx_bind": (C.c_int, [_P, _I, _P, C.c_size_t]),
+    "es_ctx_set_options": (C.c_int, [_P, C.POINTER(C.c_float), _F, _F, _I]),
+    "es_ctx_set_alphas_cumprod": (C.c_int, [_P, C.POINTER(C.c_float), _I]),
+    "es_ctx_plan_size": (C.c_int, [_P, _I]),
+    "es_denoise_step": (C.c_int, [_P, _P, _F, _P, C.POINTER(_P), C.POINTER(C.c_float), _P, _P]),
+    "es_denoise_loop": (C.c_int, [_P, _P, _P, _F, C.POINTER(C.c_float), _I, _P]),
+    "es_vae_decode": (C.c_int, [_P, _P, _P, _P]),
 }
 
 _lib = None
@@ -137,7 +173,7 @@ def load():
         fn = getattr(lib, name)           # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.es_abi_version() != 1:
+    if lib.es_abi_version() != 2:
         raise EdgeStyleHipError("libedgestyle_hip.so ABI version mismatch")
     for i, st in enumerate((GemmDesc, AttnDesc, GnDesc, FusionDesc, LnDesc, XsDesc)):
         if lib.es_sizeof_desc(i) != C.sizeof(st):

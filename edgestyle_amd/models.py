@@ -618,10 +618,9 @@ class StepState:
         self.ctx_nets: Optional[List[List[torch.Tensor]]] = None
         self.ctx_grouped: Optional[List[torch.Tensor]] = None
         self.ctx_guess: Optional[List[List[torch.Tensor]]] = None
-        self.ctx_single: Optional[List[torch.Tensor]] = None
-        self.cond_cat = self.x_rep = None
+        self.cond_cat = None
         self.cond_src = None
-        self.tproj_table = self.tproj_cur = None
+        self.tproj_table = self.tproj_cur = self.tproj_gen = None
 
     def signature(self) -> Tuple[int, ...]:
         sig = []
@@ -634,17 +633,10 @@ class StepState:
                     walk(x)
             else:
                 sig.append(0)
-        for name in ("ctx_unet", "ctx_nets", "ctx_grouped", "ctx_guess", "ctx_single", "cond_cat", "x_rep", "tproj_table",
-                     "tproj_cur"):
+        for name in ("ctx_unet", "ctx_nets", "ctx_grouped", "ctx_guess", "cond_cat", "tproj_table", "tproj_cur",
+                     "tproj_gen"):
             walk(getattr(self, name))
         return tuple(sig)
-
-
-def _fill_context(engine, ehs, outs):
-    """engine.context into `outs` when they fit (in place: graph-stable), else fresh tensors."""
-    if outs is not None and outs[0].shape[0] == ehs.shape[0]:
-        return engine.context(ehs, outs)
-    return engine.context(ehs)
 
 
 class StepRunner:
@@ -693,29 +685,47 @@ class StepRunner:
 
     def set_context(self, ehs: torch.Tensor, guess_mode: bool = False, n_cn: Optional[int] = None):
         """ehs: [N,77,D] device dtype. Computes every cross-attention K/V projection once (constant over the loop),
-        in place into the current StepState's buffers when they exist.
+        in place into the current StepState's buffers (allocated on first use): C-ABI launches only, so the whole
+        preparation can be recorded into a native plan (edgestyle_amd/native.py).  The K/V tensors of the encoder
+        transformers live batch-concatenated in group order [net groups..., UNet] (what the grouped lockstep pass reads);
+        the per-net and UNet contexts are views of their slices.  The k nets of a weight-sharing group see the same text
+        states: one launch writes their k copies (es_gemm_desc.x_nmod).
         guess_mode: the ControlNets see the last n_cn rows of ehs — under CFG only the conditional half (PL:453-459)."""
         st = self.state
-        st.ctx_unet = _fill_context(self.unet.engine, ehs, st.ctx_unet)
+        N = ehs.shape[0]
+        ue = self.unet.engine
+        utr = ue.transformers()
+        n_enc = len(self.groups[0][0].engine.transformers())
+        T77, dev, dt = ehs.shape[1], self.device, self.dtype
+        ks = [len(pos) for _, pos in self.groups]
         if guess_mode:
-            ehs_c = ehs[ehs.shape[0] - (n_cn or ehs.shape[0]):]
-            old = st.ctx_guess or [None] * len(self.groups)
-            st.ctx_guess = [_fill_context(net.engine, ehs_c.repeat(len(pos), 1, 1) if len(pos) > 1 else ehs_c, o)
-                            for (net, pos), o in zip(self.groups, old)]
+            Nc = n_cn or N
+            ehs_c = ehs[N - Nc:]
+            if st.ctx_unet is None or st.ctx_unet[0].shape[0] != N:
+                st.ctx_unet = [torch.empty((N, T77, t.kv2.cout), dtype=dt, device=dev) for t in utr]
+            for t, o in zip(utr, st.ctx_unet):
+                t.context(ehs, o)
+            if st.ctx_guess is None or st.ctx_guess[0][0].shape[0] != ks[0] * Nc:
+                st.ctx_guess = [[torch.empty((k * Nc, T77, t.kv2.cout), dtype=dt, device=dev) for t in net.engine.transformers()]
+                                for (net, _), k in zip(self.groups, ks)]
+            for (net, _), k, outs in zip(self.groups, ks, st.ctx_guess):
+                for t, o in zip(net.engine.transformers(), outs):
+                    t.context(ehs_c, o, rep=k)
             return
-        old = st.ctx_nets or [None] * len(self.groups)
-        st.ctx_nets = []
-        for (net, pos), o in zip(self.groups, old):
-            k = len(pos)
-            st.ctx_nets.append(_fill_context(net.engine, ehs.repeat(k, 1, 1) if k > 1 else ehs, o))
-        # batch-concatenated K/V projections for the grouped lockstep pass (static buffers: graph-stable pointers)
-        n_enc = len(st.ctx_nets[0])
-        cat = [torch.cat([c[i] for c in st.ctx_nets] + [st.ctx_unet[i]]) for i in range(n_enc)]
-        if st.ctx_grouped is not None and st.ctx_grouped[0].shape == cat[0].shape:
-            for dst, src in zip(st.ctx_grouped, cat):
-                dst.copy_(src)
-        else:
-            st.ctx_grouped = cat
+        ntot = (sum(ks) + 1) * N
+        if st.ctx_grouped is None or st.ctx_grouped[0].shape[0] != ntot:
+            st.ctx_grouped = [torch.empty((ntot, T77, utr[i].kv2.cout), dtype=dt, device=dev) for i in range(n_enc)]
+            st.ctx_nets, a = [], 0
+            for k in ks:
+                st.ctx_nets.append([g[a:a + k * N] for g in st.ctx_grouped])
+                a += k * N
+            st.ctx_unet = [g[a:a + N] for g in st.ctx_grouped] + \
+                [torch.empty((N, T77, t.kv2.cout), dtype=dt, device=dev) for t in utr[n_enc:]]
+        for (net, _), k, outs in zip(self.groups, ks, st.ctx_nets):
+            for t, o in zip(net.engine.transformers(), outs):
+                t.context(ehs, o, rep=k)
+        for t, o in zip(utr, st.ctx_unet):
+            t.context(ehs, o)
 
     def _grouped_encoder(self, N: int):
         ue = self.unet.engine
@@ -735,10 +745,13 @@ class StepRunner:
         if st.tproj_table is None or tuple(st.tproj_table.shape) != shape:
             st.tproj_table = torch.zeros(shape, dtype=self.dtype, device=self.device)
             st.tproj_cur = torch.zeros(shape[1:], dtype=self.dtype, device=self.device)
+        es = st.tproj_table.element_size()
         a = 0
         for e, n in zip(ge.encs, ge.counts):
             proj = e.time_proj(timesteps)                                # [T, width_e]
-            st.tproj_table[:, a:a + n, : e.tproj_width] = proj[:, None, :]
+            for j in range(n):                                           # every sample row of the group: a strided copy
+                ops.memcpy2d(st.tproj_table[0, a + j].data_ptr(), ge.ntot * ge.width * es, proj.data_ptr(),
+                             e.tproj_width * es, e.tproj_width * es, T)
             a += n
 
     def set_conds(self, conds: Sequence[torch.Tensor]):
@@ -747,13 +760,12 @@ class StepRunner:
         ge = self._grouped_encoder(N)
         st = self.state
         if st.cond_cat is None or tuple(st.cond_cat.shape) != (ge.ntot, H, W, C0):
-            st.x_rep = torch.zeros((ge.ntot, H, W, self.unet.engine.in_pad), dtype=self.dtype, device=self.device)
             st.cond_cat = torch.zeros((ge.ntot, H, W, C0), dtype=self.dtype, device=self.device)
         st.cond_src = [c.data_ptr() for c in conds]      # the step only trusts cond_cat for these very buffers
         a = 0
         for _, pos in self.groups:
             for p in pos:
-                st.cond_cat[a:a + N].copy_(conds[p])
+                ops.memcpy(st.cond_cat[a:a + N], conds[p])
                 a += N                                   # the UNet's slot stays zero
 
     def clear_time_table(self):
@@ -872,11 +884,10 @@ class StepRunner:
         ncn = sum(counts[:-1])
         c0 = ue.conv_in.cout
         h0 = torch.empty((ge.ntot, x.shape[1], x.shape[2], c0), dtype=x.dtype, device=x.device)
-        if st.cond_cat is not None and st.cond_cat.shape == h0.shape and st.x_rep.shape[-1] == x.shape[-1] \
-                and [c.data_ptr() for c in conds] == st.cond_src:
-            # sample = conv_in(sample) + cond (CL:197-203) for every net, and the UNet's conv_in, in one grouped launch
-            st.x_rep.view(ge.ntot // N, N, *x.shape[1:]).copy_(x.unsqueeze(0).expand(ge.ntot // N, *x.shape))
-            ops.conv_gemm(st.x_rep, [e.conv_in for e in encs], residual=st.cond_cat, group_n=counts, out=h0)
+        if st.cond_cat is not None and st.cond_cat.shape == h0.shape and [c.data_ptr() for c in conds] == st.cond_src:
+            # sample = conv_in(sample) + cond (CL:197-203) for every net, and the UNet's conv_in, in one grouped launch:
+            # every slot reads the same sample tensor (x_rep), the conditions are batch-concatenated in slot order
+            ops.conv_gemm(x, [e.conv_in for e in encs], residual=st.cond_cat, group_n=counts, out=h0, x_rep=ge.ntot // N)
         else:
             a = 0
             for net, pos in self.groups:                  # sample = conv_in(sample) + cond   (CL:197-203)
@@ -890,7 +901,9 @@ class StepRunner:
             ops.gather_row(st.tproj_table.view(T, -1).view(torch.float32), step_idx, st.tproj_cur.view(-1).view(torch.float32))
             tproj = st.tproj_cur
         else:
-            tproj = ge.time_proj(t_rows)
+            if st.tproj_gen is None or st.tproj_gen.shape != (ge.ntot, ge.width):
+                st.tproj_gen = torch.zeros((ge.ntot, ge.width), dtype=self.dtype, device=self.device)
+            tproj = ge.time_proj(t_rows, st.tproj_gen)
         skips, h = ge.run(h0, tproj, st.ctx_grouped)
         cn_counts = counts[:-1]
         cn_engs = encs[:-1]

@@ -399,8 +399,12 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
               residual: Optional[torch.Tensor] = None, act: int = L.ACT_NONE, out_scale: float = 1.0,
               out_scale_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
               out_hw=None, splitk: Optional[int] = None, stages: int = 0,
-              group_n: Optional[Sequence[int]] = None, tail: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+              group_n: Optional[Sequence[int]] = None, tail: Optional[Sequence[torch.Tensor]] = None,
+              x_rep: int = 1) -> torch.Tensor:
     """x: [N,H,W,C1] (+ x2 [N,H,W,C2]); returns [N,Hout,Wout,Cout] (Cout/2 for GEGLU).
+
+    x_rep > 1: the launch covers x_rep * N samples, sample n reading x[n % N] (es_gemm_desc.x_nmod): one sample tensor
+    feeding several groups of a grouped launch without a replicated copy.
 
     Grouped launch: `pw` is a list of PackedWeights of identical geometry and `group_n` the number of consecutive
     samples of x each of them applies to (sum = N): one launch instead of len(pw)."""
@@ -411,6 +415,11 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         if len(pws) == 1:
             pws = None
     N, H, W, C1 = x.shape
+    nsrc = N
+    if x_rep > 1:
+        if x2 is not None or tail:
+            raise L.EdgeStyleHipError("conv_gemm: x_rep needs a single source")
+        N = N * x_rep
     C2 = 0 if x2 is None else x2.shape[3]
     if C1 + C2 != pw.cin:
         raise L.EdgeStyleHipError(f"conv_gemm: input channels {C1}+{C2} != packed {pw.cin}")
@@ -432,7 +441,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         out = torch.empty((N, Hout, Wout, cstore), dtype=x.dtype, device=x.device)
     M = N * Hout * Wout
     if (k == 1 and stride == 1 and not upsample and x2 is None and temb is None and residual is None and not tails
-            and act == L.ACT_NONE and out_scale == 1.0 and out_scale_dev is None and splitk is None and FORCE_BN == 0
+            and x_rep == 1 and act == L.ACT_NONE and out_scale == 1.0 and out_scale_dev is None and splitk is None and FORCE_BN == 0
             and x.is_contiguous() and out.is_contiguous()
             and xs_eligible(M, pw, pws, group_n, Hout * Wout)):
         linear_xs(x.reshape(M, C1), pws if pws is not None else pw, M, out.reshape(M, cstore),
@@ -464,10 +473,11 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     d.act, d.splitk, d.bn, d.dtype, d.out_scale = act_i, splitk, bn, _dt(x), out_scale
     d.stages = stages or FORCE_STAGES
     # XCD chunk order: keep the larger operand's tiles together on one XCD (see conv_gemm_kernel)
-    d.xcd_m_fastest = (1 if (pws is None and splitk == 1 and M <= 2048 and pw.w.numel() > x.numel() + (x2.numel() if x2 is not None else 0)) else 0) \
+    d.xcd_m_fastest = (1 if (pws is None and splitk == 1 and M <= 2048 and pw.w.numel() > x.numel() * x_rep + (x2.numel() if x2 is not None else 0)) else 0) \
         if XCD_ORDER < 0 else XCD_ORDER
     d.bm = FORCE_BM
     d.bk = FORCE_BK
+    d.x_nmod = nsrc if x_rep > 1 else 0
     if FORCE_WAVES:
         d.waves = FORCE_WAVES
     elif EIGHT_WAVES and FORCE_BK != 32 and k == 1 and M <= 65536 and C1 % BK == 0 and C2 % BK == 0 and bn not in (64, 320) and FORCE_BM != 256 \
@@ -538,11 +548,14 @@ def linear(x: torch.Tensor, pw: PackedWeight, **kw) -> torch.Tensor:
     M = x.numel() // shp[-1]
     out = kw.pop("out", None)
     res = kw.pop("residual", None)
+    rep = kw.get("x_rep", 1)
     p0 = pw[0] if isinstance(pw, (list, tuple)) else pw
     cstore = p0.cout // 2 if p0.geglu else p0.cout
     y = conv_gemm(x.reshape(M, 1, 1, shp[-1]), pw,
-                  residual=None if res is None else res.reshape(M, 1, 1, cstore),
-                  out=None if out is None else out.reshape(M, 1, 1, cstore), **kw)
+                  residual=None if res is None else res.reshape(M * rep, 1, 1, cstore),
+                  out=None if out is None else out.reshape(M * rep, 1, 1, cstore), **kw)
+    if rep > 1:
+        return y.reshape(shp[0] * rep, *shp[1:-1], cstore)
     return y.reshape(*shp[:-1], cstore)
 
 
@@ -692,6 +705,31 @@ def cfg_unipc_step(noise, latents, last_sample, m0, m1, model_in, coef, step_idx
                                        _ptr(model_in), _ptr(coef), _ptr(step_idx), guidance_scale, B, H * W, Lc,
                                        model_in.shape[3], 1 if cfg else 0, coef.shape[0], _dt(noise), _stream()),
             "es_cfg_unipc_step")
+
+
+def memcpy(dst: torch.Tensor, src: torch.Tensor):
+    """dst[:] = src, both contiguous device tensors of equal byte size (a C-ABI call: part of recorded plans)."""
+    nb = src.numel() * src.element_size()
+    if not (dst.is_contiguous() and src.is_contiguous()) or dst.numel() * dst.element_size() != nb:
+        raise L.EdgeStyleHipError("memcpy: contiguous tensors of equal byte size")
+    L.check(L.load().es_memcpy(_ptr(dst), _ptr(src), nb, _stream()), "es_memcpy")
+
+
+def memcpy2d(dst_ptr: int, dpitch: int, src_ptr: int, spitch: int, width: int, height: int):
+    """`height` rows of `width` bytes, pitches in bytes (src pitch 0 = broadcast one row is NOT supported: use height 1)."""
+    L.check(L.load().es_memcpy2d(C.c_void_p(dst_ptr), dpitch, C.c_void_p(src_ptr), spitch, width, height, _stream()),
+            "es_memcpy2d")
+
+
+def fill_f32(dst: torch.Tensor, value: float):
+    L.check(L.load().es_fill_f32(_ptr(dst), float(value), dst.numel(), _stream()), "es_fill_f32")
+
+
+def latents_to_input(latents: torch.Tensor, model_in: torch.Tensor, cfg: bool):
+    """latents fp32 [B,H,W,L] -> model_in [2B|B,H,W,Ls] compute dtype, channel-padded, both CFG halves (PL:443-447)."""
+    B, H, W, Lc = latents.shape
+    L.check(L.load().es_latents_to_input(_ptr(latents), _ptr(model_in), B, H * W, Lc, model_in.shape[3], 1 if cfg else 0,
+                                         _dt(model_in), _stream()), "es_latents_to_input")
 
 
 def incr(ctr: torch.Tensor):

@@ -93,14 +93,9 @@ class _Loop:
         return self.state.signature() + tuple(t.data_ptr() for t in (self.t_table, self.scale_table, self.coef)) + \
             (ops.LANE,)
 
-    def set_model_in(self, lat_nchw: torch.Tensor):
-        """latents [B,L,h,w] (device) -> the networks' input: both CFG halves, compute dtype, channel-padded (PL:443-447)."""
-        mi = lat_nchw.permute(0, 2, 3, 1).to(self.model_in.dtype)
-        B = self.B
-        self.model_in.zero_()
-        self.model_in[:B, ..., : mi.shape[-1]] = mi
-        if self.cfg_on:
-            self.model_in[B:, ..., : mi.shape[-1]] = mi
+    def set_model_in(self):
+        """self.latents (fp32 NHWC) -> the networks' input: both CFG halves, compute dtype, channel-padded (PL:443-447)."""
+        ops.latents_to_input(self.latents, self.model_in, self.cfg_on)
 
     def one_step(self):
         """Everything between PL:435 and PL:522 for the step selected by the device counter."""
@@ -411,7 +406,7 @@ class StableDiffusionControlNetPipeline:
         loop.coef.copy_(self.scheduler.coef_table())
         loop.step_idx.zero_()
         loop.latents.copy_(lat.permute(0, 2, 3, 1))
-        loop.set_model_in(lat.to(dev))                                            # PL:443-447
+        loop.set_model_in()                                                       # PL:443-447
         for dst, src in zip(loop.conds, conds):
             dst.copy_(src)
         loop.ehs.copy_(ehs.to(dev, self.dtype))
@@ -437,7 +432,7 @@ class StableDiffusionControlNetPipeline:
                         # PL:529-531: the returned latents are what the next step's networks, the scheduler and the
                         # decode see
                         loop.latents.copy_(out["latents"].permute(0, 2, 3, 1))
-                        loop.set_model_in(out["latents"].to(dev))
+                        loop.set_model_in()
         else:
             start = 0
             if regraph:

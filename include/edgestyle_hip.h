@@ -23,7 +23,7 @@ extern "C" {
 enum { ES_F16 = 0, ES_BF16 = 1 };
 enum { ES_ACT_NONE = 0, ES_ACT_SILU = 1, ES_ACT_GEGLU = 2 };
 
-#define ES_ABI_VERSION 1
+#define ES_ABI_VERSION 2
 int es_abi_version(void);
 /* sizeof the descriptor structs as compiled (0 gemm, 1 attn, 2 gn, 3 fusion, 4 ln, 5 xs): lets a binding verify its mirror */
 size_t es_sizeof_desc(int which);
@@ -93,6 +93,11 @@ typedef struct {
   const void* t1;
   const void* t2;
   int32_t Ct1, Ct2;
+  /* source batch modulo: sample n of the launch reads source sample n % x_nmod of x (x then holds x_nmod samples): the
+   * same tensor feeds several groups of a grouped launch (conv_in of all ControlNets + the UNet on ONE sample tensor,
+   * CL:197-203; text states shared by the nets of a weight-sharing group) without a replicated copy.  0 = off.
+   * Needs one source (no x2), no tail sources. */
+  int32_t x_nmod;
 } es_gemm_desc;
 int es_conv_gemm(const es_gemm_desc* d, void* stream);
 size_t es_conv_gemm_workspace_bytes(const es_gemm_desc* d);
@@ -235,6 +240,83 @@ int es_incr(int32_t* ctr, void* stream);
 /* out[0..row_len) = table[clamp(*idx, 0, nrows-1)][0..row_len) — selects this step's timestep / conditioning-scale row inside a
  * captured graph (PL:435, PL:464-470) so a replay needs no host-side scalar update */
 int es_gather_row(const float* table, const int32_t* idx, float* out, int row_len, int nrows, void* stream);
+
+/* DiagonalGaussian / scheduler glue used by the native loop: latents fp32 [B,HW,L] -> the networks' input (dtype,
+ * channels zero-padded to Lstride, duplicated for CFG; PL:443-447) */
+int es_latents_to_input(const float* latents, void* model_in, int B, int HW, int L, int Lstride, int cfg, int dtype,
+                        void* stream);
+/* device-to-device copy / strided copy / fp32 fill on `stream`, as C-ABI calls so that they are part of a recorded plan */
+int es_memcpy(void* dst, const void* src, size_t bytes, void* stream);
+int es_memcpy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, void* stream);
+int es_fill_f32(float* dst, float value, size_t n, void* stream);
+
+/* =========================================================================================================
+ * Step-level ABI: a denoising step, the denoising loop and the VAE decode behind plain device pointers.
+ *
+ * es_plan — a recorded launch list.  Between es_plan_begin_record and es_plan_end_record every C-ABI call made on the
+ * calling thread is appended to the plan (and still executed / stream-captured as usual); es_plan_launch re-issues the
+ * list on any stream.  The pointers inside are the ones recorded: the builder keeps those buffers alive.
+ * es_ctx  — owns up to ES_PLAN_COUNT plans plus the static device buffers they read and write (bound by slot), and
+ * runs them: as hipGraphs instantiated from the launch lists (default) or launch by launch.
+ * The reference has no FFI; what these entry points replace is Python:
+ *   es_denoise_step  == OnnxUNetAndControlnets.forward                 export_onnx.py:43-74
+ *   es_denoise_loop  == the loop of EdgeStyleStableDiffusionControlNetPipeline.__call__   model/edgestyle_pipeline.py:435-543
+ *   es_vae_decode    == vae.decode(latents / scaling_factor) + postprocess               model/edgestyle_pipeline.py:552-572
+ * A context is BUILT by a host that can walk the model (edgestyle_amd/native.py does: it packs the weights, allocates
+ * the static buffers, records the plans); after that no interpreter is involved in these calls.
+ * ========================================================================================================= */
+typedef struct es_plan es_plan;
+typedef struct es_ctx es_ctx;
+es_plan* es_plan_create(void);
+void es_plan_destroy(es_plan* p);
+int es_plan_begin_record(es_plan* p);
+int es_plan_end_record(es_plan* p);
+int es_plan_size(const es_plan* p);                    /* number of recorded calls */
+int es_plan_count(const es_plan* p, int kind);         /* ... of one kind (csrc/plan.h: 1 = es_conv_gemm, 2 = es_linear_xs, ...) */
+int es_plan_launch(const es_plan* p, void* stream);
+
+enum { ES_PLAN_STEP_GENERIC = 0,   /* es_denoise_step: text K/V projections + condition slots + time embedding + step */
+       ES_PLAN_PREP = 1,           /* es_denoise_loop, once: text K/V projections, condition slots, time-projection table */
+       ES_PLAN_STEP = 2,           /* es_denoise_loop, per step: table-driven step + CFG + scheduler + counter */
+       ES_PLAN_DECODE = 3,         /* es_vae_decode */
+       ES_PLAN_COUNT = 4 };
+enum { ES_BUF_SAMPLE = 0,          /* dtype [N,h,w,latent_pad]: the networks' input (both CFG halves) */
+       ES_BUF_T_ROWS, ES_BUF_EHS,  /* fp32 [kmax*N] timestep copies; dtype [N,77,D] text states */
+       ES_BUF_COND0, ES_BUF_COND1, ES_BUF_COND2, ES_BUF_COND3, ES_BUF_COND4, ES_BUF_COND5,   /* dtype [N,h,w,C0] each */
+       ES_BUF_SCALES,              /* fp32 [n_conds] conditioning scales of the current step */
+       ES_BUF_NOISE,               /* dtype [N,h,w,out_channels] noise prediction */
+       ES_BUF_LATENTS,             /* fp32 [B,h,w,L] */
+       ES_BUF_STEP_IDX,            /* int32 device step counter */
+       ES_BUF_T_TABLE, ES_BUF_SCALE_TABLE, ES_BUF_COEF, ES_BUF_TIMESTEPS,   /* fp32 [T,kmax*N], [T,n_conds], [T,4], [T] */
+       ES_BUF_IMAGE,               /* fp32 [B,3,8h,8w] NCHW decoded image in [0,1] */
+       ES_BUF_COUNT };
+typedef struct {
+  int32_t B, cfg;                  /* images per call; 1 = classifier-free guidance (N = 2B) */
+  int32_t h, w;                    /* latent size */
+  int32_t latent_channels, latent_pad;
+  int32_t n_conds;                 /* 6 (the fused multi-ControlNet) or 1 (a single ControlNet) */
+  int32_t n_steps;                 /* the ES_PLAN_PREP time table is built for this many steps */
+  int32_t dtype;
+} es_ctx_geometry;
+int es_ctx_create(int device, es_ctx** out);
+void es_ctx_destroy(es_ctx* c);                         /* destroys its plans too */
+int es_ctx_set_geometry(es_ctx* c, const es_ctx_geometry* g);
+int es_ctx_set_plan(es_ctx* c, int which, es_plan* p);  /* the context takes ownership of the plan */
+int es_ctx_bind(es_ctx* c, int slot, void* dev, size_t bytes);
+/* cond_scales: float[6] or NULL (keep); control guidance window (PL:419-427); use_graphs 0 = re-issue launch by launch */
+int es_ctx_set_options(es_ctx* c, const float* cond_scales, float control_guidance_start, float control_guidance_end,
+                       int use_graphs);
+int es_ctx_set_alphas_cumprod(es_ctx* c, const float* alphas_cumprod, int n);   /* scheduler schedule (default: SD1.5's) */
+int es_ctx_plan_size(const es_ctx* c, int which);
+/* sample dtype [N,h,w,latent_pad]; ehs dtype [N,77,D]; cond_embeds[n_conds] dtype [N,h,w,C0]; scales float[n_conds] (host)
+ * or NULL (ones); out_noise dtype [N,h,w,out_channels].  All device pointers except `scales`. */
+int es_denoise_step(es_ctx* c, const void* sample, float t, const void* ehs, const void* const* cond_embeds,
+                    const float* scales, void* out_noise, void* stream);
+/* latents fp32 [B,h,w,L] (device, in/out); ehs as above; timesteps: HOST float[n_steps] (981, 961, ... for 50 steps);
+ * the condition embeddings are the ones last copied into ES_BUF_COND* (es_denoise_step does, or the builder). */
+int es_denoise_loop(es_ctx* c, float* latents_inout, const void* ehs, float guidance_scale, const float* timesteps,
+                    int n_steps, void* stream);
+int es_vae_decode(es_ctx* c, const float* latents, float* out_img, void* stream);
 
 #ifdef __cplusplus
 }

@@ -22,15 +22,36 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "edgestyle_hip.h")).read()
     declared = set(re.findall(r"\b(es_[a-z0-9_]+)\s*\(", header))
     declared = {d for d in declared if not d.endswith("_desc") or d == "es_sizeof_desc"}
+    declared -= {"es_ctx_geometry"}
     assert declared == set(lib.SYMBOLS), declared ^ set(lib.SYMBOLS)
     h = ctypes.CDLL(lib.LIB_PATH)
     for name in declared:
         assert getattr(h, name) is not None
     L = lib.load()
-    assert L.es_abi_version() == 1
+    assert L.es_abi_version() == 2
     # struct layouts agree with the C side (sizes are what the kernels index with)
-    for i, st in enumerate((lib.GemmDesc, lib.AttnDesc, lib.GnDesc, lib.FusionDesc, lib.LnDesc)):
+    for i, st in enumerate((lib.GemmDesc, lib.AttnDesc, lib.GnDesc, lib.FusionDesc, lib.LnDesc, lib.XsDesc)):
         assert L.es_sizeof_desc(i) == ctypes.sizeof(st)
+
+
+def test_plan_records_nothing_and_launches_nothing_without_a_gpu():
+    """es_plan object life cycle on the host (no compute calls): create / begin / end / size / destroy; a second plan
+    cannot start recording while one records."""
+    L = lib.load()
+    a, b = ctypes.c_void_p(L.es_plan_create()), ctypes.c_void_p(L.es_plan_create())
+    assert L.es_plan_size(a) == 0
+    assert L.es_plan_begin_record(a) == 0
+    assert L.es_plan_begin_record(b) != 0 and b"recording" in L.es_last_error()
+    assert L.es_plan_end_record(b) != 0
+    assert L.es_plan_end_record(a) == 0 and L.es_plan_size(a) == 0
+    ctx = ctypes.c_void_p()
+    assert L.es_ctx_create(0, ctypes.byref(ctx)) == 0
+    assert L.es_ctx_plan_size(ctx, lib.PLAN_STEP) == -1
+    assert L.es_ctx_set_plan(ctx, lib.PLAN_STEP, a) == 0 and L.es_ctx_plan_size(ctx, lib.PLAN_STEP) == 0
+    geo = lib.CtxGeometry(B=1, cfg=1, h=8, w=8, latent_channels=4, latent_pad=8, n_conds=7, n_steps=4, dtype=0)
+    assert L.es_ctx_set_geometry(ctx, ctypes.byref(geo)) != 0            # 7 conditions: refused
+    L.es_ctx_destroy(ctx)                                               # destroys plan a
+    L.es_plan_destroy(b)
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -1,0 +1,133 @@
+"""The step-level C ABI (include/edgestyle_hip.h: es_ctx / es_plan / es_denoise_step / es_denoise_loop / es_vae_decode)
+driven through ctypes with raw device pointers, against the Python host path that built the context — bit for bit —
+and against the CPU oracle.  What is replaced: OnnxUNetAndControlnets.forward (export_onnx.py:43-74), the loop of
+model/edgestyle_pipeline.py:435-543 and the decode of PL:552-572."""
+import ctypes as C
+
+import pytest
+import torch
+
+from edgestyle_amd import config as Cfg, lib as L
+from tests.helpers import make_weights, quantize, oracle_nets, psnr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def built():
+    import dataclasses
+    from edgestyle_amd.models import StepRunner, AutoencoderKL
+    from edgestyle_amd.pipeline import EdgeStyleStableDiffusionControlNetPipeline
+    from edgestyle_amd.native import NativeEngine
+    # tiny width, but 64x64 latents: the groups tile in 128-pixel units, so the step is the grouped lockstep one
+    ucfg, vcfg = dataclasses.replace(Cfg.tiny_unet(), sample_size=64), Cfg.tiny_vae()
+    ws = {k: quantize(v) for k, v in make_weights(ucfg, vcfg, seed=2).items()}
+    runner = StepRunner.from_state_dicts(ws, ucfg, torch.float16, DEV)
+    vae = AutoencoderKL(ws["vae"], vcfg).to(DEV)
+    pipe = EdgeStyleStableDiffusionControlNetPipeline(vae=vae, unet=runner.unet, controlnet=runner.controlnet).to(DEV)
+    eng = NativeEngine(pipe, batch_size=1, num_inference_steps=6)
+    return pipe, eng, ws, ucfg, vcfg
+
+
+def _inputs(ucfg, seed):
+    g = torch.Generator().manual_seed(seed)
+    s, c0 = ucfg.sample_size, ucfg.block_out_channels[0]
+    lat = torch.randn(1, 4, s, s, generator=g)
+    pe = (torch.randn(1, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+    ne = (torch.randn(1, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+    conds = [(torch.randn(1, c0, s, s, generator=g) * 0.3).half().float() for _ in range(6)]
+    return lat, pe, ne, conds
+
+
+def test_plans_hold_the_launch_lists(built):
+    pipe, eng, ws, ucfg, vcfg = built
+    lib = L.load()
+    n_step = lib.es_ctx_plan_size(eng.ctx, L.PLAN_STEP)
+    assert n_step == eng.plan_sizes[L.PLAN_STEP] and 200 < n_step < 600
+    assert lib.es_ctx_plan_size(eng.ctx, L.PLAN_PREP) > 20 and lib.es_ctx_plan_size(eng.ctx, L.PLAN_DECODE) > 50
+    assert lib.es_ctx_plan_size(eng.ctx, L.PLAN_STEP_GENERIC) > n_step      # + context and time embedding
+
+
+def test_es_denoise_step_raw_pointers_equals_python_step_bitwise_and_oracle(built):
+    """es_denoise_step(ctx, sample, t, ehs, cond_embeds[6], scales[6], out) called through ctypes with data_ptr()s."""
+    from oracle import sd15_oracle as O
+    from edgestyle_amd.models import _as_nhwc, _as_nchw_view
+    pipe, eng, ws, ucfg, vcfg = built
+    lat, pe, ne, conds = _inputs(ucfg, 11)
+    x = torch.cat([lat, lat]).half().float()
+    ehs = torch.cat([ne, pe])
+    conds2 = [c.repeat(2, 1, 1, 1) for c in conds]
+    scales = [1.0, 0.8, 1.0, 1.0, 0.5, 1.0]
+    t = 441
+    ref = O.denoise_step(ws["unet"], ucfg, ws["fusion"], oracle_nets(ws, ucfg), x, t, ehs, conds2, scales)
+    runner = pipe._runner
+    want = runner.step_nchw(x.to(DEV), t, ehs.to(DEV), [c.to(DEV) for c in conds2], scales).clone()
+    assert runner.mode == "grouped" and runner._grouped_encoder(2).groupable(8 * 8)
+    # the C call: contiguous device buffers, raw pointers
+    lib = L.load()
+    sample = _as_nhwc(x, torch.float16, DEV, pipe.unet.engine.in_pad).contiguous()
+    ehs_d = ehs.to(DEV, torch.float16).contiguous()
+    cond_d = [_as_nhwc(c, torch.float16, DEV).contiguous() for c in conds2]
+    out = torch.zeros((2, ucfg.sample_size, ucfg.sample_size, 4), dtype=torch.float16, device=DEV)
+    ptrs = (C.c_void_p * 6)(*[c.data_ptr() for c in cond_d])
+    sc = (C.c_float * 6)(*scales)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for use_graphs in (1, 0, 1):
+        eng.set_options(use_graphs=bool(use_graphs))
+        out.zero_()
+        rc = lib.es_denoise_step(eng.ctx, C.c_void_p(sample.data_ptr()), float(t), C.c_void_p(ehs_d.data_ptr()), ptrs, sc,
+                                 C.c_void_p(out.data_ptr()), stream)
+        assert rc == 0, lib.es_last_error()
+        torch.cuda.synchronize()
+        got = _as_nchw_view(out)
+        assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+    assert float((got.float().cpu() - ref).abs().max()) < 2e-2
+    # a second call with another timestep / prompt: nothing of the first one sticks
+    want2 = runner.step_nchw(x.to(DEV), 101, torch.flip(ehs, [0]).to(DEV), [c.to(DEV) for c in conds2], scales).clone()
+    ehs2 = torch.flip(ehs, [0]).to(DEV, torch.float16).contiguous()
+    assert lib.es_denoise_step(eng.ctx, C.c_void_p(sample.data_ptr()), 101.0, C.c_void_p(ehs2.data_ptr()), ptrs, sc,
+                               C.c_void_p(out.data_ptr()), stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(_as_nchw_view(out), want2)
+
+
+def test_es_denoise_loop_and_vae_decode_equal_the_pipeline_bitwise(built):
+    from oracle import sd15_oracle as O
+    from edgestyle_amd.models import _as_nhwc
+    pipe, eng, ws, ucfg, vcfg = built
+    lat, pe, ne, conds = _inputs(ucfg, 23)
+    gs, T = 5.0, eng.T
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, latents=lat, guidance_scale=gs, num_inference_steps=T)
+    want_lat = pipe(output_type="latent", **kw).images.clone()
+    want_img = pipe(output_type="pt", **kw).images.clone()
+    # native: conditions into the context's slots, then the loop and the decode with raw pointers
+    eng.set_options(use_graphs=True)
+    eng.set_conds([_as_nhwc(c.repeat(2, 1, 1, 1), torch.float16, DEV) for c in conds])
+    ehs = torch.cat([ne, pe]).to(DEV, torch.float16).contiguous()
+    x = lat.permute(0, 2, 3, 1).contiguous().to(DEV)
+    for use_graphs in (True, False):
+        eng.set_options(use_graphs=use_graphs)
+        got = eng.denoise_loop(x.clone(), ehs, gs)
+        img = eng.vae_decode(got)
+        torch.cuda.synchronize()
+        assert torch.equal(got.permute(0, 3, 1, 2), want_lat), float((got.permute(0, 3, 1, 2) - want_lat).abs().max())
+        assert torch.equal(img, want_img)
+    # another guidance scale on the same context (the scheduler node of the step graph carries it: re-instantiated)
+    eng.set_options(use_graphs=True)
+    want3 = pipe(output_type="latent", **dict(kw, guidance_scale=2.5)).images
+    got3 = eng.denoise_loop(x.clone(), ehs, 2.5)
+    assert torch.equal(got3.permute(0, 3, 1, 2), want3)
+    # conditioning scales / control-guidance window live in the context (PL:419-427, 464-470)
+    scales = [1.0, 0.5, 1.0, 1.0, 0.7, 1.0]
+    want4 = pipe(output_type="latent", **dict(kw, controlnet_conditioning_scale=scales, control_guidance_end=0.5)).images
+    eng.set_options(cond_scales=scales, control_guidance_end=0.5)
+    got4 = eng.denoise_loop(x.clone(), ehs, gs)
+    assert torch.equal(got4.permute(0, 3, 1, 2), want4)
+    eng.set_options(cond_scales=[1.0] * 6)
+    # and the whole thing against the oracle
+    ref = O.pipeline(ws["unet"], ucfg, ws["fusion"], oracle_nets(ws, ucfg), ws["vae"], vcfg, lat, pe, ne,
+                     [c.repeat(2, 1, 1, 1) for c in conds], num_inference_steps=T, guidance_scale=gs)
+    assert psnr(want_img, ref) >= 40.0
+    with pytest.raises(L.EdgeStyleHipError):
+        eng.denoise_loop(x.clone(), ehs, gs, timesteps=[981.0, 961.0])      # built for T steps
