@@ -167,26 +167,36 @@ int run(es_ctx* c, int which, hipStream_t st, const float* guidance) {
 // steps, set_alpha_to_one False, steps_offset 1, eta 0): {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)} per step,
 // a_prev = alphas_cumprod of the NEXT timestep of the list (t - 1000 / n), alphas_cumprod[0] after the last one
 void default_alphas(std::vector<float>& ac) {
+  // torch.linspace(sqrt(b0), sqrt(b1), 1000, fp32) ** 2 -> cumprod(1 - betas), with torch's fp32 rounding points
+  // (linspace fills the second half from the end), so that the default table equals the host scheduler's bit for bit
   ac.resize(1000);
-  const float b0 = sqrtf(0.00085f), b1 = sqrtf(0.012f);
-  float prod = 1.0f;
+  volatile float b0 = (float)sqrt(0.00085), b1 = (float)sqrt(0.012);
+  volatile float step = (b1 - b0) / 999.0f;
+  volatile float prod = 1.0f;
   for (int i = 0; i < 1000; ++i) {
-    const float b = b0 + (b1 - b0) * (float)i / 999.0f;
-    prod *= 1.0f - b * b;
+    volatile float m = i < 500 ? step * (float)i : step * (float)(999 - i);
+    volatile float b = i < 500 ? b0 + m : b1 - m;
+    volatile float b2 = b * b;
+    volatile float om = 1.0f - b2;
+    prod = prod * om;
     ac[i] = prod;
+  }
+}
+void ddim_coef_from(const std::vector<float>& ac, const float* ts, int n, float* out) {
+  const int last = (int)ac.size() - 1;
+  auto at = [&](float t) { int i = (int)t; i = i < 0 ? 0 : (i > last ? last : i); return ac[i]; };
+  for (int i = 0; i < n; ++i) {
+    // volatile: every value is rounded to fp32 exactly where the host scheduler (torch fp32 tensors) rounds it
+    volatile float a_t = at(ts[i]);
+    volatile float a_p = i + 1 < n ? at(ts[i + 1]) : ac[0];
+    volatile float b_t = 1.0f - a_t, b_p = 1.0f - a_p;
+    out[i * 4 + 0] = sqrtf(a_t); out[i * 4 + 1] = sqrtf(b_t);
+    out[i * 4 + 2] = sqrtf(a_p); out[i * 4 + 3] = sqrtf(b_p);
   }
 }
 void ddim_coef(es_ctx* c, const float* ts, int n, float* out) {
   if (c->alphas_cumprod.empty()) default_alphas(c->alphas_cumprod);
-  const std::vector<float>& ac = c->alphas_cumprod;
-  const int last = (int)ac.size() - 1;
-  auto at = [&](float t) { int i = (int)t; i = i < 0 ? 0 : (i > last ? last : i); return ac[i]; };
-  for (int i = 0; i < n; ++i) {
-    const float a_t = at(ts[i]);
-    const float a_p = i + 1 < n ? at(ts[i + 1]) : ac[0];
-    out[i * 4 + 0] = sqrtf(a_t); out[i * 4 + 1] = sqrtf(1.0f - a_t);
-    out[i * 4 + 2] = sqrtf(a_p); out[i * 4 + 3] = sqrtf(1.0f - a_p);
-  }
+  ddim_coef_from(c->alphas_cumprod, ts, n, out);
 }
 }  // namespace
 
@@ -235,6 +245,21 @@ extern "C" int es_ctx_set_options(es_ctx* c, const float* cond_scales, float con
 extern "C" int es_ctx_set_alphas_cumprod(es_ctx* c, const float* alphas_cumprod, int n) {
   if (!c || !alphas_cumprod || n < 1) { es_set_error("es_ctx_set_alphas_cumprod: bad arguments"); return -1; }
   c->alphas_cumprod.assign(alphas_cumprod, alphas_cumprod + n);
+  return 0;
+}
+/* one plan of the context on `stream` (what es_denoise_loop does n_steps times with ES_PLAN_STEP): lets a host single-step
+ * a loop it has prepared, e.g. to look at intermediate latents */
+extern "C" int es_ctx_launch_plan(es_ctx* c, int which, const float* guidance_scale, void* stream) {
+  if (!c || which < 0 || which >= ES_PLAN_COUNT) { es_set_error("es_ctx_launch_plan: bad arguments"); return -1; }
+  return run(c, which, (hipStream_t)stream, guidance_scale);
+}
+/* host-only: the per-step DDIM coefficient rows es_denoise_loop derives from `timesteps` (no GPU involved) */
+extern "C" int es_ddim_coef_table(const float* alphas_cumprod, int n_alphas, const float* timesteps, int n, float* out) {
+  if (!timesteps || !out || n < 1) { es_set_error("es_ddim_coef_table: bad arguments"); return -1; }
+  std::vector<float> ac;
+  if (alphas_cumprod && n_alphas > 0) ac.assign(alphas_cumprod, alphas_cumprod + n_alphas);
+  else default_alphas(ac);
+  ddim_coef_from(ac, timesteps, n, out);
   return 0;
 }
 extern "C" int es_ctx_plan_size(const es_ctx* c, int which) {

@@ -49,15 +49,19 @@ class DDIMScheduler:
         return sample
 
     def coef_table(self) -> torch.Tensor:
-        """[steps, 4] fp32: sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev) for each timestep in order."""
-        rows = []
-        ratio = self.num_train_timesteps // self.num_inference_steps
-        for t in self.timesteps.tolist():
-            prev = t - ratio
-            a_t = self.alphas_cumprod[t]
-            a_p = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
-            rows.append(torch.stack([a_t.sqrt(), (1 - a_t).sqrt(), a_p.sqrt(), (1 - a_p).sqrt()]))
-        return torch.stack(rows).float().contiguous()
+        """[steps, 4] fp32: sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev) for each timestep in order
+        (a_prev: alphas_cumprod at t - num_train // steps = the next timestep of the list; alphas_cumprod[0] after the
+        last).  Computed by the library's host-side helper es_ddim_coef_table - the very code es_denoise_loop uses - so the
+        Python loop and the native loop see the same bits."""
+        import ctypes as C
+        from . import lib as L
+        ts = self.timesteps.to(torch.float32).contiguous()
+        ac = self.alphas_cumprod.to(torch.float32).contiguous()
+        out = torch.empty((ts.numel(), 4), dtype=torch.float32)
+        fp = C.POINTER(C.c_float)
+        L.check(L.load().es_ddim_coef_table(C.cast(ac.data_ptr(), fp), ac.numel(), C.cast(ts.data_ptr(), fp), ts.numel(),
+                                            C.cast(out.data_ptr(), fp)), "es_ddim_coef_table")
+        return out
 
 
 class UniPCMultistepScheduler:

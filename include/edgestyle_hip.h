@@ -308,6 +308,13 @@ int es_ctx_set_options(es_ctx* c, const float* cond_scales, float control_guidan
                        int use_graphs);
 int es_ctx_set_alphas_cumprod(es_ctx* c, const float* alphas_cumprod, int n);   /* scheduler schedule (default: SD1.5's) */
 int es_ctx_plan_size(const es_ctx* c, int which);
+/* run ONE plan of the context on `stream` (guidance_scale: pointer to the CFG scale for the scheduler call of
+ * ES_PLAN_STEP, or NULL = as recorded): single-stepping a prepared loop */
+int es_ctx_launch_plan(es_ctx* c, int which, const float* guidance_scale, void* stream);
+/* host-only helper: out[n][4] = {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)} for the DDIM (eta 0) update of
+ * each timestep of the list, a_prev = alphas_cumprod of the next timestep (alphas_cumprod[0] after the last one: the
+ * SD1.5 scheduler_config's set_alpha_to_one False); alphas_cumprod NULL = SD1.5's scaled_linear schedule */
+int es_ddim_coef_table(const float* alphas_cumprod, int n_alphas, const float* timesteps, int n, float* out);
 /* sample dtype [N,h,w,latent_pad]; ehs dtype [N,77,D]; cond_embeds[n_conds] dtype [N,h,w,C0]; scales float[n_conds] (host)
  * or NULL (ones); out_noise dtype [N,h,w,out_channels].  All device pointers except `scales`. */
 int es_denoise_step(es_ctx* c, const void* sample, float t, const void* ehs, const void* const* cond_embeds,

@@ -54,6 +54,24 @@ def test_plan_records_nothing_and_launches_nothing_without_a_gpu():
     L.es_plan_destroy(b)
 
 
+def test_native_ddim_coefficients_match_the_host_scheduler():
+    """es_ddim_coef_table (what es_denoise_loop derives from `timesteps`, host-only code) vs DDIMScheduler.coef_table():
+    bit for bit with the scheduler's alphas_cumprod handed over, within 1e-6 with the library's own SD1.5 schedule."""
+    import numpy as np
+    L = lib.load()
+    fp = ctypes.POINTER(ctypes.c_float)
+    for T in (4, 20, 50):
+        s = DDIMScheduler()
+        ts = s.set_timesteps(T).float().numpy().astype(np.float32)
+        want = s.coef_table().numpy()
+        ac = s.alphas_cumprod.numpy().astype(np.float32)
+        out = np.zeros((T, 4), dtype=np.float32)
+        assert L.es_ddim_coef_table(ac.ctypes.data_as(fp), len(ac), ts.ctypes.data_as(fp), T, out.ctypes.data_as(fp)) == 0
+        assert np.array_equal(out, want)
+        assert L.es_ddim_coef_table(None, 0, ts.ctypes.data_as(fp), T, out.ctypes.data_as(fp)) == 0
+        assert np.abs(out - want).max() < 1e-6
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(lib, "_lib", None)
     monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libedgestyle_hip.so")
