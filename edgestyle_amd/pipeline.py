@@ -84,13 +84,17 @@ class _Loop:
         self.scale_table = None
         self.coef = None
         self.graph = None
+        self.prep_graph = None           # text K/V projections + condition slots + time table, captured like the step
+        self.decode_graph = None         # VAE decode + [0,1] post-process
+        self.image = None                # the decode graph's output buffer
+        self.ts_dev = None               # fp32 [T] timesteps the time table is built from
         self.sig = None
         self.captures = 0                # how often this loop's graph was (re)captured (tests)
         self.guidance_scale = None
         self.steps = None
 
     def signature(self):
-        return self.state.signature() + tuple(t.data_ptr() for t in (self.t_table, self.scale_table, self.coef)) + \
+        return self.state.signature() + tuple(t.data_ptr() for t in (self.t_table, self.scale_table, self.coef, self.ts_dev)) + \
             (ops.LANE,)
 
     def set_model_in(self):
@@ -399,6 +403,7 @@ class StableDiffusionControlNetPipeline:
             loop.t_table = torch.empty((T, k * N), dtype=torch.float32, device=dev)
             loop.scale_table = torch.empty((T, nn), dtype=torch.float32, device=dev)
             loop.coef = torch.empty((T, cw), dtype=torch.float32, device=dev)
+            loop.ts_dev = torch.empty((T,), dtype=torch.float32, device=dev)
         for hbuf in loop.hist:
             hbuf.zero_()
         loop.t_table.copy_(ts.float()[:, None].expand(T, k * N))
@@ -413,17 +418,25 @@ class StableDiffusionControlNetPipeline:
         # every buffer the step reads between calls belongs to THIS loop (StepState): filled in place, and the graph
         # is re-captured whenever one of them sits at another address than at capture time
         runner = self._runner
-        runner.state = loop.state
-        runner.set_context(loop.ehs, guess, loop.conds[0].shape[0])
-        if runner.mode == "grouped" and not guess:
-            runner.set_conds(loop.conds)                                  # conv_in + cond of all nets as one launch
-            if os.environ.get("ES_TIME_TABLE", "1") == "1":
-                runner.set_time_table(ts.float().to(dev), N)              # every step's time projections, once per call
+        loop.ts_dev.copy_(ts.float())
+
+        def prep():
+            runner.state = loop.state
+            runner.set_context(loop.ehs, guess, loop.conds[0].shape[0])
+            if runner.mode == "grouped" and not guess:
+                runner.set_conds(loop.conds)                              # conv_in + cond of all nets as one launch
+                if os.environ.get("ES_TIME_TABLE", "1") == "1":
+                    runner.set_time_table(loop.ts_dev, N)                 # every step's time projections, once per call
+        graphs = self.use_graph and callback_on_step_end is None
+        if graphs and not regraph and loop.prep_graph is not None and loop.sig is not None:
+            loop.prep_graph.replay()
+        else:
+            prep()
         if loop.signature() != loop.sig:
             regraph = True
 
         # PL:435-543 — the denoising loop
-        if callback_on_step_end is not None or not self.use_graph:
+        if not graphs:
             for i in range(T):
                 loop.one_step()
                 if callback_on_step_end is not None:
@@ -444,9 +457,13 @@ class StableDiffusionControlNetPipeline:
                 with torch.cuda.graph(g):
                     loop.one_step()
                 loop.graph = g
+                loop.step_idx.copy_(saved)            # capture does not execute; keep the counter where it was
+                gp = torch.cuda.CUDAGraph()           # the per-call preparation replays from the next call on
+                with torch.cuda.graph(gp):
+                    prep()
+                loop.prep_graph, loop.decode_graph = gp, None
                 loop.sig = loop.signature()
                 loop.captures += 1
-                loop.step_idx.copy_(saved)            # capture does not execute; keep the counter where it was
             for _ in range(start, T):
                 loop.graph.replay()
 
@@ -455,8 +472,21 @@ class StableDiffusionControlNetPipeline:
         else:
             # PL:552-557 decode(latents / scaling_factor); PL:570-572 (x/2+0.5).clamp(0,1)
             # model_in[:B] already holds the final latents in the compute dtype, channel-padded (es_cfg_ddim_step)
-            dec = self.vae.decode_nhwc(loop.model_in[:B], unscaled_latents=True)
-            img = ops.nhwc_to_nchw(dec, channels=3, scale=0.5, shift=0.5, clamp01=True)
+            def decode():
+                dec = self.vae.decode_nhwc(loop.model_in[:B], unscaled_latents=True)
+                return ops.nhwc_to_nchw(dec, channels=3, scale=0.5, shift=0.5, clamp01=True)
+            if graphs:
+                if loop.decode_graph is None:
+                    decode()                          # eager once: kernels warm, scratch sized outside the capture
+                    torch.cuda.synchronize()
+                    gd = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gd):
+                        loop.image = decode()
+                    loop.decode_graph = gd
+                loop.decode_graph.replay()
+                img = loop.image.clone()              # the graph's output buffer is overwritten by the next call
+            else:
+                img = decode()
             if output_type in ("np", "pil"):
                 arr = img.permute(0, 2, 3, 1).cpu().numpy()
                 if output_type == "pil":

@@ -391,3 +391,30 @@ def test_service_latents_depend_on_the_request_seed_only():
     from edgestyle_amd.serve import latents_for
     a, b = latents_for(42, 4, 8, 8), latents_for(42, 4, 8, 8)
     assert torch.equal(a, b) and not torch.equal(a, latents_for(43, 4, 8, 8)) and a.shape == (1, 4, 8, 8)
+
+
+def test_best_embeddings_prompt_picker():
+    """BestEmbeddings (model/utils.py:647-684): top-2 colours + top-2 items by CLIP image-text probability, joined into
+    "edgestyle, c1, c2, i1, i2"; here with a stand-in model whose logits are known."""
+    from types import SimpleNamespace
+    from edgestyle_amd.prompts import BestEmbeddings, DEFAULT_COLORS
+
+    class Proc:
+        def __call__(self, text, images, return_tensors, padding):
+            return {"text": text, "n_images": len(images)}
+
+    class Model:
+        device = None
+
+        def __call__(self, text, n_images):
+            # image i prefers entries i, i+1, ... (descending logits from index i, cyclic)
+            n = len(text)
+            logits = torch.stack([torch.roll(torch.arange(n, 0, -1).float(), i) for i in range(n_images)])
+            return SimpleNamespace(logits_per_image=logits)
+
+    colors = ["red", "green", "blue", "black"]
+    items = ["dress", "shirt", "coat"]
+    be = BestEmbeddings(Model(), Proc(), colors=colors, clothing_items=items)
+    assert be([object(), object()]) == ["edgestyle, red, green, dress, shirt", "edgestyle, green, blue, shirt, coat"]
+    assert BestEmbeddings(Model(), Proc()).colors == DEFAULT_COLORS
+    assert be.find_best(colors, [object()], n=3) == [["red", "green", "blue"]]
