@@ -4,8 +4,9 @@ Same flag names as TT:76-212 / test_inference.sh; same flow as TT:215-365: load 
 EdgeStyle multi-ControlNet (load_pattern [0,None,1,None,1,None]), tie the LoRA nets to the UNet, UniPC scheduler,
 seed 42, six guidance scales linspace(1,7,6), 50 steps, 3x3 JPEG grid of [subject, target, target2, 6 results].
 
-Differences, all forced by what exists offline: the CLIP prompt picker `BestEmbeddings` (model/utils.py:647-684) is not
-part of the denoising path — pass `--prompt`; `--random_init DIR` writes seeded random-init model directories in the
+Differences, all forced by what exists offline: the CLIP prompt picker `BestEmbeddings` (model/utils.py:647-684,
+edgestyle_amd/prompts.py) needs a local CLIP checkpoint (`--clip_model_name_or_path`) — without one pass `--prompt`;
+`--random_init DIR` writes seeded random-init model directories in the
 reference's on-disk layout first (no trained weights exist here) and uses random prompt embeddings when no
 tokenizer/text_encoder directory is given.
 
@@ -35,6 +36,11 @@ def parse_args(argv: Optional[List[str]] = None):
     p.add_argument("--prompt", type=str, default="edgestyle")
     p.add_argument("--prompt_text_to_add", type=str, default="")
     p.add_argument("--negative_prompt", type=str, default="")
+    p.add_argument("--clip_model_name_or_path", type=str, default=None,
+                   help="local CLIP directory (transformers CLIPModel + CLIPProcessor): the prompt is then picked from the "
+                        "first target's clothes image by BestEmbeddings like TT:52-55, 316; --prompt_vocab names a JSON "
+                        "with the reference's colour / clothing-item lists")
+    p.add_argument("--prompt_vocab", type=str, default=None)
     p.add_argument("--source_path", type=str, default=None)
     p.add_argument("--source_image_name", type=str, default="1.jpg")
     p.add_argument("--target_path", type=str, default=None)
@@ -159,7 +165,16 @@ def main(args):
         d = unet.cfg.cross_attention_dim
         kw = dict(prompt_embeds=torch.randn(1, 77, d, generator=g) * 0.5, negative_prompt_embeds=torch.randn(1, 77, d, generator=g) * 0.5)
     else:
-        kw = dict(prompt=args.prompt + " " + args.prompt_text_to_add, negative_prompt=args.negative_prompt)
+        prompt = args.prompt
+        if args.clip_model_name_or_path:                                                          # TT:52-55, TT:316
+            from transformers import CLIPModel, CLIPProcessor
+            from .prompts import BestEmbeddings
+            clip = CLIPModel.from_pretrained(args.clip_model_name_or_path).eval()
+            proc = CLIPProcessor.from_pretrained(args.clip_model_name_or_path)
+            be = (BestEmbeddings.from_vocab_file(clip, proc, args.prompt_vocab) if args.prompt_vocab
+                  else BestEmbeddings(clip, proc))
+            prompt = be([Image.open(os.path.join(args.target_path, "clothes", args.target_image_name)).convert("RGB")])[0]
+        kw = dict(prompt=prompt + " " + args.prompt_text_to_add, negative_prompt=args.negative_prompt)
     for gs in np.linspace(1.0, 7.0, NUM_IMAGES):                                                  # TT:318, 326-359
         out = pipeline(guidance_scale=float(gs), image=conds, num_inference_steps=args.num_inference_steps,
                        generator=generator, **kw).images[0]
