@@ -140,6 +140,8 @@ class StableDiffusionControlNetPipeline:
         self._runner = None
         self._loops: Dict[Any, _Loop] = {}
         self._last_loop: Optional[_Loop] = None
+        self.collect_timing = False      # tools: HIP events at the phase boundaries of a call -> self.timing (ms)
+        self.timing: Dict[str, float] = {}
 
     @classmethod
     def from_pretrained(cls, path=None, **components):
@@ -371,12 +373,21 @@ class StableDiffusionControlNetPipeline:
         if self._runner is None:
             self._runner = StepRunner(self.unet, self.controlnet)
 
+        ev = []
+
+        def mark(name):
+            if self.collect_timing:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                ev.append((name, e))
+        mark("start")
         # PL:352-377 — condition images, embedded ONCE
         guess = bool(guess_mode)
         conds = self.prepare_images(image, B, do_cfg and not guess, cond_noise, generator,
                                     num_images_per_prompt)                                      # PL:352-377, 657-658
         h, w = conds[0].shape[1:3]
 
+        mark("cond_embed")
         # PL:382-398
         ts = self.scheduler.set_timesteps(num_inference_steps)
         T = len(ts)
@@ -435,6 +446,7 @@ class StableDiffusionControlNetPipeline:
         if loop.signature() != loop.sig:
             regraph = True
 
+        mark("prep")
         # PL:435-543 — the denoising loop
         if not graphs:
             for i in range(T):
@@ -467,6 +479,7 @@ class StableDiffusionControlNetPipeline:
             for _ in range(start, T):
                 loop.graph.replay()
 
+        mark("loop")
         if output_type == "latent":
             img = _as_nchw_view(loop.latents).clone()
         else:
@@ -496,6 +509,10 @@ class StableDiffusionControlNetPipeline:
                     img = arr
             elif output_type != "pt":
                 raise ValueError(f"unknown output_type {output_type}")
+        mark("decode")
+        if ev:
+            torch.cuda.synchronize()
+            self.timing = {b[0]: a[1].elapsed_time(b[1]) for a, b in zip(ev[:-1], ev[1:])}
         if not return_dict:
             return (img, None)
         return StableDiffusionPipelineOutput(images=img, nsfw_content_detected=None)

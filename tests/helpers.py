@@ -46,7 +46,7 @@ def to_nhwc(x, device, dtype=torch.float16, cpad=None):
 
 def tiny_step_check(device="cuda:0", seed=0):
     """One full 6-cond multi-ControlNet + UNet step (== export_onnx.py:43-74) on the tiny config: HIP vs oracle.
-    Returns max abs error of noise_pred."""
+    Returns (max abs error, error relative to the reference's largest magnitude) of noise_pred."""
     from oracle import sd15_oracle as O
     from edgestyle_amd import engine as E
     ucfg, vcfg = C.tiny_unet(), C.tiny_vae()
@@ -64,7 +64,8 @@ def tiny_step_check(device="cuda:0", seed=0):
     runner = StepRunner.from_state_dicts(ws, ucfg, torch.float16, device)
     out = runner.step_nchw(x.to(device), t, ehs.to(device), [c.to(device) for c in conds], scales)
     torch.cuda.synchronize()
-    return float((out.float().cpu() - ref).abs().max())
+    err = (out.float().cpu() - ref).abs().max()
+    return float(err), float(err / ref.abs().max())
 
 
 # ----------------------------------------------------------------------------------------------------------------
