@@ -45,6 +45,11 @@ constexpr int BK = 64;
 #ifndef ES_ABLATE
 #define ES_ABLATE 0
 #endif
+// Tool-only diagnostic build (tools/gemm_stamps.py): ES_STAMPS=1 writes s_memtime stamps of the four waves of two
+// workgroups (loop top / after the barrier / after the DMA issue / after the MFMAs of K-steps 8..15) into `prof`.
+#ifndef ES_STAMPS
+#define ES_STAMPS 0
+#endif
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -120,7 +125,15 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
     if (p.xcd_m_fastest) { tile_m = w % tm; const int t = w / tm; tile_n = t % tn; z = t / tn; }
     else                 { tile_n = w % tn; const int t = w / tn; tile_m = t % tm; z = t / tm; }
   }
+#if ES_STAMPS
+  const int sblk = blockIdx.x == 40 ? 0 : (blockIdx.x == 333 ? 1 : -1);
+  auto stamp = [&](int ks, int what) __attribute__((always_inline)) {
+    if (p.prof && sblk >= 0 && lane == 0 && wave < 4 && ks >= 8 && ks < 16)
+      p.prof[((sblk * 4 + wave) * 8 + (ks - 8)) * 4 + what] = __builtin_amdgcn_s_memtime();
+  };
+#else
   if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 
   const int ks0 = (int)(((long long)nk * z) / p.splitk);
   const int ks1 = (int)(((long long)nk * (z + 1)) / p.splitk);
@@ -316,10 +329,43 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
     for (int e = 0; e < 8; ++e) ln_ones[e] = from_f32<T>(1.0f);
   }
   int stage = 0, istage = STAGES - 1;
-#if ES_ABLATE & 4
+  // operand fragments of the default K-step form (read from LDS each K-step, live across the barrier for `late` waves)
   typename Traits<T>::vec8 xa0[FM], wa0[FN], xa1[FM], wa1[FN];
+  auto do_mfmas = [&]() __attribute__((always_inline)) {
+#if ES_ABLATE & 1
+#pragma unroll
+    for (int j = 0; j < FM; ++j) { asm volatile("" ::"v"(xa0[j]), "v"(xa1[j])); }
+#pragma unroll
+    for (int i = 0; i < FN; ++i) { asm volatile("" ::"v"(wa0[i]), "v"(wa1[i])); }
+#else
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(wa0[i], xa0[j], acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(wa1[i], xa1[j], acc[i][j]);
 #endif
+  };
+  // 256-pixel tile = ONE 8-wave workgroup per CU: the two waves of a SIMD (w, w + 4) run the same program between the
+  // same barriers, so left alone they issue their DMAs / LDS reads together and their MFMAs together and nothing
+  // overlaps (why this tile never beat two independent 128-pixel workgroups per CU although it moves 28 % fewer L2->LDS
+  // bytes per FLOP, and L2->LDS bandwidth per CU is what bounds the K loop).  Waves 4-7 therefore run half a K-step out
+  // of phase: they read their fragments of stage k like everyone, but issue the MFMAs of stage k right AFTER the next
+  // barrier (the fragments already sit in registers), beside their partners' DMA issue and LDS reads; one static
+  // s_setprio for that (younger) half, which otherwise loses the SIMD's issue arbitration on every phase
+  // (MI355X_MICROARCH.md, two waves per SIMD, items 2, 4, 9).  Per accumulator the summation order is unchanged.
+#ifndef ES_STAGGER
+#define ES_STAGGER 1
+#endif
+  constexpr bool STAG = ES_STAGGER && BM == 256 && FN <= 5 && BKT == 64 && !LN && NW == 8;
+  const bool late = STAG && wave >= NW / 2;
+  if (late) __builtin_amdgcn_s_setprio(1);
   for (int ks = ks0; ks < ks1; ++ks) {
+#if ES_STAMPS
+    stamp(ks - ks0, 0);
+#endif
     // tile ks must have landed; up to STAGES-2 younger tiles (NI DMA instructions each) may stay in flight
     if (!(ES_ABLATE & 8)) {
       if (STAGES > 2 && ks + STAGES - 2 < ks1) {
@@ -329,6 +375,9 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
       }
       __builtin_amdgcn_s_barrier();                    // everyone's DMA of tile ks landed; everyone finished tile ks-1
     }
+#if ES_STAMPS
+    stamp(ks - ks0, 1);
+#endif
     const char* xs = smem + stage * (XT + WT);
     const char* ws = xs + XT;
     // Fragment reads are software-pipelined against the MFMAs: the reads of the second 32-deep half are in flight
@@ -380,9 +429,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(wa[i], xa[j], acc[i][j]);
     } else {
-#if !(ES_ABLATE & 4)
-    typename Traits<T>::vec8 xa0[FM], wa0[FN], xa1[FM], wa1[FN];
-#endif
+    if (late && ks > ks0) do_mfmas();                  // of K-step ks - 1
     if (!(ES_ABLATE & 4) || ks == ks0) {
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
@@ -396,6 +443,9 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
     }
     }
     if (!(ES_ABLATE & 2) && ks + STAGES - 1 < ks1) issue_tile(ks + STAGES - 1, istage);
+#if ES_STAMPS
+    stamp(ks - ks0, 2);
+#endif
     if (!(ES_ABLATE & 4) || ks == ks0) {
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
@@ -419,26 +469,18 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
         ln_sum[jj] = mfma16(ln_ones, f1, ln_sum[jj]);
       }
     }
-#if ES_ABLATE & 1
-#pragma unroll
-    for (int j = 0; j < FM; ++j) { asm volatile("" ::"v"(xa0[j]), "v"(xa1[j])); }
-#pragma unroll
-    for (int i = 0; i < FN; ++i) { asm volatile("" ::"v"(wa0[i]), "v"(wa1[i])); }
-#else
-#pragma unroll
-    for (int i = 0; i < FN; ++i)
-#pragma unroll
-      for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(wa0[i], xa0[j], acc[i][j]);
-#pragma unroll
-    for (int i = 0; i < FN; ++i)
-#pragma unroll
-      for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(wa1[i], xa1[j], acc[i][j]);
-#endif
+    if (!late) do_mfmas();
     }
+#if ES_STAMPS
+    stamp(ks - ks0, 3);
+#endif
     istage = istage + 1 == STAGES ? 0 : istage + 1;
     stage = stage + 1 == STAGES ? 0 : stage + 1;
   }
 
+  if constexpr (FN <= 5 && BKT == 64) {
+    if (late && ks1 > ks0) do_mfmas();                   // the deferred MFMAs of the last K-step
+  }
   // ---------------- split-K: raw fp32 partials (16 B per lane) ----------------
   const int prow = wm * (16 * FM) + frow;                 // + j*16 : pixel row inside the tile
   const int pcol = wn * (BN / 2) + fq * 4;                // + i*16 : cout column inside the tile
@@ -453,7 +495,9 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
           store16(wsp + (size_t)m * p.rows_padded + tile_n * BN + pcol + i * 16, __builtin_bit_cast(u32x4, acc[i][j]));
       }
     }
+#if !ES_STAMPS
     if (p.prof && tid == 0) atomicMax(p.prof + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
     return;
   }
 
@@ -616,7 +660,9 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
       }
     }
   }
+#if !ES_STAMPS
   if (p.prof && tid == 0) atomicMax(p.prof + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 template <typename T>

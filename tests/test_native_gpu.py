@@ -131,3 +131,37 @@ def test_es_denoise_loop_and_vae_decode_equal_the_pipeline_bitwise(built):
     assert psnr(want_img, ref) >= 40.0
     with pytest.raises(L.EdgeStyleHipError):
         eng.denoise_loop(x.clone(), ehs, gs, timesteps=[981.0, 961.0])      # built for T steps
+
+
+@pytest.mark.parametrize("guidance", [True, False])
+def test_native_context_for_a_single_controlnet_and_without_cfg(built, guidance):
+    """es_ctx with n_conds = 1 (BASELINE configs[0]: one plain ControlNetModel) and with CFG off (N = B): loop and decode
+    equal the pipeline bit for bit."""
+    from edgestyle_amd.models import _as_nhwc
+    from edgestyle_amd.pipeline import StableDiffusionControlNetPipeline
+    from edgestyle_amd.native import NativeEngine
+    pipe, _eng, ws, ucfg, vcfg = built
+    pose = pipe.controlnet.nets[1]
+    p1 = StableDiffusionControlNetPipeline(vae=pipe.vae, unet=pipe.unet, controlnet=pose).to(DEV)
+    eng = NativeEngine(p1, batch_size=2, guidance=guidance, num_inference_steps=4)
+    try:
+        g = torch.Generator().manual_seed(5)
+        s, c0 = ucfg.sample_size, ucfg.block_out_channels[0]
+        lat = torch.randn(2, 4, s, s, generator=g)
+        pe = (torch.randn(2, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+        ne = (torch.randn(2, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+        cond = (torch.randn(1, c0, s, s, generator=g) * 0.3).half().float()
+        gs = 6.0 if guidance else 1.0
+        kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne if guidance else None, image=cond, latents=lat,
+                  guidance_scale=gs, num_inference_steps=4, controlnet_conditioning_scale=0.7)
+        want_lat = p1(output_type="latent", **kw).images.clone()
+        want_img = p1(output_type="pt", **kw).images.clone()
+        N = 4 if guidance else 2
+        eng.set_options(cond_scales=[0.7])
+        eng.set_conds([_as_nhwc(cond.repeat(N, 1, 1, 1), torch.float16, DEV)])
+        ehs = (torch.cat([ne, pe]) if guidance else pe).to(DEV, torch.float16).contiguous()
+        got = eng.denoise_loop(lat.permute(0, 2, 3, 1).contiguous().to(DEV), ehs, gs)
+        img = eng.vae_decode(got)
+        assert torch.equal(got.permute(0, 3, 1, 2), want_lat) and torch.equal(img, want_img)
+    finally:
+        eng.close()
