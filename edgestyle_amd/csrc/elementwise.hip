@@ -43,7 +43,11 @@ __global__ void cfg_ddim_kernel(const T* __restrict__ noise, float* __restrict__
   }
   const float x = lat[i];
   const float x0 = (x - c[1] * eps) / c[0];
-  const float xn = c[2] * x0 + c[3] * eps;
+  float xn = c[2] * x0 + c[3] * eps;
+  // the networks' input is the ROUNDED fp32 latent converted once more, exactly what es_latents_to_input derives from the
+  // stored latents: without this barrier hipcc fuses the last multiply-add with the conversion (v_fma_mixlo_f16, one
+  // rounding instead of two) and one value in ~10^4 lands on the neighbouring fp16
+  asm volatile("" : "+v"(xn));
   lat[i] = xn;
   const T xt = from_f32<T>(xn);
   model_in[mi] = xt;
@@ -92,7 +96,8 @@ __global__ void cfg_unipc_kernel(const T* __restrict__ noise, float* __restrict_
   const float x0 = (x - c[1] * eps) / c[0];
   const float m0 = m0b[i], m1 = m1b[i];
   const float xc = c[2] != 0.f ? c[3] * last[i] + c[4] * m0 + c[5] * m1 + c[6] * x0 : x;
-  const float xn = c[7] * xc + c[8] * x0 + c[9] * m0;
+  float xn = c[7] * xc + c[8] * x0 + c[9] * m0;
+  asm volatile("" : "+v"(xn));            // as in cfg_ddim_kernel: model_in == fp16(stored latent), bit for bit
   m1b[i] = m0;
   m0b[i] = x0;
   last[i] = xc;

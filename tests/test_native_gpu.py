@@ -162,6 +162,7 @@ def test_native_context_for_a_single_controlnet_and_without_cfg(built, guidance)
         ehs = (torch.cat([ne, pe]) if guidance else pe).to(DEV, torch.float16).contiguous()
         got = eng.denoise_loop(lat.permute(0, 2, 3, 1).contiguous().to(DEV), ehs, gs)
         img = eng.vae_decode(got)
-        assert torch.equal(got.permute(0, 3, 1, 2), want_lat) and torch.equal(img, want_img)
+        assert torch.equal(got.permute(0, 3, 1, 2), want_lat), float((got.permute(0, 3, 1, 2) - want_lat).abs().max())
+        assert torch.equal(img, want_img), float((img - want_img).abs().max())
     finally:
         eng.close()
