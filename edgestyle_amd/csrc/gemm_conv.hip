@@ -828,7 +828,7 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
 #undef ES_LAUNCH_F
 #undef ES_LAUNCH_K
 #undef ES_LAUNCH_LN
-  if (d.splitk > 1) {
+  if (d.splitk > 1 && !d.no_reduce) {
     const long long total = (long long)M * (d.rows_padded / 8);
     hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, M);
   }
@@ -877,6 +877,8 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
                 (size_t)d->N * d->Hout * d->Wout * (d->Ct1 > d->Ct2 ? d->Ct1 : d->Ct2) * 2 >= 0x7FFFFFFFull)) {
     es_set_error("es_conv_gemm: 1x1 tail sources need stride 1, no upsample, same-size output, 64-aligned channels"); return -1; }
   if (!d->t1 && (d->t2 || d->Ct1 || d->Ct2)) { es_set_error("es_conv_gemm: tail fields set without t1"); return -1; }
+  if (d->no_reduce && (d->splitk <= 1 || d->act != ES_ACT_NONE || d->residual || d->out_scale_dev || d->out_scale != 1.0f)) {
+    es_set_error("es_conv_gemm: no_reduce needs splitk > 1, no activation, no residual, scale 1"); return -1; }
   if (d->x_nmod < 0 || (d->x_nmod && (d->x2 || d->t1 || d->x_nmod > d->N))) { es_set_error("es_conv_gemm: x_nmod needs a single source and 0 < x_nmod <= N"); return -1; }
   if (d->splitk < 1 || d->splitk > d->Kpad / BK) { es_set_error("es_conv_gemm: bad splitk"); return -1; }
   if (d->splitk > 1 && (!d->workspace || d->act == ES_ACT_GEGLU)) { es_set_error("es_conv_gemm: splitk needs workspace and no GEGLU"); return -1; }

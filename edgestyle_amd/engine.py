@@ -116,7 +116,8 @@ class Resnet:
     def __call__(self, x, tproj, x2=None):
         h = ops.group_norm(x, self.n1[0], self.n1[1], self.groups, self.eps, True, x2=x2)
         temb = None if self.temb_off is None else tproj[:, self.temb_off:]
-        h = ops.conv_gemm(h, self.conv1, temb=temb)
+        # a split-K conv1 leaves its partial slabs for norm2 to sum (one-launch GroupNorm geometries only)
+        h = ops.conv_gemm(h, self.conv1, temb=temb, defer_reduce=ops.gn_is_slab(h.shape[1] * h.shape[2], self.cout, self.groups))
         h = ops.group_norm(h, self.n2[0], self.n2[1], self.groups, self.eps, True)
         if self.conv2s is not None and (x2 is None or (x.shape[3] % 64 == 0 and x2.shape[3] % 64 == 0)):
             return ops.conv_gemm(h, self.conv2s, tail=(x, x2))
@@ -513,7 +514,8 @@ class GroupedEncoder:
         c = self.counts
         r0 = rs[0]
         h = ops.group_norm(x, [r.n1[0] for r in rs], [r.n1[1] for r in rs], r0.groups, r0.eps, True, group_n=c)
-        h = ops.conv_gemm(h, [r.conv1 for r in rs], temb=tproj[:, r0.temb_off:], group_n=c)
+        h = ops.conv_gemm(h, [r.conv1 for r in rs], temb=tproj[:, r0.temb_off:], group_n=c,
+                          defer_reduce=ops.gn_is_slab(h.shape[1] * h.shape[2], r0.cout, r0.groups))
         h = ops.group_norm(h, [r.n2[0] for r in rs], [r.n2[1] for r in rs], r0.groups, r0.eps, True, group_n=c)
         if all(r.conv2s is not None for r in rs):
             return ops.conv_gemm(h, [r.conv2s for r in rs], tail=(x,), group_n=c)

@@ -29,7 +29,7 @@ class GemmDesc(C.Structure):
         ("bk", C.c_int32), ("out_scale", C.c_float),
         ("ln_colsum", C.c_void_p), ("ln_colsum_g", C.c_void_p * 4), ("ln_eps", C.c_float),
         ("t1", C.c_void_p), ("t2", C.c_void_p), ("Ct1", C.c_int32), ("Ct2", C.c_int32),
-        ("x_nmod", C.c_int32),
+        ("x_nmod", C.c_int32), ("no_reduce", C.c_int32),
     ]
 
 
@@ -74,6 +74,8 @@ class GnDesc(C.Structure):
         ("N", C.c_int32), ("HW", C.c_int32), ("C1", C.c_int32), ("C2", C.c_int32), ("groups", C.c_int32),
         ("eps", C.c_float), ("silu", C.c_int32), ("dtype", C.c_int32),
         ("ngroups", C.c_int32), ("n_end", C.c_int32 * 4), ("gamma_g", C.c_void_p * 4), ("beta_g", C.c_void_p * 4),
+        ("sk_ws", C.c_void_p), ("sk_bias", C.c_void_p), ("sk_bias_g", C.c_void_p * 4), ("sk_temb", C.c_void_p),
+        ("sk_n", C.c_int32), ("sk_rows", C.c_int32), ("sk_temb_stride", C.c_int32),
     ]
 
 
@@ -111,6 +113,7 @@ SYMBOLS = {
     "es_attention": (C.c_int, [C.POINTER(AttnDesc), _P]),
     "es_group_norm": (C.c_int, [C.POINTER(GnDesc), _P]),
     "es_group_norm_partials_bytes": (C.c_size_t, [_I, _I]),
+    "es_group_norm_is_slab": (C.c_int, [_I, _I, _I]),
     "es_layer_norm": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _I, _P]),
     "es_fusion_block": (C.c_int, [C.POINTER(FusionDesc), _P]),
     "es_fusion_scratch_bytes": (C.c_size_t, [_I]),

@@ -313,6 +313,22 @@ def plan_launch(M: int, pw: "PackedWeight", bn: int):
     return sk, st
 
 
+@dataclass
+class SplitKPartial:
+    """What conv_gemm(..., defer_reduce=True) returns when the launch was split along K: the fp32 partial slabs stay in
+    the split-K workspace and the next op (group_norm) sums them itself - no reduce launch.  Must be consumed before the
+    next split-K launch on the same lane overwrites the workspace."""
+    ws: torch.Tensor
+    splitk: int
+    rows_padded: int
+    bias: object                  # fp32 tensor, list of tensors (grouped launch) or None
+    temb: Optional[torch.Tensor]
+    shape: tuple                  # (N, H, W, C) of the tensor the reduce would have produced
+    dtype: torch.dtype
+    device: torch.device
+
+
+SK_DEFER = _os.environ.get("ES_SK_DEFER", "1") == "1"     # split-K reduce folded into the GroupNorm that follows
 XS_ENABLED = _os.environ.get("ES_XS", "1") == "1"      # row-stationary short-K linear kernel (csrc/linear_xs.hip)
 XS_TARGET_WGS = 256
 XS_MIN_M = int(_os.environ.get("ES_XS_MIN_M", "8192"))   # 0: no size policy (tests exercise every shape)
@@ -400,7 +416,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
               out_scale_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
               out_hw=None, splitk: Optional[int] = None, stages: int = 0,
               group_n: Optional[Sequence[int]] = None, tail: Optional[Sequence[torch.Tensor]] = None,
-              x_rep: int = 1) -> torch.Tensor:
+              x_rep: int = 1, defer_reduce: bool = False):
     """x: [N,H,W,C1] (+ x2 [N,H,W,C2]); returns [N,Hout,Wout,Cout] (Cout/2 for GEGLU).
 
     x_rep > 1: the launch covers x_rep * N samples, sample n reading x[n % N] (es_gemm_desc.x_nmod): one sample tensor
@@ -486,9 +502,12 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         # DMA issue, fragment reads and MFMAs (tools/gemm_tune.py: 3-15 % on every 1x1 shape of a batch-1 step, none on 3x3 or on the
         # memory-bound 1x1 launches of large batches)
         d.waves = 8
+    defer = defer_reduce and SK_DEFER and splitk > 1 and residual is None and act_i == L.ACT_NONE and out_scale == 1.0 \
+        and out_scale_dev is None
     if splitk > 1:
         ws = _get_workspace(splitk * M * pw.rows_padded * 4, x.device)
         d.workspace = ws.data_ptr()
+        d.no_reduce = 1 if defer else 0
     if pw.ln_colsum is not None:
         if (pws is not None and any(q.ln_colsum is None for q in pws)) or x2 is not None or k != 1:
             raise L.EdgeStyleHipError("LayerNorm-folded weights need a plain linear launch (all groups folded)")
@@ -529,6 +548,9 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         dd.prof = None
         PROFILE.descs.append(dd)
     L.check(L.load().es_conv_gemm(C.byref(d), _stream()), "es_conv_gemm")
+    if defer:
+        return SplitKPartial(ws, splitk, pw.rows_padded, [q.bias for q in pws] if pws is not None else pw.bias, temb,
+                             (N, Hout, Wout, cstore), x.dtype, x.device)
     return out
 
 
@@ -588,6 +610,9 @@ def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu: bool
                x2: Optional[torch.Tensor] = None, group_n: Optional[Sequence[int]] = None) -> torch.Tensor:
     """x: [N,H,W,C1] (+x2 [N,H,W,C2]) -> normalised [N,H,W,C1+C2].  gamma/beta may be lists (one per group of
     `group_n` consecutive samples): one launch for several nets' GroupNorms."""
+    part_in = x if isinstance(x, SplitKPartial) else None
+    if part_in is not None and x2 is not None:
+        raise L.EdgeStyleHipError("group_norm: a split-K source cannot be concatenated with a second tensor")
     N, H, W, C1 = x.shape
     C2 = 0 if x2 is None else x2.shape[3]
     out = torch.empty((N, H, W, C1 + C2), dtype=x.dtype, device=x.device)
@@ -597,7 +622,16 @@ def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu: bool
         part = torch.empty(L.load().es_group_norm_partials_bytes(N, groups) // 4, dtype=torch.float32, device=x.device)
         _gn_partials[key] = part
     d = L.GnDesc()
-    d.x, d.x2, d.out = x.data_ptr(), (x2.data_ptr() if x2 is not None else None), out.data_ptr()
+    d.x, d.x2, d.out = (None if part_in is not None else x.data_ptr()), (x2.data_ptr() if x2 is not None else None), out.data_ptr()
+    if part_in is not None:
+        d.sk_ws, d.sk_n, d.sk_rows = part_in.ws.data_ptr(), part_in.splitk, part_in.rows_padded
+        if isinstance(part_in.bias, (list, tuple)):
+            for g, b in enumerate(part_in.bias):
+                d.sk_bias_g[g] = None if b is None else b.data_ptr()
+        elif part_in.bias is not None:
+            d.sk_bias = part_in.bias.data_ptr()
+        if part_in.temb is not None:
+            d.sk_temb, d.sk_temb_stride = part_in.temb.data_ptr(), part_in.temb.stride(0)
     if isinstance(gamma, (list, tuple)) and len(gamma) > 1:
         if len(gamma) > 4 or len(group_n) != len(gamma) or sum(group_n) != N:
             raise L.EdgeStyleHipError("grouped group_norm: bad group table")
@@ -617,6 +651,11 @@ def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu: bool
     d.eps, d.silu, d.dtype = eps, 1 if silu else 0, _dt(x)
     L.check(L.load().es_group_norm(C.byref(d), _stream()), "es_group_norm")
     return out
+
+
+def gn_is_slab(hw: int, c: int, groups: int) -> bool:
+    """True when GroupNorm of this geometry runs as one launch - the form that can read a split-K source."""
+    return bool(L.load().es_group_norm_is_slab(hw, c, groups))
 
 
 def layer_norm(x: torch.Tensor, gamma, beta, eps: float = 1e-5, group_rows: Optional[Sequence[int]] = None) -> torch.Tensor:

@@ -98,6 +98,10 @@ typedef struct {
    * CL:197-203; text states shared by the nets of a weight-sharing group) without a replicated copy.  0 = off.
    * Needs one source (no x2), no tail sources. */
   int32_t x_nmod;
+  /* splitk > 1 only: 1 = leave the fp32 partial slabs in `workspace` and launch no reduce kernel; the consumer sums them
+   * (es_group_norm with sk_ws: the GroupNorm that follows conv1 of a ResnetBlock2D reads the slabs directly - one launch
+   * and one fp16 round trip less).  Needs act NONE, out_scale 1, no residual, no out_scale_dev. */
+  int32_t no_reduce;
 } es_gemm_desc;
 int es_conv_gemm(const es_gemm_desc* d, void* stream);
 size_t es_conv_gemm_workspace_bytes(const es_gemm_desc* d);
@@ -157,9 +161,19 @@ typedef struct {
   int32_t n_end[4];
   const float* gamma_g[4];
   const float* beta_g[4];
+  /* split-K source: x = round_to_dtype( sum_z sk_ws[z][m][c] + sk_bias[c] + sk_temb[n][c] ), m = n*HW + pixel, the
+   * partial slabs of an es_conv_gemm launched with no_reduce (row pitch sk_rows = its rows_padded) - exactly what its
+   * reduce kernel would have stored.  One-launch (slab) form only: es_group_norm_is_slab(HW, C, groups) != 0; C2 = 0;
+   * x may be NULL.  sk_ws NULL: off. */
+  const float* sk_ws;
+  const float* sk_bias;            /* or NULL */
+  const float* sk_bias_g[4];       /* grouped launches: per sample group, like gamma_g */
+  const void* sk_temb;             /* or NULL: dtype [N, sk_temb_stride] */
+  int32_t sk_n, sk_rows, sk_temb_stride;
 } es_gn_desc;
 int es_group_norm(const es_gn_desc* d, void* stream);
 size_t es_group_norm_partials_bytes(int N, int groups);
+int es_group_norm_is_slab(int HW, int C, int groups);   /* 1: this geometry runs as ONE launch (slab form) */
 
 /* LayerNorm over the last dim of [M, C] (BasicTransformerBlock.norm1/2/3), eps 1e-5. */
 int es_layer_norm(const void* x, void* out, const float* gamma, const float* beta, int M, int C, float eps,

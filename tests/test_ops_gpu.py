@@ -780,3 +780,40 @@ def test_linear_xs_row_stationary_kernel(dtype):
     # deterministic: same launch twice, bit for bit
     assert torch.equal(yg, ops.linear(xg.to(DEV, dtype), pws, group_n=counts))
     ops.XS_MIN_M = 8192
+
+
+def test_group_norm_sums_split_k_partials_itself():
+    """conv (split along K, no_reduce) -> GroupNorm reading the fp32 partial slabs == conv + reduce -> GroupNorm, bit for
+    bit (same summation order, same rounding point), single and grouped launches, with and without a time embedding."""
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(123)
+    for dtype in (torch.float16, torch.bfloat16):
+        N, H, Cin, Cout, groups = 6, 8, 256, 320, 32
+        x = torch.randn(N, H, H, Cin, generator=g).to(DEV, dtype)
+        counts = [2, 4]
+        pws = [ops.pack_weight(torch.randn(Cout, Cin, 3, 3, generator=g) / 48, torch.randn(Cout, generator=g) * 0.1, dtype, DEV)
+               for _ in counts]
+        temb = torch.randn(N, Cout + 64, generator=g).to(DEV, dtype)[:, 64:]
+        gam = [(1 + 0.1 * torch.randn(Cout, generator=g)).to(DEV) for _ in counts]
+        bet = [(0.1 * torch.randn(Cout, generator=g)).to(DEV) for _ in counts]
+        assert ops.gn_is_slab(H * H, Cout, groups)
+        for grouped in (False, True):
+            pw = pws if grouped else pws[0]
+            kw = dict(group_n=counts) if grouped else {}
+            ga, be = (gam, bet) if grouped else (gam[0], bet[0])
+            for tb in (None, temb):
+                part = ops.conv_gemm(x, pw, temb=tb, splitk=3, defer_reduce=True, **kw)
+                assert isinstance(part, ops.SplitKPartial) and part.splitk == 3
+                fused = ops.group_norm(part, ga, be, groups, 1e-5, True, **kw)
+                plain = ops.group_norm(ops.conv_gemm(x, pw, temb=tb, splitk=3, **kw), ga, be, groups, 1e-5, True, **kw)
+                assert torch.equal(fused, plain), (dtype, grouped, tb is not None)
+        # no split -> an ordinary tensor comes back and nothing changes
+        y = ops.conv_gemm(x, pws[0], splitk=1, defer_reduce=True)
+        assert torch.is_tensor(y)
+        # the two-launch GroupNorm form cannot read slabs: refused loudly
+        big = torch.randn(1, 64, 64, 64, generator=g).to(DEV, dtype)
+        pwb = ops.pack_weight(torch.randn(320, 64, 3, 3, generator=g) / 24, None, dtype, DEV)
+        assert not ops.gn_is_slab(64 * 64, 320, 32)
+        part = ops.conv_gemm(big, pwb, splitk=2, defer_reduce=True)
+        with pytest.raises(Exception):
+            ops.group_norm(part, gam[0], bet[0], 32, 1e-5, True)
