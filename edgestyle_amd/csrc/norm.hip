@@ -245,7 +245,15 @@ __global__ __launch_bounds__(256) void gn_slab_kernel(const es_gn_desc p, const 
         if (px < p.HW) {
           const float* w = p.sk_ws + ((size_t)n * p.HW + px) * p.sk_rows + c;
           f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-          for (int z = 0; z < p.sk_n; ++z) { s0 += *(const f32x4*)(w + z * zstride); s1 += *(const f32x4*)(w + z * zstride + 4); }
+          int z = 0;
+          for (; z + 4 <= p.sk_n; z += 4) {                  // four slices' loads in flight, summed in slice order
+            f32x4 a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = *(const f32x4*)(w + (z + u) * zstride); b[u] = *(const f32x4*)(w + (z + u) * zstride + 4); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s0 += a[u]; s1 += b[u]; }
+          }
+          for (; z < p.sk_n; ++z) { s0 += *(const f32x4*)(w + z * zstride); s1 += *(const f32x4*)(w + z * zstride + 4); }
           typename Traits<T>::vec8 r8;
 #pragma unroll
           for (int r = 0; r < 4; ++r) { r8[r] = from_f32<T>(s0[r] + bt[r] + tv[r]); r8[4 + r] = from_f32<T>(s1[r] + bt[4 + r] + tv[4 + r]); }

@@ -787,6 +787,7 @@ def test_group_norm_sums_split_k_partials_itself():
     bit (same summation order, same rounding point), single and grouped launches, with and without a time embedding."""
     from edgestyle_amd import ops
     g = torch.Generator().manual_seed(123)
+    ops.SK_DEFER = True               # opt-in feature (ES_SK_DEFER=1)
     for dtype in (torch.float16, torch.bfloat16):
         N, H, Cin, Cout, groups = 6, 8, 256, 320, 32
         x = torch.randn(N, H, H, Cin, generator=g).to(DEV, dtype)
@@ -817,3 +818,4 @@ def test_group_norm_sums_split_k_partials_itself():
         part = ops.conv_gemm(big, pwb, splitk=2, defer_reduce=True)
         with pytest.raises(Exception):
             ops.group_norm(part, gam[0], bet[0], 32, 1e-5, True)
+    ops.SK_DEFER = False
