@@ -131,6 +131,11 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
     if (p.prof && sblk >= 0 && lane == 0 && wave < 4 && ks >= 8 && ks < 16)
       p.prof[((sblk * 4 + wave) * 8 + (ks - 8)) * 4 + what] = __builtin_amdgcn_s_memtime();
   };
+  auto pstamp = [&](int what) __attribute__((always_inline)) {
+    if (p.prof && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
+      p.prof[256 + (blockIdx.x == 0 ? 0 : 1) * 8 + what] = __builtin_amdgcn_s_memtime();
+  };
+  pstamp(0);
 #else
   if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
@@ -304,6 +309,9 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
   for (int s = 0; s < STAGES - 1; ++s)
     if (ks0 + s < ks1) issue_tile(ks0 + s, s);
 
+#if ES_STAMPS
+  pstamp(1);
+#endif
   const int frow = lane & 15, fq = lane >> 4;
   // the epilogue's bias is fetched here, behind the first tile's DMA: loading it after the K loop put one more HBM
   // round trip (~1 us) on the critical path of every launch
@@ -377,6 +385,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
     }
 #if ES_STAMPS
     stamp(ks - ks0, 1);
+    if (ks == ks0) pstamp(2);
 #endif
     const char* xs = smem + stage * (XT + WT);
     const char* ws = xs + XT;
@@ -481,6 +490,9 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
   if constexpr (FN <= 5 && BKT == 64) {
     if (late && ks1 > ks0) do_mfmas();                   // the deferred MFMAs of the last K-step
   }
+#if ES_STAMPS
+  pstamp(3);
+#endif
   // ---------------- split-K: raw fp32 partials (16 B per lane) ----------------
   const int prow = wm * (16 * FM) + frow;                 // + j*16 : pixel row inside the tile
   const int pcol = wn * (BN / 2) + fq * 4;                // + i*16 : cout column inside the tile
@@ -662,6 +674,8 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
   }
 #if !ES_STAMPS
   if (p.prof && tid == 0) atomicMax(p.prof + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#else
+  pstamp(4);
 #endif
 }
 

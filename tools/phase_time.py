@@ -38,6 +38,7 @@ def main():
          num_inference_steps=50, output_type="latent", cond_noise=cn)
     loop = list(pipe._loops.values())[-1]
     r = pipe._runner
+    r.state = loop.state
     x, t_rows, conds = loop.model_in, loop.t_rows, loop.conds
     N = x.shape[0]
     ue = r.unet.engine
@@ -47,11 +48,11 @@ def main():
         net, pos = r.groups[gi]
         eng = net.engine
         tproj = eng.time_proj(t_rows[: len(pos) * N])
-        res[gi] = eng.forward(x, tproj, r.ctx_nets[gi], [conds[p] for p in pos])
+        res[gi] = eng.forward(x, tproj, r.state.ctx_nets[gi], [conds[p] for p in pos])
 
     def unet_enc():
         tproj = ue.time_proj(t_rows[:N])
-        res["u"] = (tproj, ue.encode(x, tproj, r.ctx_unet))
+        res["u"] = (tproj, ue.encode(x, tproj, r.state.ctx_unet))
 
     for gi, (net, pos) in enumerate(r.groups):
         print(f"chain {gi} ({type(net).__name__} x{len(pos)}): {timeit(lambda gi=gi: chain(gi)):.3f} ms", flush=True)
@@ -69,7 +70,7 @@ def main():
 
     def decoder():
         tproj, enc = res["u"]
-        ue.forward(x, tproj, r.ctx_unet, res["f"][:-1], res["f"][-1], encoded=enc)
+        ue.forward(x, tproj, r.state.ctx_unet, res["f"][:-1], res["f"][-1], encoded=enc)
 
     print(f"unet decoder: {timeit(decoder):.3f} ms", flush=True)
     for mode in ("grouped", "streams", "serial"):
