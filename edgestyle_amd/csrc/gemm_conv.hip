@@ -122,8 +122,12 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
     const int nwg = gridDim.x, b = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
     const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);      // bijective for any nwg
-    if (p.xcd_m_fastest) { tile_m = w % tm; const int t = w / tm; tile_n = t % tn; z = t / tn; }
-    else                 { tile_n = w % tn; const int t = w / tn; tile_m = t % tm; z = t / tm; }
+    // (float-reciprocal divisions, exact below 2^24: an integer division is ~35 instructions, and the prologue of every
+    //  workgroup - ~950 instructions, 1.3 us before its first DMA, tools/gemm_phase_stamps.py - is on the critical path of
+    //  the ~100 single-round launches of a batch-1 step)
+    const float inv_tm = __builtin_amdgcn_rcpf((float)tm), inv_tn = __builtin_amdgcn_rcpf((float)tn);
+    if (p.xcd_m_fastest) { const int t = fast_div(w, tm, inv_tm); tile_m = w - t * tm; z = fast_div(t, tn, inv_tn); tile_n = t - z * tn; }
+    else                 { const int t = fast_div(w, tn, inv_tn); tile_n = w - t * tn; z = fast_div(t, tm, inv_tm); tile_m = t - z * tm; }
   }
 #if ES_STAMPS
   const int sblk = blockIdx.x == 40 ? 0 : (blockIdx.x == 333 ? 1 : -1);
@@ -140,8 +144,12 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
   if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
 
-  const int ks0 = (int)(((long long)nk * z) / p.splitk);
-  const int ks1 = (int)(((long long)nk * (z + 1)) / p.splitk);
+  int ks0 = 0, ks1 = nk;
+  if (p.splitk > 1) {                                   // nk * (z + 1) <= 360 * 32: exact in the float-reciprocal form
+    const float inv_sk = __builtin_amdgcn_rcpf((float)p.splitk);
+    ks0 = fast_div(nk * z, p.splitk, inv_sk);
+    ks1 = fast_div(nk * (z + 1), p.splitk, inv_sk);
+  }
 
   // ---------------- loader state ----------------
   const int lrow = lane / CPR;                     // row inside an RPP-row DMA piece
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
   // convs use a float reciprocal + one correction step, exact below 2^24)
   int iy0[XI], ix0[XI], nb[XI];
   const bool small_m = M < (1 << 24);
-  const float inv_hw = 1.0f / (float)HWout, inv_w = 1.0f / (float)p.Wout;
+  const float inv_hw = __builtin_amdgcn_rcpf((float)HWout), inv_w = __builtin_amdgcn_rcpf((float)p.Wout);
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
     const int m = tile_m * BM + RPP * (wave * XI + i) + lrow;
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
   int tap, cpos;
   {
     const int kg = ks0 * BKT + (ALIGNED ? 0 : kc * 8);
-    tap = kg / Ctot;
+    tap = kg == 0 ? 0 : fast_div(kg, Ctot, __builtin_amdgcn_rcpf((float)Ctot));      // kg < Kpad < 2^24
     cpos = kg - tap * Ctot;
     if (ALIGNED && tap >= KK) { tap = KK; cpos = kg - KK * Ctot; }      // a split-K slice that starts inside the tail
   }
@@ -529,11 +537,12 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
   if constexpr (RPF > 0) {
     if (resp && vec_store) {
       const int CH = (geglu ? BN / 2 : BN) / 8;
+      const float inv_ch = __builtin_amdgcn_rcpf((float)CH);
       const int c_tile = tile_n * (geglu ? BN / 2 : BN);
 #pragma unroll
       for (int k = 0; k < RPF; ++k) {
         const int idx = tid + k * NT;
-        const int row = idx / CH, ch = idx - row * CH;
+        const int row = fast_div(idx, CH, inv_ch), ch = idx - row * CH;
         const int m = tile_m * BM + row, c = c_tile + ch * 8;
         rpre[k] = u32x4{0u, 0u, 0u, 0u};
         if (idx < BM * CH && m < M && c < Cstore) rpre[k] = *(const u32x4*)(resp + (size_t)m * Cstore + c);
@@ -571,7 +580,8 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
 #pragma unroll
       for (int j = 0; j < FM; ++j) {
         const int m = tile_m * BM + prow + j * 16;
-        const int n = (m < M ? m : M - 1) / HWout;
+        const int mc = m < M ? m : M - 1;
+        const int n = small_m ? fast_div(mc, HWout, inv_hw) : mc / HWout;
         float ln_mean = 0.f, ln_rstd = 1.f;
         if constexpr (LN) { ln_mean = rowstat[(prow + j * 16) * 2]; ln_rstd = rowstat[(prow + j * 16) * 2 + 1]; }
         if (geglu) {
@@ -628,11 +638,12 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
     const int c_tile = tile_n * (geglu ? BN / 2 : BN) + pass * BNP;
     if (vec_store) {
       const int CH = BNo / 8;
+      const float inv_ch = __builtin_amdgcn_rcpf((float)CH);
       if constexpr (RPF > 0) {
 #pragma unroll
         for (int k = 0; k < RPF; ++k) {
           const int idx = tid + k * NT;
-          const int row = idx / CH, ch = idx - row * CH;
+          const int row = fast_div(idx, CH, inv_ch), ch = idx - row * CH;
           const int m = tile_m * BM + row, c = c_tile + ch * 8;
           if (idx < BM * CH && m < M && c < Cstore) {
             auto v = as_vec8<T>(*(const u32x4*)(et + row * EROW + ch * 16));
@@ -646,7 +657,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
         }
       } else {
         for (int idx = tid; idx < BM * CH; idx += NT) {
-          const int row = idx / CH, ch = idx - row * CH;
+          const int row = fast_div(idx, CH, inv_ch), ch = idx - row * CH;
           const int m = tile_m * BM + row, c = c_tile + ch * 8;
           if (m < M && c < Cstore) {
             auto v = as_vec8<T>(*(const u32x4*)(et + row * EROW + ch * 16));
@@ -661,8 +672,9 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
       }
     } else {
       // narrow outputs (conv_out: 4 or 3 channels): scalar tail path
+      const float inv_bno = __builtin_amdgcn_rcpf((float)BNo);
       for (int idx = tid; idx < BM * BNo; idx += NT) {
-        const int row = idx / BNo, cc = idx - row * BNo;
+        const int row = fast_div(idx, BNo, inv_bno), cc = idx - row * BNo;
         const int m = tile_m * BM + row, c = c_tile + cc;
         if (m < M && c < Cstore) {
           float x = to_f32(*(const T*)(et + row * EROW + cc * 2));
