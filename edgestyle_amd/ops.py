@@ -334,6 +334,10 @@ class SplitKPartial:
 SK_DEFER = _os.environ.get("ES_SK_DEFER", "0") == "1"
 XS_ENABLED = _os.environ.get("ES_XS", "1") == "1"      # row-stationary short-K linear kernel (csrc/linear_xs.hip)
 XS_TARGET_WGS = 256
+# "1": every linear_xs launch on 32x32x16 MFMAs, "geglu": the GEGLU ones, "0" (default): none.  Built on the expectation that
+# a 32x32x16 MFMA stream leaves the partner wave's epilogue more vector-issue slots; measured 5-9 % SLOWER on every shape
+# (tools/xs_bench.py: level-0 GEGLU 149 vs 137 us, to_q|k|v 60 vs 54 us) - kept selectable, tested, not used
+XS_MFMA32 = _os.environ.get("ES_XS_MFMA32", "0")
 XS_MIN_M = int(_os.environ.get("ES_XS_MIN_M", "8192"))   # 0: no size policy (tests exercise every shape)
 _zero_bias = {}
 
@@ -389,6 +393,7 @@ def linear_xs(x: torch.Tensor, pw, M: int, out: torch.Tensor, group_rows=None) -
     d.ldo = out.shape[-1]
     d.geglu, d.ln, d.ln_eps = int(pw.geglu), int(pw.ln_colsum is not None), pw.ln_eps
     d.nslices, d.chunks_per_slice, d.dtype = nslices, lps * pline, _dt(x)
+    d.mfma32 = 1 if (XS_MFMA32 == "1" or (XS_MFMA32 == "geglu" and pw.geglu)) else 0
     if pws is not None:
         d.ngroups = len(pws)
         acc = 0

@@ -131,6 +131,8 @@ typedef struct {
   float ln_eps;
   int32_t nslices, chunks_per_slice;
   int32_t dtype;
+  int32_t mfma32;             /* 1: 32x32x16 MFMAs (leaves the partner wave 75 % of the SIMD's vector issue: the GEGLU
+                               * launches are bound by it), 0: 16x16x32 */
 } es_xs_desc;
 int es_linear_xs(const es_xs_desc* d, void* stream);
 

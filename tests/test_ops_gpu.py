@@ -756,14 +756,19 @@ def test_linear_xs_row_stationary_kernel(dtype):
             pw = ops.pack_weight(w, b, dtype, DEV, geglu=geglu)
         xd = x.to(DEV, dtype)
         assert ops.xs_eligible(M, pw, None, None, 1)
-        got = ops.linear(xd, pw)
         ops.XS_ENABLED = False
         try:
             tiled = ops.linear(xd, pw)
         finally:
             ops.XS_ENABLED = True
-        assert rel_err(got, y) < tol, (M, C, Cout, geglu, ln, rel_err(got, y))
-        assert rel_err(got, tiled) < tol, (M, C, Cout, geglu, ln)
+        for m32 in ("0", "1"):                            # 16x16x32 and 32x32x16 MFMA forms of the kernel
+            ops.XS_MFMA32 = m32
+            try:
+                got = ops.linear(xd, pw)
+            finally:
+                ops.XS_MFMA32 = "0"
+            assert rel_err(got, y) < tol, (M, C, Cout, geglu, ln, m32, rel_err(got, y))
+            assert rel_err(got, tiled) < tol, (M, C, Cout, geglu, ln, m32)
     # grouped: four weight sets over [2, 6, 4, 2] x 256 rows (the lockstep encoder's group table), GEGLU
     C, Cout, counts = 320, 2560, [512, 1536, 1024, 512]
     xg = q16(torch.randn(sum(counts), C, generator=g) * 2 + 0.3, dtype)
@@ -775,8 +780,13 @@ def test_linear_xs_row_stationary_kernel(dtype):
         hh, gate = F.linear(F.layer_norm(xg[a:a + n], (C,), gamma, beta, 1e-5), w, b).chunk(2, dim=-1)
         refs.append(hh * F.gelu(gate))
         a += n
-    yg = ops.linear(xg.to(DEV, dtype), pws, group_n=counts)
-    assert rel_err(yg, torch.cat(refs)) < tol
+    for m32 in ("0", "1"):
+        ops.XS_MFMA32 = m32
+        try:
+            yg = ops.linear(xg.to(DEV, dtype), pws, group_n=counts)
+        finally:
+            ops.XS_MFMA32 = "0"
+        assert rel_err(yg, torch.cat(refs)) < tol, m32
     # deterministic: same launch twice, bit for bit
     assert torch.equal(yg, ops.linear(xg.to(DEV, dtype), pws, group_n=counts))
     ops.XS_MIN_M = 8192
