@@ -118,11 +118,26 @@ struct es_ctx {
   int use_graphs = 1;
   hipStream_t cap_stream = nullptr; // plans are captured into graphs on a stream of the context's own (the caller's may
                                     // be the legacy default stream, which cannot capture); the graphs launch on the caller's
-  std::vector<float> host;          // staging for the per-call tables
+  float* host = nullptr;            // PINNED staging for the per-call tables (hipHostMalloc): the H2D copies are truly
+  size_t host_cap = 0;              // asynchronous, so the buffer is only rewritten after `staged` - recorded behind the
+  hipEvent_t staged = nullptr;      // previous call's copies - has completed
   std::vector<float> alphas_cumprod;   // the scheduler's schedule (es_ctx_set_alphas_cumprod; SD1.5 default otherwise)
 };
 
 namespace {
+// pinned staging of at least n floats whose previous contents the device no longer reads
+float* staging(es_ctx* c, size_t n) {
+  if (c->staged && hipEventSynchronize(c->staged) != hipSuccess) return nullptr;
+  if (n > c->host_cap) {
+    if (c->host) (void)hipHostFree(c->host);
+    c->host = nullptr;
+    c->host_cap = 0;
+    if (hipHostMalloc((void**)&c->host, n * sizeof(float), hipHostMallocDefault) != hipSuccess) return nullptr;
+    c->host_cap = n;
+  }
+  if (!c->staged && hipEventCreateWithFlags(&c->staged, hipEventDisableTiming) != hipSuccess) return nullptr;
+  return c->host;
+}
 int need(const es_ctx* c, int slot, const char* what) {
   if (!c->buf[slot]) { es_set_error(what); return -1; }
   return 0;
@@ -214,6 +229,8 @@ extern "C" void es_ctx_destroy(es_ctx* c) {
     if (c->plan[i]) es_plan_destroy(c->plan[i]);
   }
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
+  if (c->staged) { (void)hipEventSynchronize(c->staged); (void)hipEventDestroy(c->staged); }
+  if (c->host) (void)hipHostFree(c->host);
   delete c;
 }
 extern "C" int es_ctx_set_geometry(es_ctx* c, const es_ctx_geometry* g) {
@@ -282,9 +299,11 @@ extern "C" int es_denoise_step(es_ctx* c, const void* sample, float t, const voi
     if ((rc = d2d(c->buf[ES_BUF_COND0 + i], cond_embeds[i], c->bytes[ES_BUF_COND0 + i], st))) return rc;
   }
   if (hipMemsetD32Async((hipDeviceptr_t)c->buf[ES_BUF_T_ROWS], __builtin_bit_cast(int, t), c->bytes[ES_BUF_T_ROWS] / 4, st) != hipSuccess) { es_set_error("es_denoise_step: fill failed"); return -2; }
-  c->host.resize(8);
-  for (int i = 0; i < 6; ++i) c->host[i] = scales ? scales[i] : 1.f;
-  if ((rc = h2d(c->buf[ES_BUF_SCALES], c->host.data(), (size_t)c->g.n_conds * 4, st))) return rc;
+  float* hs = staging(c, 8);
+  if (!hs) { es_set_error("es_denoise_step: pinned staging allocation failed"); return -2; }
+  for (int i = 0; i < 6; ++i) hs[i] = scales ? scales[i] : 1.f;
+  if ((rc = h2d(c->buf[ES_BUF_SCALES], hs, (size_t)c->g.n_conds * 4, st))) return rc;
+  (void)hipEventRecord(c->staged, st);
   if ((rc = run(c, ES_PLAN_STEP_GENERIC, st, nullptr))) return rc;
   return d2d(out_noise, c->buf[ES_BUF_NOISE], c->bytes[ES_BUF_NOISE], st);
 }
@@ -301,8 +320,8 @@ extern "C" int es_denoise_loop(es_ctx* c, float* latents_inout, const void* ehs,
   const es_ctx_geometry& g = c->g;
   const int T = n_steps, nc = g.n_conds;
   const size_t trow = c->bytes[ES_BUF_T_TABLE] / 4 / T;          // kmax * N timestep copies per step
-  c->host.resize((size_t)T * (trow + nc + 4 + 1));
-  float* tt = c->host.data();
+  float* tt = staging(c, (size_t)T * (trow + nc + 4 + 1));
+  if (!tt) { es_set_error("es_denoise_loop: pinned staging allocation failed"); return -2; }
   float* sc = tt + (size_t)T * trow;
   float* cf = sc + (size_t)T * nc;
   float* tsd = cf + (size_t)T * 4;
@@ -318,6 +337,7 @@ extern "C" int es_denoise_loop(es_ctx* c, float* latents_inout, const void* ehs,
   if ((rc = h2d(c->buf[ES_BUF_SCALE_TABLE], sc, (size_t)T * nc * 4, st))) return rc;
   if ((rc = h2d(c->buf[ES_BUF_COEF], cf, (size_t)T * 16, st))) return rc;
   if ((rc = h2d(c->buf[ES_BUF_TIMESTEPS], tsd, (size_t)T * 4, st))) return rc;
+  (void)hipEventRecord(c->staged, st);
   if (hipMemsetAsync(c->buf[ES_BUF_STEP_IDX], 0, 4, st) != hipSuccess) { es_set_error("es_denoise_loop: memset failed"); return -2; }
   if ((rc = d2d(c->buf[ES_BUF_LATENTS], latents_inout, c->bytes[ES_BUF_LATENTS], st))) return rc;
   if ((rc = d2d(c->buf[ES_BUF_EHS], ehs, c->bytes[ES_BUF_EHS], st))) return rc;
