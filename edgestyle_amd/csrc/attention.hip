@@ -327,6 +327,32 @@ __global__ __launch_bounds__(256, (QF == 1 && KS <= 3) ? 3 : ((KS <= 5 && QF <= 
 // queries 0..15 in all four lane groups, Y queries 16..31).  k index 8g+j of that operand is key
 // 16(g&1) + 4(g>>1) + 8(j>>2) + (j&3) of the tile; the V^T fragments are read with the same map.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Tool-only builds (tools/attn_ablate.sh).  ATTN_ABLATE: time attention32_kernel with one ingredient removed (results wrong by
+// construction): 1 = no v_exp, 2 = no PV MFMAs, 4 = no QK^T MFMAs, 8 = no row max.  The product library has ATTN_ABLATE == 0.
+#ifndef ATTN_ABLATE
+#define ATTN_ABLATE 0
+#endif
+// ATTN_PRIO: static s_setprio from the wave's hardware slot on its SIMD (HW_ID.WAVE_ID): co-resident waves of different
+// workgroups run the same program; at equal priority they share the matrix pipe and the vector issue evenly, stay in phase
+// and the SIMD does MFMA phases and softmax phases one after the other.  0 = off, 1 = slot & 1, 2 = slot & 3.
+#ifndef ATTN_PRIO
+#define ATTN_PRIO 0
+#endif
+ES_DEVICE void attn_static_prio() {
+#if ATTN_PRIO
+  const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4);     // HW_REG_HW_ID[3:0] = wave slot on the SIMD
+#if ATTN_PRIO == 1
+  if (slot & 1) __builtin_amdgcn_s_setprio(1);
+#else
+  switch (slot & 3) {
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    case 3: __builtin_amdgcn_s_setprio(3); break;
+    default: break;
+  }
+#endif
+#endif
+}
 ES_DEVICE f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 ES_DEVICE f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
@@ -358,6 +384,7 @@ __global__ __launch_bounds__(256, 2) void attention32_kernel(const es_attn_desc 
   const int q0 = blockIdx.x * 128 + wave * 32;
   const int d = p.d;
   const int dch = d / 8;
+  attn_static_prio();
 
   const T* Q = (const T*)p.q + (size_t)n * p.bsq + (size_t)h * d;
   const T* K = (const T*)p.k + (size_t)n * p.bsk + (size_t)h * d;
@@ -461,7 +488,12 @@ __global__ __launch_bounds__(256, 2) void attention32_kernel(const es_attn_desc 
 #pragma unroll
       for (int ksx = 0; ksx < KS; ++ksx) {
         const auto ka = as_vec8<T>(*(const u32x4*)(kb + (t * 32 + n32) * KROW + (2 * ksx + hi) * 16));
+#if ATTN_ABLATE & 4
+        if (ksx == 0) s[t] = negm;
+        asm volatile("" : "+v"(s[t]) : "v"(ka), "v"(qf[ksx]));
+#else
         s[t] = mfma32(ka, qf[ksx], ksx == 0 ? negm : s[t]);
+#endif
       }
     if (__builtin_expect(kv0 + KVT > p.Skv, 0)) {
 #pragma unroll
@@ -471,11 +503,13 @@ __global__ __launch_bounds__(256, 2) void attention32_kernel(const es_attn_desc 
           s[t][r] = (kv0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.Skv) ? -3.0e38f : s[t][r];
     }
     float mx = s[0][0];
+#if !(ATTN_ABLATE & 8)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[t][r]), s[t][r + 1]);
     mx = xor32_max(mx);
+#endif
     if (kv0 == 0 || !__all(mx <= LAZY)) {
       const float dlt = kv0 == 0 ? mx : fmaxf(mx, 0.f);
       const float nm = negm[0] - dlt;
@@ -498,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void attention32_kernel(const es_attn_desc 
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[t][r] = __builtin_amdgcn_exp2f(s[t][r]);
+      for (int r = 0; r < 16; ++r) s[t][r] = (ATTN_ABLATE & 1) ? s[t][r] : __builtin_amdgcn_exp2f(s[t][r]);
     if constexpr (!ONES) {
       float rs = 0.f;
 #pragma unroll
@@ -531,8 +565,12 @@ __global__ __launch_bounds__(256, 2) void attention32_kernel(const es_attn_desc 
         const u32x2 lo = lds_read_tr16(base);
         const u32x2 hi2 = lds_read_tr16(base + 8 * VROW);
         const auto va = as_vec8<T>(u32x4{lo[0], lo[1], hi2[0], hi2[1]});
+#if ATTN_ABLATE & 2
+        asm volatile("" : "+v"(o[0][j]), "+v"(o[1][j]) : "v"(va), "v"(pb[0][t]), "v"(pb[1][t]));
+#else
         o[0][j] = mfma16(va, pb[0][t], o[0][j]);
         o[1][j] = mfma16(va, pb[1][t], o[1][j]);
+#endif
       }
     if (kv0 + KVT < p.Skv) {
       store_kv(buf ^ 1);

@@ -174,7 +174,10 @@ def test_full_width_step_768_bf16_config4(full):
     from oracle import sd15_oracle as O
     from edgestyle_amd.models import StepRunner
     ucfg = dataclasses.replace(full["ucfg"], sample_size=96)
-    ws = {k: H.quantize(v, torch.bfloat16) for k, v in full["ws"].items() if k != "vae"}
+    from edgestyle_amd import weights as W
+    ws = {k: H.quantize(v, torch.bfloat16) for k, v in full["ws"].items() if k not in ("vae", "fusion")}
+    # the fusion blocks' LayerNorm parameters are [3C, h, w] (MC:14-16): they exist per latent size
+    ws["fusion"] = H.quantize(W.random_state_dict(W.fusion_shapes(ucfg), 0, "fusion."), torch.bfloat16)
     g = torch.Generator().manual_seed(45)
     N, s, c0 = 2, 96, ucfg.block_out_channels[0]
     x = torch.randn(N, 4, s, s, generator=g).bfloat16().float()

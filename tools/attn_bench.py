@@ -17,7 +17,9 @@ def main():
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
     print("N heads Sq Skv d | us  TFLOP/s(unpadded)")
-    for N, h, Sq, Skv, d in SHAPES:
+    pick = os.environ.get("ATTN_BENCH_SHAPES")
+    shapes = SHAPES if not pick else [SHAPES[int(i)] for i in pick.split(",")]
+    for N, h, Sq, Skv, d in shapes:
         C = h * d
         qkv = torch.randn(N, Sq, 3 * C, generator=g, device=dev).half()
         kv = torch.randn(N, Skv, 2 * C, generator=g, device=dev).half()
