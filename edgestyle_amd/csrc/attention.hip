@@ -334,12 +334,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 // ATTN_PRIO: static s_setprio from the wave's hardware slot on its SIMD (HW_ID.WAVE_ID): co-resident waves of different
 // workgroups run the same program; at equal priority they share the matrix pipe and the vector issue evenly, stay in phase
-// and the SIMD does MFMA phases and softmax phases one after the other.  0 = off, 1 = slot & 1, 2 = slot & 3.
+// and the SIMD does MFMA phases and softmax phases one after the other.  0 = off, 1 = slot & 1, 2 = slot & 3,
+// 3 = by phase: priority 1 while a wave issues its MFMA clusters (8 issue cycles per 16-32 cycles of matrix pipe), 0 in its softmax.
 #ifndef ATTN_PRIO
-#define ATTN_PRIO 0
+#define ATTN_PRIO 3
 #endif
 ES_DEVICE void attn_static_prio() {
-#if ATTN_PRIO
+#if ATTN_PRIO == 1 || ATTN_PRIO == 2
   const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4);     // HW_REG_HW_ID[3:0] = wave slot on the SIMD
 #if ATTN_PRIO == 1
   if (slot & 1) __builtin_amdgcn_s_setprio(1);
@@ -363,7 +364,8 @@ template <typename T> ES_DEVICE unsigned pack2(float a, float b) {
   return __builtin_bit_cast(unsigned, r);
 }
 
-template <typename T, int KS /* QK k-steps of 16: DPAD = 16*KS */, int DF /* dv fragments of 16 */, bool ONES>
+template <typename T, int KS /* QK k-steps of 16: DPAD = 16*KS */, int DF /* dv fragments of 16 */, bool ONES,
+          int QB = 1 /* 32-query blocks per wave: every K / V fragment read from LDS serves all of them */>
 __global__ __launch_bounds__(256, 2) void attention32_kernel(const es_attn_desc p) {
   constexpr int KVT = 64;
   constexpr int DPAD = 16 * KS;
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void attention32_kernel(const es_attn_desc 
   const int n32 = lane & 31, hi = lane >> 5;      // 32x32 layouts: query column / key half
   const int col = lane & 15, g = lane >> 4;       // 16x16 layouts (PV product, epilogue)
   const int h = blockIdx.y, n = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB);
   const int d = p.d;
   const int dch = d / 8;
   attn_static_prio();
@@ -393,9 +395,10 @@ __global__ __launch_bounds__(256, 2) void attention32_kernel(const es_attn_desc 
 
   const float sl2 = p.scale * 1.4426950408889634f;
   // Q^T fragments (B operand of 32x32x16): lane holds Q[query = n32][16*ks + 8*hi .. +7], pre-scaled by scale*log2(e)
-  typename Traits<T>::vec8 qf[KS];
-  {
-    int qi = q0 + n32;
+  typename Traits<T>::vec8 qf[QB][KS];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    int qi = q0 + qb * 32 + n32;
     qi = qi < p.Sq ? qi : p.Sq - 1;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -405,14 +408,18 @@ __global__ __launch_bounds__(256, 2) void attention32_kernel(const es_attn_desc 
       auto qv = as_vec8<T>(v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) qv[e] = from_f32<T>(to_f32(qv[e]) * sl2);
-      qf[s] = qv;
+      qf[qb][s] = qv;
     }
   }
 
   for (int b = 0; b < 2; ++b) {
     for (int i = tid; i < KVT * KCH; i += 256) {
       const int r = i / KCH, c = i - r * KCH;
-      if (c >= dch) *(u32x4*)(ks_ + b * TILE_BYTES + r * KROW + c * 16) = u32x4{0u, 0u, 0u, 0u};
+      // ONES (head_dim % 16 == 8): element d of every K row is 1.0 and element d of the lane's Q row holds the negated
+      // running reference, so S^T = K Q^T leaves the matrix core with the reference already subtracted and the MFMA
+      // chains start from the inline constant 0 - no 16-register splat of the reference to copy into each chain
+      const unsigned kone = (ONES && c == dch) ? (Traits<T>::is_bf16 ? 0x3F80u : 0x3C00u) : 0u;
+      if (c >= dch) *(u32x4*)(ks_ + b * TILE_BYTES + r * KROW + c * 16) = u32x4{kone, 0u, 0u, 0u};
     }
     for (int i = tid; i < KVT * VCH; i += 256) {
       const int r = i / VCH, c = i - r * VCH;
@@ -461,15 +468,20 @@ __global__ __launch_bounds__(256, 2) void attention32_kernel(const es_attn_desc 
   };
 
   constexpr float LAZY = 8.0f;
-  f32x4 o[2][DF];                 // O^T of the two 16-query halves, 16x16 layout
-  f32x16 negm;                    // negated running reference of this lane's query, splatted: the S^T chains start from it
-  float lrun = 0.f;
+  f32x4 o[QB][2][DF];             // O^T of the two 16-query halves of each block, 16x16 layout
+  f32x16 negm[QB];                // !ONES: negated running reference of this lane's query, splatted: the S^T chains start from it
+  float negm_f[QB];               // ONES: the same reference as a scalar (it lives in the pad element of the Q operand)
+  float lrun[QB];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+  for (int qb = 0; qb < QB; ++qb) {
+    negm_f[qb] = 0.f; lrun[qb] = 0.f;
 #pragma unroll
-  for (int f = 0; f < 2; ++f)
+    for (int r = 0; r < 16; ++r) negm[qb][r] = 0.f;
 #pragma unroll
-    for (int j = 0; j < DF; ++j) o[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int j = 0; j < DF; ++j) o[qb][f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   load_kv();
   store_kv(0);
   if (KVT < p.Skv) load_kv();
@@ -482,81 +494,116 @@ __global__ __launch_bounds__(256, 2) void attention32_kernel(const es_attn_desc 
     const char* kb = ks_ + buf * TILE_BYTES;
     const char* vb = vs_ + buf * TILE_BYTES;
 
-    f32x16 s[2];
+    f32x16 s[QB][2];
+#if ATTN_PRIO == 3
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int ksx = 0; ksx < KS; ++ksx) {
         const auto ka = as_vec8<T>(*(const u32x4*)(kb + (t * 32 + n32) * KROW + (2 * ksx + hi) * 16));
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
 #if ATTN_ABLATE & 4
-        if (ksx == 0) s[t] = negm;
-        asm volatile("" : "+v"(s[t]) : "v"(ka), "v"(qf[ksx]));
+          if (ksx == 0) s[qb][t] = negm[qb];
+          asm volatile("" : "+v"(s[qb][t]) : "v"(ka), "v"(qf[qb][ksx]));
 #else
-        s[t] = mfma32(ka, qf[ksx], ksx == 0 ? negm : s[t]);
+          s[qb][t] = mfma32(ka, qf[qb][ksx], ksx == 0 ? (ONES ? f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f} : negm[qb]) : s[qb][t]);
 #endif
+        }
       }
+#if ATTN_PRIO == 3
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (__builtin_expect(kv0 + KVT > p.Skv, 0)) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          s[t][r] = (kv0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.Skv) ? -3.0e38f : s[t][r];
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            s[qb][t][r] = (kv0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.Skv) ? -3.0e38f : s[qb][t][r];
     }
-    float mx = s[0][0];
+    float mx[QB];
+    bool calm = true;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      mx[qb] = s[qb][0][0];
 #if !(ATTN_ABLATE & 8)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[t][r]), s[t][r + 1]);
-    mx = xor32_max(mx);
+        for (int r = 0; r < 16; r += 2) mx[qb] = fmaxf(fmaxf(mx[qb], s[qb][t][r]), s[qb][t][r + 1]);
+      mx[qb] = xor32_max(mx[qb]);
 #endif
-    if (kv0 == 0 || !__all(mx <= LAZY)) {
-      const float dlt = kv0 == 0 ? mx : fmaxf(mx, 0.f);
-      const float nm = negm[0] - dlt;
+      calm = calm && mx[qb] <= LAZY;
+    }
+    if (kv0 == 0 || !__all(calm)) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) negm[r] = nm;
+      for (int qb = 0; qb < QB; ++qb) {
+        float dlt = kv0 == 0 ? mx[qb] : fmaxf(mx[qb], 0.f);
+        if constexpr (ONES) {
+          // the reference must be a value of T (it is an element of the Q operand); what the scores and O are rescaled
+          // by is the step it actually made.  Any reference is exact - O / l does not depend on it.
+          const T nmt = from_f32<T>(negm_f[qb] - dlt);
+          dlt = negm_f[qb] - to_f32(nmt);
+          negm_f[qb] = to_f32(nmt);
+          if (hi) qf[qb][KS - 1][0] = nmt;
+        } else {
+          const float nm = negm[qb][0] - dlt;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) negm[qb][r] = nm;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[qb][t][r] -= dlt;
+        if (kv0 != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(-dlt);
+          lrun[qb] *= alpha;
+          // alpha lives on the 32-query layout (query = lane & 31); O^T on the 16x16 one (query = 16 f + (lane & 15))
+          float a0 = alpha, a1 = alpha;
+          asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a0), "+v"(a1));
+#pragma unroll
+          for (int j = 0; j < DF; ++j) { o[qb][0][j] *= a0; o[qb][1][j] *= a1; }
+        }
+      }
+    }
+    typename Traits<T>::vec8 pb[QB][2][2];     // [block][query half][tile]
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[t][r] -= dlt;
-      if (kv0 != 0) {
-        const float alpha = __builtin_amdgcn_exp2f(-dlt);
-        lrun *= alpha;
-        // alpha lives on the 32-query layout (query = lane & 31); O^T on the 16x16 one (query = 16 f + (lane & 15))
-        float a0 = alpha, a1 = alpha;
-        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a0), "+v"(a1));
+        for (int r = 0; r < 16; ++r) s[qb][t][r] = (ATTN_ABLATE & 1) ? s[qb][t][r] : __builtin_amdgcn_exp2f(s[qb][t][r]);
+      if constexpr (!ONES) {
+        float rs = 0.f;
 #pragma unroll
-        for (int j = 0; j < DF; ++j) { o[0][j] *= a0; o[1][j] *= a1; }
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rs += s[qb][t][r];
+        lrun[qb] += rs;
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        unsigned x[4], y[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          x[i] = pack2<T>(s[qb][t][2 * i], s[qb][t][2 * i + 1]);
+          y[i] = pack2<T>(s[qb][t][8 + 2 * i], s[qb][t][9 + 2 * i]);
+        }
+        asm volatile("s_nop 1\n\t"
+                     "v_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
+                     "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 1"
+                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+        pb[qb][0][t] = as_vec8<T>(u32x4{x[0], x[1], x[2], x[3]});
+        pb[qb][1][t] = as_vec8<T>(u32x4{y[0], y[1], y[2], y[3]});
       }
     }
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[t][r] = (ATTN_ABLATE & 1) ? s[t][r] : __builtin_amdgcn_exp2f(s[t][r]);
-    if constexpr (!ONES) {
-      float rs = 0.f;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rs += s[t][r];
-      lrun += rs;
-    }
-    typename Traits<T>::vec8 pb[2][2];     // [query half][tile]
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      unsigned x[4], y[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        x[i] = pack2<T>(s[t][2 * i], s[t][2 * i + 1]);
-        y[i] = pack2<T>(s[t][8 + 2 * i], s[t][9 + 2 * i]);
-      }
-      asm volatile("s_nop 1\n\t"
-                   "v_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
-                   "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 1"
-                   : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
-      pb[0][t] = as_vec8<T>(u32x4{x[0], x[1], x[2], x[3]});
-      pb[1][t] = as_vec8<T>(u32x4{y[0], y[1], y[2], y[3]});
-    }
+#if ATTN_PRIO == 3
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -565,13 +612,19 @@ __global__ __launch_bounds__(256, 2) void attention32_kernel(const es_attn_desc 
         const u32x2 lo = lds_read_tr16(base);
         const u32x2 hi2 = lds_read_tr16(base + 8 * VROW);
         const auto va = as_vec8<T>(u32x4{lo[0], lo[1], hi2[0], hi2[1]});
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
 #if ATTN_ABLATE & 2
-        asm volatile("" : "+v"(o[0][j]), "+v"(o[1][j]) : "v"(va), "v"(pb[0][t]), "v"(pb[1][t]));
+          asm volatile("" : "+v"(o[qb][0][j]), "+v"(o[qb][1][j]) : "v"(va), "v"(pb[qb][0][t]), "v"(pb[qb][1][t]));
 #else
-        o[0][j] = mfma16(va, pb[0][t], o[0][j]);
-        o[1][j] = mfma16(va, pb[1][t], o[1][j]);
+          o[qb][0][j] = mfma16(va, pb[qb][0][t], o[qb][0][j]);
+          o[qb][1][j] = mfma16(va, pb[qb][1][t], o[qb][1][j]);
 #endif
+        }
       }
+#if ATTN_PRIO == 3
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (kv0 + KVT < p.Skv) {
       store_kv(buf ^ 1);
       if (kv0 + 2 * KVT < p.Skv) load_kv();
@@ -580,39 +633,42 @@ __global__ __launch_bounds__(256, 2) void attention32_kernel(const es_attn_desc 
   }
 
   // ---- epilogue: O[query][dv] = O^T / l ----
-  float l0, l1;
-  if constexpr (ONES) {
-    l0 = __shfl(o[0][DF - 1][0], 32 + col, 64);
-    l1 = __shfl(o[1][DF - 1][0], 32 + col, 64);
-  } else {
-    const float l = xor32_sum(lrun);                       // per query, 32-query layout
-    l0 = l; l1 = l;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(l0), "+v"(l1));
-  }
 #pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    const int qi = q0 + f * 16 + col;
-    const float inv = 1.0f / (f ? l1 : l0);
-    if (qi < p.Sq) {
+  for (int qb = 0; qb < QB; ++qb) {
+    float l0, l1;
+    if constexpr (ONES) {
+      l0 = __shfl(o[qb][0][DF - 1][0], 32 + col, 64);
+      l1 = __shfl(o[qb][1][DF - 1][0], 32 + col, 64);
+    } else {
+      const float l = xor32_sum(lrun[qb]);                   // per query, 32-query layout
+      l0 = l; l1 = l;
+      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(l0), "+v"(l1));
+    }
 #pragma unroll
-      for (int j = 0; j < DF; ++j) {
-        const int dv = j * 16 + g * 4;
-        if (dv < d) {
-          typename Traits<T>::vec4 pk;
+    for (int f = 0; f < 2; ++f) {
+      const int qi = q0 + qb * 32 + f * 16 + col;
+      const float inv = 1.0f / (f ? l1 : l0);
+      if (qi < p.Sq) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pk[r] = from_f32<T>(o[f][j][r] * inv);
-          store8(O + (size_t)qi * p.ldo + dv, __builtin_bit_cast(u32x2, pk));
+        for (int j = 0; j < DF; ++j) {
+          const int dv = j * 16 + g * 4;
+          if (dv < d) {
+            typename Traits<T>::vec4 pk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pk[r] = from_f32<T>(o[qb][f][j][r] * inv);
+            store8(O + (size_t)qi * p.ldo + dv, __builtin_bit_cast(u32x2, pk));
+          }
         }
       }
     }
   }
 }
 
-template <typename T, int KS, int DF, bool ONES>
+template <typename T, int KS, int DF, bool ONES, int QB = 1>
 int launch_attn32(const es_attn_desc& d, hipStream_t st) {
   constexpr int lds = 2 * (64 * (16 * KS * 2 + 16) + 64 * (16 * DF * 2 + 16));
-  auto kfn = attention32_kernel<T, KS, DF, ONES>;
-  dim3 grid((d.Sq + 127) / 128, d.heads, d.N);
+  auto kfn = attention32_kernel<T, KS, DF, ONES, QB>;
+  dim3 grid((d.Sq + 128 * QB - 1) / (128 * QB), d.heads, d.N);
   hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, d);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -641,6 +697,10 @@ int dispatch(const es_attn_desc& d, hipStream_t st) {
     // measured (tools/attn_bench.py, 14 x 8 x 4096^2): head_dim 40 476 -> 449 us; head_dim 80 is no faster (189 VGPRs,
     // two waves per SIMD instead of three) and stays on the 16x16 kernel unless asked for (ES_ATTN32=2, tests)
     static const bool tile32_80 = getenv("ES_ATTN32") && atoi(getenv("ES_ATTN32")) == 2;
+    // 64 queries per wave where that still leaves two 256-query blocks per CU: the kernel is bound by LDS reads of the K / V
+    // fragments (tool build with MFMAs, v_exp and row max removed: 265 of 448 us), and a fragment then serves two blocks
+    static const int qb2 = getenv("ES_ATTN_QB") ? atoi(getenv("ES_ATTN_QB")) : 2;
+    if (d.d == 40 && qb2 == 2 && (long long)((d.Sq + 255) / 256) * d.heads * d.N >= big_thr) return launch_attn32<T, 3, 3, true, 2>(d, st);
     if (d.d == 40) return launch_attn32<T, 3, 3, true>(d, st);
     if (d.d == 80 && tile32_80) return launch_attn32<T, 5, 5, false>(d, st);
   }

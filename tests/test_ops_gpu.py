@@ -138,6 +138,10 @@ ATTN_CASES = [
     (8, 8, 1000, 77, 40),      # ragged queries and keys
     (8, 8, 1024, 200, 80),
     (16, 8, 520, 136, 80),
+    # >= 512 blocks of 256 queries at head_dim 40: two 32-query blocks per wave share every K / V fragment read
+    (16, 8, 1024, 1024, 40),
+    (16, 8, 1000, 77, 40),     # ragged queries (last wave: one block partly, one block entirely out of range) and keys
+    (5, 32, 900, 333, 40),
 ]
 
 
@@ -153,6 +157,24 @@ def test_attention(N, heads, Sq, Skv, d):
     ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(N, Sq, C)
     y = ops.attention(q.to(DEV, torch.float16), k.to(DEV, torch.float16), v.to(DEV, torch.float16), heads)
     assert rel_err(y, ref) < 4e-3
+
+
+@pytest.mark.parametrize("N,heads,Sq,Skv,d", [(2, 8, 256, 256, 40), (8, 8, 1024, 1024, 40), (16, 8, 1024, 1024, 40), (1, 8, 128, 128, 80)])
+def test_attention_bf16(N, heads, Sq, Skv, d):
+    """bf16 (BASELINE configs[4]); at head_dim 40 the running softmax reference rides in the pad element of the bf16 Q operand
+    (8 mantissa bits): a spiking key forces it to move by large, inexactly representable steps."""
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(Sq + d + N)
+    C = heads * d
+    q = torch.randn(N, Sq, C, generator=g).bfloat16().float()
+    k = torch.randn(N, Skv, C, generator=g)
+    k[:, Skv // 2 + 3] *= 7.3
+    k = k.bfloat16().float()
+    v = torch.randn(N, Skv, C, generator=g).bfloat16().float()
+    qh, kh, vh = (t.view(N, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(N, Sq, C)
+    y = ops.attention(q.to(DEV, torch.bfloat16), k.to(DEV, torch.bfloat16), v.to(DEV, torch.bfloat16), heads)
+    assert rel_err(y, ref) < 2e-2
 
 
 def test_attention_forced_rescale_and_strided_qkv():
@@ -198,12 +220,13 @@ def test_attention32_head_dim_80_variant():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("d", [40, 80])
-def test_attention32_forced_rescale(d):
-    """32x32-tile kernel: a late key dominates some queries only (lazy rescale on the mixed 32-query / 16-query layouts)"""
+@pytest.mark.parametrize("d,N", [(40, 8), (80, 8), (40, 16)])
+def test_attention32_forced_rescale(d, N):
+    """32x32-tile kernel: a late key dominates some queries only (lazy rescale on the mixed 32-query / 16-query layouts);
+    N = 16 at head_dim 40 runs the two-blocks-per-wave form, where one block of a wave rescales and the other may not"""
     from edgestyle_amd import ops
     g = torch.Generator().manual_seed(d)
-    N, heads, S = 8, 8, 1024
+    heads, S = 8, 1024
     C = heads * d
     qkv = torch.randn(N, S, 3 * C, generator=g)
     qkv[:, 700, C:2 * C] *= 6.0

@@ -5,13 +5,12 @@ cd "$(dirname "$0")/../edgestyle_amd/csrc"
 mkdir -p ../lib/ablate
 OBJS="../lib/obj/gemm_conv.o ../lib/obj/linear_xs.o ../lib/obj/norm.o ../lib/obj/fusion.o ../lib/obj/elementwise.o ../lib/obj/plan.o"
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=fast"
-for v in "p0:-DATTN_PRIO=0" "p1:-DATTN_PRIO=1" "p2:-DATTN_PRIO=2" "p0a1:-DATTN_PRIO=0 -DATTN_ABLATE=1" "p0a2:-DATTN_PRIO=0 -DATTN_ABLATE=2" \
-         "p0a4:-DATTN_PRIO=0 -DATTN_ABLATE=4" "p0a6:-DATTN_PRIO=0 -DATTN_ABLATE=6" "p0a9:-DATTN_PRIO=0 -DATTN_ABLATE=9" "p0a15:-DATTN_PRIO=0 -DATTN_ABLATE=15"; do
+for v in "p0:-DATTN_PRIO=0" "p3:-DATTN_PRIO=3"; do
   tag=${v%%:*}; defs=${v#*:}
   /opt/rocm/bin/hipcc $FLAGS $defs -c attention.hip -o ../lib/ablate/attn_$tag.o &
 done
 wait
-for tag in p0 p1 p2 p0a1 p0a2 p0a4 p0a6 p0a9 p0a15; do
+for tag in p0 p3; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/ablate/libes_attn_$tag.so $OBJS ../lib/ablate/attn_$tag.o
 done
 ls -la ../lib/ablate/libes_attn_*.so
