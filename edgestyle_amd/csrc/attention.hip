@@ -9,6 +9,7 @@
 // Block = 4 waves; each wave owns QF x 16 queries (QF = 2 -> 128 queries per block), K/V tiles of KVT keys are
 // shared by the 4 waves through LDS; the next tile's global loads are in flight behind the current tile's MFMAs.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "../../include/edgestyle_hip.h"
 #include "plan.h"
@@ -673,6 +674,293 @@ int launch_attn32(const es_attn_desc& d, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// head_dim 40 self-attention, software-pipelined inside the wave.  attention32_kernel is bound by the vector pipe (32 v_exp
+// = 256 issue cycles + 16 packed converts + the row max per 32 queries x 64 keys, against 384 cycles of matrix pipe), and
+// its waves run [MFMA cluster | softmax | MFMA cluster] one after the other: the co-resident waves of other workgroups
+// do the same program in near lockstep, so the two pipes take turns instead of overlapping (tool builds: no MFMAs at
+// all -27 %, no v_exp -17 %; a probe kernel with the same instructions interleaved hides the MFMAs completely).  Here a
+// wave owns TWO 32-query blocks half a tile out of phase:
+//     phase 1:  softmax(A, tile t)   beside   O_B += V(t-1) P_B(t-1)   and   S_B(t) = K(t) Q_B
+//     phase 2:  softmax(B, tile t)   beside   O_A += V(t) P_A(t)       and   S_A(t+1) = K(t+1) Q_A
+// with the instruction order pinned (sched_barrier after every MFMA + its share of the vector work): each 16x16x32 MFMA
+// is followed by two v_exp, each 32x32x16 by ~50 issue cycles of softmax, so the matrix pipe runs in the shadow of the
+// vector pipe.  K runs one tile ahead of V in the LDS ring (2 + 2 buffers, still one barrier per tile).  Same
+// arithmetic as attention32_kernel<T, 3, 3, true, 2>: the softmax reference rides in the pad element of Q, the row sum
+// comes from the ones column of V (the reference moves per block here, per wave there: results agree to rounding).
+// Measured: no faster (448 vs 430 us on the 14-sample launch) - both run at the package power limit, see dispatch().
+// Requires Skv % 64 == 0 (self-attention); the dispatcher falls back to attention32_kernel otherwise.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attention40p_kernel(const es_attn_desc p) {
+  constexpr int KS = 3, DF = 3, KVT = 64;
+  constexpr int KROW = 16 * KS * 2 + 16, VROW = 16 * DF * 2 + 16;
+  constexpr int KBUF = KVT * KROW, VBUF = KVT * VROW;
+  constexpr int d = 40, dch = 5;
+  constexpr float LAZY = 8.0f;
+  typedef typename Traits<T>::vec8 vec8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* kbase = smem;                    // K[b] = kbase + b * KBUF
+  char* vbase = smem + 2 * KBUF;         // V[b] = vbase + b * VBUF
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n32 = lane & 31, hi = lane >> 5;      // 32x32 layouts: query column / key half
+  const int col = lane & 15, g = lane >> 4;       // 16x16 layouts (PV product, epilogue)
+  const int h = blockIdx.y, n = blockIdx.z;
+  const int q0 = blockIdx.x * 256 + wave * 64;
+
+  const T* Q = (const T*)p.q + (size_t)n * p.bsq + (size_t)h * d;
+  const T* K = (const T*)p.k + (size_t)n * p.bsk + (size_t)h * d;
+  const T* V = (const T*)p.v + (size_t)n * p.bsv + (size_t)h * d;
+  T* O = (T*)p.o + (size_t)n * p.bso + (size_t)h * d;
+
+  const float sl2 = p.scale * 1.4426950408889634f;
+  vec8 qf[2][KS];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    int qi = q0 + qb * 32 + n32;
+    qi = qi < p.Sq ? qi : p.Sq - 1;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int ch = 2 * s + hi;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ch < dch) v = *(const u32x4*)(Q + (size_t)qi * p.ldq + ch * 8);
+      auto qv = as_vec8<T>(v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qv[e] = from_f32<T>(to_f32(qv[e]) * sl2);
+      qf[qb][s] = qv;
+    }
+  }
+  // pad chunk of every K / V row: element d = 1.0 (reference subtraction / row sum); V[1] starts as zeros: the first
+  // phase multiplies it with P_B(-1) = 0
+  {
+    const unsigned one = Traits<T>::is_bf16 ? 0x3F80u : 0x3C00u;
+    for (int i = tid; i < 2 * KVT; i += 256) {
+      *(u32x4*)(kbase + (i / KVT) * KBUF + (i % KVT) * KROW + dch * 16) = u32x4{one, 0u, 0u, 0u};
+      *(u32x4*)(vbase + (i / KVT) * VBUF + (i % KVT) * VROW + dch * 16) = u32x4{one, 0u, 0u, 0u};
+    }
+    for (int i = tid; i < KVT * dch; i += 256)
+      *(u32x4*)(vbase + VBUF + (i / dch) * VROW + (i % dch) * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+
+  constexpr int KPT = (KVT * dch + 255) / 256;
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  u32x4 kr[KPT], vr[KPT];
+  const auto rK = __builtin_amdgcn_make_buffer_rsrc((void*)K, (short)0, (int)(((size_t)(p.Skv - 1) * p.ldk + d) * 2), 0x00020000);
+  const auto rV = __builtin_amdgcn_make_buffer_rsrc((void*)V, (short)0, (int)(((size_t)(p.Skv - 1) * p.ldv + d) * 2), 0x00020000);
+  unsigned koff[KPT], voffs[KPT];
+  int klds[KPT], vlds[KPT];
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) {
+    const int idx = tid + i * 256;
+    const bool own = idx < KVT * dch;
+    const int r = own ? idx / dch : 0;
+    const int c = own ? idx - r * dch : 0;
+    koff[i] = own ? (unsigned)((r * p.ldk + c * 8) * 2) : OOB;
+    voffs[i] = own ? (unsigned)((r * p.ldv + c * 8) * 2) : OOB;
+    klds[i] = own ? r * KROW + c * 16 : -1;
+    vlds[i] = own ? r * VROW + c * 16 : -1;
+  }
+  const unsigned kstep = (unsigned)(KVT * p.ldk * 2), vstep = (unsigned)(KVT * p.ldv * 2);
+  // tiles past the end read as zeros (range-checked loads): the pipeline's look-ahead needs no special case
+  auto load_k = [&]() {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      kr[i] = __builtin_amdgcn_raw_buffer_load_b128(rK, (int)koff[i], 0, 0);
+      koff[i] = koff[i] >= OOB - kstep ? OOB : koff[i] + kstep;
+    }
+  };
+  auto load_v = [&]() {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      vr[i] = __builtin_amdgcn_raw_buffer_load_b128(rV, (int)voffs[i], 0, 0);
+      voffs[i] = voffs[i] >= OOB - vstep ? OOB : voffs[i] + vstep;
+    }
+  };
+  auto store_k = [&](int b) {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i)
+      if (klds[i] >= 0) *(u32x4*)(kbase + b * KBUF + klds[i]) = kr[i];
+  };
+  auto store_v = [&](int b) {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i)
+      if (vlds[i] >= 0) *(u32x4*)(vbase + b * VBUF + vlds[i]) = vr[i];
+  };
+
+  f32x16 s[2][2];                 // raw scores of the block's current tile (two 32-key halves)
+  f32x4 o[2][2][DF];              // O^T of the two 16-query halves of each block
+  vec8 pb[2][2][2];               // packed exp'd scores [block][query half][key half], B operands of the PV product
+  float negm_f[2] = {0.f, 0.f};
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+#pragma unroll
+      for (int j = 0; j < DF; ++j) o[qb][f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 2; ++t) pb[qb][f][t] = as_vec8<T>(u32x4{0u, 0u, 0u, 0u});
+    }
+  const int vrow0 = 16 * (g & 1) + 4 * (g >> 1) + (col >> 2);
+  const int vcol0 = 4 * (col & 3);
+  auto kread = [&](const char* kb, int t, int ksx) __attribute__((always_inline)) {
+    return as_vec8<T>(*(const u32x4*)(kb + (t * 32 + n32) * KROW + (2 * ksx + hi) * 16));
+  };
+  auto vread = [&](const char* vb, int t, int j) __attribute__((always_inline)) {
+    const char* base = vb + (32 * t + vrow0) * VROW + (j * 16 + vcol0) * 2;
+    const u32x2 lo = lds_read_tr16(base);
+    const u32x2 hi2 = lds_read_tr16(base + 8 * VROW);
+    return as_vec8<T>(u32x4{lo[0], lo[1], hi2[0], hi2[1]});
+  };
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // prologue: K(0), V(0), K(1) staged; K(2), V(1) in flight; S_A(0)
+  load_k(); load_v();
+  store_k(0); store_v(0);
+  load_k();
+  store_k(1);
+  load_k(); load_v();
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ksx = 0; ksx < KS; ++ksx)
+      s[0][t] = mfma32(kread(kbase, t, ksx), qf[0][ksx], ksx == 0 ? zero16 : s[0][t]);
+
+  // one phase: softmax of block X on its scores s[X] (-> pb[X]) beside the matrix work of block Y = 1 - X:
+  // O_Y += V P_Y from the tile in vb, then S_Y = K Q_Y from the tile in kb
+  auto phase = [&](auto XC, const char* vb, const char* kb, const bool first) __attribute__((always_inline)) {
+    constexpr int X = decltype(XC)::value, Y = 1 - X;
+    vec8 vf[2][DF], kf[2][KS];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < DF; ++j) vf[t][j] = vread(vb, t, j);
+    // ---- (a) row max of S_X beside the first 6 PV MFMAs ----
+    float mx = s[X][0][0];
+    constexpr int MXB[7] = {0, 3, 6, 9, 12, 14, 16};       // max3 steps per MFMA slot
+#pragma unroll
+    for (int slot = 0; slot < 6; ++slot) {
+      o[Y][slot & 1][slot >> 1] = mfma16(vf[0][slot >> 1], pb[Y][slot & 1][0], o[Y][slot & 1][slot >> 1]);
+#pragma unroll
+      for (int u = MXB[slot]; u < MXB[slot + 1]; ++u) mx = fmaxf(fmaxf(mx, s[X][u >> 3][(2 * u) & 15]), s[X][u >> 3][((2 * u) & 15) + 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int ksx = 0; ksx < KS; ++ksx) kf[0][ksx] = kread(kb, 0, ksx);
+    mx = xor32_max(mx);
+    if (first || !__all(mx <= LAZY)) {
+      float dlt = first ? mx : fmaxf(mx, 0.f);
+      const T nmt = from_f32<T>(negm_f[X] - dlt);
+      dlt = negm_f[X] - to_f32(nmt);
+      negm_f[X] = to_f32(nmt);
+      if (hi) qf[X][KS - 1][0] = nmt;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[X][t][r] -= dlt;
+      if (!first) {
+        const float alpha = __builtin_amdgcn_exp2f(-dlt);
+        float a0 = alpha, a1 = alpha;
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a0), "+v"(a1));
+#pragma unroll
+        for (int j = 0; j < DF; ++j) { o[X][0][j] *= a0; o[X][1][j] *= a1; }
+      }
+    }
+    // ---- (b) exp / pack / re-deal of S_X beside the other 6 PV MFMAs and the 6 QK^T MFMAs ----
+    // vector micro-steps: 0..31 v_exp of element (u >> 4, u & 15); 32..47 packed convert of pair (u - 32); 48, 49 the
+    // permlane re-deal of key half 0 / 1
+    unsigned x[2][4], y[2][4];
+    auto vstep = [&](int u) __attribute__((always_inline)) {
+      if (u < 32) {
+        s[X][u >> 4][u & 15] = __builtin_amdgcn_exp2f(s[X][u >> 4][u & 15]);
+      } else if (u < 48) {
+        const int t = (u - 32) >> 3, i = (u - 32) & 7;
+        if (i < 4) x[t][i] = pack2<T>(s[X][t][2 * i], s[X][t][2 * i + 1]);
+        else y[t][i - 4] = pack2<T>(s[X][t][8 + 2 * (i - 4)], s[X][t][9 + 2 * (i - 4)]);
+      } else {
+        const int t = u - 48;
+        asm volatile("s_nop 1\n\t"
+                     "v_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
+                     "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 1"
+                     : "+v"(x[t][0]), "+v"(x[t][1]), "+v"(x[t][2]), "+v"(x[t][3]), "+v"(y[t][0]), "+v"(y[t][1]), "+v"(y[t][2]), "+v"(y[t][3]));
+        pb[X][0][t] = as_vec8<T>(u32x4{x[t][0], x[t][1], x[t][2], x[t][3]});
+        pb[X][1][t] = as_vec8<T>(u32x4{y[t][0], y[t][1], y[t][2], y[t][3]});
+      }
+    };
+    constexpr int VSB[13] = {0, 2, 4, 6, 8, 10, 12, 18, 24, 30, 40, 49, 50};
+#pragma unroll
+    for (int slot = 0; slot < 12; ++slot) {
+      if (slot < 6) {
+        o[Y][slot & 1][slot >> 1] = mfma16(vf[1][slot >> 1], pb[Y][slot & 1][1], o[Y][slot & 1][slot >> 1]);
+      } else {
+        const int m = slot - 6, t = m / KS, ksx = m - t * KS;
+        s[Y][t] = mfma32(kf[t][ksx], qf[Y][ksx], ksx == 0 ? zero16 : s[Y][t]);
+      }
+      if (slot == 5) {
+#pragma unroll
+        for (int ksx = 0; ksx < KS; ++ksx) kf[1][ksx] = kread(kb, 1, ksx);
+      }
+#pragma unroll
+      for (int u = VSB[slot]; u < VSB[slot + 1]; ++u) vstep(u);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  const int T_ = p.Skv / KVT;
+  for (int t = 0; t < T_; ++t) {
+    const int b = t & 1;
+    phase(std::integral_constant<int, 0>{}, vbase + (b ^ 1) * VBUF, kbase + b * KBUF, t == 0);
+    __syncthreads();                 // every wave is done with K(t) and V(t-1): their buffers take K(t+2), V(t+1)
+    store_k(b); store_v(b ^ 1);
+    load_k(); load_v();
+    phase(std::integral_constant<int, 1>{}, vbase + b * VBUF, kbase + (b ^ 1) * KBUF, t == 0);
+  }
+  // drain: O_B += V(T-1) P_B(T-1)
+  {
+    const char* vb = vbase + ((T_ - 1) & 1) * VBUF;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < DF; ++j) {
+        const auto va = vread(vb, t, j);
+        o[1][0][j] = mfma16(va, pb[1][0][t], o[1][0][j]);
+        o[1][1][j] = mfma16(va, pb[1][1][t], o[1][1][j]);
+      }
+  }
+
+  // ---- epilogue: O[query][dv] = O^T / l, l = the ones row of O^T ----
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const float l0 = __shfl(o[qb][0][DF - 1][0], 32 + col, 64);
+    const float l1 = __shfl(o[qb][1][DF - 1][0], 32 + col, 64);
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int qi = q0 + qb * 32 + f * 16 + col;
+      const float inv = 1.0f / (f ? l1 : l0);
+      if (qi < p.Sq) {
+#pragma unroll
+        for (int j = 0; j < DF; ++j) {
+          const int dv = j * 16 + g * 4;
+          if (dv < d) {
+            typename Traits<T>::vec4 pk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pk[r] = from_f32<T>(o[qb][f][j][r] * inv);
+            store8(O + (size_t)qi * p.ldo + dv, __builtin_bit_cast(u32x2, pk));
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch_attn40p(const es_attn_desc& d, hipStream_t st) {
+  constexpr int lds = 2 * (64 * (16 * 3 * 2 + 16) + 64 * (16 * 3 * 2 + 16));
+  dim3 grid((d.Sq + 255) / 256, d.heads, d.N);
+  hipLaunchKernelGGL(attention40p_kernel<T>, grid, dim3(256), lds, st, d);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 template <typename T, int KS, int DF, int QF, int KVT, bool ONES = false>
 int launch_attn(const es_attn_desc& d, hipStream_t st) {
   constexpr int lds = (KS <= 5 ? 2 : 1) * (KVT * (32 * KS * 2 + 16) + KVT * (16 * DF * 2 + 16));
@@ -700,7 +988,14 @@ int dispatch(const es_attn_desc& d, hipStream_t st) {
     // 64 queries per wave where that still leaves two 256-query blocks per CU: the kernel is bound by LDS reads of the K / V
     // fragments (tool build with MFMAs, v_exp and row max removed: 265 of 448 us), and a fragment then serves two blocks
     static const int qb2 = getenv("ES_ATTN_QB") ? atoi(getenv("ES_ATTN_QB")) : 2;
-    if (d.d == 40 && qb2 == 2 && (long long)((d.Sq + 255) / 256) * d.heads * d.N >= big_thr) return launch_attn32<T, 3, 3, true, 2>(d, st);
+    // opt-in: measured 448 vs 430 us on the 14-sample launch.  Both forms run at the package power limit (rocm-smi while the
+    // launch repeats: ~1.38 kW, 2.18 GHz pipelined / 2.24 GHz plain): overlapping the pipes in time does not lower the energy
+    // per tile, which is what sets the pace there
+    static const bool pipe40 = getenv("ES_ATTN_PIPE") && atoi(getenv("ES_ATTN_PIPE")) == 1;
+    if (d.d == 40 && qb2 == 2 && (long long)((d.Sq + 255) / 256) * d.heads * d.N >= big_thr) {
+      if (pipe40 && d.Skv % 64 == 0) return launch_attn40p<T>(d, st);
+      return launch_attn32<T, 3, 3, true, 2>(d, st);
+    }
     if (d.d == 40) return launch_attn32<T, 3, 3, true>(d, st);
     if (d.d == 80 && tile32_80) return launch_attn32<T, 5, 5, false>(d, st);
   }

@@ -220,6 +220,47 @@ def test_attention32_head_dim_80_variant():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_attention40_pipelined_kernel_matches_default(tmp_path):
+    """The in-wave software-pipelined head_dim-40 kernel (opt-in, ES_ATTN_PIPE=1, read once per process) against the default
+    two-blocks-per-wave kernel and the fp32 reference, including the lazy-rescale path (spiking keys) and the first / last
+    tiles of the look-ahead.  Not bit-identical: the default kernel moves the softmax reference of both blocks of a wave
+    when either needs it, the pipelined one per block, so the exp'd scores are rounded relative to different references."""
+    import os
+    import subprocess
+    import sys
+    from edgestyle_amd import ops
+    code = (
+        "import sys, torch\n"
+        "from edgestyle_amd import ops\n"
+        "g = torch.Generator().manual_seed(11)\n"
+        "N, heads, S, d = 16, 8, 1024, 40\n"
+        "C = heads * d\n"
+        "qkv = torch.randn(N, S, 3 * C, generator=g); qkv[:, 700, C:2 * C] *= 6.0; qkv[:, 70, C:C + d] *= 9.0\n"
+        "dq = qkv.half().cuda()\n"
+        "y = ops.attention(dq[:, :, :C], dq[:, :, C:2 * C], dq[:, :, 2 * C:], heads)\n"
+        "torch.save(y.cpu(), sys.argv[1])\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for pipe in ("0", "1"):
+        f = str(tmp_path / f"y{pipe}.pt")
+        r = subprocess.run([sys.executable, "-c", code, f], cwd=root, env=dict(os.environ, ES_ATTN_PIPE=pipe),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(torch.load(f, weights_only=True))
+    assert rel_err(outs[0], outs[1]) < 2e-3
+    # and both against the fp32 reference
+    g = torch.Generator().manual_seed(11)
+    N, heads, S, d = 16, 8, 1024, 40
+    C = heads * d
+    qkv = torch.randn(N, S, 3 * C, generator=g)
+    qkv[:, 700, C:2 * C] *= 6.0
+    qkv[:, 70, C:C + d] *= 9.0
+    qkv = q16(qkv)
+    qh, kh, vh = (t.reshape(N, S, heads, d).transpose(1, 2) for t in qkv.split(C, dim=-1))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(N, S, C)
+    assert rel_err(outs[0], ref) < 4e-3 and rel_err(outs[1], ref) < 4e-3
+
+
 @pytest.mark.parametrize("d,N", [(40, 8), (80, 8), (40, 16)])
 def test_attention32_forced_rescale(d, N):
     """32x32-tile kernel: a late key dominates some queries only (lazy rescale on the mixed 32-query / 16-query layouts);

@@ -26,7 +26,43 @@ def poll():
         time.sleep(0.3)
 
 
+def attn_main():
+    """--attn: the 14-sample head_dim-40 self-attention of UNet level 0, back to back."""
+    N, h, S, d = 14, 8, 4096, 40
+    g = torch.Generator(device="cuda").manual_seed(0)
+    qkv = torch.randn(N, S, 3 * h * d, generator=g, device="cuda").half()
+    C = h * d
+    q, k, v = qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
+    out = ops.attention(q, k, v, h)
+    torch.cuda.synchronize()
+    th = threading.Thread(target=poll)
+    th.start()
+    time.sleep(1.0)
+    t0 = time.time()
+    n = 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    while time.time() - t0 < 5.0:
+        for _ in range(8):
+            ops.attention(q, k, v, h, out=out)
+        n += 8
+        if n % 64 == 0:
+            torch.cuda.synchronize()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    print(f"busy phase: {n} attention launches, {ms * 1e3:.1f} us each", flush=True)
+    time.sleep(1.0)
+    global stop
+    stop = True
+    th.join()
+    for t, keep in samples:
+        print(f"{t - t0:6.2f}s", " | ".join(keep)[:230])
+
+
 def main():
+    if "--attn" in sys.argv:
+        return attn_main()
     N, H, C, k = 112, 64, 320, 3
     g = torch.Generator(device="cuda").manual_seed(0)
     x = torch.randn(N, H, H, C, generator=g, device="cuda").half()
