@@ -21,6 +21,14 @@ struct es_plan {
   struct Op { int kind; size_t off, bytes; };
   std::vector<Op> ops;
   std::vector<char> blob;
+  // side section (ES_OP_SIDE_*): a stream and two events of the plan's own, created on first use
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_done = nullptr;
+  ~es_plan() {
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_done) (void)hipEventDestroy(ev_done);
+    if (side) (void)hipStreamDestroy(side);
+  }
 };
 
 namespace {
@@ -60,12 +68,44 @@ int launch_op(const es_plan* p, const es_plan::Op& op, hipStream_t st, const flo
   }
 }
 
-int run_plan(const es_plan* p, hipStream_t st, const float* guidance_override) {
+int side_init(es_plan* p) {
+  if (p->side) return 0;
+  if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming) != hipSuccess) { es_set_error("es_plan_launch: side stream / event creation failed"); return -2; }
+  return 0;
+}
+
+int run_plan(const es_plan* cp, hipStream_t st, const float* guidance_override) {
   if (g_rec) { es_set_error("es_plan_launch: a plan is recording on this thread"); return -1; }
+  es_plan* p = const_cast<es_plan*>(cp);
   g_replaying = true;
   int rc = 0;
-  for (const auto& op : p->ops)
-    if ((rc = launch_op(p, op, st, guidance_override)) != 0) break;
+  hipStream_t cur = st;
+  int open = 0;                   // 0: no side section pending, 1: inside one, 2: ended but not joined
+  for (const auto& op : p->ops) {
+    if (op.kind == ES_OP_SIDE_BEGIN) {
+      // fork: the side stream starts behind everything issued so far (under stream capture this pulls it into the capture)
+      if (open || (rc = side_init(p)) != 0) { if (!rc) { es_set_error("es_plan_launch: nested side section"); rc = -1; } break; }
+      if (hipEventRecord(p->ev_fork, st) != hipSuccess || hipStreamWaitEvent(p->side, p->ev_fork, 0) != hipSuccess) { es_set_error("es_plan_launch: fork failed"); rc = -2; break; }
+      cur = p->side; open = 1;
+    } else if (op.kind == ES_OP_SIDE_END) {
+      if (open != 1) { es_set_error("es_plan_launch: SIDE_END without SIDE_BEGIN"); rc = -1; break; }
+      if (hipEventRecord(p->ev_done, p->side) != hipSuccess) { es_set_error("es_plan_launch: side event failed"); rc = -2; break; }
+      cur = st; open = 2;
+    } else if (op.kind == ES_OP_SIDE_JOIN) {
+      if (open != 2) { es_set_error("es_plan_launch: SIDE_JOIN without a finished side section"); rc = -1; break; }
+      if (hipStreamWaitEvent(st, p->ev_done, 0) != hipSuccess) { es_set_error("es_plan_launch: join failed"); rc = -2; break; }
+      open = 0;
+    } else if ((rc = launch_op(p, op, cur, guidance_override)) != 0) {
+      break;
+    }
+  }
+  if (!rc && open) {
+    // never leave a fork dangling (a capture could not end, an eager caller would race): join it here
+    if (open == 1) (void)hipEventRecord(p->ev_done, p->side);
+    (void)hipStreamWaitEvent(st, p->ev_done, 0);
+  }
   g_replaying = false;
   return rc;
 }
@@ -78,6 +118,12 @@ extern "C" void es_plan_record(int kind, const void* args, size_t bytes) {
   p->blob.resize(off + bytes);
   memcpy(p->blob.data() + off, args, bytes);
   p->ops.push_back({kind, off, bytes});
+}
+
+extern "C" int es_plan_mark(int kind) {
+  if (kind != ES_OP_SIDE_BEGIN && kind != ES_OP_SIDE_END && kind != ES_OP_SIDE_JOIN) { es_set_error("es_plan_mark: unknown marker"); return -1; }
+  if (es_plan_recording()) g_rec->ops.push_back({kind, g_rec->blob.size(), 0});
+  return 0;
 }
 
 extern "C" es_plan* es_plan_create(void) { return new es_plan(); }

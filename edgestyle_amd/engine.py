@@ -382,13 +382,16 @@ class Fusion:
             self.params.append(ops.pack_fusion_params(sd, p, dtype, device))
 
     def forward(self, res_per_net: Sequence[Sequence[torch.Tensor]], bs: Sequence[Sequence[int]], N: int,
-                scales: Sequence[float], scales_dev=None, addends=None):
-        """res_per_net[i][lvl]: tensor view whose data_ptr is sample 0 of net i at level lvl.  addends: optional 13
-        UNet skip / mid tensors; the outputs are then already `skip + residual` (PL:500-510)."""
-        blocks = [([res_per_net[i][lvl] for i in range(6)], [bs[i][lvl] for i in range(6)], self.params[lvl], s * s, c)
-                  for lvl, (c, s) in enumerate(self.table)]
-        outs = ops.fusion_blocks(blocks, N, scales, scales_dev, addends=addends)   # 3 launches for all 13 blocks
-        return [o.reshape(N, s, s, c) for o, (c, s) in zip(outs, self.table)]
+                scales: Sequence[float], scales_dev=None, addends=None, first_level: int = 0):
+        """res_per_net[i][k]: tensor view whose data_ptr is sample 0 of net i at level first_level + k.  addends: optional
+        UNet skip / mid tensors of the same levels; the outputs are then already `skip + residual` (PL:500-510).
+        The levels given (all 13 by default) go through one batched call: three launches."""
+        nl = len(res_per_net[0])
+        table = self.table[first_level:first_level + nl]
+        blocks = [([res_per_net[i][k] for i in range(6)], [bs[i][k] for i in range(6)], self.params[first_level + k], s * s, c)
+                  for k, (c, s) in enumerate(table)]
+        outs = ops.fusion_blocks(blocks, N, scales, scales_dev, addends=addends, first_block=first_level)
+        return [o.reshape(N, s, s, c) for o, (c, s) in zip(outs, table)]
 
 
 class VAE:
@@ -548,8 +551,9 @@ class GroupedEncoder:
         tok = ops.linear(f, [t.ff2 for t in ts], residual=tok, group_n=rows)
         return ops.conv_gemm(tok.reshape(N, H, W, C), [t.proj_out for t in ts], residual=x, group_n=c)
 
-    def run(self, h, tproj, ctx: List[torch.Tensor]):
-        """h: [ntot,H,W,C0] (each group's conv_in(sample)+cond already applied) -> (skips, mid) over the whole batch."""
+    def run(self, h, tproj, ctx: List[torch.Tensor], after_block=None):
+        """h: [ntot,H,W,C0] (each group's conv_in(sample)+cond already applied) -> (skips, mid) over the whole batch.
+        after_block(i, skips) is called when resolution level i is complete (its skips, downsample included, exist)."""
         skips = [h]
         ci = 0
         e0 = self.encs[0]
@@ -562,6 +566,8 @@ class GroupedEncoder:
             if e0.downsample[i] is not None:
                 h = ops.conv_gemm(h, [e.downsample[i] for e in self.encs], stride=2, group_n=self.counts)
                 skips.append(h)
+            if after_block is not None:
+                after_block(i, skips)
         h = self._resnet([e.mid0 for e in self.encs], h, tproj)
         h = self._transformer([e.mid_attn for e in self.encs], h, ctx[ci])
         h = self._resnet([e.mid1 for e in self.encs], h, tproj)

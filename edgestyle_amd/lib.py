@@ -56,6 +56,7 @@ PLAN_STEP_GENERIC, PLAN_PREP, PLAN_STEP, PLAN_DECODE = 0, 1, 2, 3
 (BUF_SAMPLE, BUF_T_ROWS, BUF_EHS, BUF_COND0, BUF_COND1, BUF_COND2, BUF_COND3, BUF_COND4, BUF_COND5, BUF_SCALES, BUF_NOISE,
  BUF_LATENTS, BUF_STEP_IDX, BUF_T_TABLE, BUF_SCALE_TABLE, BUF_COEF, BUF_TIMESTEPS, BUF_IMAGE) = range(18)
 OP_CONV_GEMM, OP_LINEAR_XS, OP_ATTENTION = 1, 2, 3      # csrc/plan.h es_op_kind (es_plan_count)
+PLAN_SIDE_BEGIN, PLAN_SIDE_END, PLAN_SIDE_JOIN = 64, 65, 66   # es_plan_mark
 
 
 class AttnDesc(C.Structure):
@@ -137,6 +138,7 @@ SYMBOLS = {
     "es_plan_destroy": (None, [_P]),
     "es_plan_begin_record": (C.c_int, [_P]),
     "es_plan_end_record": (C.c_int, [_P]),
+    "es_plan_mark": (C.c_int, [_I]),
     "es_plan_size": (C.c_int, [_P]),
     "es_plan_count": (C.c_int, [_P, _I]),
     "es_plan_launch": (C.c_int, [_P, _P]),

@@ -904,9 +904,38 @@ class StepRunner:
             if st.tproj_gen is None or st.tproj_gen.shape != (ge.ntot, ge.width):
                 st.tproj_gen = torch.zeros((ge.ntot, ge.width), dtype=self.dtype, device=self.device)
             tproj = ge.time_proj(t_rows, st.tproj_gen)
-        skips, h = ge.run(h0, tproj, st.ctx_grouped)
         cn_counts = counts[:-1]
         cn_engs = encs[:-1]
+        nn = self.n_nets
+
+        def zero_and_fuse(levels, srcs, addends, first_level):
+            """zero-convs of the given levels (grouped over the ControlNets) -> their fusion blocks (+ the UNet's own tensors)"""
+            res = [ops.conv_gemm(srcs[k][:ncn], [e.zero[lvl] if lvl < len(e.zero) else e.zero_mid for e in cn_engs], group_n=cn_counts)
+                   for k, lvl in enumerate(levels)]
+            res_per_net, bs = [None] * nn, [None] * nn
+            a = 0
+            for net, pos in self.groups:
+                for p in pos:
+                    res_per_net[p] = [r[a:] for r in res]
+                    bs[p] = [r.stride(0) for r in res]
+                    a += N
+            # the fusion kernel adds the UNet's own skip / mid tensors: its outputs ARE the decoder's inputs
+            return self.controlnet.engine.forward(res_per_net, bs, N, scales, scales_dev, addends=addends, first_level=first_level)
+
+        # The zero-convs and fusion blocks of the two shallow resolution levels (7 of the 13 tensors, 92 % of their bytes)
+        # move ~0.4 GB per step and compute almost nothing; they run on a side stream as soon as level 1 is complete,
+        # beside the deep encoder levels whose split-K launches leave most of the memory system idle (DESIGN.md S7).
+        early = {}
+        n_blocks = len(ue.cfg.block_out_channels)
+
+        def after_block(i, skips):
+            if i == 1 and ops.SIDE_ENABLED and not self.single and n_blocks > 2:
+                ne = len(skips)
+                with ops.side_section():
+                    early["fused"] = zero_and_fuse(list(range(ne)), skips, [s[ncn:] for s in skips], 0)
+                early["n"] = ne
+
+        skips, h = ge.run(h0, tproj, st.ctx_grouped, after_block=after_block)
         enc = ([s[ncn:] for s in skips], h[ncn:])
         if self.single:
             # one ControlNet: skip + scale * zero_conv(cn_skip) straight out of the zero-conv epilogue (PL:500-510)
@@ -915,18 +944,12 @@ class StepRunner:
             fused = [ops.conv_gemm(s[:ncn], e.zero[i], residual=enc[0][i], **kw) for i, s in enumerate(skips)]
             fused.append(ops.conv_gemm(h[:ncn], e.zero_mid, residual=enc[1], **kw))
             return ue.forward(x, tproj[ncn:], st.ctx_unet, fused[:-1], fused[-1], out=out, encoded=enc, presummed=True)
-        res = [ops.conv_gemm(s[:ncn], [e.zero[i] for e in cn_engs], group_n=cn_counts) for i, s in enumerate(skips)]
-        res.append(ops.conv_gemm(h[:ncn], [e.zero_mid for e in cn_engs], group_n=cn_counts))
-        nn = self.n_nets
-        res_per_net, bs = [None] * nn, [None] * nn
-        a = 0
-        for net, pos in self.groups:
-            for p in pos:
-                res_per_net[p] = [r[a:] for r in res]
-                bs[p] = [r.stride(0) for r in res]
-                a += N
-        # the fusion kernel adds the UNet's own skip / mid tensors: its outputs ARE the decoder's inputs
-        fused = self.controlnet.engine.forward(res_per_net, bs, N, scales, scales_dev, addends=enc[0] + [enc[1]])
+        ne = early.get("n", 0)
+        srcs = skips + [h]
+        fused = zero_and_fuse(list(range(ne, len(srcs))), srcs[ne:], (enc[0] + [enc[1]])[ne:], ne)
+        if ne:
+            ops.join_side()
+            fused = early["fused"] + fused
         if self.keep_debug:
             self.debug = dict(presummed=[f.clone() for f in fused], skips=[e.clone() for e in enc[0] + [enc[1]]])
         return ue.forward(x, tproj[ncn:], st.ctx_unet, fused[:-1], fused[-1], out=out, encoded=enc, presummed=True)

@@ -86,7 +86,7 @@ class NativeEngine:
         geo = L.CtxGeometry(B=B, cfg=int(guidance), h=h, w=w, latent_channels=ucfg.in_channels,
                             latent_pad=pipe.unet.engine.in_pad, n_conds=nn, n_steps=T, dtype=L.ES_F16 if self.dtype == torch.float16 else L.ES_BF16)
         L.check(self.lib.es_ctx_set_geometry(ctx, C.byref(geo)), "es_ctx_set_geometry")
-        self.plan_sizes = {}
+        self.plan_sizes, self.plan_forks = {}, {}
         for which, fn in ((L.PLAN_PREP, prep), (L.PLAN_STEP, loop.one_step), (L.PLAN_STEP_GENERIC, generic), (L.PLAN_DECODE, decode)):
             fn()                                     # eager: anything that allocates scratch does it outside the capture
             torch.cuda.synchronize()
@@ -100,6 +100,7 @@ class NativeEngine:
                 L.check(self.lib.es_plan_end_record(plan), "es_plan_end_record")
             self._keep.append(graph)                 # owns the memory the plan's pointers refer to
             self.plan_sizes[which] = self.lib.es_plan_size(plan)
+            self.plan_forks[which] = self.lib.es_plan_count(plan, L.PLAN_SIDE_BEGIN)
             L.check(self.lib.es_ctx_set_plan(ctx, which, plan), "es_ctx_set_plan")
         self.image = out["img"]
         binds = {L.BUF_SAMPLE: loop.model_in, L.BUF_T_ROWS: loop.t_rows, L.BUF_EHS: loop.ehs, L.BUF_SCALES: loop.scales_cur,

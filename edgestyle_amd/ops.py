@@ -33,6 +33,49 @@ class lane:
         LANE = self.prev
 
 
+# opt-in (ES_SIDE_FUSION=1): measured 484.1 vs 476.2 ms per image at batch 1 - the memory-bound side work takes CUs and power
+# from the GEMMs it runs beside, which costs more than the serial 0.3 ms it hides
+SIDE_ENABLED = _os.environ.get("ES_SIDE_FUSION", "0") == "1"
+_side_streams = {}
+
+
+class side_section:
+    """with ops.side_section(): ... — the launches inside go to a second HIP stream forked behind everything issued so far
+    on the current stream, and run beside what the current stream is given next; ops.join_side() makes the current stream
+    wait for them.  A recording plan gets the matching markers (es_plan_mark), torch's graph capture follows the fork
+    through the stream waits.  Scratch buffers come from lane 1."""
+
+    def __enter__(self):
+        main = torch.cuda.current_stream()
+        key = main.device
+        side = _side_streams.get(key)
+        if side is None:
+            side = _side_streams[key] = torch.cuda.Stream(device=main.device)
+        self.side = side
+        L.check(L.load().es_plan_mark(L.PLAN_SIDE_BEGIN), "es_plan_mark")
+        side.wait_stream(main)
+        self._ctx = torch.cuda.stream(side)
+        self._ctx.__enter__()
+        self._lane = lane(1)
+        self._lane.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        self._lane.__exit__(*a)
+        self._ctx.__exit__(*a)
+        L.check(L.load().es_plan_mark(L.PLAN_SIDE_END), "es_plan_mark")
+
+
+def join_side():
+    """The current stream waits for the side section opened (and closed) before."""
+    main = torch.cuda.current_stream()
+    side = _side_streams.get(main.device)
+    if side is None:
+        return
+    L.check(L.load().es_plan_mark(L.PLAN_SIDE_JOIN), "es_plan_mark")
+    main.wait_stream(side)
+
+
 XCD_ORDER = -1      # tuning knob: -1 auto, 0 tile_n fastest, 1 tile_m fastest
 DEEP_RING = _os.environ.get("ES_DEEP_RING", "1") == "1"     # 4-stage LDS ring for launches of <= 1 workgroup per CU
 FORCE_BN = 0        # tuning knob: 0 = per-launch choice between the legal N tiles
@@ -828,7 +871,7 @@ def fusion_block(res, res_bs, params: dict, N: int, HW: int, Cc: int, scales, sc
     return out
 
 
-def fusion_blocks(blocks, N: int, scales, scales_dev=None, eps: float = 1e-5, addends=None):
+def fusion_blocks(blocks, N: int, scales, scales_dev=None, eps: float = 1e-5, addends=None, first_block: int = 0):
     """All fusion blocks of a step in three launches.  blocks: list of (res, res_bs, params, HW, Cc) as for
     fusion_block; returns the list of [N,HW,Cc] outputs.  addends: optional list of [N,HW,Cc] tensors added to the
     outputs (the UNet skip tensors: saves the 13 separate adds of PL:500-510)."""
@@ -837,7 +880,7 @@ def fusion_blocks(blocks, N: int, scales, scales_dev=None, eps: float = 1e-5, ad
         part = blocks[k0:k0 + L.FUSION_MAX_BATCH]
         arr = (L.FusionDesc * len(part))()
         for k, (res, res_bs, params, HW, Cc) in enumerate(part):
-            d, u, out = _fusion_desc(res, res_bs, params, N, HW, Cc, scales, scales_dev, None, eps, k0 + k,
+            d, u, out = _fusion_desc(res, res_bs, params, N, HW, Cc, scales, scales_dev, None, eps, first_block + k0 + k,
                                      None if addends is None else addends[k0 + k])
             arr[k] = d
             keep.append(u)

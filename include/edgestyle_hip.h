@@ -287,7 +287,17 @@ es_plan* es_plan_create(void);
 void es_plan_destroy(es_plan* p);
 int es_plan_begin_record(es_plan* p);
 int es_plan_end_record(es_plan* p);
-int es_plan_size(const es_plan* p);                    /* number of recorded calls */
+/* Stream markers of a recording plan (no-ops when none records): the calls recorded between ES_PLAN_SIDE_BEGIN and
+ * ES_PLAN_SIDE_END are re-issued on a second stream of the plan's own, forked behind everything recorded before and running
+ * beside what is recorded after ES_PLAN_SIDE_END; ES_PLAN_SIDE_JOIN makes the launching stream wait for them.  The host that
+ * builds the plan issues the same calls on a side stream of its own at that point (edgestyle_amd/ops.py side_section).
+ * Used for the shallow-level zero-convs + fusion blocks of a step (models.py), which are memory-bound and overlap the
+ * under-filled launches of the deep encoder levels. */
+#define ES_PLAN_SIDE_BEGIN 64
+#define ES_PLAN_SIDE_END 65
+#define ES_PLAN_SIDE_JOIN 66
+int es_plan_mark(int kind);
+int es_plan_size(const es_plan* p);                    /* number of recorded calls (markers included) */
 int es_plan_count(const es_plan* p, int kind);         /* ... of one kind (csrc/plan.h: 1 = es_conv_gemm, 2 = es_linear_xs, ...) */
 int es_plan_launch(const es_plan* p, void* stream);
 

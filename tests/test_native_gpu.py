@@ -166,3 +166,42 @@ def test_native_context_for_a_single_controlnet_and_without_cfg(built, guidance)
         assert torch.equal(img, want_img), float((img - want_img).abs().max())
     finally:
         eng.close()
+
+
+def test_side_section_fork_and_join_in_the_pipeline_graph_and_in_the_native_plan(built):
+    """ES_SIDE_FUSION (opt-in): the zero-convs + fusion blocks of the two shallow levels run on a forked stream beside the
+    deep encoder levels.  Same kernels on the same data: results equal the single-stream run bit for bit - eager, as a
+    torch-captured graph, and as a native plan (es_plan_mark fork / join markers) replayed as a hipGraph or launch by launch."""
+    from edgestyle_amd import ops
+    from edgestyle_amd.models import _as_nhwc
+    from edgestyle_amd.native import NativeEngine
+    from edgestyle_amd.pipeline import EdgeStyleStableDiffusionControlNetPipeline
+    pipe, eng0, ws, ucfg, vcfg = built
+    assert eng0.plan_forks[L.PLAN_STEP] == 0
+    lat, pe, ne, conds = _inputs(ucfg, 31)
+    gs, T = 4.0, 6
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, latents=lat, guidance_scale=gs, num_inference_steps=T)
+    want = pipe(output_type="latent", **kw).images.clone()
+    prev = ops.SIDE_ENABLED
+    ops.SIDE_ENABLED = True
+    eng = None
+    try:
+        pipe2 = EdgeStyleStableDiffusionControlNetPipeline(vae=pipe.vae, unet=pipe.unet, controlnet=pipe.controlnet).to(DEV)
+        assert torch.equal(pipe2(output_type="latent", **kw).images, want)            # captured with the fork inside
+        pipe2.use_graph = False
+        assert torch.equal(pipe2(output_type="latent", **kw).images, want)            # eager, two streams
+        pipe2.use_graph = True
+        eng = NativeEngine(pipe2, batch_size=1, num_inference_steps=T)
+        assert eng.plan_forks[L.PLAN_STEP] == 1 and eng.plan_forks[L.PLAN_STEP_GENERIC] == 1
+        eng.set_conds([_as_nhwc(c.repeat(2, 1, 1, 1), torch.float16, DEV) for c in conds])
+        ehs = torch.cat([ne, pe]).to(DEV, torch.float16).contiguous()
+        x = lat.permute(0, 2, 3, 1).contiguous().to(DEV)
+        for use_graphs in (True, False):
+            eng.set_options(use_graphs=use_graphs)
+            got = eng.denoise_loop(x.clone(), ehs, gs)
+            torch.cuda.synchronize()
+            assert torch.equal(got.permute(0, 3, 1, 2), want), use_graphs
+    finally:
+        ops.SIDE_ENABLED = prev
+        if eng is not None:
+            eng.close()
