@@ -26,6 +26,15 @@ def poll():
         time.sleep(0.3)
 
 
+def fmt(line):
+    """'GPU[0] : sclk clock level: 1: (2200Mhz)' -> 'sclk 2200Mhz'; 'GPU[0] : Current Socket Graphics Package Power (W): 1385.0' -> '1385.0 W'"""
+    if "sclk" in line:
+        return "sclk " + line.split("(")[-1].rstrip(")")
+    if "ower (W)" in line:
+        return line.rsplit(":", 1)[-1].strip() + " W"
+    return ""
+
+
 def attn_main():
     """--attn: the 14-sample head_dim-40 self-attention of UNet level 0, back to back."""
     N, h, S, d = 14, 8, 4096, 40
@@ -57,12 +66,43 @@ def attn_main():
     stop = True
     th.join()
     for t, keep in samples:
-        print(f"{t - t0:6.2f}s", " | ".join(keep)[:230])
+        print(f"{t - t0:6.2f}s", " | ".join(k for k in (fmt(k) for k in keep) if k))
+
+
+def pipeline_main(batch):
+    """--pipeline [--batch B]: the whole 50-step try-on loop (bench.py's workload), images back to back."""
+    import bench
+    dev = torch.device("cuda", 0)
+    pipe, ws, ucfg, vcfg = bench.build_pipeline(dev, torch.float16)
+    lat, pe, ne, imgs, cn = bench.make_inputs(ucfg, vcfg, batch, dev)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=imgs, latents=lat, guidance_scale=7.5, num_inference_steps=50,
+              output_type="pt", cond_noise=cn)
+    pipe(**kw)
+    pipe(**kw)
+    torch.cuda.synchronize()
+    th = threading.Thread(target=poll)
+    th.start()
+    time.sleep(1.0)
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < 6.0:
+        pipe(**kw)
+        n += 1
+    torch.cuda.synchronize()
+    print(f"busy phase: {n} calls of batch {batch}, {(time.time() - t0) / n * 1e3:.1f} ms each", flush=True)
+    time.sleep(1.0)
+    global stop
+    stop = True
+    th.join()
+    for t, keep in samples:
+        print(f"{t - t0:6.2f}s", " | ".join(k for k in (fmt(k) for k in keep) if k))
 
 
 def main():
     if "--attn" in sys.argv:
         return attn_main()
+    if "--pipeline" in sys.argv:
+        return pipeline_main(int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 1)
     N, H, C, k = 112, 64, 320, 3
     g = torch.Generator(device="cuda").manual_seed(0)
     x = torch.randn(N, H, H, C, generator=g, device="cuda").half()
@@ -93,7 +133,7 @@ def main():
     stop = True
     th.join()
     for t, keep in samples:
-        print(f"{t - t0:6.2f}s", " | ".join(keep)[:230])
+        print(f"{t - t0:6.2f}s", " | ".join(k for k in (fmt(k) for k in keep) if k))
 
 
 if __name__ == "__main__":

@@ -21,4 +21,10 @@ cp gpurun_out/traffic_b8/traffic.json $out/${R}_gemm_pmc_traffic_b8.json
 cp gpurun_out/traffic_b8/launches.json $out/${R}_gemm_step_launches_b8.json
 # 4. clock / power while the loop runs
 python3 tools/clock_probe.py > $out/${R}_clock_power_probe.txt 2>&1 || true
+python3 tools/clock_probe.py --attn > $out/${R}_clock_power_probe_attention.txt 2>&1 || true
+python3 tools/clock_probe.py --pipeline > $out/${R}_clock_power_probe_pipeline_b1.txt 2>&1 || true
+python3 tools/clock_probe.py --pipeline --batch 8 > $out/${R}_clock_power_probe_pipeline_b8.txt 2>&1 || true
+# 5. micro-benchmarks quoted in DESIGN.md
+python3 tools/attn_bench.py > $out/${R}_attn_bench.txt 2>&1 || true
+python3 tools/norm_bench.py > $out/${R}_norm_bench.txt 2>&1 || true
 ls -la $out
