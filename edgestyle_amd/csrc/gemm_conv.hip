@@ -34,6 +34,11 @@
 #include "../../include/edgestyle_hip.h"
 #include "plan.h"
 
+// Tool-only: cache policy of the weight-tile DMAs (aux bits of buffer_load ... lds: 2 = nt).  Product builds use 0.
+#ifndef ES_W_AUX
+#define ES_W_AUX 0
+#endif
+
 namespace {
 
 constexpr int BK = 64;
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
     for (int i = 0; i < WI; ++i)
       if (!(ES_ABLATE & 32) && wave * WI + i < WP)    // wave-uniform
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(ws + (wave * WI + i) * 1024), 16,
-                                                 (ES_ABLATE & 64) ? (int)OOB : (int)woff[i], soff_w, 0, 0);
+                                                 (ES_ABLATE & 64) ? (int)OOB : (int)woff[i], soff_w, 0, ES_W_AUX);
     if constexpr ((ES_ABLATE & 16) != 0) {
       // ablation: no activation DMAs
     } else if constexpr (ALIGNED) {
