@@ -8,6 +8,6 @@ FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -Wn
 for n in "$@"; do
   /opt/rocm/bin/hipcc $FLAGS -DES_ABLATE=$n -c gemm_conv.hip -o ../lib/ablate/gemm_abl$n.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/ablate/libes_abl$n.so ../lib/ablate/gemm_abl$n.o \
-      ../lib/obj/attention.o ../lib/obj/norm.o ../lib/obj/fusion.o ../lib/obj/elementwise.o
+      ../lib/obj/linear_xs.o ../lib/obj/attention.o ../lib/obj/norm.o ../lib/obj/fusion.o ../lib/obj/elementwise.o ../lib/obj/plan.o
   echo built abl$n
 done
