@@ -229,3 +229,63 @@ def test_full_size_pipeline_768_bf16_config4_vs_oracle(full96):
     p_ = H.psnr(img, ref)
     record("full_pipeline2_768_bf16", psnr_vs_live_oracle=p_)
     assert p_ >= 30.0, p_
+
+
+def test_full_width_chain_modes_agree(full):
+    """ES_CHAIN_MODE: the grouped lockstep pass (default, what the bench replays), the four chains one after the other and the
+    four chains on four HIP streams do the same arithmetic with different tile plans / launch groupings: at SD1.5 width
+    they agree to 5e-3 of the tensor's max (the tiny-width tests compare each with the oracle)."""
+    from edgestyle_amd.models import StepRunner
+    pipe = full["pipe"]
+    x, ehs, conds = H.full_step_inputs()
+    runner = StepRunner(pipe.unet, pipe.controlnet)
+    outs = {}
+    for mode in ("grouped", "serial", "streams"):
+        runner.mode = mode
+        o = runner.step_nchw(x.to(DEV), H.FULL_STEP_T, ehs.to(DEV), [c.to(DEV) for c in conds], H.FULL_STEP_SCALES)
+        torch.cuda.synchronize()
+        outs[mode] = o.float().cpu()
+    record("full_step_chain_modes", serial_vs_grouped=H.rel_err(outs["serial"], outs["grouped"]),
+           streams_vs_serial=H.rel_err(outs["streams"], outs["serial"]))
+    assert H.rel_err(outs["serial"], outs["grouped"]) <= 5e-3
+    assert H.rel_err(outs["streams"], outs["serial"]) <= 5e-3
+
+
+def test_full_size_guess_mode_and_unipc_vs_oracle(full):
+    """The two optional loop variants at the benchmarked geometry, latents only (no decode): guess_mode (CL:256-264, PL:453-459,
+    487-497: un-grouped per-net chains on the conditional half, log-spaced level scales) over 2 DDIM steps, and the UniPC
+    scheduler the reference's callers assign (TT:273) over 3 steps (fused predictor-corrector kernel), each vs the oracle."""
+    from oracle import sd15_oracle as O
+    from edgestyle_amd.schedulers import UniPCMultistepScheduler
+    pipe, ws, ucfg, vcfg = full["pipe"], full["ws"], full["ucfg"], full["vcfg"]
+    lat, pe, ne, pc = H.full_pipeline_inputs(seed=47)
+    nets = H.oracle_nets(ws, ucfg)
+    gs = 5.0
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=pc, latents=lat, guidance_scale=gs, output_type="latent")
+    got_g = pipe(num_inference_steps=2, guess_mode=True, **kw).images.float().cpu()
+    with torch.no_grad():
+        ref_g = O.pipeline(ws["unet"], ucfg, ws["fusion"], nets, ws["vae"], vcfg, lat, pe, ne, list(pc), num_inference_steps=2,
+                           guidance_scale=gs, guess_mode=True, decode=False)
+    e_g = H.rel_err(got_g, ref_g)
+    # UniPC: the oracle's scheduler restatement around the oracle's step
+    steps = 3
+    sch = O.UniPC()
+    ts = sch.set_timesteps(steps)
+    xo = lat.clone()
+    ehs = torch.cat([ne, pe])
+    oconds = [c.repeat(2, 1, 1, 1) for c in pc]
+    with torch.no_grad():
+        for t in ts.tolist():
+            eps = O.denoise_step(ws["unet"], ucfg, ws["fusion"], nets, torch.cat([xo] * 2), t, ehs, oconds, [1.0] * 6)
+            e_u, e_t = eps.chunk(2)
+            xo = sch.step(e_u + gs * (e_t - e_u), t, xo)
+    old = pipe.scheduler
+    pipe.scheduler = UniPCMultistepScheduler.from_config(getattr(old, "config", None))
+    try:
+        got_u = pipe(num_inference_steps=steps, **kw).images.float().cpu()
+    finally:
+        pipe.scheduler = old
+    e_u_ = H.rel_err(got_u, xo)
+    record("full_guess_mode_and_unipc", guess_latents_rel=e_g, unipc_latents_rel=e_u_)
+    assert e_g <= 3e-2, e_g
+    assert e_u_ <= 3e-2, e_u_
