@@ -395,6 +395,23 @@ extern "C" int es_denoise_loop(es_ctx* c, float* latents_inout, const void* ehs,
   return d2d(latents_inout, c->buf[ES_BUF_LATENTS], c->bytes[ES_BUF_LATENTS], st);
 }
 
+// == prepare_image (PL:629-664) + the one-time conditioning embedding (CL:28-42, 289-290) for all nets of the context
+extern "C" int es_prepare_conds(es_ctx* c, const float* const* images, const float* const* noise, void* stream) {
+  if (!c || !images) { es_set_error("es_prepare_conds: null argument"); return -1; }
+  if (!c->plan[ES_PLAN_CONDS]) { es_set_error("es_prepare_conds: the context has no ES_PLAN_CONDS (built from pre-embedded conditions)"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  for (int i = 0; i < c->g.n_conds; ++i) {
+    if (!images[i] || !c->buf[ES_BUF_COND_IMG0 + i]) { es_set_error("es_prepare_conds: condition image missing / ES_BUF_COND_IMG not bound"); return -1; }
+    if ((rc = d2d(c->buf[ES_BUF_COND_IMG0 + i], images[i], c->bytes[ES_BUF_COND_IMG0 + i], st))) return rc;
+    if (c->buf[ES_BUF_COND_NOISE0 + i]) {
+      if (!noise || !noise[i]) { es_set_error("es_prepare_conds: a VAE-conditioned net needs its latent sampling noise"); return -1; }
+      if ((rc = d2d(c->buf[ES_BUF_COND_NOISE0 + i], noise[i], c->bytes[ES_BUF_COND_NOISE0 + i], st))) return rc;
+    }
+  }
+  return run(c, ES_PLAN_CONDS, st, nullptr);
+}
+
 // == vae.decode(latents / scaling_factor) + image_processor.postprocess(output_type "pt") (PL:552-572):
 // latents fp32 [B,h,w,L] NHWC -> image fp32 [B,3,8h,8w] NCHW in [0,1]
 extern "C" int es_vae_decode(es_ctx* c, const float* latents, float* out_img, void* stream) {

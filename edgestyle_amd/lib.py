@@ -52,9 +52,10 @@ class CtxGeometry(C.Structure):
 
 
 # es_plan / es_ctx enums (include/edgestyle_hip.h)
-PLAN_STEP_GENERIC, PLAN_PREP, PLAN_STEP, PLAN_DECODE = 0, 1, 2, 3
+PLAN_STEP_GENERIC, PLAN_PREP, PLAN_STEP, PLAN_DECODE, PLAN_CONDS = 0, 1, 2, 3, 4
 (BUF_SAMPLE, BUF_T_ROWS, BUF_EHS, BUF_COND0, BUF_COND1, BUF_COND2, BUF_COND3, BUF_COND4, BUF_COND5, BUF_SCALES, BUF_NOISE,
  BUF_LATENTS, BUF_STEP_IDX, BUF_T_TABLE, BUF_SCALE_TABLE, BUF_COEF, BUF_TIMESTEPS, BUF_IMAGE) = range(18)
+BUF_COND_IMG0, BUF_COND_NOISE0 = 18, 24          # + net index
 OP_CONV_GEMM, OP_LINEAR_XS, OP_ATTENTION = 1, 2, 3      # csrc/plan.h es_op_kind (es_plan_count)
 PLAN_SIDE_BEGIN, PLAN_SIDE_END, PLAN_SIDE_JOIN = 64, 65, 66   # es_plan_mark
 
@@ -155,6 +156,7 @@ SYMBOLS = {
     "es_denoise_step": (C.c_int, [_P, _P, _F, _P, C.POINTER(_P), C.POINTER(C.c_float), _P, _P]),
     "es_denoise_loop": (C.c_int, [_P, _P, _P, _F, C.POINTER(C.c_float), _I, _P]),
     "es_vae_decode": (C.c_int, [_P, _P, _P, _P]),
+    "es_prepare_conds": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), _P]),
 }
 
 _lib = None
@@ -181,7 +183,7 @@ def load():
         fn = getattr(lib, name)           # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.es_abi_version() != 2:
+    if lib.es_abi_version() != 3:
         raise EdgeStyleHipError("libedgestyle_hip.so ABI version mismatch")
     for i, st in enumerate((GemmDesc, AttnDesc, GnDesc, FusionDesc, LnDesc, XsDesc)):
         if lib.es_sizeof_desc(i) != C.sizeof(st):

@@ -28,7 +28,10 @@ def _p(t: Optional[torch.Tensor]):
 
 class NativeEngine:
     def __init__(self, pipe, batch_size: int = 1, guidance: bool = True, num_inference_steps: int = 50,
-                 height: Optional[int] = None, width: Optional[int] = None, use_graphs: bool = True):
+                 height: Optional[int] = None, width: Optional[int] = None, use_graphs: bool = True,
+                 embed_conditions: bool = True):
+        """embed_conditions: also record ES_PLAN_CONDS (es_prepare_conds: RGB condition images -> embeddings), when every
+        net's conditioning path is one this builder knows (VAE-conditioned ControlLoRA nets, conv-stack ControlNets)."""
         if not isinstance(pipe.scheduler, DDIMScheduler):
             raise EdgeStyleHipError("the native loop implements the DDIM update (the BASELINE metric's scheduler)")
         self.pipe, self.lib = pipe, L.load()
@@ -79,6 +82,10 @@ class NativeEngine:
             dec = pipe.vae.decode_nhwc(loop.model_in[:B], unscaled_latents=True)
             out["img"] = ops.nhwc_to_nchw(dec, channels=3, scale=0.5, shift=0.5, clamp01=True)
 
+        # -- es_prepare_conds: static inputs + the embedding walk of pipeline.prepare_images as C-ABI launches only --------
+        self.cond_img, self.cond_noise = [None] * nn, [None] * nn
+        conds_fn = self._conds_fn(pipe, loop, B, guidance, h, w) if embed_conditions else None
+
         self._keep = []
         ctx = C.c_void_p()
         L.check(self.lib.es_ctx_create(dev.index or 0, C.byref(ctx)), "es_ctx_create")
@@ -87,7 +94,10 @@ class NativeEngine:
                             latent_pad=pipe.unet.engine.in_pad, n_conds=nn, n_steps=T, dtype=L.ES_F16 if self.dtype == torch.float16 else L.ES_BF16)
         L.check(self.lib.es_ctx_set_geometry(ctx, C.byref(geo)), "es_ctx_set_geometry")
         self.plan_sizes, self.plan_forks = {}, {}
-        for which, fn in ((L.PLAN_PREP, prep), (L.PLAN_STEP, loop.one_step), (L.PLAN_STEP_GENERIC, generic), (L.PLAN_DECODE, decode)):
+        todo = [(L.PLAN_PREP, prep), (L.PLAN_STEP, loop.one_step), (L.PLAN_STEP_GENERIC, generic), (L.PLAN_DECODE, decode)]
+        if conds_fn is not None:
+            todo.append((L.PLAN_CONDS, conds_fn))
+        for which, fn in todo:
             fn()                                     # eager: anything that allocates scratch does it outside the capture
             torch.cuda.synchronize()
             plan = C.c_void_p(self.lib.es_plan_create())
@@ -108,6 +118,10 @@ class NativeEngine:
                  L.BUF_SCALE_TABLE: loop.scale_table, L.BUF_COEF: loop.coef, L.BUF_TIMESTEPS: self.ts_dev, L.BUF_IMAGE: self.image}
         for i, c in enumerate(loop.conds):
             binds[L.BUF_COND0 + i] = c
+            if conds_fn is not None:
+                binds[L.BUF_COND_IMG0 + i] = self.cond_img[i]
+                if self.cond_noise[i] is not None:
+                    binds[L.BUF_COND_NOISE0 + i] = self.cond_noise[i]
         for slot, t in binds.items():
             L.check(self.lib.es_ctx_bind(ctx, slot, _p(t), t.numel() * t.element_size()), "es_ctx_bind")
         ac = pipe.scheduler.alphas_cumprod.float().contiguous()
@@ -116,6 +130,62 @@ class NativeEngine:
         self.set_options(use_graphs=use_graphs)
         loop.graph = None                            # the pipeline's own graph of this loop saw other table contents: re-capture
         loop.sig = None
+
+    def _conds_fn(self, pipe, loop, B, guidance, h, w):
+        """The one-time conditioning embedding (PL:352-377, 629-664; CL:28-42, 289-290) as pipeline.prepare_images does it -
+        each shared encoder once over the un-duplicated images of all its nets, the VAE sampling noise per CFG half -
+        on static inputs and through C-ABI launches only, so that a plan can record it.  None if a net's conditioning
+        path is not one of the two known ones."""
+        from .models import ControlLoRAModel, ControlNetModel
+        nets = pipe._nets
+        dev, dt = pipe.device, self.dtype
+        rep = 2 if guidance else 1
+        N = B * rep
+        groups = {}
+        for i, net in enumerate(nets):
+            if isinstance(net, ControlLoRAModel) and net.config.uses_vae:
+                if net._vae is None:
+                    return None
+                groups.setdefault(("vae", id(net._vae)), []).append(i)
+            elif isinstance(net, ControlNetModel):
+                groups.setdefault(("stack", id(net)), []).append(i)
+            else:
+                return None
+        scale = pipe.vae.cfg.scale
+        H, W = h * scale, w * scale
+        gbufs = []
+        for (kind, _), idx in groups.items():
+            gb = torch.zeros((len(idx) * B, 3, H, W), dtype=torch.float32, device=dev)
+            gbufs.append(gb)
+            for k, i in enumerate(idx):
+                self.cond_img[i] = gb[k * B:(k + 1) * B]
+                if kind == "vae":
+                    self.cond_noise[i] = torch.zeros((N, nets[i]._vae.cfg.latent_channels, h, w), dtype=torch.float32, device=dev)
+
+        def fn():
+            for ((kind, _), idx), gb in zip(groups.items(), gbufs):
+                x8 = ops.nchw_to_nhwc(gb, dt, 8)
+                if kind == "vae":
+                    vae = nets[idx[0]]._vae
+                    mom = vae.engine.encode_moments(x8)               # one encoder pass for all its nets, no CFG copy
+                    for k, i in enumerate(idx):
+                        mk = mom[k * B:(k + 1) * B]
+                        if rep > 1:
+                            mn = torch.empty((N,) + tuple(mk.shape[1:]), dtype=mk.dtype, device=dev)
+                            ops.memcpy(mn[:B], mk)
+                            ops.memcpy(mn[B:], mk)
+                        else:
+                            mn = mk
+                        z = ops.vae_sample(mn, self.cond_noise[i], vae.cfg.latent_channels, nets[i].engine.in_pad, vae.cfg.scaling_factor)
+                        ops.memcpy(loop.conds[i], nets[i].engine.embed_latent(z))
+                else:
+                    emb = nets[idx[0]].engine.embed_cond(x8)
+                    for k, i in enumerate(idx):
+                        e = emb[k * B:(k + 1) * B]
+                        ops.memcpy(loop.conds[i][:B], e)
+                        if rep > 1:
+                            ops.memcpy(loop.conds[i][B:], e)
+        return fn
 
     # -- thin ctypes drivers: raw device pointers in, raw device pointers out ------------------------------------------
     def set_options(self, cond_scales: Optional[Sequence[float]] = None, control_guidance_start: float = 0.0,
@@ -160,6 +230,23 @@ class NativeEngine:
         L.check(self.lib.es_denoise_loop(self.ctx, _p(latents), _p(ehs.contiguous()), float(guidance_scale), ts, len(timesteps),
                                          self._stream()), "es_denoise_loop")
         return latents
+
+    def prepare_conds(self, images: Sequence[torch.Tensor], noise: Optional[Sequence[Optional[torch.Tensor]]] = None):
+        """images: n x device fp32 [B,3,H,W]; noise: per net None or device fp32 [N,L,h,w] (VAE-conditioned nets need it)."""
+        if L.PLAN_CONDS not in self.plan_sizes:
+            raise EdgeStyleHipError("this context was built without ES_PLAN_CONDS")
+        imgs = [im.to(self.pipe.device, torch.float32).contiguous() for im in images]
+        nz = [None if (noise is None or noise[i] is None) else noise[i].to(self.pipe.device, torch.float32).contiguous()
+              for i in range(len(imgs))]
+        for i, im in enumerate(imgs):
+            if im.shape != self.cond_img[i].shape:
+                raise EdgeStyleHipError(f"prepare_conds: image {i} must be {tuple(self.cond_img[i].shape)}")
+            if nz[i] is not None and self.cond_noise[i] is not None and nz[i].shape != self.cond_noise[i].shape:
+                raise EdgeStyleHipError(f"prepare_conds: noise {i} must be {tuple(self.cond_noise[i].shape)}")
+        ip = (C.c_void_p * len(imgs))(*[im.data_ptr() for im in imgs])
+        npz = (C.c_void_p * len(imgs))(*[None if z is None else z.data_ptr() for z in nz])
+        L.check(self.lib.es_prepare_conds(self.ctx, ip, npz, self._stream()), "es_prepare_conds")
+        self._live = (imgs, nz)               # the copies are asynchronous: keep the sources until the next call
 
     def vae_decode(self, latents: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:

@@ -23,7 +23,7 @@ extern "C" {
 enum { ES_F16 = 0, ES_BF16 = 1 };
 enum { ES_ACT_NONE = 0, ES_ACT_SILU = 1, ES_ACT_GEGLU = 2 };
 
-#define ES_ABI_VERSION 2
+#define ES_ABI_VERSION 3
 int es_abi_version(void);
 /* sizeof the descriptor structs as compiled (0 gemm, 1 attn, 2 gn, 3 fusion, 4 ln, 5 xs): lets a binding verify its mirror */
 size_t es_sizeof_desc(int which);
@@ -278,6 +278,7 @@ int es_fill_f32(float* dst, float value, size_t n, void* stream);
  *   es_denoise_step  == OnnxUNetAndControlnets.forward                 export_onnx.py:43-74
  *   es_denoise_loop  == the loop of EdgeStyleStableDiffusionControlNetPipeline.__call__   model/edgestyle_pipeline.py:435-543
  *   es_vae_decode    == vae.decode(latents / scaling_factor) + postprocess               model/edgestyle_pipeline.py:552-572
+ *   es_prepare_conds == prepare_image + CachedControlNetModel.preprocess_image            model/edgestyle_pipeline.py:629-664, controllora.py:289-290
  * A context is BUILT by a host that can walk the model (edgestyle_amd/native.py does: it packs the weights, allocates
  * the static buffers, records the plans); after that no interpreter is involved in these calls.
  * ========================================================================================================= */
@@ -305,7 +306,8 @@ enum { ES_PLAN_STEP_GENERIC = 0,   /* es_denoise_step: text K/V projections + co
        ES_PLAN_PREP = 1,           /* es_denoise_loop, once: text K/V projections, condition slots, time-projection table */
        ES_PLAN_STEP = 2,           /* es_denoise_loop, per step: table-driven step + CFG + scheduler + counter */
        ES_PLAN_DECODE = 3,         /* es_vae_decode */
-       ES_PLAN_COUNT = 4 };
+       ES_PLAN_CONDS = 4,          /* es_prepare_conds: RGB condition images -> the condition embeddings in ES_BUF_COND* */
+       ES_PLAN_COUNT = 5 };
 enum { ES_BUF_SAMPLE = 0,          /* dtype [N,h,w,latent_pad]: the networks' input (both CFG halves) */
        ES_BUF_T_ROWS, ES_BUF_EHS,  /* fp32 [kmax*N] timestep copies; dtype [N,77,D] text states */
        ES_BUF_COND0, ES_BUF_COND1, ES_BUF_COND2, ES_BUF_COND3, ES_BUF_COND4, ES_BUF_COND5,   /* dtype [N,h,w,C0] each */
@@ -315,6 +317,11 @@ enum { ES_BUF_SAMPLE = 0,          /* dtype [N,h,w,latent_pad]: the networks' in
        ES_BUF_STEP_IDX,            /* int32 device step counter */
        ES_BUF_T_TABLE, ES_BUF_SCALE_TABLE, ES_BUF_COEF, ES_BUF_TIMESTEPS,   /* fp32 [T,kmax*N], [T,n_conds], [T,4], [T] */
        ES_BUF_IMAGE,               /* fp32 [B,3,8h,8w] NCHW decoded image in [0,1] */
+       /* es_prepare_conds inputs: the RGB condition image of net i, fp32 NCHW [B,3,8h,8w] (VAE-conditioned nets: in [-1,1],
+        * pose nets: in [0,1], as the reference's callers pass them, TT:29-48), and - VAE-conditioned nets only - the
+        * latent_dist.sample() noise of CL:39 for the CFG-duplicated batch, fp32 [N,latent_channels,h,w] */
+       ES_BUF_COND_IMG0, ES_BUF_COND_IMG1, ES_BUF_COND_IMG2, ES_BUF_COND_IMG3, ES_BUF_COND_IMG4, ES_BUF_COND_IMG5,
+       ES_BUF_COND_NOISE0, ES_BUF_COND_NOISE1, ES_BUF_COND_NOISE2, ES_BUF_COND_NOISE3, ES_BUF_COND_NOISE4, ES_BUF_COND_NOISE5,
        ES_BUF_COUNT };
 typedef struct {
   int32_t B, cfg;                  /* images per call; 1 = classifier-free guidance (N = 2B) */
@@ -350,6 +357,13 @@ int es_denoise_step(es_ctx* c, const void* sample, float t, const void* ehs, con
 int es_denoise_loop(es_ctx* c, float* latents_inout, const void* ehs, float guidance_scale, const float* timesteps,
                     int n_steps, void* stream);
 int es_vae_decode(es_ctx* c, const float* latents, float* out_img, void* stream);
+/* == prepare_image + the one-time conditioning embedding (model/edgestyle_pipeline.py:352-377, 629-664;
+ * model/controllora.py:28-42, 289-290): images[n_conds] device fp32 NCHW [B,3,8h,8w]; noise[n_conds] device fp32
+ * [N,latent_channels,h,w] for the nets whose ES_BUF_COND_NOISE slot is bound (the VAE-conditioned ones: the library has no
+ * RNG, the host draws what the reference's global generator would), ignored (may be NULL) for the others.  Each shared
+ * encoder (the VAE of the LoRA nets, the conv stack of the pose net) runs once over the un-duplicated images of all its
+ * nets; results land in ES_BUF_COND0.. as [N,h,w,C0], ready for es_denoise_loop / es_ctx_launch_plan. */
+int es_prepare_conds(es_ctx* c, const float* const* images, const float* const* noise, void* stream);
 
 #ifdef __cplusplus
 }

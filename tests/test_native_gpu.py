@@ -205,3 +205,50 @@ def test_side_section_fork_and_join_in_the_pipeline_graph_and_in_the_native_plan
         ops.SIDE_ENABLED = prev
         if eng is not None:
             eng.close()
+
+
+def test_es_prepare_conds_from_rgb_images_equals_the_pipeline_bitwise(built):
+    """es_prepare_conds(ctx, images[6], noise[6]) == prepare_image + the one-time conditioning embedding (PL:629-664,
+    CL:28-42, 289-290): raw RGB condition images (LoRA nets: [-1,1] through the VAE encoder + latent_dist.sample() with the
+    caller's noise; pose nets: [0,1] through the conv stack), then es_denoise_loop + es_vae_decode - the whole try-on behind
+    device pointers - against the pipeline called with the same images and `cond_noise`, bit for bit."""
+    from edgestyle_amd.native import NativeEngine
+    pipe, eng0, ws, ucfg, vcfg = built
+    assert L.PLAN_CONDS not in eng0.plan_sizes             # built before the LoRA nets had an autoencoder: nothing to record
+    for net in pipe.controlnet.nets:
+        if getattr(net.config, "uses_vae", False):
+            net.set_autoencoder(pipe.vae)                  # TT:252-258 (vae= of from_pretrained)
+    eng = NativeEngine(pipe, batch_size=1, num_inference_steps=6)
+    assert eng.plan_sizes[L.PLAN_CONDS] > 50
+    g = torch.Generator().manual_seed(77)
+    s = ucfg.sample_size
+    H = s * vcfg.scale
+    lat = torch.randn(1, 4, s, s, generator=g)
+    pe = (torch.randn(1, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+    ne = (torch.randn(1, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+    nets = pipe.controlnet.nets
+    imgs, noise = [], []
+    for net in nets:
+        uses_vae = bool(getattr(net.config, "uses_vae", False))
+        im = torch.rand(1, 3, H, H, generator=g)
+        imgs.append(im * 2 - 1 if uses_vae else im)                       # TT:29-48
+        noise.append(torch.randn(2, vcfg.latent_channels, s, s, generator=g) if uses_vae else None)
+    gs, T = 5.0, eng.T
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=imgs, latents=lat, guidance_scale=gs, num_inference_steps=T,
+              cond_noise=noise)
+    want_lat = pipe(output_type="latent", **kw).images.clone()
+    want_img = pipe(output_type="pt", **kw).images.clone()
+    ehs = torch.cat([ne, pe]).to(DEV, torch.float16).contiguous()
+    x = lat.permute(0, 2, 3, 1).contiguous().to(DEV)
+    for use_graphs in (True, False):
+        eng.set_options(use_graphs=use_graphs)
+        eng.prepare_conds([im.to(DEV) for im in imgs], [None if z is None else z.to(DEV) for z in noise])
+        got = eng.denoise_loop(x.clone(), ehs, gs)
+        img = eng.vae_decode(got)
+        torch.cuda.synchronize()
+        assert torch.equal(got.permute(0, 3, 1, 2), want_lat), float((got.permute(0, 3, 1, 2) - want_lat).abs().max())
+        assert torch.equal(img, want_img)
+    # a VAE-conditioned net without its sampling noise is refused (the library has no RNG)
+    with pytest.raises(L.EdgeStyleHipError):
+        eng.prepare_conds([im.to(DEV) for im in imgs], None)
+    eng.close()
