@@ -1,5 +1,10 @@
 #!/usr/bin/env python
-"""Sample rocm-smi (sclk / power) while a big conv GEMM runs back to back: what clock does the MFMA path sustain?"""
+"""Sample rocm-smi (sclk / power) while a workload repeats: what clock does the chip sustain under it?
+
+    python tools/clock_probe.py                       a big conv GEMM back to back (the MFMA path)
+    python tools/clock_probe.py --attn                the 14-sample head_dim-40 self-attention of UNet level 0
+    python tools/clock_probe.py --pipeline [--batch B]   the whole 50-step try-on loop (bench.py's workload)
+"""
 import os
 import subprocess
 import sys

@@ -1,5 +1,6 @@
+"""Two conv3x3 launches in a loop and nothing else: the workload for stamp / ablation builds (ES_HIP_LIB) under rocprofv3."""
 import sys, os, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from edgestyle_amd import ops
 dev="cuda"; g=torch.Generator(device=dev).manual_seed(0)
 def run(N,H,Cin,Cout,k,R=20):
