@@ -9,6 +9,7 @@
 // torch, no allocation in these calls.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
 #include <vector>
 
@@ -150,6 +151,34 @@ extern "C" int es_plan_launch(const es_plan* p, void* stream) {
   return run_plan(p, (hipStream_t)stream, nullptr);
 }
 
+// Flat image of a plan (es_ctx_save / es_ctx_load): u64 n_ops, u64 blob bytes, n_ops x {i64 kind, u64 off, u64 bytes}, blob.
+// The blob still holds the RECORDED device addresses: whoever moves it relocates them (edgestyle_amd/native.py save()).
+extern "C" size_t es_plan_export(const es_plan* p, void* out, size_t cap) {
+  if (!p) return 0;
+  const size_t need = 16 + p->ops.size() * 24 + p->blob.size();
+  if (!out || cap < need) return need;
+  unsigned long long* w = (unsigned long long*)out;
+  w[0] = p->ops.size(); w[1] = p->blob.size();
+  size_t k = 2;
+  for (const auto& op : p->ops) { w[k++] = (unsigned long long)(long long)op.kind; w[k++] = op.off; w[k++] = op.bytes; }
+  if (!p->blob.empty()) memcpy(w + k, p->blob.data(), p->blob.size());
+  return need;
+}
+extern "C" es_plan* es_plan_import(const void* data, size_t size) {
+  if (!data || size < 16) { es_set_error("es_plan_import: truncated image"); return nullptr; }
+  const unsigned long long* w = (const unsigned long long*)data;
+  const size_t n = (size_t)w[0], nb = (size_t)w[1];
+  if (n > (1u << 24) || size < 16 + n * 24 + nb) { es_set_error("es_plan_import: truncated image"); return nullptr; }
+  es_plan* p = new es_plan();
+  p->ops.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    p->ops[i] = {(int)(long long)w[2 + 3 * i], (size_t)w[3 + 3 * i], (size_t)w[4 + 3 * i]};
+    if (p->ops[i].off + p->ops[i].bytes > nb) { delete p; es_set_error("es_plan_import: op outside the blob"); return nullptr; }
+  }
+  p->blob.assign((const char*)(w + 2 + 3 * n), (const char*)(w + 2 + 3 * n) + nb);
+  return p;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 struct es_ctx {
   int device = 0;
@@ -168,6 +197,7 @@ struct es_ctx {
   size_t host_cap = 0;              // asynchronous, so the buffer is only rewritten after `staged` - recorded behind the
   hipEvent_t staged = nullptr;      // previous call's copies - has completed
   std::vector<float> alphas_cumprod;   // the scheduler's schedule (es_ctx_set_alphas_cumprod; SD1.5 default otherwise)
+  void* arena = nullptr;               // es_ctx_load: the one device allocation every recorded pointer was relocated into
 };
 
 namespace {
@@ -277,6 +307,7 @@ extern "C" void es_ctx_destroy(es_ctx* c) {
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   if (c->staged) { (void)hipEventSynchronize(c->staged); (void)hipEventDestroy(c->staged); }
   if (c->host) (void)hipHostFree(c->host);
+  if (c->arena) (void)hipFree(c->arena);
   delete c;
 }
 extern "C" int es_ctx_set_geometry(es_ctx* c, const es_ctx_geometry* g) {
@@ -325,6 +356,78 @@ extern "C" int es_ddim_coef_table(const float* alphas_cumprod, int n_alphas, con
   ddim_coef_from(ac, timesteps, n, out);
   return 0;
 }
+extern "C" es_plan* es_ctx_plan(es_ctx* c, int which) {           // borrowed: the context keeps ownership
+  return (c && which >= 0 && which < ES_PLAN_COUNT) ? c->plan[which] : nullptr;
+}
+
+// A context image written by edgestyle_amd/native.py NativeEngine.save(): geometry, options, the five plans with a
+// relocation table each, the bound slots, and the contents of every device block a recorded pointer falls into (packed
+// weights, tables, static buffers, activation scratch).  Loading it needs no Python, no torch and no model code: one
+// hipMalloc, one pass of copies, pointer relocation - the counterpart of SURVEY 8b's es_load_weights for a host that cannot
+// walk the model itself.  Layout (little endian, 8-byte aligned): see save().
+extern "C" int es_ctx_load(const char* path, int device, es_ctx** out) {
+  if (!path || !out) { es_set_error("es_ctx_load: null argument"); return -1; }
+  FILE* f = fopen(path, "rb");
+  if (!f) { es_set_error("es_ctx_load: cannot open the file"); return -1; }
+  es_ctx* c = nullptr;
+  std::vector<char> buf;
+  auto fail = [&](const char* msg) { es_set_error(msg); if (c) es_ctx_destroy(c); fclose(f); return -1; };
+  auto rd = [&](void* dst, size_t n) { return fread(dst, 1, n, f) == n; };
+  struct { char magic[8]; unsigned abi, n_blocks; unsigned long long arena_bytes; } h;
+  if (!rd(&h, sizeof(h)) || memcmp(h.magic, "ESCTX\1\0\0", 8) != 0) return fail("es_ctx_load: not a context image");
+  if (h.abi != ES_ABI_VERSION) return fail("es_ctx_load: the image was written for another ABI version");
+  if (hipSetDevice(device) != hipSuccess) return fail("es_ctx_load: hipSetDevice failed");
+  c = new es_ctx();
+  c->device = device;
+  struct { float cond_scales[6]; float start, end; int use_graphs; unsigned n_alphas; } o;
+  if (!rd(&c->g, sizeof(c->g)) || !rd(&o, sizeof(o))) return fail("es_ctx_load: truncated header");
+  memcpy(c->cond_scales, o.cond_scales, sizeof(o.cond_scales));
+  c->control_start = o.start; c->control_end = o.end; c->use_graphs = o.use_graphs;
+  c->alphas_cumprod.resize(o.n_alphas);
+  if (o.n_alphas && !rd(c->alphas_cumprod.data(), o.n_alphas * sizeof(float))) return fail("es_ctx_load: truncated schedule");
+  if ((o.n_alphas & 1) && fseek(f, 4, SEEK_CUR)) return fail("es_ctx_load: truncated schedule");
+  struct Blk { unsigned long long off, bytes; };
+  std::vector<Blk> blocks(h.n_blocks);
+  if (h.n_blocks && !rd(blocks.data(), h.n_blocks * sizeof(Blk))) return fail("es_ctx_load: truncated block table");
+  for (const auto& b : blocks) if (b.off + b.bytes > h.arena_bytes) return fail("es_ctx_load: block outside the arena");
+  if (hipMalloc(&c->arena, h.arena_bytes ? h.arena_bytes : 256) != hipSuccess) return fail("es_ctx_load: hipMalloc of the arena failed");
+  char* base = (char*)c->arena;
+  for (int which = 0; which < ES_PLAN_COUNT; ++which) {
+    unsigned long long pb = 0, nrel = 0;
+    if (!rd(&pb, 8)) return fail("es_ctx_load: truncated plan table");
+    if (!pb) continue;
+    buf.resize(pb);
+    if (!rd(buf.data(), pb) || !rd(&nrel, 8)) return fail("es_ctx_load: truncated plan");
+    es_plan* p = es_plan_import(buf.data(), pb);
+    if (!p) { if (c) es_ctx_destroy(c); fclose(f); return -1; }
+    c->plan[which] = p;
+    for (unsigned long long i = 0; i < nrel; ++i) {
+      unsigned long long r[2];
+      if (!rd(r, 16) || r[0] + 8 > p->blob.size() || r[1] >= h.arena_bytes) return fail("es_ctx_load: bad relocation");
+      const unsigned long long addr = (unsigned long long)(base + r[1]);
+      memcpy(p->blob.data() + r[0], &addr, 8);
+    }
+  }
+  for (int slot = 0; slot < ES_BUF_COUNT; ++slot) {
+    long long r[2];
+    if (!rd(r, 16)) return fail("es_ctx_load: truncated slot table");
+    if (r[0] >= 0) { c->buf[slot] = base + r[0]; c->bytes[slot] = (size_t)r[1]; }
+  }
+  // block contents, in table order, through a bounded staging buffer
+  buf.resize(64u << 20);
+  for (const auto& b : blocks) {
+    for (unsigned long long done = 0; done < b.bytes;) {
+      const size_t n = (size_t)((b.bytes - done) < buf.size() ? (b.bytes - done) : buf.size());
+      if (!rd(buf.data(), n)) return fail("es_ctx_load: truncated block data");
+      if (hipMemcpy(base + b.off + done, buf.data(), n, hipMemcpyHostToDevice) != hipSuccess) return fail("es_ctx_load: copy to the device failed");
+      done += n;
+    }
+  }
+  fclose(f);
+  *out = c;
+  return 0;
+}
+
 extern "C" int es_ctx_plan_size(const es_ctx* c, int which) {
   return (c && which >= 0 && which < ES_PLAN_COUNT && c->plan[which]) ? es_plan_size(c->plan[which]) : -1;
 }

@@ -151,6 +151,10 @@ SYMBOLS = {
     "es_ctx_set_options": (C.c_int, [_P, C.POINTER(C.c_float), _F, _F, _I]),
     "es_ctx_set_alphas_cumprod": (C.c_int, [_P, C.POINTER(C.c_float), _I]),
     "es_ctx_plan_size": (C.c_int, [_P, _I]),
+    "es_ctx_plan": (_P, [_P, _I]),
+    "es_ctx_load": (C.c_int, [C.c_char_p, _I, C.POINTER(_P)]),
+    "es_plan_export": (C.c_size_t, [_P, _P, C.c_size_t]),
+    "es_plan_import": (_P, [_P, C.c_size_t]),
     "es_ctx_launch_plan": (C.c_int, [_P, _I, C.POINTER(C.c_float), _P]),
     "es_ddim_coef_table": (C.c_int, [C.POINTER(C.c_float), _I, C.POINTER(C.c_float), _I, C.POINTER(C.c_float)]),
     "es_denoise_step": (C.c_int, [_P, _P, _F, _P, C.POINTER(_P), C.POINTER(C.c_float), _P, _P]),

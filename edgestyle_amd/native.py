@@ -35,6 +35,7 @@ class NativeEngine:
         if not isinstance(pipe.scheduler, DDIMScheduler):
             raise EdgeStyleHipError("the native loop implements the DDIM update (the BASELINE metric's scheduler)")
         self.pipe, self.lib = pipe, L.load()
+        self._cond_scales = [1.0] * 6
         dev = pipe.device
         ucfg, vcfg = pipe.unet.cfg, pipe.vae.cfg
         h = (height // vcfg.scale) if height else ucfg.sample_size
@@ -93,6 +94,7 @@ class NativeEngine:
         geo = L.CtxGeometry(B=B, cfg=int(guidance), h=h, w=w, latent_channels=ucfg.in_channels,
                             latent_pad=pipe.unet.engine.in_pad, n_conds=nn, n_steps=T, dtype=L.ES_F16 if self.dtype == torch.float16 else L.ES_BF16)
         L.check(self.lib.es_ctx_set_geometry(ctx, C.byref(geo)), "es_ctx_set_geometry")
+        self._geo = geo
         self.plan_sizes, self.plan_forks = {}, {}
         todo = [(L.PLAN_PREP, prep), (L.PLAN_STEP, loop.one_step), (L.PLAN_STEP_GENERIC, generic), (L.PLAN_DECODE, decode)]
         if conds_fn is not None:
@@ -122,6 +124,7 @@ class NativeEngine:
                 binds[L.BUF_COND_IMG0 + i] = self.cond_img[i]
                 if self.cond_noise[i] is not None:
                     binds[L.BUF_COND_NOISE0 + i] = self.cond_noise[i]
+        self._binds = binds
         for slot, t in binds.items():
             L.check(self.lib.es_ctx_bind(ctx, slot, _p(t), t.numel() * t.element_size()), "es_ctx_bind")
         ac = pipe.scheduler.alphas_cumprod.float().contiguous()
@@ -193,6 +196,8 @@ class NativeEngine:
         arr = None
         if cond_scales is not None:
             arr = (C.c_float * 6)(*([float(s) for s in cond_scales] + [1.0] * (6 - len(cond_scales))))
+            self._cond_scales = list(arr)
+        self._cg, self._use_graphs = (float(control_guidance_start), float(control_guidance_end)), bool(use_graphs)
         L.check(self.lib.es_ctx_set_options(self.ctx, arr, control_guidance_start, control_guidance_end, int(use_graphs)),
                 "es_ctx_set_options")
 
@@ -253,6 +258,103 @@ class NativeEngine:
             out = torch.empty_like(self.image)
         L.check(self.lib.es_vae_decode(self.ctx, _p(latents), _p(out), self._stream()), "es_vae_decode")
         return out
+
+    # -- context image: everything es_ctx_load needs to run this context without Python ---------------------------------
+    def save(self, path: str) -> dict:
+        """Write a context image for es_ctx_load (include/edgestyle_hip.h).  Every 8-byte word of the recorded launch lists
+        that falls inside a device segment of the allocator is a recorded pointer: it is replaced by an offset into one arena
+        that holds a copy of each segment referenced (packed weights, norm parameters, tables, static buffers, activation
+        scratch - the activations' contents do not matter but their space does).  Returns a summary dict."""
+        import struct
+        import numpy as np
+        torch.cuda.synchronize()
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        # the caching allocator's segments (hipMalloc granules; graph-private pools included), sorted by address.  Whole
+        # segments, not blocks: an activation freed DURING a capture is an inactive block of its private pool, and the
+        # captured kernels still write there at every replay
+        starts, sizes = [], []
+        for seg in torch.cuda.memory_snapshot():
+            starts.append(seg["address"])
+            sizes.append(seg["total_size"])
+        order = np.argsort(np.array(starts, dtype=np.uint64))
+        starts = np.array(starts, dtype=np.uint64)[order]
+        ends = starts + np.array(sizes, dtype=np.uint64)[order]
+
+        def locate(addrs):
+            """block index of every address (or -1)"""
+            idx = np.searchsorted(starts, addrs, side="right").astype(np.int64) - 1
+            ok = (idx >= 0) & (addrs < ends[np.clip(idx, 0, len(ends) - 1)])
+            return np.where(ok, idx, -1)
+
+        plans, used = {}, set()
+        for which in range(5):
+            pl = self.lib.es_ctx_plan(self.ctx, which)
+            if not pl:
+                continue
+            n = self.lib.es_plan_export(pl, None, 0)
+            raw = (C.c_char * n)()
+            self.lib.es_plan_export(pl, raw, n)
+            img = np.frombuffer(raw, dtype=np.uint8).copy()
+            n_ops = int(img[:8].view(np.uint64)[0])
+            blob0 = 16 + 24 * n_ops
+            words = img[blob0:blob0 + (len(img) - blob0) // 8 * 8].view(np.uint64)
+            blk = locate(words)
+            hit = np.nonzero(blk >= 0)[0]
+            rel = [(int(i) * 8, int(blk[i]), int(words[i] - starts[blk[i]])) for i in hit]
+            used.update(b for _, b, _ in rel)
+            plans[which] = (img, rel)
+        binds = {}
+        for slot, t in self._binds.items():
+            b = int(locate(np.array([t.data_ptr()], dtype=np.uint64))[0])
+            if b < 0:
+                raise EdgeStyleHipError("save: a bound buffer is not a live allocation")
+            used.add(b)
+            binds[slot] = (b, t.data_ptr() - int(starts[b]), t.numel() * t.element_size())
+        # arena layout
+        off, arena = {}, 0
+        for b in sorted(used):
+            off[b] = arena
+            arena += (int(ends[b] - starts[b]) + 255) // 256 * 256
+        g = self._geo
+        ac = self.pipe.scheduler.alphas_cumprod.float().contiguous().numpy()
+        with open(path, "wb") as f:
+            f.write(b"ESCTX\x01\x00\x00" + struct.pack("<IIQ", 3, len(used), arena))
+            f.write(bytes(g))
+            f.write(struct.pack("<6fffiI", *self._cond_scales, self._cg[0], self._cg[1], int(self._use_graphs), len(ac)))
+            f.write(ac.tobytes())
+            if len(ac) & 1:
+                f.write(b"\0" * 4)
+            for b in sorted(used):
+                f.write(struct.pack("<QQ", off[b], int(ends[b] - starts[b])))
+            for which in range(5):
+                if which not in plans:
+                    f.write(struct.pack("<Q", 0))
+                    continue
+                img, rel = plans[which]
+                f.write(struct.pack("<Q", len(img)))
+                f.write(img.tobytes())
+                f.write(struct.pack("<Q", len(rel)))
+                for blob_off, b, o in rel:
+                    f.write(struct.pack("<QQ", blob_off, off[b] + o))
+            nslots = L.BUF_COND_NOISE0 + 6
+            for slot in range(nslots):
+                if slot in binds:
+                    b, o, nb = binds[slot]
+                    f.write(struct.pack("<qQ", off[b] + o, nb))
+                else:
+                    f.write(struct.pack("<qQ", -1, 0))
+            host = np.empty(64 << 20, dtype=np.uint8)
+            for b in sorted(used):
+                nb, done = int(ends[b] - starts[b]), 0
+                while done < nb:
+                    n = min(nb - done, host.nbytes)
+                    rc = hip.hipMemcpy(host.ctypes.data, C.c_void_p(int(starts[b]) + done), n, 2)
+                    if rc != 0:
+                        raise EdgeStyleHipError(f"save: hipMemcpy failed ({rc})")
+                    f.write(host[:n].tobytes())
+                    done += n
+        return dict(blocks=len(used), arena_bytes=arena, relocations={w: len(r) for w, (_, r) in plans.items()})
 
     def close(self):
         if self.ctx:

@@ -301,6 +301,10 @@ int es_plan_mark(int kind);
 int es_plan_size(const es_plan* p);                    /* number of recorded calls (markers included) */
 int es_plan_count(const es_plan* p, int kind);         /* ... of one kind (csrc/plan.h: 1 = es_conv_gemm, 2 = es_linear_xs, ...) */
 int es_plan_launch(const es_plan* p, void* stream);
+/* flat image of a plan: returns the bytes needed; writes them when cap suffices.  The recorded device addresses inside
+ * are NOT relocated (edgestyle_amd/native.py save() builds the relocation tables es_ctx_load applies) */
+size_t es_plan_export(const es_plan* p, void* out, size_t cap);
+es_plan* es_plan_import(const void* data, size_t size);
 
 enum { ES_PLAN_STEP_GENERIC = 0,   /* es_denoise_step: text K/V projections + condition slots + time embedding + step */
        ES_PLAN_PREP = 1,           /* es_denoise_loop, once: text K/V projections, condition slots, time-projection table */
@@ -341,6 +345,11 @@ int es_ctx_set_options(es_ctx* c, const float* cond_scales, float control_guidan
                        int use_graphs);
 int es_ctx_set_alphas_cumprod(es_ctx* c, const float* alphas_cumprod, int n);   /* scheduler schedule (default: SD1.5's) */
 int es_ctx_plan_size(const es_ctx* c, int which);
+es_plan* es_ctx_plan(es_ctx* c, int which);             /* borrowed */
+/* Load a context image written by NativeEngine.save(path) (edgestyle_amd/native.py): packed weights, tables, static buffers,
+ * the five launch lists and their pointer relocations.  No Python, torch or model code is needed to load or run it - this is
+ * what stands in for SURVEY 8b's es_load_weights when the host cannot walk the model itself: build once, ship the image. */
+int es_ctx_load(const char* path, int device, es_ctx** out);
 /* run ONE plan of the context on `stream` (guidance_scale: pointer to the CFG scale for the scheduler call of
  * ES_PLAN_STEP, or NULL = as recorded): single-stepping a prepared loop */
 int es_ctx_launch_plan(es_ctx* c, int which, const float* guidance_scale, void* stream);

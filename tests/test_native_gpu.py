@@ -252,3 +252,59 @@ def test_es_prepare_conds_from_rgb_images_equals_the_pipeline_bitwise(built):
     with pytest.raises(L.EdgeStyleHipError):
         eng.prepare_conds([im.to(DEV) for im in imgs], None)
     eng.close()
+
+
+def test_context_image_saved_here_runs_in_a_process_without_torch(built, tmp_path):
+    """NativeEngine.save(path) -> es_ctx_load(path) in a child process that imports neither torch nor this package
+    (tests/run_ctx_image.py: ctypes on the library and the HIP runtime only): RGB condition images -> es_prepare_conds ->
+    es_denoise_loop -> es_vae_decode there equals the pipeline here, bit for bit.  This is the stand-in for SURVEY 8b's
+    es_load_weights: the image carries the packed weights, the static buffers and the relocated launch lists."""
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    from edgestyle_amd.native import NativeEngine
+    pipe, eng0, ws, ucfg, vcfg = built
+    for net in pipe.controlnet.nets:
+        if getattr(net.config, "uses_vae", False):
+            net.set_autoencoder(pipe.vae)
+    T, gs = 4, 6.0
+    eng = NativeEngine(pipe, batch_size=1, num_inference_steps=T)
+    try:
+        g = torch.Generator().manual_seed(91)
+        s = ucfg.sample_size
+        H = s * vcfg.scale
+        lat = torch.randn(1, 4, s, s, generator=g)
+        pe = (torch.randn(1, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+        ne = (torch.randn(1, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+        imgs, noise = [], []
+        for net in pipe.controlnet.nets:
+            uses_vae = bool(getattr(net.config, "uses_vae", False))
+            im = torch.rand(1, 3, H, H, generator=g)
+            imgs.append(im * 2 - 1 if uses_vae else im)
+            noise.append(torch.randn(2, vcfg.latent_channels, s, s, generator=g) if uses_vae else None)
+        kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=imgs, latents=lat, guidance_scale=gs, num_inference_steps=T,
+                  cond_noise=noise)
+        want_lat = pipe(output_type="latent", **kw).images.float().cpu()
+        want_img = pipe(output_type="pt", **kw).images.float().cpu()
+        path = str(tmp_path / "ctx.esctx")
+        info = eng.save(path)
+        assert info["relocations"][L.PLAN_STEP] > 1000 and os.path.getsize(path) > info["arena_bytes"]
+        arrs = dict(n_conds=np.int64(len(imgs)), latents=lat.permute(0, 2, 3, 1).contiguous().numpy(),
+                    ehs=torch.cat([ne, pe]).half().numpy(), guidance_scale=np.float32(gs),
+                    timesteps=pipe.scheduler.set_timesteps(T).float().numpy())
+        for i, (im, nz) in enumerate(zip(imgs, noise)):
+            arrs[f"img{i}"] = im.numpy()
+            if nz is not None:
+                arrs[f"noise{i}"] = nz.numpy()
+        np.savez(str(tmp_path / "in.npz"), **arrs)
+    finally:
+        eng.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "run_ctx_image.py"), path, str(tmp_path / "in.npz"),
+                        str(tmp_path / "out.npz")], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = np.load(str(tmp_path / "out.npz"))
+    got_lat = torch.from_numpy(out["latents"]).permute(0, 3, 1, 2)
+    assert torch.equal(got_lat, want_lat), float((got_lat - want_lat).abs().max())
+    assert torch.equal(torch.from_numpy(out["image"]), want_img)
