@@ -54,6 +54,34 @@ def test_plan_records_nothing_and_launches_nothing_without_a_gpu():
     L.es_plan_destroy(b)
 
 
+def test_plan_image_round_trip_markers_and_context_image_errors(tmp_path):
+    """Host-only parts of the context-image machinery: es_plan_export / es_plan_import round trip (stream markers recorded
+    through es_plan_mark included), refusal of truncated images, and es_ctx_load's errors on a missing / foreign file
+    (nothing touches a GPU: the file is rejected before any HIP call)."""
+    L = lib.load()
+    p = ctypes.c_void_p(L.es_plan_create())
+    assert L.es_plan_mark(lib.PLAN_SIDE_BEGIN) == 0 and L.es_plan_size(p) == 0      # nothing records: a no-op
+    assert L.es_plan_mark(7) != 0 and b"marker" in L.es_last_error()
+    assert L.es_plan_begin_record(p) == 0
+    for k in (lib.PLAN_SIDE_BEGIN, lib.PLAN_SIDE_END, lib.PLAN_SIDE_JOIN):
+        assert L.es_plan_mark(k) == 0
+    assert L.es_plan_end_record(p) == 0 and L.es_plan_size(p) == 3
+    n = L.es_plan_export(p, None, 0)
+    assert n == 16 + 3 * 24
+    buf = (ctypes.c_char * n)()
+    assert L.es_plan_export(p, buf, n) == n
+    q = ctypes.c_void_p(L.es_plan_import(buf, n))
+    assert q.value and L.es_plan_size(q) == 3 and L.es_plan_count(q, lib.PLAN_SIDE_JOIN) == 1
+    assert not L.es_plan_import(buf, n - 8) and b"truncated" in L.es_last_error()
+    L.es_plan_destroy(p)
+    L.es_plan_destroy(q)
+    ctx = ctypes.c_void_p()
+    assert L.es_ctx_load(str(tmp_path / "missing.esctx").encode(), 0, ctypes.byref(ctx)) != 0 and b"open" in L.es_last_error()
+    bad = tmp_path / "bad.esctx"
+    bad.write_bytes(b"not a context image at all, just some bytes" * 4)
+    assert L.es_ctx_load(str(bad).encode(), 0, ctypes.byref(ctx)) != 0 and b"not a context image" in L.es_last_error()
+
+
 def test_native_ddim_coefficients_match_the_host_scheduler():
     """es_ddim_coef_table (what es_denoise_loop derives from `timesteps`, host-only code) vs DDIMScheduler.coef_table():
     bit for bit with the scheduler's alphas_cumprod handed over, within 1e-6 with the library's own SD1.5 schedule."""
