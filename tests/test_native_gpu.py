@@ -256,9 +256,10 @@ def test_es_prepare_conds_from_rgb_images_equals_the_pipeline_bitwise(built):
 
 def test_context_image_saved_here_runs_in_a_process_without_torch(built, tmp_path):
     """NativeEngine.save(path) -> es_ctx_load(path) in a child process that imports neither torch nor this package
-    (tests/run_ctx_image.py: ctypes on the library and the HIP runtime only): RGB condition images -> es_prepare_conds ->
-    es_denoise_loop -> es_vae_decode there equals the pipeline here, bit for bit.  This is the stand-in for SURVEY 8b's
-    es_load_weights: the image carries the packed weights, the static buffers and the relocated launch lists."""
+    (tests/run_ctx_image.py: ctypes on the library and the HIP runtime only), and in a compiled C++ host
+    (examples/tryon_host.cpp): RGB condition images -> es_prepare_conds -> es_denoise_loop -> es_vae_decode there equals the
+    pipeline here, bit for bit.  This is the stand-in for SURVEY 8b's es_load_weights: the image carries the packed weights,
+    the static buffers and the relocated launch lists."""
     import os
     import subprocess
     import sys
@@ -298,6 +299,18 @@ def test_context_image_saved_here_runs_in_a_process_without_torch(built, tmp_pat
             if nz is not None:
                 arrs[f"noise{i}"] = nz.numpy()
         np.savez(str(tmp_path / "in.npz"), **arrs)
+        # the same inputs as one flat file for the C++ host (examples/tryon_host.cpp documents the layout)
+        with open(str(tmp_path / "in.bin"), "wb") as f:
+            has_noise = [int(z is not None) for z in noise]
+            f.write(np.array([1, s, s, 4, ucfg.cross_attention_dim, len(imgs), T] + has_noise, dtype=np.int32).tobytes())
+            f.write(np.float32(gs).tobytes())
+            f.write(arrs["timesteps"].astype(np.float32).tobytes())
+            f.write(arrs["latents"].astype(np.float32).tobytes())
+            f.write(arrs["ehs"].astype(np.float16).tobytes())
+            for im, nz in zip(imgs, noise):
+                f.write(im.numpy().astype(np.float32).tobytes())
+                if nz is not None:
+                    f.write(nz.numpy().astype(np.float32).tobytes())
     finally:
         eng.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -308,3 +321,18 @@ def test_context_image_saved_here_runs_in_a_process_without_torch(built, tmp_pat
     got_lat = torch.from_numpy(out["latents"]).permute(0, 3, 1, 2)
     assert torch.equal(got_lat, want_lat), float((got_lat - want_lat).abs().max())
     assert torch.equal(torch.from_numpy(out["image"]), want_img)
+    # and a host with no Python at all: examples/tryon_host.cpp compiled against include/edgestyle_hip.h
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "tryon_host")
+    libdir = os.path.join(root, "edgestyle_amd", "lib")
+    c = subprocess.run([hipcc, "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "tryon_host.cpp"),
+                        "-L" + libdir, "-ledgestyle_hip", "-Wl,-rpath," + libdir, "-o", exe], capture_output=True, text=True, timeout=600)
+    assert c.returncode == 0, c.stderr[-2000:]
+    r = subprocess.run([exe, path, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = np.fromfile(str(tmp_path / "out.bin"), dtype=np.float32)
+    nl = s * s * 4
+    got_lat = torch.from_numpy(raw[:nl].reshape(1, s, s, 4).copy()).permute(0, 3, 1, 2)
+    got_img = torch.from_numpy(raw[nl:].reshape(1, 3, H, H).copy())
+    assert torch.equal(got_lat, want_lat) and torch.equal(got_img, want_img)
