@@ -198,6 +198,9 @@ struct es_ctx {
   hipEvent_t staged = nullptr;      // previous call's copies - has completed
   std::vector<float> alphas_cumprod;   // the scheduler's schedule (es_ctx_set_alphas_cumprod; SD1.5 default otherwise)
   void* arena = nullptr;               // es_ctx_load: the one device allocation every recorded pointer was relocated into
+  hipGraphExec_t loop_exec = nullptr;  // use_graphs == 2: preparation + all steps of es_denoise_loop as one graph
+  int loop_steps = 0;
+  float loop_guidance = 0.f;
 };
 
 namespace {
@@ -304,6 +307,7 @@ extern "C" void es_ctx_destroy(es_ctx* c) {
     if (c->exec[i]) (void)hipGraphExecDestroy(c->exec[i]);
     if (c->plan[i]) es_plan_destroy(c->plan[i]);
   }
+  if (c->loop_exec) (void)hipGraphExecDestroy(c->loop_exec);
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   if (c->staged) { (void)hipEventSynchronize(c->staged); (void)hipEventDestroy(c->staged); }
   if (c->host) (void)hipHostFree(c->host);
@@ -318,6 +322,7 @@ extern "C" int es_ctx_set_geometry(es_ctx* c, const es_ctx_geometry* g) {
 extern "C" int es_ctx_set_plan(es_ctx* c, int which, es_plan* p) {
   if (!c || which < 0 || which >= ES_PLAN_COUNT || !p) { es_set_error("es_ctx_set_plan: bad arguments"); return -1; }
   if (c->exec[which]) { (void)hipGraphExecDestroy(c->exec[which]); c->exec[which] = nullptr; }
+  if (c->loop_exec) { (void)hipGraphExecDestroy(c->loop_exec); c->loop_exec = nullptr; }
   if (c->plan[which] && c->plan[which] != p) es_plan_destroy(c->plan[which]);
   c->plan[which] = p;
   return 0;
@@ -492,9 +497,32 @@ extern "C" int es_denoise_loop(es_ctx* c, float* latents_inout, const void* ehs,
   if ((rc = d2d(c->buf[ES_BUF_EHS], ehs, c->bytes[ES_BUF_EHS], st))) return rc;
   if ((rc = es_latents_to_input((const float*)c->buf[ES_BUF_LATENTS], c->buf[ES_BUF_SAMPLE], g.B, g.h * g.w, g.latent_channels,
                                 g.latent_pad, g.cfg, g.dtype, stream))) return rc;
-  if ((rc = run(c, ES_PLAN_PREP, st, nullptr))) return rc;        // text K/V projections, condition slots, time-projection table
-  for (int i = 0; i < T; ++i)
-    if ((rc = run(c, ES_PLAN_STEP, st, &guidance_scale))) return rc;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cs);
+  if (c->use_graphs == 2 && cs == hipStreamCaptureStatusNone) {
+    // the preparation and all n step lists as ONE graph (BASELINE configs[2]: "hipGraph-captured scheduler loop"): every
+    // step is the same launch list - the device step counter picks its rows of the tables - so the graph depends on
+    // (n_steps, guidance scale) only
+    if (c->loop_exec && (c->loop_steps != T || c->loop_guidance != guidance_scale)) { (void)hipGraphExecDestroy(c->loop_exec); c->loop_exec = nullptr; }
+    if (!c->loop_exec) {
+      hipGraph_t graph = nullptr;
+      if (!c->cap_stream && hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking) != hipSuccess) { es_set_error("es_ctx: hipStreamCreate failed"); return -2; }
+      if (hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { es_set_error("es_ctx: hipStreamBeginCapture failed"); return -2; }
+      rc = run_plan(c->plan[ES_PLAN_PREP], c->cap_stream, nullptr);
+      for (int i = 0; i < T && !rc; ++i) rc = run_plan(c->plan[ES_PLAN_STEP], c->cap_stream, &guidance_scale);
+      const hipError_t e = hipStreamEndCapture(c->cap_stream, &graph);
+      if (rc || e != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); if (!rc) es_set_error("es_ctx: hipStreamEndCapture failed"); return rc ? rc : -2; }
+      const hipError_t ei = hipGraphInstantiate(&c->loop_exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (ei != hipSuccess) { c->loop_exec = nullptr; es_set_error("es_ctx: hipGraphInstantiate failed"); return -2; }
+      c->loop_steps = T; c->loop_guidance = guidance_scale;
+    }
+    if (hipGraphLaunch(c->loop_exec, st) != hipSuccess) { es_set_error("es_ctx: hipGraphLaunch failed"); return -2; }
+  } else {
+    if ((rc = run(c, ES_PLAN_PREP, st, nullptr))) return rc;      // text K/V projections, condition slots, time-projection table
+    for (int i = 0; i < T; ++i)
+      if ((rc = run(c, ES_PLAN_STEP, st, &guidance_scale))) return rc;
+  }
   return d2d(latents_inout, c->buf[ES_BUF_LATENTS], c->bytes[ES_BUF_LATENTS], st);
 }
 

@@ -192,12 +192,13 @@ class NativeEngine:
 
     # -- thin ctypes drivers: raw device pointers in, raw device pointers out ------------------------------------------
     def set_options(self, cond_scales: Optional[Sequence[float]] = None, control_guidance_start: float = 0.0,
-                    control_guidance_end: float = 1.0, use_graphs: bool = True):
+                    control_guidance_end: float = 1.0, use_graphs=True):
+        """use_graphs: False = launch by launch, True = one hipGraph per plan, 2 = the whole loop as one hipGraph."""
         arr = None
         if cond_scales is not None:
             arr = (C.c_float * 6)(*([float(s) for s in cond_scales] + [1.0] * (6 - len(cond_scales))))
             self._cond_scales = list(arr)
-        self._cg, self._use_graphs = (float(control_guidance_start), float(control_guidance_end)), bool(use_graphs)
+        self._cg, self._use_graphs = (float(control_guidance_start), float(control_guidance_end)), int(use_graphs)
         L.check(self.lib.es_ctx_set_options(self.ctx, arr, control_guidance_start, control_guidance_end, int(use_graphs)),
                 "es_ctx_set_options")
 

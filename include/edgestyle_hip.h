@@ -340,7 +340,9 @@ void es_ctx_destroy(es_ctx* c);                         /* destroys its plans to
 int es_ctx_set_geometry(es_ctx* c, const es_ctx_geometry* g);
 int es_ctx_set_plan(es_ctx* c, int which, es_plan* p);  /* the context takes ownership of the plan */
 int es_ctx_bind(es_ctx* c, int slot, void* dev, size_t bytes);
-/* cond_scales: float[6] or NULL (keep); control guidance window (PL:419-427); use_graphs 0 = re-issue launch by launch */
+/* cond_scales: float[6] or NULL (keep); control guidance window (PL:419-427); use_graphs: 0 = re-issue launch by launch,
+ * 1 = one hipGraph per plan (es_denoise_loop launches the step graph n times), 2 = additionally the preparation and all n
+ * steps of es_denoise_loop as ONE graph (instantiated on first use per (n_steps, guidance scale)) */
 int es_ctx_set_options(es_ctx* c, const float* cond_scales, float control_guidance_start, float control_guidance_end,
                        int use_graphs);
 int es_ctx_set_alphas_cumprod(es_ctx* c, const float* alphas_cumprod, int n);   /* scheduler schedule (default: SD1.5's) */

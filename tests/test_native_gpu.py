@@ -106,7 +106,7 @@ def test_es_denoise_loop_and_vae_decode_equal_the_pipeline_bitwise(built):
     eng.set_conds([_as_nhwc(c.repeat(2, 1, 1, 1), torch.float16, DEV) for c in conds])
     ehs = torch.cat([ne, pe]).to(DEV, torch.float16).contiguous()
     x = lat.permute(0, 2, 3, 1).contiguous().to(DEV)
-    for use_graphs in (True, False):
+    for use_graphs in (True, False, 2, 2):                   # 2: preparation + all steps as ONE graph (second pass: cached)
         eng.set_options(use_graphs=use_graphs)
         got = eng.denoise_loop(x.clone(), ehs, gs)
         img = eng.vae_decode(got)
@@ -118,6 +118,9 @@ def test_es_denoise_loop_and_vae_decode_equal_the_pipeline_bitwise(built):
     want3 = pipe(output_type="latent", **dict(kw, guidance_scale=2.5)).images
     got3 = eng.denoise_loop(x.clone(), ehs, 2.5)
     assert torch.equal(got3.permute(0, 3, 1, 2), want3)
+    eng.set_options(use_graphs=2)                            # ... and of the whole-loop graph
+    assert torch.equal(eng.denoise_loop(x.clone(), ehs, 2.5).permute(0, 3, 1, 2), want3)
+    eng.set_options(use_graphs=True)
     # conditioning scales / control-guidance window live in the context (PL:419-427, 464-470)
     scales = [1.0, 0.5, 1.0, 1.0, 0.7, 1.0]
     want4 = pipe(output_type="latent", **dict(kw, controlnet_conditioning_scale=scales, control_guidance_end=0.5)).images
