@@ -53,6 +53,9 @@ class StableDiffusionPipelineOutput:
     nsfw_content_detected: Optional[List[bool]] = None
 
 
+LOOP_GRAPH = os.environ.get("ES_LOOP_GRAPH", "1") == "1"     # all steps of a call as one hipGraph (from the second call on)
+
+
 class _Loop:
     """Static device buffers + the captured step graph for one (B, cfg, h, w, guess) shape.  Everything the graph reads
     between calls is owned here (the StepState included) and refilled in place; `sig` records the addresses the graph
@@ -90,6 +93,7 @@ class _Loop:
         self.ts_dev = None               # fp32 [T] timesteps the time table is built from
         self.sig = None
         self.captures = 0                # how often this loop's graph was (re)captured (tests)
+        self.loop_graph = None           # all steps of a call as one graph (captured with the step graph)
         self.guidance_scale = None
         self.steps = None
 
@@ -474,10 +478,27 @@ class StableDiffusionControlNetPipeline:
                 with torch.cuda.graph(gp):
                     prep()
                 loop.prep_graph, loop.decode_graph = gp, None
+                loop.loop_graph = None
                 loop.sig = loop.signature()
                 loop.captures += 1
-            for _ in range(start, T):
-                loop.graph.replay()
+            elif LOOP_GRAPH and loop.loop_graph is None:
+                # second call in a row with the same configuration: capture all T steps as ONE graph (BASELINE configs[2]:
+                # "hipGraph-captured scheduler loop").  Every step is the same launch list - the device step counter picks
+                # its table rows -, so from now on a call costs one graph launch instead of T (a graph launch is ~30 us of
+                # device idle on this stack).  Not at the first call: a caller that alternates configurations re-captures
+                # the one-step graph on every switch and would pay T host walks each time.
+                saved = loop.step_idx.clone()
+                gl = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gl):
+                    for _ in range(T):
+                        loop.one_step()
+                loop.step_idx.copy_(saved)
+                loop.loop_graph = gl
+            if start == 0 and loop.loop_graph is not None:
+                loop.loop_graph.replay()
+            else:
+                for _ in range(start, T):
+                    loop.graph.replay()
 
         mark("loop")
         if output_type == "latent":

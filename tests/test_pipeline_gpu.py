@@ -69,6 +69,11 @@ def test_pipeline_vs_oracle_psnr(built, B, steps, gs):
     out2 = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, latents=lat, guidance_scale=gs,
                 num_inference_steps=steps, output_type="pt").images
     assert torch.equal(out, out2)
+    # ... and that second call captured all steps as ONE graph, which the third call only replays
+    assert pipe._last_loop.loop_graph is not None
+    out4 = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, latents=lat, guidance_scale=gs,
+                num_inference_steps=steps, output_type="pt").images
+    assert torch.equal(out, out4)
     pipe.use_graph = False
     try:
         out3 = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, latents=lat, guidance_scale=gs,
