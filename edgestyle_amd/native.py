@@ -275,7 +275,10 @@ class NativeEngine:
         # segments, not blocks: an activation freed DURING a capture is an inactive block of its private pool, and the
         # captured kernels still write there at every replay
         starts, sizes = [], []
+        dev_index = self.pipe.device.index or 0
         for seg in torch.cuda.memory_snapshot():
+            if seg.get("device", dev_index) != dev_index:
+                continue
             starts.append(seg["address"])
             sizes.append(seg["total_size"])
         order = np.argsort(np.array(starts, dtype=np.uint64))
