@@ -82,20 +82,45 @@ def build_pipeline(device, dtype, seed=0, tiny=False, keep_cpu=False, resolution
     return pipe, ws, ucfg, vcfg
 
 
-def make_inputs(ucfg, vcfg, B, device, seed=42):
-    """SURVEY.md §8d synthetic inputs, seed 42 (TT:274); image conds in [-1,1], pose conds in [0,1] (TT:29-48)."""
-    g = torch.Generator().manual_seed(seed)
+def make_inputs(ucfg, vcfg, B, device, seed=42, first_index=0):
+    """SURVEY.md §8d synthetic inputs, seed 42 (TT:274); image conds in [-1,1], pose conds in [0,1] (TT:29-48).
+    Everything that belongs to ONE try-on (latents, prompt embeddings, VAE sampling noise of its conditions) is drawn
+    from a generator seeded with seed + the image's GLOBAL index (first_index + position in the batch), so an image does
+    not depend on the world size or on which rank serves it; the six condition images are shared."""
     s = ucfg.sample_size
     res = s * vcfg.scale
-    lat = torch.randn(B, 4, s, s, generator=g)
-    pe = torch.randn(B, 77, ucfg.cross_attention_dim, generator=g) * 0.5
-    ne = torch.randn(B, 77, ucfg.cross_attention_dim, generator=g) * 0.5
+    g = torch.Generator().manual_seed(seed)
     imgs = []
     for i in range(6):
         u = torch.rand(1, 3, res, res, generator=g)
         imgs.append((u * 2 - 1 if i % 2 == 0 else u).to(device))
-    cond_noise = [torch.randn(2 * B, 4, s, s, generator=g) if i % 2 == 0 else None for i in range(6)]
+    lat = torch.empty(B, 4, s, s)
+    pe = torch.empty(B, 77, ucfg.cross_attention_dim)
+    ne = torch.empty(B, 77, ucfg.cross_attention_dim)
+    cond_noise = [torch.empty(2 * B, 4, s, s) if i % 2 == 0 else None for i in range(6)]
+    for j in range(B):
+        gj = torch.Generator().manual_seed(seed + 1 + first_index + j)
+        lat[j] = torch.randn(4, s, s, generator=gj)
+        pe[j] = torch.randn(77, ucfg.cross_attention_dim, generator=gj) * 0.5
+        ne[j] = torch.randn(77, ucfg.cross_attention_dim, generator=gj) * 0.5
+        for i in range(0, 6, 2):                     # CFG-duplicated batch (CL:39): rows j (uncond half) and B + j
+            cond_noise[i][j] = torch.randn(4, s, s, generator=gj)
+            cond_noise[i][B + j] = torch.randn(4, s, s, generator=gj)
     return lat, pe.to(device), ne.to(device), imgs, cond_noise
+
+
+class _FakePipeline:
+    """Stand-in for the CPU rehearsal of this script's multi-rank control flow (tests/test_dist_gloo.py, `--fake-pipeline`):
+    "decodes" image j as a constant plane holding the mean of its latents, so the gathered batch can be checked against
+    the per-image seeds.  Never used for a measurement."""
+    def __init__(self, ucfg, vcfg):
+        self.res = ucfg.sample_size * vcfg.scale
+        self.use_graph = False
+
+    def __call__(self, latents=None, **kw):
+        import types
+        img = latents.float().mean(dim=(1, 2, 3)).reshape(-1, 1, 1, 1).expand(-1, 3, 8, 8).contiguous()
+        return types.SimpleNamespace(images=img)
 
 
 def cpu_model() -> str:
@@ -221,12 +246,14 @@ def cpu_baseline_and_parity(pipe, ws, ucfg, B, steps_total, tiny):
     return base, parity
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step (BASELINE config 2: 1, config 3: 8)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="images per GPU per step; default 1 on one GPU (BASELINE configs[1]) and 8 per GPU when --gpus > 1 "
+                         "(BASELINE configs[3]: 64 independent try-ons over 8 GPUs)")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--resolution", type=int, default=512, help="512 (the metric) or 768 (BASELINE config 5 stress)")
@@ -239,7 +266,9 @@ def main():
                     help="skip the extra 768x768 bf16 batch-4 (BASELINE configs[4]) measurement")
     ap.add_argument("--no-throughput-mode", action="store_true",
                     help="skip the extra batch-8 (BASELINE configs[2]) measurement reported beside the headline value")
-    args = ap.parse_args()
+    ap.add_argument("--fake-pipeline", action="store_true",
+                    help="CPU rehearsal of the multi-rank control flow (gloo, no GPU, no kernels): NOT a measurement")
+    args = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -247,24 +276,35 @@ def main():
     # rehearsal knobs (a 1-GPU box cannot host two RCCL ranks): ES_DIST_BACKEND=gloo ES_FORCE_DEVICE=0 runs the
     # multi-rank control flow of this script with every rank on one GPU; the driver's runs use neither
     dev_index = int(os.environ.get("ES_FORCE_DEVICE", local_rank))
-    torch.cuda.set_device(dev_index)
+    fake = args.fake_pipeline
+    if not fake:
+        torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("ES_DIST_BACKEND", "nccl"))          # nccl == RCCL over xGMI
+        dist.init_process_group("gloo" if fake else os.environ.get("ES_DIST_BACKEND", "nccl"))   # nccl == RCCL over xGMI
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    device = torch.device("cuda", dev_index)
+    device = torch.device("cpu") if fake else torch.device("cuda", dev_index)
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    if args.batch is None:
+        args.batch = 1 if world == 1 else 8           # BASELINE configs[1] on one GPU, configs[3] (8 try-ons per GPU) on N
 
     import faulthandler
     faulthandler.dump_traceback_later(600, repeat=True, file=sys.stderr)     # where are we, if something stalls
     log(f"rank {rank}/{world}: building weights + packing on {device}")
-    pipe, ws, ucfg, vcfg = build_pipeline(device, dtype, tiny=args.tiny, resolution=args.resolution)
+    if fake:
+        from edgestyle_amd import config as C
+        ucfg, vcfg = C.tiny_unet(), C.tiny_vae()
+        pipe, ws = _FakePipeline(ucfg, vcfg), None
+        args.no_roofline = args.no_cpu_baseline = args.no_throughput_mode = args.no_stress_mode = True
+    else:
+        pipe, ws, ucfg, vcfg = build_pipeline(device, dtype, tiny=args.tiny, resolution=args.resolution)
     B = args.batch
     if args.no_graph:
         pipe.use_graph = False
-    from edgestyle_amd.dist import shard_seed, gather_images
-    lat, pe, ne, imgs, cn = make_inputs(ucfg, vcfg, B, device, seed=shard_seed(42, rank, B))
+    from edgestyle_amd.dist import gather_images
+    # rank r serves the global images [r * B, (r + 1) * B): per-image seeds, world-size independent
+    lat, pe, ne, imgs, cn = make_inputs(ucfg, vcfg, B, device, seed=42, first_index=rank * B)
 
     out = {}
 
@@ -273,16 +313,20 @@ def main():
                  num_inference_steps=args.ddim_steps, output_type="pt", cond_noise=cn)
         out["img"] = gather_images(r.images, world)          # the single RCCL gather of the path
 
+    def sync():
+        if not fake:
+            torch.cuda.synchronize()
+
     def barrier():
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     # (the first call captures the step graph, the second - same configuration - the whole-loop graph: at least two
     #  untimed calls, so that no capture falls into the timed region whatever W was asked for)
     for i in range(max(args.warmup, 2) if args.steps else args.warmup):
         one()
-        torch.cuda.synchronize()
+        sync()
         log(f"warmup {i} done")
     barrier()
     t0 = time.perf_counter()
@@ -291,7 +335,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)       # MAX over ranks
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -308,11 +352,17 @@ def main():
             "data": "synthetic (seeded random-init SD1.5-shaped weights, random conds/latents/prompt embeds, seed 42)",
             "config": {"workload": "", "images_per_gpu": B, "ddim_steps": args.ddim_steps, "parallelism": f"dp{world} (independent images, one RCCL gather)"},
         }
-        cfg_idx = 4 if args.resolution != 512 else (1 if B == 1 else 2)
+        cfg_idx = 4 if args.resolution != 512 else (3 if world > 1 else (1 if B == 1 else 2))
+        what = f"{world}xMI355X data-parallel, {world * B} independent try-ons ({B} per GPU, per-image seeds), one RCCL gather of the decoded images; " if world > 1 else ""
         line["config"]["workload"] = ("TINY plumbing config" if args.tiny else
-                                      f"BASELINE configs[{cfg_idx}]: full 6-cond edgestyle_multicontrolnet + controllora, "
+                                      f"BASELINE configs[{cfg_idx}]: {what}full 6-cond edgestyle_multicontrolnet + controllora, "
                                       f"{args.resolution}x{args.resolution}, {args.ddim_steps} DDIM steps, CFG 7.5, batch={B}/GPU, "
                                       "hipGraph-captured step, cond embedding + VAE decode included")
+        if fake:
+            line["data"] = "FAKE pipeline (CPU rehearsal of the multi-rank control flow: not a measurement)"
+            line["config"]["workload"] = "REHEARSAL (no kernels run): " + line["config"]["workload"]
+            line["rehearsal"] = {"gathered_image_means": [round(float(v), 6) for v in img[:, 0, 0, 0]],
+                                 "expected": [round(float(make_inputs(ucfg, vcfg, 1, device, 42, j)[0].mean()), 6) for j in range(world * B)]}
         if not args.no_roofline:
             line["roofline"] = gemm_roofline(pipe)
             log("roofline leg done")

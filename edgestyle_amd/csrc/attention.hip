@@ -1027,10 +1027,10 @@ extern "C" int es_attn_debug_read(unsigned long long* host16) {
 #endif
 
 extern "C" int es_attention(const es_attn_desc* d, void* stream) {
-  ES_PLAN_RECORD(ES_OP_ATTENTION, d, sizeof(*d));
   if (!d->q || !d->k || !d->v || !d->o) { es_set_error("es_attention: null pointer"); return -1; }
   if (d->d % 8 || d->ldq % 8 || d->ldk % 8 || d->ldv % 8 || d->ldo % 4) { es_set_error("es_attention: d and strides must be multiples of 8"); return -1; }
   if (d->Sq < 1 || d->Skv < 1 || d->N < 1 || d->heads < 1) { es_set_error("es_attention: empty problem"); return -1; }
+  ES_PLAN_RECORD(ES_OP_ATTENTION, d, sizeof(*d));       // after validation: a rejected call never enters a recording plan
   hipStream_t st = (hipStream_t)stream;
   int rc = d->dtype == ES_F16 ? dispatch<f16>(*d, st) : dispatch<bf16>(*d, st);
   if (rc == -3) es_set_error("es_attention: unsupported head_dim (8,16,24,32,40,48,64,80,128,160,512)");

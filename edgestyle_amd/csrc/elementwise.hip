@@ -199,8 +199,8 @@ extern "C" int es_abi_version(void) { return ES_ABI_VERSION; }
   } while (0)
 
 extern "C" int es_timestep_embedding(const float* t, void* out, int N, int dim, int dtype, void* stream) {
-  if (es_plan_recording()) { const es_op_timestep a{t, out, N, dim, dtype}; es_plan_record(ES_OP_TIMESTEP_EMBEDDING, &a, sizeof(a)); }
   if (!t || !out || dim % 2 || N < 1) { es_set_error("es_timestep_embedding: bad arguments"); return -1; }
+  if (es_plan_recording()) { const es_op_timestep a{t, out, N, dim, dtype}; es_plan_record(ES_OP_TIMESTEP_EMBEDDING, &a, sizeof(a)); }
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)N * (dim / 2);
   if (dtype == ES_F16) hipLaunchKernelGGL(timestep_kernel<f16>, dim3(nblk(n)), dim3(256), 0, st, t, (f16*)out, N, dim);
@@ -211,12 +211,12 @@ extern "C" int es_timestep_embedding(const float* t, void* out, int N, int dim, 
 extern "C" int es_cfg_ddim_step(const void* noise, float* latents, void* model_in, const float* coef,
                                 const int32_t* step_idx, float guidance_scale, int B, int HW, int L, int Lstride,
                                 int cfg, int nsteps, int dtype, void* stream) {
+  if (!noise || !latents || !model_in || !coef || !step_idx || B < 1 || HW < 1 || L < 1 || Lstride < L || nsteps < 1) {
+    es_set_error("es_cfg_ddim_step: bad arguments"); return -1;
+  }
   if (es_plan_recording()) {
     const es_op_cfg_ddim a{noise, latents, model_in, coef, step_idx, guidance_scale, B, HW, L, Lstride, cfg, nsteps, dtype};
     es_plan_record(ES_OP_CFG_DDIM, &a, sizeof(a));
-  }
-  if (!noise || !latents || !model_in || !coef || !step_idx || B < 1 || HW < 1 || L < 1 || Lstride < L || nsteps < 1) {
-    es_set_error("es_cfg_ddim_step: bad arguments"); return -1;
   }
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)B * HW * L;
@@ -232,13 +232,13 @@ extern "C" int es_cfg_ddim_step(const void* noise, float* latents, void* model_i
 extern "C" int es_cfg_unipc_step(const void* noise, float* latents, float* last_sample, float* m0, float* m1,
                                  void* model_in, const float* coef, const int32_t* step_idx, float guidance_scale,
                                  int B, int HW, int L, int Lstride, int cfg, int nsteps, int dtype, void* stream) {
-  if (es_plan_recording()) {
-    const es_op_cfg_unipc a{noise, latents, last_sample, m0, m1, model_in, coef, step_idx, guidance_scale, B, HW, L, Lstride, cfg, nsteps, dtype};
-    es_plan_record(ES_OP_CFG_UNIPC, &a, sizeof(a));
-  }
   if (!noise || !latents || !last_sample || !m0 || !m1 || !model_in || !coef || !step_idx || B < 1 || HW < 1 ||
       L < 1 || Lstride < L || nsteps < 1) {
     es_set_error("es_cfg_unipc_step: bad arguments"); return -1;
+  }
+  if (es_plan_recording()) {
+    const es_op_cfg_unipc a{noise, latents, last_sample, m0, m1, model_in, coef, step_idx, guidance_scale, B, HW, L, Lstride, cfg, nsteps, dtype};
+    es_plan_record(ES_OP_CFG_UNIPC, &a, sizeof(a));
   }
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)B * HW * L;
@@ -253,8 +253,8 @@ extern "C" int es_cfg_unipc_step(const void* noise, float* latents, float* last_
 
 extern "C" int es_nchw_f32_to_nhwc(const float* in, void* out, int N, int C, int HW, int Cpad, int dtype,
                                    void* stream) {
-  if (es_plan_recording()) { const es_op_nchw_to_nhwc a{in, out, N, C, HW, Cpad, dtype}; es_plan_record(ES_OP_NCHW_TO_NHWC, &a, sizeof(a)); }
   if (!in || !out || Cpad < C || N < 1) { es_set_error("es_nchw_f32_to_nhwc: bad arguments"); return -1; }
+  if (es_plan_recording()) { const es_op_nchw_to_nhwc a{in, out, N, C, HW, Cpad, dtype}; es_plan_record(ES_OP_NCHW_TO_NHWC, &a, sizeof(a)); }
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)N * HW * Cpad;
   if (dtype == ES_F16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16>, dim3(nblk(n)), dim3(256), 0, st, in, (f16*)out, N, C, HW, Cpad);
@@ -264,8 +264,8 @@ extern "C" int es_nchw_f32_to_nhwc(const float* in, void* out, int N, int C, int
 
 extern "C" int es_nhwc_to_nchw_f32(const void* in, float* out, int N, int C, int HW, int Cstride, float scale,
                                    float shift, int clamp01, int dtype, void* stream) {
-  if (es_plan_recording()) { const es_op_nhwc_to_nchw a{in, out, N, C, HW, Cstride, scale, shift, clamp01, dtype}; es_plan_record(ES_OP_NHWC_TO_NCHW, &a, sizeof(a)); }
   if (!in || !out || Cstride < C || N < 1) { es_set_error("es_nhwc_to_nchw_f32: bad arguments"); return -1; }
+  if (es_plan_recording()) { const es_op_nhwc_to_nchw a{in, out, N, C, HW, Cstride, scale, shift, clamp01, dtype}; es_plan_record(ES_OP_NHWC_TO_NCHW, &a, sizeof(a)); }
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)N * C * HW;
   if (dtype == ES_F16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<f16>, dim3(nblk(n)), dim3(256), 0, st, (const f16*)in, out, N, C, HW, Cstride, scale, shift, clamp01);
@@ -274,8 +274,8 @@ extern "C" int es_nhwc_to_nchw_f32(const void* in, float* out, int N, int C, int
 }
 
 extern "C" int es_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream) {
-  if (es_plan_recording()) { const es_op_add rec{a, b, y, n, dtype}; es_plan_record(ES_OP_ADD, &rec, sizeof(rec)); }
   if (!a || !b || !y || n < 8 || n % 8) { es_set_error("es_add: n must be a positive multiple of 8"); return -1; }
+  if (es_plan_recording()) { const es_op_add rec{a, b, y, n, dtype}; es_plan_record(ES_OP_ADD, &rec, sizeof(rec)); }
   hipStream_t st = (hipStream_t)stream;
   const long long n8 = n / 8;
   unsigned blocks = nblk(n8);
@@ -287,8 +287,8 @@ extern "C" int es_add(const void* a, const void* b, void* y, int64_t n, int dtyp
 
 extern "C" int es_vae_sample(const void* moments, const float* noise_nchw, void* z, int N, int HW, int L, int Lpad,
                              float scaling, int dtype, void* stream) {
-  if (es_plan_recording()) { const es_op_vae_sample a{moments, noise_nchw, z, N, HW, L, Lpad, scaling, dtype}; es_plan_record(ES_OP_VAE_SAMPLE, &a, sizeof(a)); }
   if (!moments || !noise_nchw || !z || Lpad < L || N < 1) { es_set_error("es_vae_sample: bad arguments"); return -1; }
+  if (es_plan_recording()) { const es_op_vae_sample a{moments, noise_nchw, z, N, HW, L, Lpad, scaling, dtype}; es_plan_record(ES_OP_VAE_SAMPLE, &a, sizeof(a)); }
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)N * HW * Lpad;
   if (dtype == ES_F16) hipLaunchKernelGGL(vae_sample_kernel<f16>, dim3(nblk(n)), dim3(256), 0, st, (const f16*)moments, noise_nchw, (f16*)z, N, HW, L, Lpad, scaling);
@@ -297,16 +297,16 @@ extern "C" int es_vae_sample(const void* moments, const float* noise_nchw, void*
 }
 
 extern "C" int es_incr(int32_t* ctr, void* stream) {
-  if (es_plan_recording()) { const es_op_incr a{ctr}; es_plan_record(ES_OP_INCR, &a, sizeof(a)); }
   if (!ctr) { es_set_error("es_incr: null pointer"); return -1; }
+  if (es_plan_recording()) { const es_op_incr a{ctr}; es_plan_record(ES_OP_INCR, &a, sizeof(a)); }
   hipLaunchKernelGGL(incr_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ctr);
   ES_RET("es_incr");
 }
 
 extern "C" int es_gather_row(const float* table, const int32_t* idx, float* out, int row_len, int nrows,
                              void* stream) {
-  if (es_plan_recording()) { const es_op_gather_row a{table, idx, out, row_len, nrows}; es_plan_record(ES_OP_GATHER_ROW, &a, sizeof(a)); }
   if (!table || !idx || !out || row_len < 1 || nrows < 1) { es_set_error("es_gather_row: bad arguments"); return -1; }
+  if (es_plan_recording()) { const es_op_gather_row a{table, idx, out, row_len, nrows}; es_plan_record(ES_OP_GATHER_ROW, &a, sizeof(a)); }
   hipLaunchKernelGGL(gather_row_kernel, dim3(nblk(row_len)), dim3(256), 0, (hipStream_t)stream, table, idx, out,
                      row_len, nrows);
   ES_RET("es_gather_row");
@@ -314,8 +314,8 @@ extern "C" int es_gather_row(const float* table, const int32_t* idx, float* out,
 
 extern "C" int es_latents_to_input(const float* latents, void* model_in, int B, int HW, int L, int Lstride, int cfg,
                                    int dtype, void* stream) {
-  if (es_plan_recording()) { const es_op_latents_to_input a{latents, model_in, B, HW, L, Lstride, cfg, dtype}; es_plan_record(ES_OP_LATENTS_TO_INPUT, &a, sizeof(a)); }
   if (!latents || !model_in || B < 1 || HW < 1 || L < 1 || Lstride < L) { es_set_error("es_latents_to_input: bad arguments"); return -1; }
+  if (es_plan_recording()) { const es_op_latents_to_input a{latents, model_in, B, HW, L, Lstride, cfg, dtype}; es_plan_record(ES_OP_LATENTS_TO_INPUT, &a, sizeof(a)); }
   const long long n = (long long)B * HW * Lstride;
   if (dtype == ES_F16) hipLaunchKernelGGL(latents_to_input_kernel<f16>, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, latents, (f16*)model_in, B, HW, L, Lstride, cfg);
   else hipLaunchKernelGGL(latents_to_input_kernel<bf16>, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, latents, (bf16*)model_in, B, HW, L, Lstride, cfg);
@@ -324,22 +324,22 @@ extern "C" int es_latents_to_input(const float* latents, void* model_in, int B, 
 
 /* device-to-device copies and fills as C-ABI calls, so that the data movement of a step is part of a recorded plan */
 extern "C" int es_memcpy(void* dst, const void* src, size_t bytes, void* stream) {
-  if (es_plan_recording()) { const es_op_memcpy a{dst, src, bytes}; es_plan_record(ES_OP_MEMCPY, &a, sizeof(a)); }
   if (!dst || !src || !bytes) { es_set_error("es_memcpy: bad arguments"); return -1; }
+  if (es_plan_recording()) { const es_op_memcpy a{dst, src, bytes}; es_plan_record(ES_OP_MEMCPY, &a, sizeof(a)); }
   if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) { es_set_error("es_memcpy: hipMemcpyAsync failed"); return -2; }
   return 0;
 }
 
 extern "C" int es_memcpy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, void* stream) {
-  if (es_plan_recording()) { const es_op_memcpy2d a{dst, dpitch, src, spitch, width, height}; es_plan_record(ES_OP_MEMCPY2D, &a, sizeof(a)); }
   if (!dst || !src || !width || !height || dpitch < width || spitch < width) { es_set_error("es_memcpy2d: bad arguments"); return -1; }
+  if (es_plan_recording()) { const es_op_memcpy2d a{dst, dpitch, src, spitch, width, height}; es_plan_record(ES_OP_MEMCPY2D, &a, sizeof(a)); }
   if (hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) { es_set_error("es_memcpy2d: hipMemcpy2DAsync failed"); return -2; }
   return 0;
 }
 
 extern "C" int es_fill_f32(float* dst, float value, size_t n, void* stream) {
-  if (es_plan_recording()) { const es_op_fill_f32 a{dst, value, n}; es_plan_record(ES_OP_FILL_F32, &a, sizeof(a)); }
   if (!dst || !n) { es_set_error("es_fill_f32: bad arguments"); return -1; }
+  if (es_plan_recording()) { const es_op_fill_f32 a{dst, value, n}; es_plan_record(ES_OP_FILL_F32, &a, sizeof(a)); }
   if (hipMemsetD32Async((hipDeviceptr_t)dst, __builtin_bit_cast(int, value), n, (hipStream_t)stream) != hipSuccess) { es_set_error("es_fill_f32: hipMemsetD32Async failed"); return -2; }
   return 0;
 }

@@ -276,13 +276,13 @@ static int fusion_check(const es_fusion_desc* d) {
 
 extern "C" int es_fusion_blocks(const es_fusion_desc* ds, int count, void* stream) {
   if (!ds || count < 1 || count > ES_FUSION_MAX_BATCH) { es_set_error("es_fusion_blocks: 1..13 blocks per call"); return -1; }
-  ES_PLAN_RECORD(ES_OP_FUSION_BLOCKS, ds, sizeof(*ds) * count);
   for (int k = 0; k < count; ++k) {
     if (fusion_check(ds + k)) return -1;
     if (ds[k].N != ds[0].N || ds[k].dtype != ds[0].dtype) { es_set_error("es_fusion_blocks: blocks must share N and dtype"); return -1; }
     for (int j = 0; j < k; ++j)
       if (ds[j].scratch == ds[k].scratch || ds[j].u == ds[k].u) { es_set_error("es_fusion_blocks: blocks need private scratch and u buffers"); return -1; }
   }
+  ES_PLAN_RECORD(ES_OP_FUSION_BLOCKS, ds, sizeof(*ds) * count);
   hipStream_t st = (hipStream_t)stream;
   int rc = ds[0].dtype == ES_F16 ? launch_fusion_batch<f16>(ds, count, st) : launch_fusion_batch<bf16>(ds, count, st);
   if (rc) es_set_error("es_fusion_blocks: launch failed");
@@ -290,8 +290,8 @@ extern "C" int es_fusion_blocks(const es_fusion_desc* ds, int count, void* strea
 }
 
 extern "C" int es_fusion_block(const es_fusion_desc* d, void* stream) {
-  ES_PLAN_RECORD(ES_OP_FUSION_BLOCK, d, sizeof(*d));
   if (fusion_check(d)) return -1;
+  ES_PLAN_RECORD(ES_OP_FUSION_BLOCK, d, sizeof(*d));
   hipStream_t st = (hipStream_t)stream;
   int rc = d->dtype == ES_F16 ? launch_fusion<f16>(*d, st) : launch_fusion<bf16>(*d, st);
   if (rc) es_set_error("es_fusion_block: launch failed");

@@ -39,6 +39,8 @@
 #define ES_W_AUX 0
 #endif
 
+int es_conv_gemm8p_launch(const es_gemm_desc& d, hipStream_t st);   // gemm_conv8p.hip: the 256 x 320 phase-interleaved tile
+
 namespace {
 
 constexpr int BK = 64;
@@ -851,7 +853,7 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
     else                        { if (stages == 4) ES_LAUNCH_LN(128, 160, 4, 4); else ES_LAUNCH_LN(128, 160, 2, 4); }
   }
   else if (d.bn == 64)  { if (stages == 4) ES_LAUNCH_F(64, 64, true, 4, 2); else ES_LAUNCH_F(64, 64, true, 2, 2); }
-  else if (d.bn == 320) { ES_LAUNCH(256, 320, true, 2); }
+  else if (d.bn == 320) { if (es_conv_gemm8p_launch(d, st)) return -2; }
   else if (d.bn == 128) { if (aligned) ES_LAUNCH_ST(128); else ES_LAUNCH(128, 128, false, 2); }
   else                  { if (aligned) ES_LAUNCH_ST(160); else ES_LAUNCH(128, 160, false, 2); }
 #undef ES_LAUNCH_ST
@@ -876,7 +878,6 @@ extern "C" size_t es_conv_gemm_workspace_bytes(const es_gemm_desc* d) {
 }
 
 extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
-  ES_PLAN_RECORD(ES_OP_CONV_GEMM, d, sizeof(*d));
   const int Ctot = d->C1 + d->C2;
   const int Ktrue = d->ksize * d->ksize * Ctot + (d->t1 ? d->Ct1 + d->Ct2 : 0);
   if (!d->x || !d->out || (d->ngroups <= 1 && !d->w)) { es_set_error("es_conv_gemm: null pointer"); return -1; }
@@ -933,6 +934,7 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
   if (d->waves == 8 && (d->bm == 256 || d->bn == 320 || d->C1 % BK || d->C2 % BK || d->stages == 3 ||
                         (d->stages == 4 && d->bn != 128))) {
     es_set_error("es_conv_gemm: waves=8 is the 128-pixel tile on 8 waves: 64-aligned channels, 2 stages (4 with bn=128)"); return -1; }
+  ES_PLAN_RECORD(ES_OP_CONV_GEMM, d, sizeof(*d));       // after validation: a rejected call never enters a recording plan
   hipStream_t st = (hipStream_t)stream;
   // the kernels find a tile's group as (t >= end[0]) + (t >= end[1]) + (t >= end[2]): unused entries must compare false
   // (a caller's zero-initialised table sent every tile of a TWO-group launch to groups 1..3: null weights, GPU fault)

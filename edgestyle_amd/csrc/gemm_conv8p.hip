@@ -1,0 +1,488 @@
+// Implicit-GEMM convolution for gfx950, large launches: 256 pixels x 320 couts per workgroup, 8 waves, ONE workgroup
+// per CU, phase-interleaved mainloop (the structure of the CDNA4 guide's 256^2 8-phase GEMM template, re-derived for
+// this tile and for an im2col loader).
+//
+//   D[cout][pixel] = sum_k W[cout][k] * X[pixel][k]      (A operand = weights, B operand = im2col'd activations)
+//
+// Why a second kernel beside conv_gemm_kernel (gemm_conv.hip): that loop - 128 x 160 tile, one barrier per K-step,
+// two independent workgroups per CU - tops out at 1.0-1.08 PFLOP/s on the big 3x3 launches; its K-step is bound by
+// L2->LDS staging bytes per FLOP and by two workgroups issuing DMAs, fragment reads and MFMAs in lockstep.  Here:
+//   * tile 256 x 320 x 64: half the staged bytes per FLOP (0.0070 B/FLOP against 0.0141);
+//   * waves as 2 (pixel halves) x 4 (80 couts): 128 px x 80 couts = 8 x 5 MFMA 16x16x32 fragments = 160 accumulator
+//     registers per lane; the two waves of a SIMD are w and w + 4 = the two pixel halves ("groups");
+//   * a K-tile (64 deep) is FOUR phases (pixel quarter h, 32-deep K half kk) of 20 MFMAs each; a phase is
+//        fragment reads (4 or 9 ds_read_b128) | LDS-DMA issue for the NEXT K-tile | s_barrier | lgkmcnt(0) |
+//        20 MFMAs at s_setprio 1 | s_barrier
+//     and group 1 runs ONE BARRIER behind group 0, so on every SIMD one wave issues its MFMAs while its partner
+//     issues reads and DMAs: the matrix pipe sees a continuous MFMA stream from alternating waves;
+//   * LDS ring of two K-tiles (2 x 72 KB); the 9 DMA pieces (1 KB each) a wave issues per K-tile are spread over the
+//     four phases 3 | 2 | 2 | 2 in the order they are needed (weights, first pixel quarter, second pixel quarter) and
+//     retired by COUNTED s_waitcnt vmcnt: vmcnt(2) in phase 3 (weights + first quarter of the next tile landed, the
+//     second quarter stays in flight across the tile boundary), vmcnt(3) in phase 0 (second quarter landed, the three
+//     pieces just issued stay in flight).  Never vmcnt(0) inside the loop.
+// Hazards (slots = intervals between consecutive workgroup barriers; group 0 reads in even slots and computes in
+// odd ones, group 1 the other way round):
+//   RAW  a wave's counted wait sits BEFORE the first barrier of its phase; the reads of the data it retires sit at
+//        least one full phase later for both groups (phase 3 wait -> phase 0 reads, phase 0 wait -> phase 1 reads):
+//        one barrier more than the unstaggered minimum, as the guide prescribes for staggered groups.
+//   WAR  a sub-buffer of tile t - 1 is re-staged (for tile t + 1) no earlier than phase 0 of tile t for the weights
+//        (last read: phase 2 of tile t - 1, retired by lgkmcnt(0) + two barriers before any wave reaches that issue) and
+//        phase 2 / 3 for the pixel quarters.
+// The im2col loader, grouped weights, tail sources, split-K and the epilogue semantics are those of conv_gemm_kernel
+// (same rounding points: results are bit-identical to the 128-pixel tile for splitk == 1).
+#ifndef ES_WT_STORES
+#define ES_WT_STORES 1
+#endif
+#include "common.h"
+#include "../../include/edgestyle_hip.h"
+
+// Tool-only builds (tools/ab8p.sh): ES8P_SCHED picks the DMA issue schedule, ES8P_ABL removes one ingredient (results
+// are wrong by construction).  ABL bits: 1 = every DMA out of range (issued, zero-filled, no memory traffic),
+// 2 = no MFMAs, 4 = no barrier stagger.  The product library is built with ES8P_ABL == 0.
+#ifndef ES8P_SCHED
+#define ES8P_SCHED 3
+#endif
+#ifndef ES8P_ABL
+#define ES8P_ABL 0
+#endif
+#ifndef ES8P_PRIO
+#define ES8P_PRIO 1
+#endif
+#ifndef ES8P_LGKM_EARLY
+#define ES8P_LGKM_EARLY 0
+#endif
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int BM = 256, BN = 320, RB = 128;
+constexpr int XT = BM * RB, WT = BN * RB, BUF = XT + WT;      // 32 KB + 40 KB per K-tile
+constexpr int FN = 5, FM = 8;                                 // cout / pixel fragments per wave
+constexpr int XI = 4, WI = 5;                                 // DMA pieces per wave per K-tile
+constexpr unsigned OOB = 0xFFFFFF00u;
+constexpr int EROW = 160 * 2 + 16;                            // epilogue tile row stride (bytes): 160 couts per pass
+
+ES_DEVICE void row_offsets4(unsigned (&voff)[XI], const int (&iy0)[XI], const int (&ix0)[XI], const int (&nb)[XI],
+                            const int tp, const int cs, const int chan, const int ksize, const int KK, const int pad,
+                            const int Hin, const int Win, const int upsample, const int Wsrc) {
+  int ky = 0, kx = 0;
+  if (ksize == 3) { ky = (tp * 11) >> 5; kx = tp - ky * 3; }
+  if (tp >= KK) { ky = pad; kx = pad; }                              // tail tap: the output pixel
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+    const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+    const int pix = nb[i] + (iy >> upsample) * Wsrc + (ix >> upsample);
+    voff[i] = ok ? (unsigned)(((size_t)pix * cs + chan) * 2) : OOB;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc p, const int M, const int nk,
+                                                             const void* const tail1, const void* const tail2,
+                                                             const int tailC1, const int tailC2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp8 = wave >> 2;          // pixel half of the tile = stagger group (SIMD partners are w and w + 4)
+  const int wn = wave & 3;             // 80-cout column of the tile
+
+  int tile_m, tile_n, z;
+  {
+    const int tm = (M + BM - 1) / BM, tn = p.rows_padded / BN;
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);      // bijective for any nwg
+    const float inv_tm = __builtin_amdgcn_rcpf((float)tm), inv_tn = __builtin_amdgcn_rcpf((float)tn);
+    if (p.xcd_m_fastest) { const int t = fast_div(w, tm, inv_tm); tile_m = w - t * tm; z = fast_div(t, tn, inv_tn); tile_n = t - z * tn; }
+    else                 { const int t = fast_div(w, tn, inv_tn); tile_n = w - t * tn; z = fast_div(t, tm, inv_tm); tile_m = t - z * tm; }
+  }
+  if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+
+  int ks0 = 0, ks1 = nk;
+  if (p.splitk > 1) {
+    const float inv_sk = __builtin_amdgcn_rcpf((float)p.splitk);
+    ks0 = fast_div(nk * z, p.splitk, inv_sk);
+    ks1 = fast_div(nk * (z + 1), p.splitk, inv_sk);
+  }
+
+  // ---------------- loader state (as conv_gemm_kernel; ALIGNED form only: C1, C2, tails multiples of 64) ----------------
+  const int lrow = lane >> 3;                      // row inside an 8-row DMA piece
+  const int lslot = lane & 7;                      // LDS slot the DMA writes for this lane
+  const int kc = lslot ^ (lrow & 7);               // global chunk that lands there (XOR swizzle on the SOURCE side)
+  const int Ctot = p.C1 + p.C2;
+  const int KK = p.ksize * p.ksize;
+  const int pC1 = p.C1, pC2 = p.C2, pCt1 = tailC1, pCt2 = tailC2;
+  const bool has_tail = tail1 != nullptr;
+  const int Hin = p.Hsrc << p.upsample, Win = p.Wsrc << p.upsample;
+  const int HWout = p.Hout * p.Wout;
+  const bool small_m = M < (1 << 24);
+  const float inv_hw = __builtin_amdgcn_rcpf((float)HWout), inv_w = __builtin_amdgcn_rcpf((float)p.Wout);
+  // X pieces of this wave: i = 2 * h + e -> tile rows 128 * grp8 + 64 * h + 16 * wn + 8 * e + lrow (its own pixel half)
+  int iy0[XI], ix0[XI], nb[XI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int m = tile_m * BM + grp8 * 128 + (i >> 1) * 64 + wn * 16 + (i & 1) * 8 + lrow;
+    iy0[i] = -(1 << 20); ix0[i] = -(1 << 20); nb[i] = 0;
+    if (m < M) {
+      int n, oy, ox;
+      if (HWout == 1) {
+        n = m; oy = 0; ox = 0;
+      } else if (small_m) {
+        n = fast_div(m, HWout, inv_hw);
+        const int rem = m - n * HWout;
+        oy = fast_div(rem, p.Wout, inv_w);
+        ox = rem - oy * p.Wout;
+      } else {
+        n = m / HWout;
+        const int rem = m - n * HWout;
+        oy = rem / p.Wout; ox = rem - oy * p.Wout;
+      }
+      iy0[i] = oy * p.stride - p.pad;
+      ix0[i] = ox * p.stride - p.pad;
+      if (p.x_nmod) n -= (n / p.x_nmod) * p.x_nmod;
+      nb[i] = n * p.Hsrc * p.Wsrc;
+    }
+  }
+  int grp = 0;
+  if (p.ngroups > 1) {
+    const int t128 = (tile_m * BM) / 128;               // group table is in 128-pixel units
+    grp = (t128 >= p.mt_end[0]) + (t128 >= p.mt_end[1]) + (t128 >= p.mt_end[2]);
+  }
+  const void* wsel = p.ngroups > 1 ? p.w_g[grp] : p.w;
+  const float* bsel = p.ngroups > 1 ? p.bias_g[grp] : p.bias;
+  const auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)wsel, (short)0, (int)((size_t)p.rows_padded * p.Kpad * 2), 0x00020000);
+  const int Nsrc = p.x_nmod ? p.x_nmod : p.N;
+  const void* const pt1 = tail1 ? tail1 : p.x;
+  const void* const pt2 = tail2 ? tail2 : p.x;
+  const void* const px = p.x;
+  const void* const px2 = p.x2 ? p.x2 : p.x;
+  const int nX1 = (int)((size_t)Nsrc * p.Hsrc * p.Wsrc * pC1 * 2);
+  const int nX2 = (int)((size_t)Nsrc * p.Hsrc * p.Wsrc * (p.x2 ? pC2 : pC1) * 2);
+  const int nT1 = has_tail ? (int)((size_t)p.N * p.Hout * p.Wout * pCt1 * 2) : 0;
+  const int nT2 = tail2 ? (int)((size_t)p.N * p.Hout * p.Wout * pCt2 * 2) : 0;
+  unsigned woff[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i)
+    woff[i] = (unsigned)(((size_t)(tile_n * BN + 8 * (wave * WI + i) + lrow) * p.Kpad + kc * 8) * 2);
+
+  int tap, cpos;                                        // of the NEXT K-tile to stage
+  {
+    const int kg = ks0 * 64;
+    tap = kg == 0 ? 0 : fast_div(kg, Ctot, __builtin_amdgcn_rcpf((float)Ctot));
+    cpos = kg - tap * Ctot;
+    if (tap >= KK) { tap = KK; cpos = kg - KK * Ctot; }
+  }
+  unsigned voff[XI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) voff[i] = OOB;
+  int cur_tap = -1, cur_second = -1;
+  const int ks_tail = (KK * Ctot) / 64;
+  const int pk_ksize = p.ksize, pk_pad = p.pad, pk_up = p.upsample, pk_wsrc = p.Wsrc;
+
+  // staging of one K-tile in three calls: weights [i0, i1), pixel quarter 0, pixel quarter 1
+  auto issue_w = [&](int ks, int boff, int i0, int i1) __attribute__((always_inline)) {
+    const int soff_w = ks * RB;
+#pragma unroll
+    for (int i = 0; i < WI; ++i)
+      if (i >= i0 && i < i1)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(smem + boff + XT + (wave * WI + i) * 1024), 16,
+                                                 (ES8P_ABL & 1) ? (int)OOB : (int)woff[i], soff_w, 0, 0);
+  };
+  // source of the K-tile `ks` (wave-uniform): base pointer, records, channel stride, scalar channel offset
+  const void* xbase = px;
+  int xrec = 0, soff_x = 0;
+  auto select_x = [&](int ks) __attribute__((always_inline)) {
+    const bool tail = ks >= ks_tail;
+    int q0 = pC1, q1 = pC2, q2 = pCt1, q3 = pCt2;
+    asm("" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3));
+    const int c1 = tail ? q2 : q0;
+    const int second = cpos >= c1 ? 1 : 0;              // a K-tile never straddles taps or sources
+    const int cs = second ? (tail ? q3 : q1) : c1;
+    const int cc = second ? cpos - c1 : cpos;
+    if (tap != cur_tap || second != cur_second) {
+      row_offsets4(voff, iy0, ix0, nb, tap, cs, kc * 8, pk_ksize, KK, pk_pad, Hin, Win, pk_up, pk_wsrc);
+      cur_tap = tap; cur_second = second;
+    }
+    const void *b0 = px, *b1 = px2, *b2 = pt1, *b3 = pt2;
+    int n0 = nX1, n1 = nX2, n2 = nT1, n3 = nT2;
+    asm("" : "+s"(b0), "+s"(b1), "+s"(b2), "+s"(b3), "+s"(n0), "+s"(n1), "+s"(n2), "+s"(n3));
+    const void* const base = tail ? (second ? b3 : b2) : (second ? b1 : b0);
+    const int nrec = tail ? (second ? n3 : n2) : (second ? n1 : n0);
+    xbase = base; xrec = nrec;
+    soff_x = cc * 2;
+    cpos += 64;
+    if (tap < KK) { while (cpos >= Ctot) { cpos -= Ctot; ++tap; } }
+  };
+  auto issue_x = [&](int boff, int h) __attribute__((always_inline)) {
+    const auto rS = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, (short)0, xrec, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < XI; ++i)
+      if ((i >> 1) == h)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rS, (lptr_t)(smem + boff + (grp8 * 16 + (i >> 1) * 8 + wn * 2 + (i & 1)) * 1024), 16,
+            (ES8P_ABL & 1) ? (int)OOB : (int)voff[i], soff_x, 0, 0);
+  };
+
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---------------- prologue: K-tile ks0 entirely, then the stagger ----------------
+  const int nkt = ks1 - ks0;
+  if (nkt > 0) {
+    issue_w(ks0, 0, 0, WI);
+    select_x(ks0);
+    issue_x(0, 0);
+    issue_x(0, 1);
+  }
+  const int frow = lane & 15, fq = lane >> 4;
+  // per-lane fragment read offsets inside a K-tile buffer: row r of a sub-tile sits at r * 128, its 16-byte chunk c at
+  // slot c ^ (r & 7); every fragment row of this lane has r & 7 == frow & 7
+  const int xo0 = ((0 + fq) ^ (frow & 7)) << 4, xo1 = ((4 + fq) ^ (frow & 7)) << 4;
+  const int xrow = (grp8 * 128 + frow) * RB;
+  const int wrow = XT + (wn * 80 + frow) * RB;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (!(ES8P_ABL & 4) && grp8 == 1) __builtin_amdgcn_s_barrier();            // group 1 runs one barrier behind group 0
+
+  typename Traits<T>::vec8 xa[4], wa[FN];
+  int boff = 0;
+  for (int t = 0; t < nkt; ++t) {
+    const bool nxt = t + 1 < nkt;                         // wave-uniform
+    const int ksn = ks0 + t + 1;
+    const int nboff = boff ^ BUF;
+    const char* xs = smem + boff;
+#define ES_RD(off) as_vec8<T>(*(const u32x4*)(xs + (off)))
+#define ES_MFMA(H)                                                                    \
+    if (ES8P_LGKM_EARLY) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           \
+    __builtin_amdgcn_s_barrier();                                                     \
+    if (!ES8P_LGKM_EARLY) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    __builtin_amdgcn_s_setprio(ES8P_PRIO);                                            \
+    if constexpr ((ES8P_ABL & 2) != 0) {                                              \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(xa[j]));    \
+      _Pragma("unroll") for (int i = 0; i < FN; ++i) asm volatile("" ::"v"(wa[i]));   \
+    } else {                                                                          \
+    _Pragma("unroll") for (int i = 0; i < FN; ++i)                                    \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                   \
+        acc[i][(H) * 4 + j] = mfma16(wa[i], xa[j], acc[i][(H) * 4 + j]);              \
+    }                                                                                 \
+    __builtin_amdgcn_s_setprio(0);                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 0: (h 0, kk 0) ----
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xa[j] = ES_RD(xrow + xo0 + (0 * 64 + j * 16) * RB);
+#pragma unroll
+    for (int i = 0; i < FN; ++i) wa[i] = ES_RD(wrow + xo0 + i * 16 * RB);
+#if ES8P_SCHED == 0
+    if (nxt) {
+      issue_w(ksn, nboff, 0, 3);
+      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");    // the second pixel quarter of THIS tile has landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#elif ES8P_SCHED == 3
+    if (nxt) {
+      issue_w(ksn, nboff, 0, 2);
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#elif ES8P_SCHED == 1
+    // front-loaded: everything of the next tile is issued in phases 0 and 1 (at least two phases of flight)
+    if (nxt) {
+      issue_w(ksn, nboff, 0, 3);
+      select_x(ksn);
+      issue_x(nboff, 0);
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#else
+    if (nxt) {
+      issue_w(ksn, nboff, 0, 5);
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#endif
+    ES_MFMA(0)
+    // ---- phase 1: (h 1, kk 0) ----
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xa[j] = ES_RD(xrow + xo0 + (1 * 64 + j * 16) * RB);
+#if ES8P_SCHED == 0
+    if (nxt) issue_w(ksn, nboff, 3, WI);
+#elif ES8P_SCHED == 3
+    if (nxt) { issue_w(ksn, nboff, 2, WI); select_x(ksn); }
+#elif ES8P_SCHED == 1
+    if (nxt) { issue_w(ksn, nboff, 3, WI); issue_x(nboff, 1); }
+#else
+    if (nxt) { select_x(ksn); issue_x(nboff, 0); issue_x(nboff, 1); }
+#endif
+    ES_MFMA(1)
+    // ---- phase 2: (h 0, kk 1) ----
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xa[j] = ES_RD(xrow + xo1 + (0 * 64 + j * 16) * RB);
+#pragma unroll
+    for (int i = 0; i < FN; ++i) wa[i] = ES_RD(wrow + xo1 + i * 16 * RB);
+#if ES8P_SCHED == 0
+    if (nxt) { select_x(ksn); issue_x(nboff, 0); }
+#elif ES8P_SCHED == 3
+    if (nxt) issue_x(nboff, 0);
+#endif
+    ES_MFMA(0)
+    // ---- phase 3: (h 1, kk 1) ----
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xa[j] = ES_RD(xrow + xo1 + (1 * 64 + j * 16) * RB);
+#if ES8P_SCHED == 0 || ES8P_SCHED == 3
+    if (nxt) {
+      issue_x(nboff, 1);
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");    // weights + first pixel quarter of the next tile have landed
+    }
+#else
+    if (nxt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#endif
+    ES_MFMA(1)
+#undef ES_MFMA
+#undef ES_RD
+    boff = nboff;
+  }
+  if (!(ES8P_ABL & 4) && grp8 == 0) __builtin_amdgcn_s_barrier();            // balance the stagger: every wave is past its last LDS read
+
+  const int prow = grp8 * 128 + frow;                     // + j * 16 : pixel row inside the tile
+  const int pcol = wn * 80 + fq * 4;                      // + i * 16 : cout column inside the tile
+  // ---------------- split-K: raw fp32 partials ----------------
+  if (p.splitk > 1) {
+    float* wsp = p.workspace + (size_t)z * M * p.rows_padded;
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const int m = tile_m * BM + prow + j * 16;
+      if (m < M) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+          store16(wsp + (size_t)m * p.rows_padded + tile_n * BN + pcol + i * 16, __builtin_bit_cast(u32x4, acc[i][j]));
+      }
+    }
+    if (p.prof && tid == 0) atomicMax(p.prof + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    return;
+  }
+
+  // ---------------- epilogue: two passes of 160 couts through an LDS tile [pixel][cout] ----------------
+  const int Cstore = p.Cout;
+  float scale = p.out_scale;
+  if (p.out_scale_dev) scale *= *p.out_scale_dev;
+  char* et = smem;
+  T* outp = (T*)p.out;
+  const T* resp = (const T*)p.residual;
+  const bool vec_store = (Cstore & 7) == 0;
+  constexpr int CH = 20;                                   // 16-byte chunks per tile row and pass
+  constexpr int RPF = BM * CH / 512;                       // chunks per thread and pass
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int c_tile = tile_n * BN + pass * 160;
+    u32x4 rpre[RPF];
+    if (resp && vec_store) {                               // residual rows requested before the LDS transposition
+#pragma unroll
+      for (int k = 0; k < RPF; ++k) {
+        const int idx = tid + k * 512;
+        const int row = (idx * 3277) >> 16, ch = idx - row * CH;       // idx / 20 for idx < 5120
+        const int m = tile_m * BM + row, c = c_tile + ch * 8;
+        rpre[k] = u32x4{0u, 0u, 0u, 0u};
+        if (m < M && c < Cstore) rpre[k] = *(const u32x4*)(resp + (size_t)m * Cstore + c);
+      }
+    }
+    if (pass) __syncthreads();                             // previous pass's tile no longer read
+    if ((wn >> 1) == pass) {
+      f32x4 bias[FN];
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+        bias[i] = bsel ? *(const f32x4*)(bsel + tile_n * BN + pcol + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const int m = tile_m * BM + prow + j * 16;
+        const int mc = m < M ? m : M - 1;
+        const int n = small_m ? fast_div(mc, HWout, inv_hw) : mc / HWout;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+          const int c = tile_n * BN + pcol + i * 16;
+          float tv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (p.temb && c < p.Cout) {
+            const T* tp = (const T*)p.temb + (size_t)n * p.temb_stride + c;
+            if (c + 3 < p.Cout) {
+              const auto t4 = *(const typename Traits<T>::vec4*)tp;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) tv[r] = to_f32(t4[r]);
+            } else {
+              for (int r = 0; r < 4 && c + r < p.Cout; ++r) tv[r] = to_f32(tp[r]);
+            }
+          }
+          typename Traits<T>::vec4 pk;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = acc[i][j][r] + bias[i][r] + tv[r];
+            if (p.act == ES_ACT_SILU) x = silu_f(x);
+            pk[r] = from_f32<T>(x * scale);
+          }
+          *(typename Traits<T>::vec4*)(et + (prow + j * 16) * EROW + ((wn & 1) * 80 + fq * 4 + i * 16) * 2) = pk;
+        }
+      }
+    }
+    __syncthreads();
+    if (vec_store) {
+#pragma unroll
+      for (int k = 0; k < RPF; ++k) {
+        const int idx = tid + k * 512;
+        const int row = (idx * 3277) >> 16, ch = idx - row * CH;
+        const int m = tile_m * BM + row, c = c_tile + ch * 8;
+        if (m < M && c < Cstore) {
+          auto v = as_vec8<T>(*(const u32x4*)(et + row * EROW + ch * 16));
+          if (resp) {
+            const auto rv = as_vec8<T>(rpre[k]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(rv[e]));
+          }
+          store16(outp + (size_t)m * Cstore + c, __builtin_bit_cast(u32x4, v));
+        }
+      }
+    } else {
+      for (int idx = tid; idx < BM * 160; idx += 512) {
+        const int row = idx / 160, cc = idx - row * 160;
+        const int m = tile_m * BM + row, c = c_tile + cc;
+        if (m < M && c < Cstore) {
+          float x = to_f32(*(const T*)(et + row * EROW + cc * 2));
+          if (resp) x += to_f32(resp[(size_t)m * Cstore + c]);
+          outp[(size_t)m * Cstore + c] = from_f32<T>(x);
+        }
+      }
+    }
+  }
+  if (p.prof && tid == 0) atomicMax(p.prof + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+}  // namespace
+
+// called by es_conv_gemm (gemm_conv.hip) after validation, for d.bn == 320
+int es_conv_gemm8p_launch(const es_gemm_desc& d, hipStream_t st) {
+  const int M = d.N * d.Hout * d.Wout;
+  const int nk = d.Kpad / 64;
+  const int tn = d.rows_padded / BN;
+  dim3 grid(((M + BM - 1) / BM) * tn * d.splitk);
+  constexpr size_t lds = 2 * (size_t)BUF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_gemm8p_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_gemm8p_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  if (d.dtype == ES_F16)
+    hipLaunchKernelGGL(conv_gemm8p_kernel<f16>, grid, dim3(512), lds, st, d, M, nk, d.t1, d.t2, d.Ct1, d.Ct2);
+  else
+    hipLaunchKernelGGL(conv_gemm8p_kernel<bf16>, grid, dim3(512), lds, st, d, M, nk, d.t1, d.t2, d.Ct1, d.Ct2);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -596,7 +596,6 @@ int launch(const es_xs_desc& d, hipStream_t st) {
 extern "C" void es_set_error(const char* msg);
 
 extern "C" int es_linear_xs(const es_xs_desc* d, void* stream) {
-  ES_PLAN_RECORD(ES_OP_LINEAR_XS, d, sizeof(*d));
   if (!d->x || !d->out || (d->ngroups <= 1 && (!d->w || !d->bias))) { es_set_error("es_linear_xs: null pointer (bias is required: pass zeros)"); return -1; }
   if (d->K != 320 && d->K != 640) { es_set_error("es_linear_xs: K must be 320 or 640"); return -1; }
   const int CH = d->K == 320 ? 64 : 32;
@@ -622,6 +621,7 @@ extern "C" int es_linear_xs(const es_xs_desc* d, void* stream) {
     if (d->mt_end[d->ngroups - 1] != tm) { es_set_error("es_linear_xs: groups must cover M"); return -1; }
   }
   for (int g = dd.ngroups > 1 ? dd.ngroups : 0; g < 4; ++g) dd.mt_end[g] = 0x7FFFFFFF;
+  ES_PLAN_RECORD(ES_OP_LINEAR_XS, d, sizeof(*d));
   int rc = dd.dtype == ES_F16 ? launch<f16>(dd, (hipStream_t)stream) : launch<bf16>(dd, (hipStream_t)stream);
   if (rc) es_set_error("es_linear_xs: launch failed");
   return rc;

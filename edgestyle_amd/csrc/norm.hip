@@ -481,7 +481,6 @@ extern "C" int es_group_norm_is_slab(int HW, int C, int groups) {
 }
 
 extern "C" int es_group_norm(const es_gn_desc* d, void* stream) {
-  ES_PLAN_RECORD(ES_OP_GROUP_NORM, d, sizeof(*d));
   const int C = d->C1 + d->C2;
   if ((!d->x && !d->sk_ws) || !d->out || !d->partials || (d->ngroups <= 1 && (!d->gamma || !d->beta))) { es_set_error("es_group_norm: null pointer"); return -1; }
   if (d->sk_ws) {
@@ -499,6 +498,7 @@ extern "C" int es_group_norm(const es_gn_desc* d, void* stream) {
   if (C > 8192) { es_set_error("es_group_norm: C too large for the LDS tables"); return -1; }
   if (d->N < 1 || d->HW < 1) { es_set_error("es_group_norm: empty problem"); return -1; }
   if ((long long)d->HW * (C / 8) >= (1ll << 30)) { es_set_error("es_group_norm: sample too large for 32-bit chunk indices"); return -1; }
+  ES_PLAN_RECORD(ES_OP_GROUP_NORM, d, sizeof(*d));
   hipStream_t st = (hipStream_t)stream;
   es_gn_desc dd = *d;                                  // unused group-table entries must compare false (see es_conv_gemm)
   for (int g = dd.ngroups > 1 ? dd.ngroups : 0; g < 4; ++g) dd.n_end[g] = 0x7FFFFFFF;
@@ -509,12 +509,12 @@ extern "C" int es_group_norm(const es_gn_desc* d, void* stream) {
 
 extern "C" int es_layer_norm(const void* x, void* out, const float* gamma, const float* beta, int M, int C,
                              float eps, int dtype, void* stream) {
+  if (!x || !out || !gamma || !beta) { es_set_error("es_layer_norm: null pointer"); return -1; }
+  if (C % 8 || M < 1) { es_set_error("es_layer_norm: C must be a multiple of 8"); return -1; }
   if (es_plan_recording()) {
     const es_op_layer_norm a{x, out, gamma, beta, M, C, eps, dtype};
     es_plan_record(ES_OP_LAYER_NORM, &a, sizeof(a));
   }
-  if (!x || !out || !gamma || !beta) { es_set_error("es_layer_norm: null pointer"); return -1; }
-  if (C % 8 || M < 1) { es_set_error("es_layer_norm: C must be a multiple of 8"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   int rc = dtype == ES_F16 ? launch_ln<f16>(x, out, gamma, beta, M, C, eps, st)
                            : launch_ln<bf16>(x, out, gamma, beta, M, C, eps, st);
@@ -524,7 +524,6 @@ extern "C" int es_layer_norm(const void* x, void* out, const float* gamma, const
 }
 
 extern "C" int es_layer_norm_grouped(const es_ln_desc* d, void* stream) {
-  ES_PLAN_RECORD(ES_OP_LAYER_NORM_GROUPED, d, sizeof(*d));
   if (!d->x || !d->out || d->C % 8 || d->M < 1 || d->ngroups < 1 || d->ngroups > 4) { es_set_error("es_layer_norm_grouped: bad arguments"); return -1; }
   LnGroups grp;
   grp.ngroups = d->ngroups;
@@ -535,6 +534,7 @@ extern "C" int es_layer_norm_grouped(const es_ln_desc* d, void* stream) {
     if (!grp.gamma[g] || !grp.beta[g]) { es_set_error("es_layer_norm_grouped: null parameter"); return -1; }
   }
   if (d->row_end[d->ngroups - 1] != d->M) { es_set_error("es_layer_norm_grouped: group table must cover M"); return -1; }
+  ES_PLAN_RECORD(ES_OP_LAYER_NORM_GROUPED, d, sizeof(*d));
   hipStream_t st = (hipStream_t)stream;
   int rc = d->dtype == ES_F16 ? launch_ln<f16>(d->x, d->out, grp.gamma[0], grp.beta[0], d->M, d->C, d->eps, st, grp)
                               : launch_ln<bf16>(d->x, d->out, grp.gamma[0], grp.beta[0], d->M, d->C, d->eps, st, grp);

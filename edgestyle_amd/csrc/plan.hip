@@ -217,6 +217,10 @@ float* staging(es_ctx* c, size_t n) {
   if (!c->staged && hipEventCreateWithFlags(&c->staged, hipEventDisableTiming) != hipSuccess) return nullptr;
   return c->host;
 }
+bool capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
 int need(const es_ctx* c, int slot, const char* what) {
   if (!c->buf[slot]) { es_set_error(what); return -1; }
   return 0;
@@ -442,6 +446,8 @@ extern "C" int es_denoise_step(es_ctx* c, const void* sample, float t, const voi
                                const float* scales, void* out_noise, void* stream) {
   if (!c || !sample || !ehs || !cond_embeds || !out_noise) { es_set_error("es_denoise_step: null argument"); return -1; }
   hipStream_t st = (hipStream_t)stream;
+  if (capturing(st)) { es_set_error("es_denoise_step: the stream is capturing; this entry point stages host values (timestep, scales) through pinned memory and cannot be captured - capture es_ctx_launch_plan(ES_PLAN_STEP_GENERIC) on buffers you fill yourself"); return -1; }
+  if (!c->plan[ES_PLAN_STEP_GENERIC]) { es_set_error("es_denoise_step: the context has no ES_PLAN_STEP_GENERIC"); return -1; }
   if (need(c, ES_BUF_SAMPLE, "es_denoise_step: ES_BUF_SAMPLE not bound") || need(c, ES_BUF_T_ROWS, "es_denoise_step: ES_BUF_T_ROWS not bound") ||
       need(c, ES_BUF_EHS, "es_denoise_step: ES_BUF_EHS not bound") || need(c, ES_BUF_SCALES, "es_denoise_step: ES_BUF_SCALES not bound") ||
       need(c, ES_BUF_NOISE, "es_denoise_step: ES_BUF_NOISE not bound")) return -1;
@@ -455,9 +461,9 @@ extern "C" int es_denoise_step(es_ctx* c, const void* sample, float t, const voi
   if (hipMemsetD32Async((hipDeviceptr_t)c->buf[ES_BUF_T_ROWS], __builtin_bit_cast(int, t), c->bytes[ES_BUF_T_ROWS] / 4, st) != hipSuccess) { es_set_error("es_denoise_step: fill failed"); return -2; }
   float* hs = staging(c, 8);
   if (!hs) { es_set_error("es_denoise_step: pinned staging allocation failed"); return -2; }
-  for (int i = 0; i < 6; ++i) hs[i] = scales ? scales[i] : 1.f;
+  for (int i = 0; i < 6; ++i) hs[i] = (scales && i < c->g.n_conds) ? scales[i] : 1.f;     // `scales` holds n_conds values
   if ((rc = h2d(c->buf[ES_BUF_SCALES], hs, (size_t)c->g.n_conds * 4, st))) return rc;
-  (void)hipEventRecord(c->staged, st);
+  if (hipEventRecord(c->staged, st) != hipSuccess) { es_set_error("es_denoise_step: hipEventRecord failed"); return -2; }
   if ((rc = run(c, ES_PLAN_STEP_GENERIC, st, nullptr))) return rc;
   return d2d(out_noise, c->buf[ES_BUF_NOISE], c->bytes[ES_BUF_NOISE], st);
 }
@@ -471,6 +477,8 @@ extern "C" int es_denoise_loop(es_ctx* c, float* latents_inout, const void* ehs,
   const int need_slots[] = {ES_BUF_LATENTS, ES_BUF_SAMPLE, ES_BUF_EHS, ES_BUF_STEP_IDX, ES_BUF_T_TABLE, ES_BUF_SCALE_TABLE, ES_BUF_COEF, ES_BUF_TIMESTEPS};
   for (int s : need_slots) if (need(c, s, "es_denoise_loop: a static buffer is not bound")) return -1;
   hipStream_t st = (hipStream_t)stream;
+  if (capturing(st)) { es_set_error("es_denoise_loop: the stream is capturing; this entry point stages host tables through pinned memory and cannot be captured (it replays its own hipGraphs: use_graphs 1 | 2)"); return -1; }
+  if (!c->plan[ES_PLAN_PREP] || !c->plan[ES_PLAN_STEP]) { es_set_error("es_denoise_loop: the context has no ES_PLAN_PREP / ES_PLAN_STEP"); return -1; }
   const es_ctx_geometry& g = c->g;
   const int T = n_steps, nc = g.n_conds;
   const size_t trow = c->bytes[ES_BUF_T_TABLE] / 4 / T;          // kmax * N timestep copies per step
@@ -491,15 +499,13 @@ extern "C" int es_denoise_loop(es_ctx* c, float* latents_inout, const void* ehs,
   if ((rc = h2d(c->buf[ES_BUF_SCALE_TABLE], sc, (size_t)T * nc * 4, st))) return rc;
   if ((rc = h2d(c->buf[ES_BUF_COEF], cf, (size_t)T * 16, st))) return rc;
   if ((rc = h2d(c->buf[ES_BUF_TIMESTEPS], tsd, (size_t)T * 4, st))) return rc;
-  (void)hipEventRecord(c->staged, st);
+  if (hipEventRecord(c->staged, st) != hipSuccess) { es_set_error("es_denoise_loop: hipEventRecord failed"); return -2; }
   if (hipMemsetAsync(c->buf[ES_BUF_STEP_IDX], 0, 4, st) != hipSuccess) { es_set_error("es_denoise_loop: memset failed"); return -2; }
   if ((rc = d2d(c->buf[ES_BUF_LATENTS], latents_inout, c->bytes[ES_BUF_LATENTS], st))) return rc;
   if ((rc = d2d(c->buf[ES_BUF_EHS], ehs, c->bytes[ES_BUF_EHS], st))) return rc;
   if ((rc = es_latents_to_input((const float*)c->buf[ES_BUF_LATENTS], c->buf[ES_BUF_SAMPLE], g.B, g.h * g.w, g.latent_channels,
                                 g.latent_pad, g.cfg, g.dtype, stream))) return rc;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  (void)hipStreamIsCapturing(st, &cs);
-  if (c->use_graphs == 2 && cs == hipStreamCaptureStatusNone) {
+  if (c->use_graphs == 2) {
     // the preparation and all n step lists as ONE graph (BASELINE configs[2]: "hipGraph-captured scheduler loop"): every
     // step is the same launch list - the device step counter picks its rows of the tables - so the graph depends on
     // (n_steps, guidance scale) only

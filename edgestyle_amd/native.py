@@ -131,8 +131,30 @@ class NativeEngine:
         L.check(self.lib.es_ctx_set_alphas_cumprod(ctx, ac.numpy().ctypes.data_as(C.POINTER(C.c_float)), ac.numel()),
                 "es_ctx_set_alphas_cumprod")
         self.set_options(use_graphs=use_graphs)
-        loop.graph = None                            # the pipeline's own graph of this loop saw other table contents: re-capture
-        loop.sig = None
+        # The recorded plans hold raw pointers into this loop's static buffers and StepState tensors (time-projection table,
+        # batch-concatenated conditions, text K/V projections): the loop becomes PRIVATE to the engine.  It leaves the
+        # pipeline's cache - a later pipe(...) with the same (B, cfg, h, w) builds its own loop and may replace ITS tables
+        # (another num_inference_steps re-allocates tproj_table) without freeing anything a plan still reads - and every
+        # tensor the plans can reference is pinned here for the life of the context.
+        pipe._loops.pop((B, guidance, h, w, False), None)
+        if getattr(pipe, "_last_loop", None) is loop:
+            pipe._last_loop = None
+        from .models import StepState
+        pinned = []
+
+        def pin(o):
+            if torch.is_tensor(o):
+                pinned.append(o)
+            elif isinstance(o, (list, tuple)):
+                for x in o:
+                    pin(x)
+        for v in vars(loop.state).values():
+            pin(v)
+        for v in vars(loop).values():
+            pin(v)
+        self._keep.append(pinned)
+        if runner.state is loop.state:
+            runner.state = StepState()               # stand-alone StepRunner calls get a fresh default state again
 
     def _conds_fn(self, pipe, loop, B, guidance, h, w):
         """The one-time conditioning embedding (PL:352-377, 629-664; CL:28-42, 289-290) as pipeline.prepare_images does it -

@@ -282,13 +282,15 @@ def _get_workspace(nbytes: int, device) -> torch.Tensor:
 #   * the big tile (256 px x 320 couts, one workgroup per CU) does the work of two 160-wide workgroups in ~4 % less
 #     time (half the L2->LDS bytes); it only pays on launches of many rounds, so it is offered from 32k pixels up.
 PLAN_T160, PLAN_ALONE, PLAN_TFIX, PLAN_RED_FIX, PLAN_SLAB_BYTES_PER_UNIT = 1.25, 0.9, 2.0, 12.0, 4.0e6
-PLAN_T320, PLAN_BIG_MIN_M = 2.4, 32768
+PLAN_T320, PLAN_BIG_MIN_M, PLAN_T320_FIX, PLAN_BIG_MIN_NK = 2.15, 16384, 4.0, 16
 #   * the 64x64 tile (tiny launches): a K-step costs 0.5 units with the CU to itself and 0.5 + 0.16 (w - 1)^2 with w
 #     workgroups per CU (measured 0.87 at w = 2.5, 2.0 at w = 3.75); x1.5 for K > 2560, where MFMA throughput starts to
 #     matter and the small tile reads LDS twice as often per FLOP;
 #     1024 resident workgroups (32 KB of LDS each); offered up to 16k pixels.
 PLAN_T64_ALONE, PLAN_T64, PLAN_T64_LONG, PLAN_SMALL_MAX_M = 0.5, 0.16, 1.5, 16384
-BIG_TILE = _os.environ.get("ES_BIG_TILE", "0") == "1"      # opt-in: measured no end-to-end gain at batch 1 or 8
+# the 256 x 320 phase-interleaved tile (csrc/gemm_conv8p.hip): 1.03-1.15x the 128-pixel tile on launches of >= 1 round of
+# 256 workgroups with K >= 1024 (tools/gemm8p_bench.py: 1.07-1.30 PFLOP/s on the batch-8 3x3 launches)
+BIG_TILE = _os.environ.get("ES_BIG_TILE", "1") == "1"
 PLAN_SLAB_BYTES_PER_UNIT = float(_os.environ.get("ES_PLAN_SLAB", PLAN_SLAB_BYTES_PER_UNIT))
 PLAN_RED_FIX = float(_os.environ.get("ES_PLAN_REDFIX", PLAN_RED_FIX))
 PLAN_MIN_SLICE, PLAN_NK_NOSPLIT, PLAN_RESIDENT = 12, 10, 512
@@ -303,7 +305,7 @@ def plan_gemm(M: int, rows_padded: int, kpad: int, geglu: bool = False, bns=(160
     for bn in bns:
         if rows_padded % bn:
             continue
-        if bn == 320 and M < PLAN_BIG_MIN_M and len(bns) > 1:
+        if bn == 320 and (M < PLAN_BIG_MIN_M or nk < PLAN_BIG_MIN_NK) and len(bns) > 1:
             continue
         if bn == 64 and M > PLAN_SMALL_MAX_M and len(bns) > 1:
             continue
@@ -324,7 +326,7 @@ def plan_gemm(M: int, rows_padded: int, kpad: int, geglu: bool = False, bns=(160
                 tk = (PLAN_T64_ALONE + PLAN_T64 * max(0.0, w - 1.0) ** 2) * (1.0 if nk <= 40 else PLAN_T64_LONG)
             else:
                 tk = (PLAN_T160 if bn == 160 else 1.0) * (PLAN_ALONE if wgs <= PLAN_RESIDENT // 2 else 1.0)
-            t = -(-wgs // resident) * ((nk / sk) * tk + PLAN_TFIX)
+            t = -(-wgs // resident) * ((nk / sk) * tk + (PLAN_T320_FIX if bn == 320 else PLAN_TFIX))
             if sk > 1:
                 t += PLAN_RED_FIX + sk * M * rows_padded * 8.0 / PLAN_SLAB_BYTES_PER_UNIT
             if best is None or t < best[0]:

@@ -27,12 +27,22 @@ from .models import (AutoencoderKL, ControlNetModel, EdgeStyleMultiControlNetMod
 from .schedulers import DDIMScheduler, UniPCMultistepScheduler
 
 
-_HOST_GENS = {}
+from collections import OrderedDict
+
+# id(device generator) -> (generator, state we left it in, its CPU stand-in).  torch.Generator cannot be weakly referenced,
+# so the cache is a small LRU instead of a global that pins every generator ever seen.
+_HOST_GENS: "OrderedDict[int, tuple]" = OrderedDict()
+_HOST_GENS_MAX = 8
 
 
 def _host_generator(generator):
     """torch.Generator on a device -> a CPU generator seeded with its initial_seed() (one per device generator object,
-    so successive draws advance like the original would); lists are mapped element-wise; CPU generators pass through."""
+    so successive draws advance like the original would); lists are mapped element-wise; CPU generators pass through.
+
+    A caller who calls `gen.manual_seed(s)` again between two pipeline calls (the usual way to reproduce a run; the
+    reference draws from the device generator itself, TT:274, so that reproduces it there) must get the same images here:
+    every use advances the DEVICE generator by one draw and remembers the state it was left in; a generator found in any
+    other state has been re-seeded (even to the same seed) and its stand-in restarts from initial_seed()."""
     if generator is None:
         return None
     if isinstance(generator, (list, tuple)):
@@ -40,11 +50,16 @@ def _host_generator(generator):
     if generator.device.type == "cpu":
         return generator
     key = id(generator)
-    hit = _HOST_GENS.get(key)
-    if hit is None or hit[0] is not generator or hit[1] != generator.initial_seed():
-        hit = (generator, generator.initial_seed(), torch.Generator().manual_seed(generator.initial_seed()))
-        _HOST_GENS[key] = hit
-    return hit[2]
+    hit = _HOST_GENS.pop(key, None)
+    if hit is None or hit[0] is not generator or not torch.equal(hit[1], generator.get_state()):
+        host = torch.Generator().manual_seed(generator.initial_seed())
+    else:
+        host = hit[2]
+    torch.empty(1, device=generator.device).normal_(generator=generator)      # mark: "seen in this state"
+    _HOST_GENS[key] = (generator, generator.get_state().clone(), host)
+    while len(_HOST_GENS) > _HOST_GENS_MAX:
+        _HOST_GENS.popitem(last=False)
+    return host
 
 
 @dataclass
@@ -342,7 +357,22 @@ class StableDiffusionControlNetPipeline:
                  return_dict: bool = True, controlnet_conditioning_scale: Union[float, List[float]] = 1.0,
                  guess_mode: bool = False, control_guidance_start: Union[float, List[float]] = 0.0,
                  control_guidance_end: Union[float, List[float]] = 1.0,
-                 callback_on_step_end: Optional[Callable] = None, cond_noise: Optional[Sequence] = None, **kwargs):
+                 callback_on_step_end: Optional[Callable] = None, cond_noise: Optional[Sequence] = None,
+                 ip_adapter_image=None, cross_attention_kwargs=None, clip_skip: Optional[int] = None,
+                 callback_on_step_end_tensor_inputs: Sequence[str] = ("latents",), **kwargs):
+        # the reference's signature (PL:92-120) in full; what this path does not implement is refused, never ignored
+        if kwargs:
+            raise TypeError(f"unexpected keyword argument(s) {sorted(kwargs)}: this pipeline implements PL:92-120 without the "
+                            "deprecated `callback` / `callback_steps` and without extensions")
+        if ip_adapter_image is not None:
+            raise NotImplementedError("ip_adapter_image: IP-Adapter conditioning is not part of this path (no caller of the reference uses it)")
+        if cross_attention_kwargs is not None:
+            raise NotImplementedError("cross_attention_kwargs: attention processors / LoRA scale are not part of this path "
+                                      "(LoRA deltas are folded into private weight copies at load time, CL:728-777)")
+        if clip_skip is not None:
+            raise NotImplementedError("clip_skip is not implemented: pass prompt_embeds of the layer you want (PL:106-107)")
+        if list(callback_on_step_end_tensor_inputs) != ["latents"]:
+            raise NotImplementedError("callback_on_step_end receives `latents` only (the step keeps no other tensor alive)")
         if eta != 0.0:
             raise NotImplementedError("only the deterministic DDIM update (eta = 0) is implemented")
         if timesteps is not None:
@@ -390,6 +420,13 @@ class StableDiffusionControlNetPipeline:
         conds = self.prepare_images(image, B, do_cfg and not guess, cond_noise, generator,
                                     num_images_per_prompt)                                      # PL:352-377, 657-658
         h, w = conds[0].shape[1:3]
+        # PL:377: the reference takes height / width from the (embedded) condition images and never reads the arguments;
+        # here they are honoured as a check: a request for another size than the condition images define is refused
+        scale = self.vae.cfg.scale
+        for name, asked, have in (("height", height, h * scale), ("width", width, w * scale)):
+            if asked is not None and int(asked) != have:
+                raise ValueError(f"`{name}`={asked} but the condition images define {have} pixels (latent {have // scale}): "
+                                 "the output size follows the condition images (PL:377); resize them instead")
 
         mark("cond_embed")
         # PL:382-398

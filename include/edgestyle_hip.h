@@ -360,7 +360,11 @@ int es_ctx_launch_plan(es_ctx* c, int which, const float* guidance_scale, void* 
  * SD1.5 scheduler_config's set_alpha_to_one False); alphas_cumprod NULL = SD1.5's scaled_linear schedule */
 int es_ddim_coef_table(const float* alphas_cumprod, int n_alphas, const float* timesteps, int n, float* out);
 /* sample dtype [N,h,w,latent_pad]; ehs dtype [N,77,D]; cond_embeds[n_conds] dtype [N,h,w,C0]; scales float[n_conds] (host)
- * or NULL (ones); out_noise dtype [N,h,w,out_channels].  All device pointers except `scales`. */
+ * or NULL (ones); out_noise dtype [N,h,w,out_channels].  All device pointers except `scales`.
+ * Stream capture: es_denoise_step and es_denoise_loop stage host values (timestep, scales, per-step tables) through pinned
+ * memory and REFUSE a capturing stream (-1); they replay hipGraphs of their own (es_ctx_set_options use_graphs).  To place a
+ * step inside a graph of yours, fill the bound buffers yourself and capture es_ctx_launch_plan, which es_vae_decode and
+ * es_prepare_conds (device-to-device copies + one plan) also support. */
 int es_denoise_step(es_ctx* c, const void* sample, float t, const void* ehs, const void* const* cond_embeds,
                     const float* scales, void* out_noise, void* stream);
 /* latents fp32 [B,h,w,L] (device, in/out); ehs as above; timesteps: HOST float[n_steps] (981, 961, ... for 50 steps);

@@ -130,6 +130,27 @@ def single_cn_inputs(seed=44):
     return lat, pe, ne, pose
 
 
+def full_rgb_inputs(seed=49):
+    """The RGB-image form of the call (TT:328-359): six [1,3,512,512] condition images - IMG tensors in [-1,1] for the
+    three VAE-conditioned LoRA nets (even slots), COND tensors in [0,1] for the three pose nets (odd slots, TT:29-48) -,
+    the latent_dist.sample() noise of each LoRA net for the CFG-duplicated batch N = 2 (CL:39), latents, text states."""
+    ucfg, vcfg = C.sd15_unet(), C.sd15_vae()
+    g = torch.Generator().manual_seed(seed)
+    s = ucfg.sample_size
+    px = s * vcfg.scale
+    imgs = []
+    for i in range(6):
+        u = torch.rand(1, 3, px, px, generator=g)
+        # smooth images (blocks of 8 pixels blended with noise): closer to photographs than white noise is
+        u = 0.7 * torch.nn.functional.interpolate(u[:, :, ::8, ::8], scale_factor=8.0, mode="bilinear", align_corners=False) + 0.3 * u
+        imgs.append(((u * 2 - 1) if i % 2 == 0 else u).half().float())
+    noise = [torch.randn(2, vcfg.latent_channels, s, s, generator=g).half().float() if i % 2 == 0 else None for i in range(6)]
+    lat = torch.randn(1, 4, s, s, generator=g)
+    pe = (torch.randn(1, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+    ne = (torch.randn(1, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+    return imgs, noise, lat, pe, ne
+
+
 def psnr(a, b, peak=1.0):
     import math
     mse = float(((a.float().cpu() - b.float().cpu()) ** 2).mean())

@@ -47,3 +47,28 @@ def test_two_rank_shard_and_gather():
         assert p.exitcode == 0
     assert even == [42.0 + i for i in range(8)]
     assert ragged == [42.0 + i for i in range(5)]
+
+
+def test_bench_two_rank_control_flow_rehearsal():
+    """bench.py's own multi-rank control flow (`--gpus 2`, launched exactly as the driver launches it: one process per rank
+    through torch.distributed.run) on CPU with gloo and a stand-in pipeline (`--fake-pipeline`: no kernels, not a
+    measurement): default of 8 try-ons per rank = BASELINE configs[3], per-image seeds from the GLOBAL image index, barrier +
+    max-over-ranks timing, ONE gather of the decoded images on rank 0, one JSON line from rank 0 only."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2",
+                        "--steps", "2", "--warmup", "1", "--fake-pipeline"], cwd=root, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["images_per_gpu"] == 8 and "configs[3]" in d["config"]["workload"]
+    reh = d["rehearsal"]
+    assert len(reh["gathered_image_means"]) == 16 and reh["gathered_image_means"] == reh["expected"]
+    assert len(set(reh["expected"])) == 16                 # sixteen different try-ons, ordered by global index

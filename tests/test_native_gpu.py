@@ -136,6 +136,32 @@ def test_es_denoise_loop_and_vae_decode_equal_the_pipeline_bitwise(built):
         eng.denoise_loop(x.clone(), ehs, gs, timesteps=[981.0, 961.0])      # built for T steps
 
 
+def test_engine_survives_pipeline_calls_with_another_step_count(built):
+    """The plans hold raw pointers into the static buffers of the loop the engine was built on (time-projection table, condition
+    slots, text K/V projections).  That loop is private to the engine: a pipeline call with the same (batch, cfg, size) but
+    ANOTHER num_inference_steps - which re-allocates the pipeline's own time table - must neither free nor overwrite anything
+    the native plans read."""
+    from edgestyle_amd.models import _as_nhwc
+    pipe, eng, ws, ucfg, vcfg = built
+    lat, pe, ne, conds = _inputs(ucfg, 57)
+    gs, T = 5.0, eng.T
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, latents=lat, guidance_scale=gs)
+    want = pipe(output_type="latent", num_inference_steps=T, **kw).images.clone()
+    assert all(lp is not eng.loop for lp in pipe._loops.values())
+    for other_T in (T + 5, 3):                               # grows, then shrinks the pipeline's tables
+        pipe(output_type="latent", num_inference_steps=other_T, **kw)
+        junk = [torch.randn(1 << 20, device=DEV) for _ in range(8)]      # anything freed would be handed out again here
+        eng.set_conds([_as_nhwc(c.repeat(2, 1, 1, 1), torch.float16, DEV) for c in conds])
+        ehs = torch.cat([ne, pe]).to(DEV, torch.float16).contiguous()
+        for use_graphs in (True, False):
+            eng.set_options(use_graphs=use_graphs)
+            got = eng.denoise_loop(lat.permute(0, 2, 3, 1).contiguous().to(DEV), ehs, gs)
+            torch.cuda.synchronize()
+            assert torch.equal(got.permute(0, 3, 1, 2), want), (other_T, use_graphs)
+        del junk
+    eng.set_options(use_graphs=True)
+
+
 @pytest.mark.parametrize("guidance", [True, False])
 def test_native_context_for_a_single_controlnet_and_without_cfg(built, guidance):
     """es_ctx with n_conds = 1 (BASELINE configs[0]: one plain ControlNetModel) and with CFG off (N = B): loop and decode

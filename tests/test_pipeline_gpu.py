@@ -179,6 +179,19 @@ def test_errors_match_reference_behaviour(built):
     with pytest.raises(ValueError):
         pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, latents=lat, control_guidance_start=0.8,
              control_guidance_end=0.2)
+    # what the reference's signature (PL:92-120) offers and this path does not implement is refused, never ignored
+    base = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, latents=lat, num_inference_steps=2)
+    with pytest.raises(TypeError):
+        pipe(callback_steps=1, **base)
+    for kw in (dict(clip_skip=1), dict(cross_attention_kwargs={"scale": 0.5}), dict(ip_adapter_image=conds[0]),
+               dict(callback_on_step_end_tensor_inputs=["latents", "prompt_embeds"]), dict(eta=0.5), dict(timesteps=[10, 5])):
+        with pytest.raises(NotImplementedError):
+            pipe(**base, **kw)
+    px = ucfg.sample_size * vcfg.scale
+    with pytest.raises(ValueError):
+        pipe(height=px + 8 * vcfg.scale, **base)                 # another size than the condition images define (PL:377)
+    out = pipe(height=px, width=px, output_type="latent", **base).images      # the matching size is accepted
+    assert out.shape[-1] == ucfg.sample_size
 
 
 def test_pipeline_bf16_non_default_size_config5_analogue():
@@ -413,6 +426,15 @@ def test_device_generator_like_the_reference_test_script(built):
         a = pipe(generator=torch.Generator(DEV).manual_seed(42), **kw).images
     b = pipe(generator=torch.Generator().manual_seed(42), **kw).images
     assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    # one device generator across calls: draws advance like the original's would; re-seeding it (even to the SAME seed, the
+    # usual way to reproduce a run) restarts the stream, as it does for the reference that draws from the device generator
+    gen = torch.Generator(DEV).manual_seed(7)
+    first = pipe(generator=gen, **kw).images
+    second = pipe(generator=gen, **kw).images
+    assert not torch.equal(first, second)
+    gen.manual_seed(7)
+    assert torch.equal(pipe(generator=gen, **kw).images, first)
+    assert torch.equal(pipe(generator=gen, **kw).images, second)
 
 
 def test_num_images_per_prompt_repeats_a_per_prompt_image_batch(built):

@@ -1,0 +1,58 @@
+"""The 256 x 320 phase-interleaved tile (csrc/gemm_conv8p.hip, bn = 320) vs the default planner choice on the large
+launches of a step: time (hipGraph replays of R launches, best of 5), TFLOP/s, bitwise equality where splitk == 1."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from edgestyle_amd import ops
+DEV = "cuda"
+g = torch.Generator().manual_seed(0)
+
+
+def bench(fn, R=6):
+    fn(); torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        for _ in range(R):
+            fn()
+    best = 1e9
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); gr.replay(); e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / R)
+    return best * 1e3
+
+
+# (N, H, Cin, Cout, k, groups, splitk for the big tile or None)
+shapes = [(14, 64, 320, 320, 3, [2, 6, 4, 2], None), (14, 32, 640, 640, 3, [2, 6, 4, 2], None), (14, 32, 640, 640, 3, [2, 6, 4, 2], 2),
+          (14, 16, 1280, 1280, 3, [2, 6, 4, 2], 4), (14, 64, 1600, 320, 1, [2, 6, 4, 2], None),
+          (16, 64, 320, 320, 3, None, None), (16, 64, 640, 320, 3, None, None), (16, 32, 640, 640, 3, None, None),
+          (16, 32, 1280, 640, 3, None, None), (16, 16, 1280, 1280, 3, None, None), (16, 16, 1280, 1280, 3, None, 2),
+          (112, 64, 320, 320, 3, [16, 48, 32, 16], None), (112, 32, 640, 640, 3, [16, 48, 32, 16], None),
+          (112, 16, 1280, 1280, 3, [16, 48, 32, 16], None), (112, 64, 1600, 320, 1, [16, 48, 32, 16], None),
+          (2, 64, 960, 320, 3, None, 4), (2, 64, 960, 320, 3, None, 8)]
+only = os.environ.get("ES_ONLY")
+for si, (N, H, Cin, Cout, k, groups, sk) in enumerate(shapes):
+    if only and str(si) not in only.split(","):
+        continue
+    x = (torch.randn(N, H, H, Cin, generator=g)).to(DEV, torch.float16)
+    n = len(groups) if groups else 1
+    pws = [ops.pack_weight(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5, torch.randn(Cout, generator=g) * 0.1,
+                           torch.float16, DEV) for _ in range(n)]
+    pw = pws if groups else pws[0]
+    kw = dict(group_n=groups) if groups else {}
+    res, outs = {}, {}
+    for bn in (0, 320):
+        ops.FORCE_BN = bn
+        kw2 = dict(kw)
+        if bn == 320 and sk:
+            kw2["splitk"] = sk
+        try:
+            outs[bn] = ops.conv_gemm(x, pw, **kw2).clone()
+            res[bn] = bench(lambda: ops.conv_gemm(x, pw, **kw2))
+        finally:
+            ops.FORCE_BN = 0
+    fl = 2.0 * N * H * H * Cout * k * k * Cin
+    same = torch.equal(outs[0], outs[320])
+    err = float((outs[0].float() - outs[320].float()).abs().max())
+    print(f"[{si}] N={N} H={H} {Cin}->{Cout} k={k} grouped={bool(groups)} sk320={sk}: default {res[0]:.1f} us ({fl / res[0] / 1e6:.0f} TF)   "
+          f"8p {res[320]:.1f} us ({fl / res[320] / 1e6:.0f} TF)   ratio {res[0] / res[320]:.2f}  bitwise_equal={same} maxdiff={err:.2e}", flush=True)
