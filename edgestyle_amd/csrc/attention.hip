@@ -675,23 +675,22 @@ int launch_attn32(const es_attn_desc& d, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// head_dim 40 self-attention, software-pipelined inside the wave.  attention32_kernel is bound by the vector pipe (32 v_exp
-// = 256 issue cycles + 16 packed converts + the row max per 32 queries x 64 keys, against 384 cycles of matrix pipe), and
-// its waves run [MFMA cluster | softmax | MFMA cluster] one after the other: the co-resident waves of other workgroups
-// do the same program in near lockstep, so the two pipes take turns instead of overlapping (tool builds: no MFMAs at
-// all -27 %, no v_exp -17 %; a probe kernel with the same instructions interleaved hides the MFMAs completely).  Here a
-// wave owns TWO 32-query blocks half a tile out of phase:
-//     phase 1:  softmax(A, tile t)   beside   O_B += V(t-1) P_B(t-1)   and   S_B(t) = K(t) Q_B
-//     phase 2:  softmax(B, tile t)   beside   O_A += V(t) P_A(t)       and   S_A(t+1) = K(t+1) Q_A
-// with the instruction order pinned (sched_barrier after every MFMA + its share of the vector work): each 16x16x32 MFMA
-// is followed by two v_exp, each 32x32x16 by ~50 issue cycles of softmax, so the matrix pipe runs in the shadow of the
-// vector pipe.  K runs one tile ahead of V in the LDS ring (2 + 2 buffers, still one barrier per tile).  Same
-// arithmetic as attention32_kernel<T, 3, 3, true, 2>: the softmax reference rides in the pad element of Q, the row sum
-// comes from the ones column of V (the reference moves per block here, per wave there: results agree to rounding).
-// Measured: no faster (448 vs 430 us on the 14-sample launch) - both run at the package power limit, see dispatch().
-// Requires Skv % 64 == 0 (self-attention); the dispatcher falls back to attention32_kernel otherwise.
-template <typename T>
-__global__ __launch_bounds__(256, 2) void attention40p_kernel(const es_attn_desc p) {
+// head_dim 40 self-attention, PING-PONG between the two waves of a SIMD (the structure of gemm_conv8p.hip applied to
+// attention).  attention32_kernel is bound by the vector pipe (per 32 queries x 64 keys: 32 v_exp = 256 issue cycles +
+// 16 packed converts + the row max, against 384 cycles of matrix pipe), and its waves run [MFMA cluster | softmax | MFMA
+// cluster] one after the other while the co-resident waves do the same program in near lockstep: the two pipes take
+// turns (tool builds: no MFMAs at all -27 %, no v_exp -17 %).  Here a workgroup is 8 waves = two groups of four (SIMD
+// partners are w and w + 4) that alternate, separated by workgroup barriers and ONE barrier out of phase:
+//     M phase:  O += V(t) P(t)  (12 MFMA 16x16x32)   and   S(t+1) = K(t+1) Q  (6 MFMA 32x32x16)     - matrix pipe
+//     V phase:  P(t+1) = softmax step of S(t+1): row max, lazy reference, v_exp, packed converts   - vector pipe
+// so on every SIMD one wave's MFMA stream runs beside its partner's softmax by construction, not by luck of arbitration.
+// K / V tiles of 64 keys go through a 2-deep LDS ring by the register path (the +16 B row pad and the ones / reference
+// pad column rule out lane-linear LDS-DMA): in the window of two slots in which K(t+1) and V(t) are read, every thread
+// loads its chunk of K(t+2) / V(t+1) at the start of the first slot and stores it at the end of the second one.
+// Same arithmetic as attention32_kernel<T, 3, 3, true, QB>: reference in the pad element of Q, row sum from the ones
+// column of V.  Requires d == 40 and Skv % 64 == 0 (self-attention).
+template <typename T, int QB>
+__global__ __launch_bounds__(512, 2) void attention40pp_kernel(const es_attn_desc p) {
   constexpr int KS = 3, DF = 3, KVT = 64;
   constexpr int KROW = 16 * KS * 2 + 16, VROW = 16 * DF * 2 + 16;
   constexpr int KBUF = KVT * KROW, VBUF = KVT * VROW;
@@ -699,14 +698,16 @@ __global__ __launch_bounds__(256, 2) void attention40p_kernel(const es_attn_desc
   constexpr float LAZY = 8.0f;
   typedef typename Traits<T>::vec8 vec8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* kbase = smem;                    // K[b] = kbase + b * KBUF
-  char* vbase = smem + 2 * KBUF;         // V[b] = vbase + b * VBUF
+  char* ks_ = smem;                    // K ring: 2 x KBUF
+  char* vs_ = smem + 2 * KBUF;         // V ring: 2 x VBUF
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                      // stagger group
   const int n32 = lane & 31, hi = lane >> 5;      // 32x32 layouts: query column / key half
   const int col = lane & 15, g = lane >> 4;       // 16x16 layouts (PV product, epilogue)
   const int h = blockIdx.y, n = blockIdx.z;
-  const int q0 = blockIdx.x * 256 + wave * 64;
+  const int q0 = blockIdx.x * (256 * QB) + wave * (32 * QB);
 
   const T* Q = (const T*)p.q + (size_t)n * p.bsq + (size_t)h * d;
   const T* K = (const T*)p.k + (size_t)n * p.bsk + (size_t)h * d;
@@ -714,9 +715,9 @@ __global__ __launch_bounds__(256, 2) void attention40p_kernel(const es_attn_desc
   T* O = (T*)p.o + (size_t)n * p.bso + (size_t)h * d;
 
   const float sl2 = p.scale * 1.4426950408889634f;
-  vec8 qf[2][KS];
+  vec8 qf[QB][KS];
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
+  for (int qb = 0; qb < QB; ++qb) {
     int qi = q0 + qb * 32 + n32;
     qi = qi < p.Sq ? qi : p.Sq - 1;
 #pragma unroll
@@ -730,207 +731,169 @@ __global__ __launch_bounds__(256, 2) void attention40p_kernel(const es_attn_desc
       qf[qb][s] = qv;
     }
   }
-  // pad chunk of every K / V row: element d = 1.0 (reference subtraction / row sum); V[1] starts as zeros: the first
-  // phase multiplies it with P_B(-1) = 0
+  // pad chunk of every K / V row in both ring buffers: element 40 = 1.0 (reference / row-sum column), the rest zero
   {
     const unsigned one = Traits<T>::is_bf16 ? 0x3F80u : 0x3C00u;
-    for (int i = tid; i < 2 * KVT; i += 256) {
-      *(u32x4*)(kbase + (i / KVT) * KBUF + (i % KVT) * KROW + dch * 16) = u32x4{one, 0u, 0u, 0u};
-      *(u32x4*)(vbase + (i / KVT) * VBUF + (i % KVT) * VROW + dch * 16) = u32x4{one, 0u, 0u, 0u};
+    for (int i = tid; i < 2 * KVT; i += 512) {
+      *(u32x4*)(ks_ + (i >> 6) * KBUF + (i & 63) * KROW + dch * 16) = u32x4{one, 0u, 0u, 0u};
+      *(u32x4*)(vs_ + (i >> 6) * VBUF + (i & 63) * VROW + dch * 16) = u32x4{one, 0u, 0u, 0u};
     }
-    for (int i = tid; i < KVT * dch; i += 256)
-      *(u32x4*)(vbase + VBUF + (i / dch) * VROW + (i % dch) * 16) = u32x4{0u, 0u, 0u, 0u};
   }
-
-  constexpr int KPT = (KVT * dch + 255) / 256;
+  // staging: 320 chunks of 16 B per K (V) tile, one per thread (threads 320.. load out of range: zeros, never stored)
   constexpr unsigned OOB = 0xFFFFFF00u;
-  u32x4 kr[KPT], vr[KPT];
+  const bool own = tid < KVT * dch;
+  const int srow = own ? tid / dch : 0, sch = own ? tid - srow * dch : 0;
   const auto rK = __builtin_amdgcn_make_buffer_rsrc((void*)K, (short)0, (int)(((size_t)(p.Skv - 1) * p.ldk + d) * 2), 0x00020000);
   const auto rV = __builtin_amdgcn_make_buffer_rsrc((void*)V, (short)0, (int)(((size_t)(p.Skv - 1) * p.ldv + d) * 2), 0x00020000);
-  unsigned koff[KPT], voffs[KPT];
-  int klds[KPT], vlds[KPT];
-#pragma unroll
-  for (int i = 0; i < KPT; ++i) {
-    const int idx = tid + i * 256;
-    const bool own = idx < KVT * dch;
-    const int r = own ? idx / dch : 0;
-    const int c = own ? idx - r * dch : 0;
-    koff[i] = own ? (unsigned)((r * p.ldk + c * 8) * 2) : OOB;
-    voffs[i] = own ? (unsigned)((r * p.ldv + c * 8) * 2) : OOB;
-    klds[i] = own ? r * KROW + c * 16 : -1;
-    vlds[i] = own ? r * VROW + c * 16 : -1;
-  }
+  unsigned koff = own ? (unsigned)((srow * p.ldk + sch * 8) * 2) : OOB;      // of tile 0
+  unsigned voff = own ? (unsigned)((srow * p.ldv + sch * 8) * 2) : OOB;
+  const int klds = srow * KROW + sch * 16, vlds = srow * VROW + sch * 16;
   const unsigned kstep = (unsigned)(KVT * p.ldk * 2), vstep = (unsigned)(KVT * p.ldv * 2);
-  // tiles past the end read as zeros (range-checked loads): the pipeline's look-ahead needs no special case
-  auto load_k = [&]() {
-#pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-      kr[i] = __builtin_amdgcn_raw_buffer_load_b128(rK, (int)koff[i], 0, 0);
-      koff[i] = koff[i] >= OOB - kstep ? OOB : koff[i] + kstep;
-    }
-  };
-  auto load_v = [&]() {
-#pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-      vr[i] = __builtin_amdgcn_raw_buffer_load_b128(rV, (int)voffs[i], 0, 0);
-      voffs[i] = voffs[i] >= OOB - vstep ? OOB : voffs[i] + vstep;
-    }
-  };
-  auto store_k = [&](int b) {
-#pragma unroll
-    for (int i = 0; i < KPT; ++i)
-      if (klds[i] >= 0) *(u32x4*)(kbase + b * KBUF + klds[i]) = kr[i];
-  };
-  auto store_v = [&](int b) {
-#pragma unroll
-    for (int i = 0; i < KPT; ++i)
-      if (vlds[i] >= 0) *(u32x4*)(vbase + b * VBUF + vlds[i]) = vr[i];
-  };
+  const int nt = p.Skv / KVT;
+  u32x4 kr, vr;
+  auto load_k = [&](int t) { kr = __builtin_amdgcn_raw_buffer_load_b128(rK, (int)(own && t < nt ? koff + (unsigned)t * kstep : OOB), 0, 0); };
+  auto load_v = [&](int t) { vr = __builtin_amdgcn_raw_buffer_load_b128(rV, (int)(own && t < nt ? voff + (unsigned)t * vstep : OOB), 0, 0); };
+  auto store_k = [&](int t) { if (own) *(u32x4*)(ks_ + (t & 1) * KBUF + klds) = kr; };
+  auto store_v = [&](int t) { if (own) *(u32x4*)(vs_ + (t & 1) * VBUF + vlds) = vr; };
 
-  f32x16 s[2][2];                 // raw scores of the block's current tile (two 32-key halves)
-  f32x4 o[2][2][DF];              // O^T of the two 16-query halves of each block
-  vec8 pb[2][2][2];               // packed exp'd scores [block][query half][key half], B operands of the PV product
-  float negm_f[2] = {0.f, 0.f};
+  f32x4 o[QB][2][DF];
+  float negm_f[QB];
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
+  for (int qb = 0; qb < QB; ++qb) {
+    negm_f[qb] = 0.f;
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int j = 0; j < DF; ++j) o[qb][f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t = 0; t < 2; ++t) pb[qb][f][t] = as_vec8<T>(u32x4{0u, 0u, 0u, 0u});
-    }
+  }
+  // prologue: K(0), V(0), K(1) resident before the first slot
+  load_k(0); load_v(0);
+  store_k(0); store_v(0);
+  load_k(1);
+  store_k(1);
+  __syncthreads();
+
   const int vrow0 = 16 * (g & 1) + 4 * (g >> 1) + (col >> 2);
   const int vcol0 = 4 * (col & 3);
-  auto kread = [&](const char* kb, int t, int ksx) __attribute__((always_inline)) {
-    return as_vec8<T>(*(const u32x4*)(kb + (t * 32 + n32) * KROW + (2 * ksx + hi) * 16));
-  };
-  auto vread = [&](const char* vb, int t, int j) __attribute__((always_inline)) {
-    const char* base = vb + (32 * t + vrow0) * VROW + (j * 16 + vcol0) * 2;
-    const u32x2 lo = lds_read_tr16(base);
-    const u32x2 hi2 = lds_read_tr16(base + 8 * VROW);
-    return as_vec8<T>(u32x4{lo[0], lo[1], hi2[0], hi2[1]});
-  };
+  f32x16 s[QB][2];
+  vec8 pb[QB][2][2];
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  // prologue: K(0), V(0), K(1) staged; K(2), V(1) in flight; S_A(0)
-  load_k(); load_v();
-  store_k(0); store_v(0);
-  load_k();
-  store_k(1);
-  load_k(); load_v();
-  __syncthreads();
+  auto qk = [&](int t) __attribute__((always_inline)) {          // S = K(t) Q^T
+    const char* kb = ks_ + (t & 1) * KBUF;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+    for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-    for (int ksx = 0; ksx < KS; ++ksx)
-      s[0][t] = mfma32(kread(kbase, t, ksx), qf[0][ksx], ksx == 0 ? zero16 : s[0][t]);
-
-  // one phase: softmax of block X on its scores s[X] (-> pb[X]) beside the matrix work of block Y = 1 - X:
-  // O_Y += V P_Y from the tile in vb, then S_Y = K Q_Y from the tile in kb
-  auto phase = [&](auto XC, const char* vb, const char* kb, const bool first) __attribute__((always_inline)) {
-    constexpr int X = decltype(XC)::value, Y = 1 - X;
-    vec8 vf[2][DF], kf[2][KS];
+      for (int ksx = 0; ksx < KS; ++ksx) {
+        const auto ka = as_vec8<T>(*(const u32x4*)(kb + (tt * 32 + n32) * KROW + (2 * ksx + hi) * 16));
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+        for (int qb = 0; qb < QB; ++qb) s[qb][tt] = mfma32(ka, qf[qb][ksx], ksx == 0 ? zero16 : s[qb][tt]);
+      }
+  };
+  auto pv = [&](int t) __attribute__((always_inline)) {          // O += V(t) P
+    const char* vb = vs_ + (t & 1) * VBUF;
 #pragma unroll
-      for (int j = 0; j < DF; ++j) vf[t][j] = vread(vb, t, j);
-    // ---- (a) row max of S_X beside the first 6 PV MFMAs ----
-    float mx = s[X][0][0];
-    constexpr int MXB[7] = {0, 3, 6, 9, 12, 14, 16};       // max3 steps per MFMA slot
+    for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-    for (int slot = 0; slot < 6; ++slot) {
-      o[Y][slot & 1][slot >> 1] = mfma16(vf[0][slot >> 1], pb[Y][slot & 1][0], o[Y][slot & 1][slot >> 1]);
+      for (int j = 0; j < DF; ++j) {
+        const char* base = vb + (32 * tt + vrow0) * VROW + (j * 16 + vcol0) * 2;
+        const u32x2 lo = lds_read_tr16(base);
+        const u32x2 hi2 = lds_read_tr16(base + 8 * VROW);
+        const auto va = as_vec8<T>(u32x4{lo[0], lo[1], hi2[0], hi2[1]});
 #pragma unroll
-      for (int u = MXB[slot]; u < MXB[slot + 1]; ++u) mx = fmaxf(fmaxf(mx, s[X][u >> 3][(2 * u) & 15]), s[X][u >> 3][((2 * u) & 15) + 1]);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int qb = 0; qb < QB; ++qb) {
+          o[qb][0][j] = mfma16(va, pb[qb][0][tt], o[qb][0][j]);
+          o[qb][1][j] = mfma16(va, pb[qb][1][tt], o[qb][1][j]);
+        }
+      }
+  };
+  auto softmax = [&](bool first) __attribute__((always_inline)) {      // S -> P (packed B operands), lazy reference
+    float mx[QB];
+    bool calm = true;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      mx[qb] = s[qb][0][0];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mx[qb] = fmaxf(fmaxf(mx[qb], s[qb][tt][r]), s[qb][tt][r + 1]);
+      mx[qb] = xor32_max(mx[qb]);
+      calm = calm && mx[qb] <= LAZY;
     }
+    if (first || !__all(calm)) {
 #pragma unroll
-    for (int ksx = 0; ksx < KS; ++ksx) kf[0][ksx] = kread(kb, 0, ksx);
-    mx = xor32_max(mx);
-    if (first || !__all(mx <= LAZY)) {
-      float dlt = first ? mx : fmaxf(mx, 0.f);
-      const T nmt = from_f32<T>(negm_f[X] - dlt);
-      dlt = negm_f[X] - to_f32(nmt);
-      negm_f[X] = to_f32(nmt);
-      if (hi) qf[X][KS - 1][0] = nmt;
+      for (int qb = 0; qb < QB; ++qb) {
+        float dlt = first ? mx[qb] : fmaxf(mx[qb], 0.f);
+        const T nmt = from_f32<T>(negm_f[qb] - dlt);     // the reference is an element of the Q operand: a value of T
+        dlt = negm_f[qb] - to_f32(nmt);
+        negm_f[qb] = to_f32(nmt);
+        if (hi) qf[qb][KS - 1][0] = nmt;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+        for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[X][t][r] -= dlt;
-      if (!first) {
-        const float alpha = __builtin_amdgcn_exp2f(-dlt);
-        float a0 = alpha, a1 = alpha;
-        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a0), "+v"(a1));
+          for (int r = 0; r < 16; ++r) s[qb][tt][r] -= dlt;
+        if (!first) {
+          const float alpha = __builtin_amdgcn_exp2f(-dlt);
+          float a0 = alpha, a1 = alpha;
+          asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a0), "+v"(a1));
 #pragma unroll
-        for (int j = 0; j < DF; ++j) { o[X][0][j] *= a0; o[X][1][j] *= a1; }
+          for (int j = 0; j < DF; ++j) { o[qb][0][j] *= a0; o[qb][1][j] *= a1; }
+        }
       }
     }
-    // ---- (b) exp / pack / re-deal of S_X beside the other 6 PV MFMAs and the 6 QK^T MFMAs ----
-    // vector micro-steps: 0..31 v_exp of element (u >> 4, u & 15); 32..47 packed convert of pair (u - 32); 48, 49 the
-    // permlane re-deal of key half 0 / 1
-    unsigned x[2][4], y[2][4];
-    auto vstep = [&](int u) __attribute__((always_inline)) {
-      if (u < 32) {
-        s[X][u >> 4][u & 15] = __builtin_amdgcn_exp2f(s[X][u >> 4][u & 15]);
-      } else if (u < 48) {
-        const int t = (u - 32) >> 3, i = (u - 32) & 7;
-        if (i < 4) x[t][i] = pack2<T>(s[X][t][2 * i], s[X][t][2 * i + 1]);
-        else y[t][i - 4] = pack2<T>(s[X][t][8 + 2 * (i - 4)], s[X][t][9 + 2 * (i - 4)]);
-      } else {
-        const int t = u - 48;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[qb][tt][r] = __builtin_amdgcn_exp2f(s[qb][tt][r]);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        unsigned x[4], y[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          x[i] = pack2<T>(s[qb][tt][2 * i], s[qb][tt][2 * i + 1]);
+          y[i] = pack2<T>(s[qb][tt][8 + 2 * i], s[qb][tt][9 + 2 * i]);
+        }
         asm volatile("s_nop 1\n\t"
                      "v_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
                      "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 1"
-                     : "+v"(x[t][0]), "+v"(x[t][1]), "+v"(x[t][2]), "+v"(x[t][3]), "+v"(y[t][0]), "+v"(y[t][1]), "+v"(y[t][2]), "+v"(y[t][3]));
-        pb[X][0][t] = as_vec8<T>(u32x4{x[t][0], x[t][1], x[t][2], x[t][3]});
-        pb[X][1][t] = as_vec8<T>(u32x4{y[t][0], y[t][1], y[t][2], y[t][3]});
+                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+        pb[qb][0][tt] = as_vec8<T>(u32x4{x[0], x[1], x[2], x[3]});
+        pb[qb][1][tt] = as_vec8<T>(u32x4{y[0], y[1], y[2], y[3]});
       }
-    };
-    constexpr int VSB[13] = {0, 2, 4, 6, 8, 10, 12, 18, 24, 30, 40, 49, 50};
-#pragma unroll
-    for (int slot = 0; slot < 12; ++slot) {
-      if (slot < 6) {
-        o[Y][slot & 1][slot >> 1] = mfma16(vf[1][slot >> 1], pb[Y][slot & 1][1], o[Y][slot & 1][slot >> 1]);
-      } else {
-        const int m = slot - 6, t = m / KS, ksx = m - t * KS;
-        s[Y][t] = mfma32(kf[t][ksx], qf[Y][ksx], ksx == 0 ? zero16 : s[Y][t]);
-      }
-      if (slot == 5) {
-#pragma unroll
-        for (int ksx = 0; ksx < KS; ++ksx) kf[1][ksx] = kread(kb, 1, ksx);
-      }
-#pragma unroll
-      for (int u = VSB[slot]; u < VSB[slot + 1]; ++u) vstep(u);
-      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  const int T_ = p.Skv / KVT;
-  for (int t = 0; t < T_; ++t) {
-    const int b = t & 1;
-    phase(std::integral_constant<int, 0>{}, vbase + (b ^ 1) * VBUF, kbase + b * KBUF, t == 0);
-    __syncthreads();                 // every wave is done with K(t) and V(t-1): their buffers take K(t+2), V(t+1)
-    store_k(b); store_v(b ^ 1);
-    load_k(); load_v();
-    phase(std::integral_constant<int, 1>{}, vbase + b * VBUF, kbase + (b ^ 1) * KBUF, t == 0);
+  // slots (between consecutive workgroup barriers): group 0 runs  QK(0) | V(0) | M(0) | V(1) | M(1) ...,
+  // group 1 the same one slot later.  K(t+1) and V(t) are read in the two slots in which the groups run M(t); in that
+  // window every thread loads K(t+2) / V(t+1) at the start of the first slot and stores them at the end of the second:
+  //   group 0:  first slot = its M(t)   second = its V(t+1)        group 1:  first = its V(t)   second = its M(t)
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_s_setprio(1);
+  qk(0);
+  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_s_barrier();
+  for (int t = 0; t < nt; ++t) {
+    // ---- V phase: softmax of S(t) ----
+    if (grp == 1) { load_k(t + 2); load_v(t + 1); }
+    softmax(t == 0);
+    if (grp == 0 && t > 0) { store_k(t + 1); store_v(t); }
+    __builtin_amdgcn_s_barrier();
+    // ---- M phase: O += V(t) P(t), S(t+1) = K(t+1) Q ----
+    if (grp == 0) { load_k(t + 2); load_v(t + 1); }
+    __builtin_amdgcn_s_setprio(1);
+    pv(t);
+    if (t + 1 < nt) qk(t + 1);
+    __builtin_amdgcn_s_setprio(0);
+    if (grp == 1) { store_k(t + 2); store_v(t + 1); }
+    __builtin_amdgcn_s_barrier();
   }
-  // drain: O_B += V(T-1) P_B(T-1)
-  {
-    const char* vb = vbase + ((T_ - 1) & 1) * VBUF;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int j = 0; j < DF; ++j) {
-        const auto va = vread(vb, t, j);
-        o[1][0][j] = mfma16(va, pb[1][0][t], o[1][0][j]);
-        o[1][1][j] = mfma16(va, pb[1][1][t], o[1][1][j]);
-      }
-  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
 
-  // ---- epilogue: O[query][dv] = O^T / l, l = the ones row of O^T ----
+  // ---- epilogue: O[query][dv] = O^T / l  (l = the ones column: row 40 of O^T) ----
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
+  for (int qb = 0; qb < QB; ++qb) {
     const float l0 = __shfl(o[qb][0][DF - 1][0], 32 + col, 64);
     const float l1 = __shfl(o[qb][1][DF - 1][0], 32 + col, 64);
 #pragma unroll
@@ -953,11 +916,11 @@ __global__ __launch_bounds__(256, 2) void attention40p_kernel(const es_attn_desc
   }
 }
 
-template <typename T>
-int launch_attn40p(const es_attn_desc& d, hipStream_t st) {
+template <typename T, int QB>
+int launch_attn40pp(const es_attn_desc& d, hipStream_t st) {
   constexpr int lds = 2 * (64 * (16 * 3 * 2 + 16) + 64 * (16 * 3 * 2 + 16));
-  dim3 grid((d.Sq + 255) / 256, d.heads, d.N);
-  hipLaunchKernelGGL(attention40p_kernel<T>, grid, dim3(256), lds, st, d);
+  dim3 grid((d.Sq + 256 * QB - 1) / (256 * QB), d.heads, d.N);
+  hipLaunchKernelGGL((attention40pp_kernel<T, QB>), grid, dim3(512), lds, st, d);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -988,12 +951,15 @@ int dispatch(const es_attn_desc& d, hipStream_t st) {
     // 64 queries per wave where that still leaves two 256-query blocks per CU: the kernel is bound by LDS reads of the K / V
     // fragments (tool build with MFMAs, v_exp and row max removed: 265 of 448 us), and a fragment then serves two blocks
     static const int qb2 = getenv("ES_ATTN_QB") ? atoi(getenv("ES_ATTN_QB")) : 2;
-    // opt-in: measured 448 vs 430 us on the 14-sample launch.  Both forms run at the package power limit (rocm-smi while the
-    // launch repeats: ~1.38 kW, 2.18 GHz pipelined / 2.24 GHz plain): overlapping the pipes in time does not lower the energy
-    // per tile, which is what sets the pace there
-    static const bool pipe40 = getenv("ES_ATTN_PIPE") && atoi(getenv("ES_ATTN_PIPE")) == 1;
+    // the ping-pong kernel (8 waves, two groups one barrier out of phase): ES_ATTN_PP = 0 off, 1 = 32 queries per wave,
+    // 2 = 64 queries per wave, unset = by grid size
+    static const int pp = getenv("ES_ATTN_PP") ? atoi(getenv("ES_ATTN_PP")) : -1;
+    if (d.d == 40 && pp != 0 && d.Skv % 64 == 0 && d.Skv >= 128) {
+      const long long wg256 = (long long)((d.Sq + 255) / 256) * d.heads * d.N;
+      if (pp == 2 || (pp == -1 && wg256 >= 4096)) return launch_attn40pp<T, 2>(d, st);
+      if (pp == 1 || (pp == -1 && wg256 >= 256)) return launch_attn40pp<T, 1>(d, st);
+    }
     if (d.d == 40 && qb2 == 2 && (long long)((d.Sq + 255) / 256) * d.heads * d.N >= big_thr) {
-      if (pipe40 && d.Skv % 64 == 0) return launch_attn40p<T>(d, st);
       return launch_attn32<T, 3, 3, true, 2>(d, st);
     }
     if (d.d == 40) return launch_attn32<T, 3, 3, true>(d, st);

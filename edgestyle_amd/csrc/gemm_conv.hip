@@ -3,9 +3,8 @@
 //   D[cout][pixel] = sum_k W[cout][k] * X[pixel][k]      (A operand = weights, B operand = im2col'd activations)
 //
 // Tile: BM=128 pixels x BN (128|160) couts x BK=64, 256 threads = 4 waves as 2(M) x 2(N); each wave owns
-// 64 pixels x BN/2 couts = 4 x (4|5) MFMA fragments.  Large launches use the big tile BM=256 x BN=320 (512 threads =
-// 8 waves as 4(M) x 2(N), 64 px x 160 couts per wave, one workgroup per CU): it moves half the L2->LDS bytes per
-// FLOP, which is what bounds the 128-pixel tile (tools/gemm_ablate.sh: its DMA stream alone takes longer than its MFMAs).
+// 64 pixels x BN/2 couts = 4 x (4|5) MFMA fragments.  Large launches (>= one round of 256 workgroups, K >= 1024) go to the
+// 256 x 320 phase-interleaved tile of gemm_conv8p.hip (bn = 320), which moves half the L2->LDS bytes per FLOP.
 // Tiny launches (a few dozen 128x128 tiles: the deep UNet levels at batch 1) use BM=64 x BN=64: they are bound by
 // weight bytes in flight x HBM latency, and four times as many workgroups keep four times as many DMA rings busy.
 //
@@ -83,17 +82,14 @@ ES_DEVICE void row_offsets_fn(unsigned (&voff)[XI], const int (&iy0)[XI], const 
 }
 
 template <typename T, int BM, int BN, bool ALIGNED, int STAGES, int FM = 4 /* pixel fragments per wave */,
-          int BKT = 64 /* K depth of a stage */, bool LN = false /* LayerNorm folded into this linear layer */>
+          bool LN = false /* LayerNorm folded into this linear layer */>
 // (second launch bound = minimum waves per SIMD: 8-wave workgroups need 4 to keep two workgroups on a CU)
-__global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM == 128) ? (FM == 2 ? 4 : 2) : 1)) void conv_gemm_kernel(
+__global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? (FM == 2 ? 4 : 2) : 1) void conv_gemm_kernel(
     const es_gemm_desc p, const int M, const int nk, const void* const tail1, const void* const tail2, const int tailC1,
     const int tailC2) {
   // (the 1x1 tail sources travel as plain kernel arguments, not through `p`: any read of the descriptor's t1/t2/Ct1/Ct2
   //  fields inside the K loop made hipcc keep the whole by-value descriptor in scratch memory - 3.4x slower kernels)
-  // BKT = 32: half-depth stages.  The ring shrinks to 2 x 18 KB, the epilogue tile (43 KB) becomes the LDS high-water
-  // mark and THREE workgroups fit a CU: short-K launches (K = 320..1280, a handful of K-steps per tile) are bound by
-  // workgroup turnover - first-tile latency + epilogue drain - and residency is what hides it (2 vs 1 workgroups per
-  // CU: 1.5-1.6x on these launches).  Rows are 64 B; slot p of row r holds chunk p ^ (((r >> 2) & 1) << 1).
+  constexpr int BKT = BK;            // K depth of a stage
   constexpr int RB = BKT * 2;        // bytes per tile row
   constexpr int CPR = BKT / 8;       // 16-byte chunks per row
   constexpr int RPP = 1024 / RB;     // rows per 1 KB LDS-DMA piece
@@ -109,8 +105,8 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
   constexpr int WI = (WP + NW - 1) / NW;
   constexpr int XT = BM * RB;        // bytes per stage
   constexpr int WT = BN * RB;
-  constexpr int NPASS = (BKT == 64 && (size_t)BM * (BN * 2 + 16) > (size_t)STAGES * (BM + BN) * RB) ? 2 : 1;   // epilogue passes
-  constexpr int BNP = BN / NPASS;    // couts staged per epilogue pass
+  static_assert((size_t)BM * (BN * 2 + 16) <= (size_t)STAGES * (BM + BN) * RB, "the epilogue tile must fit the stage ring");
+  constexpr int BNP = BN;            // couts staged by the epilogue
   constexpr int EROW = BNP * 2 + 16; // epilogue tile row stride (bytes), padded against bank conflicts
   constexpr int NI = XI + WI;        // LDS-DMA instructions per wave per K-step
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -162,7 +158,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
   const int lrow = lane / CPR;                     // row inside an RPP-row DMA piece
   const int lslot = lane % CPR;                    // LDS slot the DMA writes for this lane
   // global chunk that lands in that slot: the XOR swizzle is applied on the SOURCE side (lane-linear destination)
-  const int kc = BKT == 64 ? (lslot ^ (lrow & 7)) : (lslot ^ (((lrow >> 2) & 1) << 1));
+  const int kc = lslot ^ (lrow & 7);
   const int Ctot = p.C1 + p.C2;
   const int KK = p.ksize * p.ksize;
   // (struct fields that meet in a select are copied to locals first: `c ? p.a : p.b` otherwise becomes a load through a
@@ -352,7 +348,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
     for (int e = 0; e < 8; ++e) ln_ones[e] = from_f32<T>(1.0f);
   }
   int stage = 0, istage = STAGES - 1;
-  // operand fragments of the default K-step form (read from LDS each K-step, live across the barrier for `late` waves)
+  // operand fragments of a K-step (read from LDS each K-step)
   typename Traits<T>::vec8 xa0[FM], wa0[FN], xa1[FM], wa1[FN];
   auto do_mfmas = [&]() __attribute__((always_inline)) {
 #if ES_ABLATE & 1
@@ -371,20 +367,6 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
       for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(wa1[i], xa1[j], acc[i][j]);
 #endif
   };
-  // 256-pixel tile = ONE 8-wave workgroup per CU: the two waves of a SIMD (w, w + 4) run the same program between the
-  // same barriers, so left alone they issue their DMAs / LDS reads together and their MFMAs together and nothing
-  // overlaps (why this tile never beat two independent 128-pixel workgroups per CU although it moves 28 % fewer L2->LDS
-  // bytes per FLOP, and L2->LDS bandwidth per CU is what bounds the K loop).  Waves 4-7 therefore run half a K-step out
-  // of phase: they read their fragments of stage k like everyone, but issue the MFMAs of stage k right AFTER the next
-  // barrier (the fragments already sit in registers), beside their partners' DMA issue and LDS reads; one static
-  // s_setprio for that (younger) half, which otherwise loses the SIMD's issue arbitration on every phase
-  // (MI355X_MICROARCH.md, two waves per SIMD, items 2, 4, 9).  Per accumulator the summation order is unchanged.
-#ifndef ES_STAGGER
-#define ES_STAGGER 1
-#endif
-  constexpr bool STAG = ES_STAGGER && BM == 256 && FN <= 5 && BKT == 64 && !LN && NW == 8;
-  const bool late = STAG && wave >= NW / 2;
-  if (late) __builtin_amdgcn_s_setprio(1);
   for (int ks = ks0; ks < ks1; ++ks) {
 #if ES_STAMPS
     stamp(ks - ks0, 0);
@@ -407,53 +389,6 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
     // Fragment reads are software-pipelined against the MFMAs: the reads of the second 32-deep half are in flight
     // behind the first half's MFMAs, and the next tile's DMA issue (address math + 9 LDS-DMA instructions) sits
     // between the two read groups where it covers the first group's LDS latency.
-    if constexpr (FN > 5) {
-      // big tile: 40 accumulator fragments per wave leave no room for all 28 operand fragments of a K-step, so the
-      // W fragments are streamed one ahead of their MFMAs; per accumulator the summation order is unchanged
-      // (32-deep half 0, then half 1).
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        typename Traits<T>::vec8 xa[FM];
-#pragma unroll
-        for (int j = 0; j < FM; ++j) {
-          const int row = wm * (16 * FM) + j * 16 + frow;
-          xa[j] = as_vec8<T>(*(const u32x4*)(xs + row * 128 + (((4 * h + fq) ^ (row & 7)) << 4)));
-        }
-        auto wfrag = [&](int i) {
-          const int row = wn * (BN / 2) + i * 16 + frow;
-          return as_vec8<T>(*(const u32x4*)(ws + row * 128 + (((4 * h + fq) ^ (row & 7)) << 4)));
-        };
-        auto wcur = wfrag(0);
-        if (h == 0 && ks + STAGES - 1 < ks1) issue_tile(ks + STAGES - 1, istage);
-#pragma unroll
-        for (int i = 0; i < FN; ++i) {
-          auto wnxt = wcur;
-          if (i + 1 < FN) wnxt = wfrag(i + 1);
-#pragma unroll
-          for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(wcur, xa[j], acc[i][j]);
-          wcur = wnxt;
-        }
-      }
-    } else if constexpr (BKT == 32) {
-      // half-depth stage: one 32-deep fragment set per K-step, 64-byte rows
-      typename Traits<T>::vec8 xa[FM], wa[FN];
-#pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        const int row = wm * (16 * FM) + j * 16 + frow;
-        xa[j] = as_vec8<T>(*(const u32x4*)(xs + row * 64 + ((fq ^ (((row >> 2) & 1) << 1)) << 4)));
-      }
-#pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        const int row = wn * (BN / 2) + i * 16 + frow;
-        wa[i] = as_vec8<T>(*(const u32x4*)(ws + row * 64 + ((fq ^ (((row >> 2) & 1) << 1)) << 4)));
-      }
-      if (ks + STAGES - 1 < ks1) issue_tile(ks + STAGES - 1, istage);
-#pragma unroll
-      for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j) acc[i][j] = mfma16(wa[i], xa[j], acc[i][j]);
-    } else {
-    if (late && ks > ks0) do_mfmas();                  // of K-step ks - 1
     if (!(ES_ABLATE & 4) || ks == ks0) {
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
@@ -493,8 +428,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
         ln_sum[jj] = mfma16(ln_ones, f1, ln_sum[jj]);
       }
     }
-    if (!late) do_mfmas();
-    }
+    do_mfmas();
 #if ES_STAMPS
     stamp(ks - ks0, 3);
 #endif
@@ -502,9 +436,6 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
     stage = stage + 1 == STAGES ? 0 : stage + 1;
   }
 
-  if constexpr (FN <= 5 && BKT == 64) {
-    if (late && ks1 > ks0) do_mfmas();                   // the deferred MFMAs of the last K-step
-  }
 #if ES_STAMPS
   pstamp(3);
 #endif
@@ -529,7 +460,6 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
   }
 
   // ---------------- epilogue phase A: registers -> LDS tile [pixel][cout] in T ----------------
-  // The big tile (256 x 320 outputs) does not fit the LDS at once: it runs two passes, one wave column (160 couts) each.
   const bool geglu = p.act == ES_ACT_GEGLU;
   const int Cstore = geglu ? p.Cout / 2 : p.Cout;
   float scale = p.out_scale;
@@ -538,10 +468,10 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
   T* outp = (T*)p.out;
   const T* resp = (const T*)p.residual;
   // residual rows are requested before the LDS transposition, so their round trip overlaps phase A
-  constexpr int RPF = NPASS == 1 ? (BM * (BN / 8) + NT - 1) / NT : 0;     // 16-byte residual chunks per thread
-  u32x4 rpre[RPF > 0 ? RPF : 1];
+  constexpr int RPF = (BM * (BN / 8) + NT - 1) / NT;     // 16-byte residual chunks per thread
+  u32x4 rpre[RPF];
   const bool vec_store = (Cstore & 7) == 0;
-  if constexpr (RPF > 0) {
+  {
     if (resp && vec_store) {
       const int CH = (geglu ? BN / 2 : BN) / 8;
       const float inv_ch = __builtin_amdgcn_rcpf((float)CH);
@@ -557,9 +487,8 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
     }
   }
   float* rowstat = (float*)(smem + (size_t)STAGES * (XT + WT) - BM * 8);    // [BM][2] mean, rstd: beyond the epilogue tile
-#pragma unroll
-  for (int pass = 0; pass < NPASS; ++pass) {
-    __syncthreads();                                      // stage buffers / previous pass's tile no longer read
+  {
+    __syncthreads();                                      // stage buffers no longer read
     if constexpr (LN) {
       // (the column sums are fetched here, not before the K loop: 4-5 more live quads push the 8-wave variants past
       // 128 VGPRs = one workgroup per CU, which costs far more than this one L2 round trip behind the barrier)
@@ -583,7 +512,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
       }
       __syncthreads();
     }
-    if (NPASS == 1 || wn == pass) {
+    {
 #pragma unroll
       for (int j = 0; j < FM; ++j) {
         const int m = tile_m * BM + prow + j * 16;
@@ -592,7 +521,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
         float ln_mean = 0.f, ln_rstd = 1.f;
         if constexpr (LN) { ln_mean = rowstat[(prow + j * 16) * 2]; ln_rstd = rowstat[(prow + j * 16) * 2 + 1]; }
         if (geglu) {
-          if constexpr (FN % 2 == 0 && NPASS == 1) {
+          if constexpr (FN % 2 == 0) {
 #pragma unroll
             for (int i = 0; i < FN; i += 2) {
               typename Traits<T>::vec4 pk;
@@ -633,7 +562,7 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
               if (p.act == ES_ACT_SILU) x = silu_f(x);
               pk[r] = from_f32<T>(x * scale);
             }
-            *(typename Traits<T>::vec4*)(et + (prow + j * 16) * EROW + (pcol - pass * BNP + i * 16) * 2) = pk;
+            *(typename Traits<T>::vec4*)(et + (prow + j * 16) * EROW + (pcol + i * 16) * 2) = pk;
           }
         }
       }
@@ -642,39 +571,23 @@ __global__ __launch_bounds__(BM * 8 / FM, BKT == 32 ? 3 : ((STAGES == 2 && BM ==
 
     // ---------------- epilogue phase B: coalesced residual add + store along the channel dim ----------------
     const int BNo = geglu ? BN / 2 : BNP;                 // tile width in stored channels (this pass)
-    const int c_tile = tile_n * (geglu ? BN / 2 : BN) + pass * BNP;
+    const int c_tile = tile_n * (geglu ? BN / 2 : BN);
     if (vec_store) {
       const int CH = BNo / 8;
       const float inv_ch = __builtin_amdgcn_rcpf((float)CH);
-      if constexpr (RPF > 0) {
 #pragma unroll
-        for (int k = 0; k < RPF; ++k) {
-          const int idx = tid + k * NT;
-          const int row = fast_div(idx, CH, inv_ch), ch = idx - row * CH;
-          const int m = tile_m * BM + row, c = c_tile + ch * 8;
-          if (idx < BM * CH && m < M && c < Cstore) {
-            auto v = as_vec8<T>(*(const u32x4*)(et + row * EROW + ch * 16));
-            if (resp) {
-              const auto rv = as_vec8<T>(rpre[k]);
+      for (int k = 0; k < RPF; ++k) {
+        const int idx = tid + k * NT;
+        const int row = fast_div(idx, CH, inv_ch), ch = idx - row * CH;
+        const int m = tile_m * BM + row, c = c_tile + ch * 8;
+        if (idx < BM * CH && m < M && c < Cstore) {
+          auto v = as_vec8<T>(*(const u32x4*)(et + row * EROW + ch * 16));
+          if (resp) {
+            const auto rv = as_vec8<T>(rpre[k]);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(rv[e]));
-            }
-            store16(outp + (size_t)m * Cstore + c, __builtin_bit_cast(u32x4, v));
+            for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(rv[e]));
           }
-        }
-      } else {
-        for (int idx = tid; idx < BM * CH; idx += NT) {
-          const int row = fast_div(idx, CH, inv_ch), ch = idx - row * CH;
-          const int m = tile_m * BM + row, c = c_tile + ch * 8;
-          if (m < M && c < Cstore) {
-            auto v = as_vec8<T>(*(const u32x4*)(et + row * EROW + ch * 16));
-            if (resp) {
-              const auto rv = as_vec8<T>(*(const u32x4*)(resp + (size_t)m * Cstore + c));
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(rv[e]));
-            }
-            store16(outp + (size_t)m * Cstore + c, __builtin_bit_cast(u32x4, v));
-          }
+          store16(outp + (size_t)m * Cstore + c, __builtin_bit_cast(u32x4, v));
         }
       }
     } else {
@@ -784,31 +697,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const es_gemm_desc p
 template <typename T>
 int launch(const es_gemm_desc& d, hipStream_t st) {
   const int M = d.N * d.Hout * d.Wout;
-  const int bk = d.bk == 32 ? 32 : BK;
-  const int nk = d.Kpad / bk;
+  const int nk = d.Kpad / BK;
   const int Ctot = d.C1 + d.C2;
   const bool aligned = (Ctot % BK == 0) && (d.C1 % BK == 0);
-  // Pixel tile: 128 rows x 4 waves (2 workgroups/CU) by default; 256 rows x 8 waves (1 workgroup/CU) selectable (bm).
+  // Pixel tile: 128 rows (4 or 8 waves) by default, 64 rows with bn = 64; bn = 320 is the 256-pixel tile of gemm_conv8p.hip
   const int tn = d.rows_padded / d.bn;
-  int bm = d.bm;
-  if (d.bn == 320) bm = 256;
-  if (d.bn == 64) bm = 64;
-  if (bm == 0) bm = 128;
+  const int bm = d.bn == 64 ? 64 : 128;
   dim3 grid(((M + bm - 1) / bm) * tn * d.splitk);
   int stages = d.stages;
   if (stages == 0) stages = 2;   // measured (tools/gemm_bench.py): 2 stages x 2 workgroups/CU beats a 3-4 deep ring at 1/CU
-#define ES_LAUNCH_K(BMV, BNV, AL, ST, FMV, BKV)                                                             \
-  do {                                                                                                      \
-    auto kfn = conv_gemm_kernel<T, BMV, BNV, AL, ST, FMV, BKV>;                                             \
-    const size_t ring = (size_t)ST * (BMV + BNV) * BKV * 2, epi = (size_t)BMV * (BNV * 2 + 16);             \
-    const size_t lds = BKV == 64 ? ring : (ring > epi ? ring : epi);                                        \
-    static bool attr_set = false;                                                                           \
-    if (!attr_set) {                                                                                        \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
-      attr_set = true;                                                                                      \
-    }                                                                                                       \
-    hipLaunchKernelGGL(kfn, grid, dim3(BMV * 8 / FMV), lds, st, d, M, nk, d.t1, d.t2, d.Ct1, d.Ct2);                                  \
-  } while (0)
 #define ES_LAUNCH_F(BMV, BNV, AL, ST, FMV)                                                                  \
   do {                                                                                                      \
     auto kfn = conv_gemm_kernel<T, BMV, BNV, AL, ST, FMV>;                                                  \
@@ -822,7 +719,7 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
   } while (0)
 #define ES_LAUNCH_LN(BMV, BNV, ST, FMV)                                                                      \
   do {                                                                                                      \
-    auto kfn = conv_gemm_kernel<T, BMV, BNV, true, ST, FMV, 64, true>;                                      \
+    auto kfn = conv_gemm_kernel<T, BMV, BNV, true, ST, FMV, true>;                                          \
     const size_t lds = (size_t)ST * (BMV + BNV) * BK * 2;                                                   \
     static bool attr_set = false;                                                                           \
     if (!attr_set) {                                                                                        \
@@ -834,11 +731,8 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
 #define ES_LAUNCH(BMV, BNV, AL, ST) ES_LAUNCH_F(BMV, BNV, AL, ST, 4)
 #define ES_LAUNCH_ST(BNV)                                                                                   \
   do {                                                                                                      \
-    if (d.bk == 32) ES_LAUNCH_K(128, BNV, true, 2, 4, 32);                                                  \
-    else if (d.waves == 8 && stages == 4 && BNV == 128) ES_LAUNCH_F(128, 128, true, 4, 2);                  \
+    if (d.waves == 8 && stages == 4 && BNV == 128) ES_LAUNCH_F(128, 128, true, 4, 2);                       \
     else if (d.waves == 8) ES_LAUNCH_F(128, BNV, true, 2, 2);                                               \
-    else if (bm == 256 && stages == 3) ES_LAUNCH(256, BNV, true, 3);                                        \
-    else if (bm == 256) ES_LAUNCH(256, BNV, true, 2);                                                       \
     else if (stages == 2) ES_LAUNCH(128, BNV, true, 2);                                                     \
     else if (stages == 3) ES_LAUNCH(128, BNV, true, 3);                                                     \
     else ES_LAUNCH(128, BNV, true, 4);                                                                      \
@@ -859,9 +753,8 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
 #undef ES_LAUNCH_ST
 #undef ES_LAUNCH
 #undef ES_LAUNCH_F
-#undef ES_LAUNCH_K
 #undef ES_LAUNCH_LN
-  if (d.splitk > 1 && !d.no_reduce) {
+  if (d.splitk > 1) {
     const long long total = (long long)M * (d.rows_padded / 8);
     hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, M);
   }
@@ -887,16 +780,15 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
     for (int g = 0; g < d->ngroups; ++g)
       if (!d->w_g[g] || d->mt_end[g] <= (g ? d->mt_end[g - 1] : 0)) { es_set_error("es_conv_gemm: bad group table"); return -1; }
     if (d->mt_end[d->ngroups - 1] != tm || (d->N * d->Hout * d->Wout) % 128) { es_set_error("es_conv_gemm: groups must tile M in whole 128-pixel tiles"); return -1; }
-    if (d->bm == 256 || d->bn == 320)
+    if (d->bn == 320)
       for (int g = 0; g < d->ngroups; ++g)
         if (d->mt_end[g] & 1) { es_set_error("es_conv_gemm: 256-pixel tiles need groups of whole 256-pixel tiles"); return -1; }
   }
   if (d->bn != 64 && d->bn != 128 && d->bn != 160 && d->bn != 320) { es_set_error("es_conv_gemm: bn must be 64, 128, 160 or 320"); return -1; }
-  if (d->bn == 64 && ((d->bm != 0 && d->bm != 64) || d->C1 % BK || d->C2 % BK || d->stages == 3 || d->waves == 8 || d->act == ES_ACT_GEGLU)) {
+  if (d->bn == 64 && (d->C1 % BK || d->C2 % BK || d->stages == 3 || d->waves == 8 || d->act == ES_ACT_GEGLU)) {
     es_set_error("es_conv_gemm: bn=64 is the 64x64 tile: 64-aligned channels, 2 or 4 stages, no GEGLU"); return -1; }
-  if (d->bm == 64 && d->bn != 64) { es_set_error("es_conv_gemm: bm=64 goes with bn=64"); return -1; }
-  if (d->bn == 320 && (d->bm == 128 || d->C1 % BK || d->C2 % BK || (d->stages != 0 && d->stages != 2) || d->act == ES_ACT_GEGLU)) {
-    es_set_error("es_conv_gemm: bn=320 is the 256-pixel tile: 64-aligned channels, 2 stages, no GEGLU"); return -1; }
+  if (d->bn == 320 && (d->C1 % BK || d->C2 % BK || (d->stages != 0 && d->stages != 2) || d->act == ES_ACT_GEGLU || d->waves == 8)) {
+    es_set_error("es_conv_gemm: bn=320 is the 256-pixel phase-interleaved tile: 64-aligned channels, 2 stages, no GEGLU"); return -1; }
   if (d->rows_padded % d->bn || d->rows_padded < d->Cout) { es_set_error("es_conv_gemm: bad rows_padded"); return -1; }
   if (d->Kpad % BK || d->Kpad < Ktrue) { es_set_error("es_conv_gemm: bad Kpad"); return -1; }
   if (d->C1 % 8 || d->C2 % 8 || (d->C2 && !d->x2)) { es_set_error("es_conv_gemm: channels must be multiples of 8"); return -1; }
@@ -909,29 +801,21 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
                 (size_t)d->N * d->Hout * d->Wout * (d->Ct1 > d->Ct2 ? d->Ct1 : d->Ct2) * 2 >= 0x7FFFFFFFull)) {
     es_set_error("es_conv_gemm: 1x1 tail sources need stride 1, no upsample, same-size output, 64-aligned channels"); return -1; }
   if (!d->t1 && (d->t2 || d->Ct1 || d->Ct2)) { es_set_error("es_conv_gemm: tail fields set without t1"); return -1; }
-  if (d->no_reduce && (d->splitk <= 1 || d->act != ES_ACT_NONE || d->residual || d->out_scale_dev || d->out_scale != 1.0f)) {
-    es_set_error("es_conv_gemm: no_reduce needs splitk > 1, no activation, no residual, scale 1"); return -1; }
   if (d->x_nmod < 0 || (d->x_nmod && (d->x2 || d->t1 || d->x_nmod > d->N))) { es_set_error("es_conv_gemm: x_nmod needs a single source and 0 < x_nmod <= N"); return -1; }
   if (d->splitk < 1 || d->splitk > d->Kpad / BK) { es_set_error("es_conv_gemm: bad splitk"); return -1; }
   if (d->splitk > 1 && (!d->workspace || d->act == ES_ACT_GEGLU)) { es_set_error("es_conv_gemm: splitk needs workspace and no GEGLU"); return -1; }
   if (d->splitk > 1 && (long long)d->N * d->Hout * d->Wout * (d->rows_padded / 8) >= (1ll << 31)) { es_set_error("es_conv_gemm: split-K output too large for 32-bit indices"); return -1; }
   if (d->act == ES_ACT_GEGLU && (d->bn != 128 || d->Cout % 32)) { es_set_error("es_conv_gemm: GEGLU needs bn=128, Cout%32==0"); return -1; }
   if (d->N < 1 || d->Hout < 1 || d->Wout < 1) { es_set_error("es_conv_gemm: empty problem"); return -1; }
-  if (d->bm != 0 && d->bm != 64 && d->bm != 128 && d->bm != 256) { es_set_error("es_conv_gemm: bm must be 0 (auto), 64, 128 or 256"); return -1; }
-  if (d->bm == 256 && (d->C1 % BK || d->C2 % BK)) { es_set_error("es_conv_gemm: bm=256 needs 64-aligned channels"); return -1; }
   if (d->stages != 0 && (d->stages < 2 || d->stages > 4)) { es_set_error("es_conv_gemm: stages must be 0 (auto), 2, 3 or 4"); return -1; }
   if (d->waves != 0 && d->waves != 4 && d->waves != 8) { es_set_error("es_conv_gemm: waves must be 0 (auto), 4 or 8"); return -1; }
-  if (d->ln_colsum && (d->ksize != 1 || d->stride != 1 || d->C2 || d->C1 % BK || d->Kpad != d->C1 || d->splitk != 1 || d->bk == 32 ||
-                       d->bn == 320 || d->bm == 256 || d->upsample || d->temb || d->stages == 3)) {
+  if (d->ln_colsum && (d->ksize != 1 || d->stride != 1 || d->C2 || d->C1 % BK || d->Kpad != d->C1 || d->splitk != 1 ||
+                       d->bn == 320 || d->upsample || d->temb || d->stages == 3)) {
     es_set_error("es_conv_gemm: LayerNorm fold needs a plain linear layer: ksize 1, one source, K = C1 (multiple of 64), splitk 1, bn 64|128|160"); return -1; }
   if (d->ln_colsum && d->ngroups > 1)
     for (int g = 0; g < d->ngroups; ++g)
       if (!d->ln_colsum_g[g]) { es_set_error("es_conv_gemm: grouped LayerNorm fold needs ln_colsum_g for every group"); return -1; }
-  if (d->bk != 0 && d->bk != 64 && d->bk != 32) { es_set_error("es_conv_gemm: bk must be 0 (auto), 64 or 32"); return -1; }
-  if (d->bk == 32 && ((d->bn != 128 && d->bn != 160) || d->bm == 256 || d->bm == 64 || d->waves == 8 || d->C1 % BK || d->C2 % BK ||
-                      (d->stages != 0 && d->stages != 2))) {
-    es_set_error("es_conv_gemm: bk=32 is the 128-pixel tile with half-depth stages: bn 128|160, 4 waves, 2 stages, 64-aligned channels"); return -1; }
-  if (d->waves == 8 && (d->bm == 256 || d->bn == 320 || d->C1 % BK || d->C2 % BK || d->stages == 3 ||
+  if (d->waves == 8 && (d->bn == 320 || d->C1 % BK || d->C2 % BK || d->stages == 3 ||
                         (d->stages == 4 && d->bn != 128))) {
     es_set_error("es_conv_gemm: waves=8 is the 128-pixel tile on 8 waves: 64-aligned channels, 2 stages (4 with bn=128)"); return -1; }
   ES_PLAN_RECORD(ES_OP_CONV_GEMM, d, sizeof(*d));       // after validation: a rejected call never enters a recording plan

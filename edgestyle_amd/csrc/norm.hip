@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const es_gn_desc p, const
 // Statistics go through the same deterministic LDS reduction as gn_stats_kernel; the normalised values are written
 // straight from the registers.  Saves the second launch and the second read (small tensors are launch-latency bound:
 // ~7 us per launch at any size).
-template <typename T, int CPT, bool SK = false /* source = split-K partial slabs of the producing conv */>
+template <typename T, int CPT>
 __global__ __launch_bounds__(256) void gn_slab_kernel(const es_gn_desc p, const int gpb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n = blockIdx.y, gb = blockIdx.x;
@@ -221,52 +221,11 @@ __global__ __launch_bounds__(256) void gn_slab_kernel(const es_gn_desc p, const 
   u32x4 raw[CPT];
   f32x4 ga[2], be[2];
   if (active) {
-    if constexpr (SK) {
-      // x = round( sum of the producing conv's K-slice partials + bias + time embedding ): what its reduce kernel would
-      // have stored (same summation order, same rounding point), read here instead - no reduce launch, no fp16 round trip
-      const float* bsel = p.sk_bias;
-      if (p.ngroups > 1) bsel = p.sk_bias_g[(n >= p.n_end[0]) + (n >= p.n_end[1]) + (n >= p.n_end[2])];
-      float bt[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, tv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (bsel) {
-        const f32x4 b0 = *(const f32x4*)(bsel + c), b1 = *(const f32x4*)(bsel + c + 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { bt[r] = b0[r]; bt[4 + r] = b1[r]; }
-      }
-      if (p.sk_temb) {
-        const auto t8 = as_vec8<T>(*(const u32x4*)((const T*)p.sk_temb + (size_t)n * p.sk_temb_stride + c));
-#pragma unroll
-        for (int r = 0; r < 8; ++r) tv[r] = to_f32(t8[r]);
-      }
-      const size_t zstride = (size_t)p.N * p.HW * p.sk_rows;
-#pragma unroll
-      for (int k = 0; k < CPT; ++k) {
-        const int px = ps + k * PS;
-        raw[k] = u32x4{0u, 0u, 0u, 0u};
-        if (px < p.HW) {
-          const float* w = p.sk_ws + ((size_t)n * p.HW + px) * p.sk_rows + c;
-          f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-          int z = 0;
-          for (; z + 4 <= p.sk_n; z += 4) {                  // four slices' loads in flight, summed in slice order
-            f32x4 a[4], b[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { a[u] = *(const f32x4*)(w + (z + u) * zstride); b[u] = *(const f32x4*)(w + (z + u) * zstride + 4); }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { s0 += a[u]; s1 += b[u]; }
-          }
-          for (; z < p.sk_n; ++z) { s0 += *(const f32x4*)(w + z * zstride); s1 += *(const f32x4*)(w + z * zstride + 4); }
-          typename Traits<T>::vec8 r8;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { r8[r] = from_f32<T>(s0[r] + bt[r] + tv[r]); r8[4 + r] = from_f32<T>(s1[r] + bt[4 + r] + tv[4 + r]); }
-          raw[k] = __builtin_bit_cast(u32x4, r8);
-        }
-      }
-    } else {
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
       const int px = ps + k * PS;
       raw[k] = u32x4{0u, 0u, 0u, 0u};
       if (px < p.HW) raw[k] = *(const u32x4*)(src + ((size_t)n * p.HW + px) * cs + cc);
-    }
     }
     ga[0] = *(const f32x4*)(gam + c); ga[1] = *(const f32x4*)(gam + c + 4);
     be[0] = *(const f32x4*)(bet + c); be[1] = *(const f32x4*)(bet + c + 4);
@@ -420,16 +379,11 @@ int launch_gn(const es_gn_desc& d, hipStream_t st) {
     const int W = gpb * (C / d.groups);
     const size_t lds = (size_t)(2 * (256 / (W / 8)) * W + 2 * gpb) * sizeof(float);
     dim3 grid(d.groups / gpb, d.N);
-    if (d.sk_ws) {
-      if (cpt <= 8) hipLaunchKernelGGL((gn_slab_kernel<T, 8, true>), grid, dim3(256), lds, st, d, gpb);
-      else if (cpt <= 16) hipLaunchKernelGGL((gn_slab_kernel<T, 16, true>), grid, dim3(256), lds, st, d, gpb);
-      else hipLaunchKernelGGL((gn_slab_kernel<T, 24, true>), grid, dim3(256), lds, st, d, gpb);
-    } else if (cpt <= 8) hipLaunchKernelGGL((gn_slab_kernel<T, 8>), grid, dim3(256), lds, st, d, gpb);
+    if (cpt <= 8) hipLaunchKernelGGL((gn_slab_kernel<T, 8>), grid, dim3(256), lds, st, d, gpb);
     else if (cpt <= 16) hipLaunchKernelGGL((gn_slab_kernel<T, 16>), grid, dim3(256), lds, st, d, gpb);
     else hipLaunchKernelGGL((gn_slab_kernel<T, 24>), grid, dim3(256), lds, st, d, gpb);
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
-  if (d.sk_ws) return -4;            // (checked by the entry point: the split-K source exists in the slab form only)
   int ppb = d.HW / GN_MAX_CHUNK;
   if (ppb < 16) ppb = 16;
   const int nchunk = (d.HW + ppb - 1) / ppb;
@@ -482,13 +436,7 @@ extern "C" int es_group_norm_is_slab(int HW, int C, int groups) {
 
 extern "C" int es_group_norm(const es_gn_desc* d, void* stream) {
   const int C = d->C1 + d->C2;
-  if ((!d->x && !d->sk_ws) || !d->out || !d->partials || (d->ngroups <= 1 && (!d->gamma || !d->beta))) { es_set_error("es_group_norm: null pointer"); return -1; }
-  if (d->sk_ws) {
-    int cpt = 0;
-    if (d->C2 || d->sk_n < 2 || d->sk_rows < C || d->sk_rows % 8 || !gn_slab_gpb(*d, cpt)) {
-      es_set_error("es_group_norm: a split-K source needs one tensor, sk_n >= 2, sk_rows >= C and the one-launch (slab) geometry"); return -1; }
-    if (d->sk_temb && (d->sk_temb_stride % 8 || ((size_t)d->sk_temb & 15))) { es_set_error("es_group_norm: sk_temb must be 16-byte aligned rows"); return -1; }
-  }
+  if (!d->x || !d->out || !d->partials || (d->ngroups <= 1 && (!d->gamma || !d->beta))) { es_set_error("es_group_norm: null pointer"); return -1; }
   if (d->ngroups > 4) { es_set_error("es_group_norm: at most 4 groups"); return -1; }
   for (int g = 0; g < d->ngroups && d->ngroups > 1; ++g)
     if (!d->gamma_g[g] || !d->beta_g[g]) { es_set_error("es_group_norm: null group parameter"); return -1; }

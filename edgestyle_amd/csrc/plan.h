@@ -11,9 +11,6 @@ enum es_op_kind {
   ES_OP_FUSION_BLOCK, ES_OP_FUSION_BLOCKS, ES_OP_TIMESTEP_EMBEDDING, ES_OP_CFG_DDIM, ES_OP_CFG_UNIPC, ES_OP_NCHW_TO_NHWC,
   ES_OP_NHWC_TO_NCHW, ES_OP_ADD, ES_OP_VAE_SAMPLE, ES_OP_INCR, ES_OP_GATHER_ROW, ES_OP_MEMCPY, ES_OP_MEMCPY2D,
   ES_OP_FILL_F32, ES_OP_LATENTS_TO_INPUT,
-  // stream markers (es_plan_mark, no arguments): the calls between SIDE_BEGIN and SIDE_END run on a second stream forked
-  // from the launching one, concurrently with what follows SIDE_END; SIDE_JOIN makes the launching stream wait for them
-  ES_OP_SIDE_BEGIN = 64, ES_OP_SIDE_END, ES_OP_SIDE_JOIN,
 };
 
 struct es_op_layer_norm { const void* x; void* out; const float* gamma; const float* beta; int M, C; float eps; int dtype; };

@@ -22,14 +22,6 @@ struct es_plan {
   struct Op { int kind; size_t off, bytes; };
   std::vector<Op> ops;
   std::vector<char> blob;
-  // side section (ES_OP_SIDE_*): a stream and two events of the plan's own, created on first use
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_done = nullptr;
-  ~es_plan() {
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
-    if (ev_done) (void)hipEventDestroy(ev_done);
-    if (side) (void)hipStreamDestroy(side);
-  }
 };
 
 namespace {
@@ -69,44 +61,12 @@ int launch_op(const es_plan* p, const es_plan::Op& op, hipStream_t st, const flo
   }
 }
 
-int side_init(es_plan* p) {
-  if (p->side) return 0;
-  if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming) != hipSuccess) { es_set_error("es_plan_launch: side stream / event creation failed"); return -2; }
-  return 0;
-}
-
-int run_plan(const es_plan* cp, hipStream_t st, const float* guidance_override) {
+int run_plan(const es_plan* p, hipStream_t st, const float* guidance_override) {
   if (g_rec) { es_set_error("es_plan_launch: a plan is recording on this thread"); return -1; }
-  es_plan* p = const_cast<es_plan*>(cp);
   g_replaying = true;
   int rc = 0;
-  hipStream_t cur = st;
-  int open = 0;                   // 0: no side section pending, 1: inside one, 2: ended but not joined
-  for (const auto& op : p->ops) {
-    if (op.kind == ES_OP_SIDE_BEGIN) {
-      // fork: the side stream starts behind everything issued so far (under stream capture this pulls it into the capture)
-      if (open || (rc = side_init(p)) != 0) { if (!rc) { es_set_error("es_plan_launch: nested side section"); rc = -1; } break; }
-      if (hipEventRecord(p->ev_fork, st) != hipSuccess || hipStreamWaitEvent(p->side, p->ev_fork, 0) != hipSuccess) { es_set_error("es_plan_launch: fork failed"); rc = -2; break; }
-      cur = p->side; open = 1;
-    } else if (op.kind == ES_OP_SIDE_END) {
-      if (open != 1) { es_set_error("es_plan_launch: SIDE_END without SIDE_BEGIN"); rc = -1; break; }
-      if (hipEventRecord(p->ev_done, p->side) != hipSuccess) { es_set_error("es_plan_launch: side event failed"); rc = -2; break; }
-      cur = st; open = 2;
-    } else if (op.kind == ES_OP_SIDE_JOIN) {
-      if (open != 2) { es_set_error("es_plan_launch: SIDE_JOIN without a finished side section"); rc = -1; break; }
-      if (hipStreamWaitEvent(st, p->ev_done, 0) != hipSuccess) { es_set_error("es_plan_launch: join failed"); rc = -2; break; }
-      open = 0;
-    } else if ((rc = launch_op(p, op, cur, guidance_override)) != 0) {
-      break;
-    }
-  }
-  if (!rc && open) {
-    // never leave a fork dangling (a capture could not end, an eager caller would race): join it here
-    if (open == 1) (void)hipEventRecord(p->ev_done, p->side);
-    (void)hipStreamWaitEvent(st, p->ev_done, 0);
-  }
+  for (const auto& op : p->ops)
+    if ((rc = launch_op(p, op, st, guidance_override)) != 0) break;
   g_replaying = false;
   return rc;
 }
@@ -119,12 +79,6 @@ extern "C" void es_plan_record(int kind, const void* args, size_t bytes) {
   p->blob.resize(off + bytes);
   memcpy(p->blob.data() + off, args, bytes);
   p->ops.push_back({kind, off, bytes});
-}
-
-extern "C" int es_plan_mark(int kind) {
-  if (kind != ES_OP_SIDE_BEGIN && kind != ES_OP_SIDE_END && kind != ES_OP_SIDE_JOIN) { es_set_error("es_plan_mark: unknown marker"); return -1; }
-  if (es_plan_recording()) g_rec->ops.push_back({kind, g_rec->blob.size(), 0});
-  return 0;
 }
 
 extern "C" es_plan* es_plan_create(void) { return new es_plan(); }
@@ -149,6 +103,84 @@ extern "C" int es_plan_count(const es_plan* p, int kind) {
 extern "C" int es_plan_launch(const es_plan* p, void* stream) {
   if (!p) { es_set_error("es_plan_launch: null plan"); return -1; }
   return run_plan(p, (hipStream_t)stream, nullptr);
+}
+
+// Pointer fields of a recorded call, by op kind: byte offset inside the argument record and how the op uses the memory
+// behind it (1 = reads, 2 = writes, 3 = both).  This is what a relocator needs (edgestyle_amd/native.py save()): exactly
+// these 8-byte words are device addresses - nothing else in a record is ever treated as one - and a block of memory that
+// every plan only READS holds persistent data (packed weights, parameters, tables) and must travel with a context image,
+// while blocks that some call writes are produced at run time and only need their space.  `elem_bytes`: records of the
+// array ops (es_fusion_blocks) repeat every elem_bytes; 0 = one record.  Returns the field count (fills at most cap).
+#include <stddef.h>
+namespace {
+struct PtrField { int off; int use; };
+#define F_IN(S, m) {(int)offsetof(S, m), 1}
+#define F_OUT(S, m) {(int)offsetof(S, m), 2}
+#define F_IO(S, m) {(int)offsetof(S, m), 3}
+#define F_IN4(S, m) {(int)offsetof(S, m), 1}, {(int)offsetof(S, m) + 8, 1}, {(int)offsetof(S, m) + 16, 1}, {(int)offsetof(S, m) + 24, 1}
+const std::vector<PtrField>& ptr_fields(int kind, int& elem) {
+  static const std::vector<PtrField> none;
+  elem = 0;
+  switch (kind) {
+    case ES_OP_CONV_GEMM: { static const std::vector<PtrField> f = {
+        F_IN(es_gemm_desc, x), F_IN(es_gemm_desc, x2), F_IN(es_gemm_desc, w), F_IN(es_gemm_desc, bias), F_IN(es_gemm_desc, temb),
+        F_IN(es_gemm_desc, residual), F_IN(es_gemm_desc, out_scale_dev), F_OUT(es_gemm_desc, out), F_IO(es_gemm_desc, workspace),
+        F_OUT(es_gemm_desc, prof), F_IN4(es_gemm_desc, w_g), F_IN4(es_gemm_desc, bias_g), F_IN(es_gemm_desc, ln_colsum),
+        F_IN4(es_gemm_desc, ln_colsum_g), F_IN(es_gemm_desc, t1), F_IN(es_gemm_desc, t2)}; return f; }
+    case ES_OP_LINEAR_XS: { static const std::vector<PtrField> f = {
+        F_IN(es_xs_desc, x), F_OUT(es_xs_desc, out), F_IN(es_xs_desc, w), F_IN(es_xs_desc, bias), F_IN4(es_xs_desc, w_g),
+        F_IN4(es_xs_desc, bias_g), F_OUT(es_xs_desc, prof)}; return f; }
+    case ES_OP_ATTENTION: { static const std::vector<PtrField> f = {
+        F_IN(es_attn_desc, q), F_IN(es_attn_desc, k), F_IN(es_attn_desc, v), F_OUT(es_attn_desc, o)}; return f; }
+    case ES_OP_GROUP_NORM: { static const std::vector<PtrField> f = {
+        F_IN(es_gn_desc, x), F_IN(es_gn_desc, x2), F_OUT(es_gn_desc, out), F_IN(es_gn_desc, gamma), F_IN(es_gn_desc, beta),
+        F_IO(es_gn_desc, partials), F_IN4(es_gn_desc, gamma_g), F_IN4(es_gn_desc, beta_g)}; return f; }
+    case ES_OP_LAYER_NORM: { static const std::vector<PtrField> f = {
+        F_IN(es_op_layer_norm, x), F_OUT(es_op_layer_norm, out), F_IN(es_op_layer_norm, gamma), F_IN(es_op_layer_norm, beta)}; return f; }
+    case ES_OP_LAYER_NORM_GROUPED: { static const std::vector<PtrField> f = {
+        F_IN(es_ln_desc, x), F_OUT(es_ln_desc, out), F_IN4(es_ln_desc, gamma_g), F_IN4(es_ln_desc, beta_g)}; return f; }
+    case ES_OP_FUSION_BLOCKS: elem = (int)sizeof(es_fusion_desc);   // same record layout, repeated
+      [[fallthrough]];
+    case ES_OP_FUSION_BLOCK: { static const std::vector<PtrField> f = {
+        F_IN4(es_fusion_desc, res), {(int)offsetof(es_fusion_desc, res) + 32, 1}, {(int)offsetof(es_fusion_desc, res) + 40, 1},
+        F_IN(es_fusion_desc, w1), F_IN(es_fusion_desc, b1), F_IN(es_fusion_desc, g1), F_IN(es_fusion_desc, be1),
+        F_IN(es_fusion_desc, w2), F_IN(es_fusion_desc, b2), F_IN(es_fusion_desc, g2), F_IN(es_fusion_desc, be2),
+        F_IN(es_fusion_desc, w3), F_IN(es_fusion_desc, b3), F_IO(es_fusion_desc, scratch), F_IO(es_fusion_desc, u),
+        F_OUT(es_fusion_desc, out), F_IN(es_fusion_desc, res_scale_dev), F_IN(es_fusion_desc, addend)}; return f; }
+    case ES_OP_TIMESTEP_EMBEDDING: { static const std::vector<PtrField> f = {F_IN(es_op_timestep, t), F_OUT(es_op_timestep, out)}; return f; }
+    case ES_OP_CFG_DDIM: { static const std::vector<PtrField> f = {
+        F_IN(es_op_cfg_ddim, noise), F_IO(es_op_cfg_ddim, latents), F_OUT(es_op_cfg_ddim, model_in), F_IN(es_op_cfg_ddim, coef),
+        F_IN(es_op_cfg_ddim, step_idx)}; return f; }
+    case ES_OP_CFG_UNIPC: { static const std::vector<PtrField> f = {
+        F_IN(es_op_cfg_unipc, noise), F_IO(es_op_cfg_unipc, latents), F_IO(es_op_cfg_unipc, last_sample), F_IO(es_op_cfg_unipc, m0),
+        F_IO(es_op_cfg_unipc, m1), F_OUT(es_op_cfg_unipc, model_in), F_IN(es_op_cfg_unipc, coef), F_IN(es_op_cfg_unipc, step_idx)}; return f; }
+    case ES_OP_NCHW_TO_NHWC: { static const std::vector<PtrField> f = {F_IN(es_op_nchw_to_nhwc, in), F_OUT(es_op_nchw_to_nhwc, out)}; return f; }
+    case ES_OP_NHWC_TO_NCHW: { static const std::vector<PtrField> f = {F_IN(es_op_nhwc_to_nchw, in), F_OUT(es_op_nhwc_to_nchw, out)}; return f; }
+    case ES_OP_ADD: { static const std::vector<PtrField> f = {F_IN(es_op_add, a), F_IN(es_op_add, b), F_OUT(es_op_add, y)}; return f; }
+    case ES_OP_VAE_SAMPLE: { static const std::vector<PtrField> f = {F_IN(es_op_vae_sample, moments), F_IN(es_op_vae_sample, noise), F_OUT(es_op_vae_sample, z)}; return f; }
+    case ES_OP_INCR: { static const std::vector<PtrField> f = {F_IO(es_op_incr, ctr)}; return f; }
+    case ES_OP_GATHER_ROW: { static const std::vector<PtrField> f = {F_IN(es_op_gather_row, table), F_IN(es_op_gather_row, idx), F_OUT(es_op_gather_row, out)}; return f; }
+    case ES_OP_MEMCPY: { static const std::vector<PtrField> f = {F_OUT(es_op_memcpy, dst), F_IN(es_op_memcpy, src)}; return f; }
+    case ES_OP_MEMCPY2D: { static const std::vector<PtrField> f = {F_OUT(es_op_memcpy2d, dst), F_IN(es_op_memcpy2d, src)}; return f; }
+    case ES_OP_FILL_F32: { static const std::vector<PtrField> f = {F_OUT(es_op_fill_f32, dst)}; return f; }
+    case ES_OP_LATENTS_TO_INPUT: { static const std::vector<PtrField> f = {F_IN(es_op_latents_to_input, latents), F_OUT(es_op_latents_to_input, model_in)}; return f; }
+    default: return none;
+  }
+}
+#undef F_IN
+#undef F_OUT
+#undef F_IO
+#undef F_IN4
+}  // namespace
+extern "C" int es_plan_pointer_fields(int kind, int32_t* offsets, int32_t* uses, int cap, int32_t* elem_bytes) {
+  int elem = 0;
+  const auto& f = ptr_fields(kind, elem);
+  if (elem_bytes) *elem_bytes = elem;
+  for (int i = 0; i < (int)f.size() && i < cap; ++i) {
+    if (offsets) offsets[i] = f[i].off;
+    if (uses) uses[i] = f[i].use;
+  }
+  return (int)f.size();
 }
 
 // Flat image of a plan (es_ctx_save / es_ctx_load): u64 n_ops, u64 blob bytes, n_ops x {i64 kind, u64 off, u64 bytes}, blob.
@@ -383,28 +415,35 @@ extern "C" int es_ctx_load(const char* path, int device, es_ctx** out) {
   auto fail = [&](const char* msg) { es_set_error(msg); if (c) es_ctx_destroy(c); fclose(f); return -1; };
   auto rd = [&](void* dst, size_t n) { return fread(dst, 1, n, f) == n; };
   struct { char magic[8]; unsigned abi, n_blocks; unsigned long long arena_bytes; } h;
-  if (!rd(&h, sizeof(h)) || memcmp(h.magic, "ESCTX\1\0\0", 8) != 0) return fail("es_ctx_load: not a context image");
+  if (!rd(&h, sizeof(h)) || memcmp(h.magic, "ESCTX\2\0\0", 8) != 0) return fail("es_ctx_load: not a context image (or one of an older format: rebuild it)");
   if (h.abi != ES_ABI_VERSION) return fail("es_ctx_load: the image was written for another ABI version");
+  if (h.arena_bytes > (1ull << 40) || h.n_blocks > (1u << 24)) return fail("es_ctx_load: implausible header");
   if (hipSetDevice(device) != hipSuccess) return fail("es_ctx_load: hipSetDevice failed");
   c = new es_ctx();
   c->device = device;
   struct { float cond_scales[6]; float start, end; int use_graphs; unsigned n_alphas; } o;
   if (!rd(&c->g, sizeof(c->g)) || !rd(&o, sizeof(o))) return fail("es_ctx_load: truncated header");
+  if (o.n_alphas > (1u << 20)) return fail("es_ctx_load: implausible schedule length");
   memcpy(c->cond_scales, o.cond_scales, sizeof(o.cond_scales));
   c->control_start = o.start; c->control_end = o.end; c->use_graphs = o.use_graphs;
   c->alphas_cumprod.resize(o.n_alphas);
   if (o.n_alphas && !rd(c->alphas_cumprod.data(), o.n_alphas * sizeof(float))) return fail("es_ctx_load: truncated schedule");
   if ((o.n_alphas & 1) && fseek(f, 4, SEEK_CUR)) return fail("es_ctx_load: truncated schedule");
   struct Blk { unsigned long long off, bytes; };
+  // (overflow-safe: off <= arena and bytes <= arena - off)
+  auto inside = [&](unsigned long long off, unsigned long long bytes) { return off <= h.arena_bytes && bytes <= h.arena_bytes - off; };
   std::vector<Blk> blocks(h.n_blocks);
   if (h.n_blocks && !rd(blocks.data(), h.n_blocks * sizeof(Blk))) return fail("es_ctx_load: truncated block table");
-  for (const auto& b : blocks) if (b.off + b.bytes > h.arena_bytes) return fail("es_ctx_load: block outside the arena");
+  for (const auto& b : blocks) if (!inside(b.off, b.bytes)) return fail("es_ctx_load: block outside the arena");
   if (hipMalloc(&c->arena, h.arena_bytes ? h.arena_bytes : 256) != hipSuccess) return fail("es_ctx_load: hipMalloc of the arena failed");
+  // run-time-produced memory (activations, split-K slabs, scratch) travels as space only: zero it once
+  if (hipMemset(c->arena, 0, h.arena_bytes ? h.arena_bytes : 256) != hipSuccess) return fail("es_ctx_load: hipMemset of the arena failed");
   char* base = (char*)c->arena;
   for (int which = 0; which < ES_PLAN_COUNT; ++which) {
     unsigned long long pb = 0, nrel = 0;
     if (!rd(&pb, 8)) return fail("es_ctx_load: truncated plan table");
     if (!pb) continue;
+    if (pb > (1ull << 32)) return fail("es_ctx_load: implausible plan size");
     buf.resize(pb);
     if (!rd(buf.data(), pb) || !rd(&nrel, 8)) return fail("es_ctx_load: truncated plan");
     es_plan* p = es_plan_import(buf.data(), pb);
@@ -412,7 +451,7 @@ extern "C" int es_ctx_load(const char* path, int device, es_ctx** out) {
     c->plan[which] = p;
     for (unsigned long long i = 0; i < nrel; ++i) {
       unsigned long long r[2];
-      if (!rd(r, 16) || r[0] + 8 > p->blob.size() || r[1] >= h.arena_bytes) return fail("es_ctx_load: bad relocation");
+      if (!rd(r, 16) || r[0] > p->blob.size() || p->blob.size() - r[0] < 8 || r[1] >= h.arena_bytes) return fail("es_ctx_load: bad relocation");
       const unsigned long long addr = (unsigned long long)(base + r[1]);
       memcpy(p->blob.data() + r[0], &addr, 8);
     }
@@ -420,14 +459,23 @@ extern "C" int es_ctx_load(const char* path, int device, es_ctx** out) {
   for (int slot = 0; slot < ES_BUF_COUNT; ++slot) {
     long long r[2];
     if (!rd(r, 16)) return fail("es_ctx_load: truncated slot table");
-    if (r[0] >= 0) { c->buf[slot] = base + r[0]; c->bytes[slot] = (size_t)r[1]; }
+    if (r[0] >= 0) {
+      if (r[1] <= 0 || !inside((unsigned long long)r[0], (unsigned long long)r[1])) return fail("es_ctx_load: bound slot outside the arena");
+      c->buf[slot] = base + r[0]; c->bytes[slot] = (size_t)r[1];
+    }
   }
-  // block contents, in table order, through a bounded staging buffer
+  // data extents (memory that every plan only reads: packed weights, parameters, tables), in table order, through a bounded
+  // staging buffer
+  unsigned long long n_ext = 0;
+  if (!rd(&n_ext, 8) || n_ext > (1ull << 24)) return fail("es_ctx_load: truncated extent table");
+  std::vector<Blk> ext((size_t)n_ext);
+  if (n_ext && !rd(ext.data(), (size_t)n_ext * sizeof(Blk))) return fail("es_ctx_load: truncated extent table");
+  for (const auto& b : ext) if (!inside(b.off, b.bytes)) return fail("es_ctx_load: extent outside the arena");
   buf.resize(64u << 20);
-  for (const auto& b : blocks) {
+  for (const auto& b : ext) {
     for (unsigned long long done = 0; done < b.bytes;) {
       const size_t n = (size_t)((b.bytes - done) < buf.size() ? (b.bytes - done) : buf.size());
-      if (!rd(buf.data(), n)) return fail("es_ctx_load: truncated block data");
+      if (!rd(buf.data(), n)) return fail("es_ctx_load: truncated extent data");
       if (hipMemcpy(base + b.off + done, buf.data(), n, hipMemcpyHostToDevice) != hipSuccess) return fail("es_ctx_load: copy to the device failed");
       done += n;
     }

@@ -117,7 +117,7 @@ class Resnet:
         h = ops.group_norm(x, self.n1[0], self.n1[1], self.groups, self.eps, True, x2=x2)
         temb = None if self.temb_off is None else tproj[:, self.temb_off:]
         # a split-K conv1 leaves its partial slabs for norm2 to sum (one-launch GroupNorm geometries only)
-        h = ops.conv_gemm(h, self.conv1, temb=temb, defer_reduce=ops.gn_is_slab(h.shape[1] * h.shape[2], self.cout, self.groups))
+        h = ops.conv_gemm(h, self.conv1, temb=temb)
         h = ops.group_norm(h, self.n2[0], self.n2[1], self.groups, self.eps, True)
         if self.conv2s is not None and (x2 is None or (x.shape[3] % 64 == 0 and x2.shape[3] % 64 == 0)):
             return ops.conv_gemm(h, self.conv2s, tail=(x, x2))
@@ -517,8 +517,7 @@ class GroupedEncoder:
         c = self.counts
         r0 = rs[0]
         h = ops.group_norm(x, [r.n1[0] for r in rs], [r.n1[1] for r in rs], r0.groups, r0.eps, True, group_n=c)
-        h = ops.conv_gemm(h, [r.conv1 for r in rs], temb=tproj[:, r0.temb_off:], group_n=c,
-                          defer_reduce=ops.gn_is_slab(h.shape[1] * h.shape[2], r0.cout, r0.groups))
+        h = ops.conv_gemm(h, [r.conv1 for r in rs], temb=tproj[:, r0.temb_off:], group_n=c)
         h = ops.group_norm(h, [r.n2[0] for r in rs], [r.n2[1] for r in rs], r0.groups, r0.eps, True, group_n=c)
         if all(r.conv2s is not None for r in rs):
             return ops.conv_gemm(h, [r.conv2s for r in rs], tail=(x,), group_n=c)
@@ -551,9 +550,8 @@ class GroupedEncoder:
         tok = ops.linear(f, [t.ff2 for t in ts], residual=tok, group_n=rows)
         return ops.conv_gemm(tok.reshape(N, H, W, C), [t.proj_out for t in ts], residual=x, group_n=c)
 
-    def run(self, h, tproj, ctx: List[torch.Tensor], after_block=None):
-        """h: [ntot,H,W,C0] (each group's conv_in(sample)+cond already applied) -> (skips, mid) over the whole batch.
-        after_block(i, skips) is called when resolution level i is complete (its skips, downsample included, exist)."""
+    def run(self, h, tproj, ctx: List[torch.Tensor]):
+        """h: [ntot,H,W,C0] (each group's conv_in(sample)+cond already applied) -> (skips, mid) over the whole batch."""
         skips = [h]
         ci = 0
         e0 = self.encs[0]
@@ -566,8 +564,6 @@ class GroupedEncoder:
             if e0.downsample[i] is not None:
                 h = ops.conv_gemm(h, [e.downsample[i] for e in self.encs], stride=2, group_n=self.counts)
                 skips.append(h)
-            if after_block is not None:
-                after_block(i, skips)
         h = self._resnet([e.mid0 for e in self.encs], h, tproj)
         h = self._transformer([e.mid_attn for e in self.encs], h, ctx[ci])
         h = self._resnet([e.mid1 for e in self.encs], h, tproj)

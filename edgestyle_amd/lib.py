@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ES_HIP_LIB") or os.path.join(_HERE, "lib", "libedgestyle_hip.so")
 
 ES_F16, ES_BF16 = 0, 1
+ABI_VERSION = 4          # include/edgestyle_hip.h ES_ABI_VERSION
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
 
 
@@ -25,11 +26,11 @@ class GemmDesc(C.Structure):
         ("upsample", C.c_int32), ("temb_stride", C.c_int32), ("act", C.c_int32), ("splitk", C.c_int32),
         ("bn", C.c_int32), ("dtype", C.c_int32),
         ("ngroups", C.c_int32), ("mt_end", C.c_int32 * 4), ("w_g", C.c_void_p * 4), ("bias_g", C.c_void_p * 4),
-        ("stages", C.c_int32), ("xcd_m_fastest", C.c_int32), ("bm", C.c_int32), ("waves", C.c_int32),
-        ("bk", C.c_int32), ("out_scale", C.c_float),
+        ("stages", C.c_int32), ("xcd_m_fastest", C.c_int32), ("waves", C.c_int32),
+        ("out_scale", C.c_float),
         ("ln_colsum", C.c_void_p), ("ln_colsum_g", C.c_void_p * 4), ("ln_eps", C.c_float),
         ("t1", C.c_void_p), ("t2", C.c_void_p), ("Ct1", C.c_int32), ("Ct2", C.c_int32),
-        ("x_nmod", C.c_int32), ("no_reduce", C.c_int32),
+        ("x_nmod", C.c_int32),
     ]
 
 
@@ -41,7 +42,6 @@ class XsDesc(C.Structure):
         ("M", C.c_int32), ("K", C.c_int32), ("Cout", C.c_int32), ("rows_padded", C.c_int32),
         ("ldo", C.c_int32), ("geglu", C.c_int32), ("ln", C.c_int32), ("ln_eps", C.c_float),
         ("nslices", C.c_int32), ("chunks_per_slice", C.c_int32), ("dtype", C.c_int32),
-        ("mfma32", C.c_int32),
     ]
 
 
@@ -57,7 +57,6 @@ PLAN_STEP_GENERIC, PLAN_PREP, PLAN_STEP, PLAN_DECODE, PLAN_CONDS = 0, 1, 2, 3, 4
  BUF_LATENTS, BUF_STEP_IDX, BUF_T_TABLE, BUF_SCALE_TABLE, BUF_COEF, BUF_TIMESTEPS, BUF_IMAGE) = range(18)
 BUF_COND_IMG0, BUF_COND_NOISE0 = 18, 24          # + net index
 OP_CONV_GEMM, OP_LINEAR_XS, OP_ATTENTION = 1, 2, 3      # csrc/plan.h es_op_kind (es_plan_count)
-PLAN_SIDE_BEGIN, PLAN_SIDE_END, PLAN_SIDE_JOIN = 64, 65, 66   # es_plan_mark
 
 
 class AttnDesc(C.Structure):
@@ -77,8 +76,6 @@ class GnDesc(C.Structure):
         ("N", C.c_int32), ("HW", C.c_int32), ("C1", C.c_int32), ("C2", C.c_int32), ("groups", C.c_int32),
         ("eps", C.c_float), ("silu", C.c_int32), ("dtype", C.c_int32),
         ("ngroups", C.c_int32), ("n_end", C.c_int32 * 4), ("gamma_g", C.c_void_p * 4), ("beta_g", C.c_void_p * 4),
-        ("sk_ws", C.c_void_p), ("sk_bias", C.c_void_p), ("sk_bias_g", C.c_void_p * 4), ("sk_temb", C.c_void_p),
-        ("sk_n", C.c_int32), ("sk_rows", C.c_int32), ("sk_temb_stride", C.c_int32),
     ]
 
 
@@ -139,7 +136,6 @@ SYMBOLS = {
     "es_plan_destroy": (None, [_P]),
     "es_plan_begin_record": (C.c_int, [_P]),
     "es_plan_end_record": (C.c_int, [_P]),
-    "es_plan_mark": (C.c_int, [_I]),
     "es_plan_size": (C.c_int, [_P]),
     "es_plan_count": (C.c_int, [_P, _I]),
     "es_plan_launch": (C.c_int, [_P, _P]),
@@ -155,6 +151,7 @@ SYMBOLS = {
     "es_ctx_load": (C.c_int, [C.c_char_p, _I, C.POINTER(_P)]),
     "es_plan_export": (C.c_size_t, [_P, _P, C.c_size_t]),
     "es_plan_import": (_P, [_P, C.c_size_t]),
+    "es_plan_pointer_fields": (C.c_int, [_I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, C.POINTER(C.c_int32)]),
     "es_ctx_launch_plan": (C.c_int, [_P, _I, C.POINTER(C.c_float), _P]),
     "es_ddim_coef_table": (C.c_int, [C.POINTER(C.c_float), _I, C.POINTER(C.c_float), _I, C.POINTER(C.c_float)]),
     "es_denoise_step": (C.c_int, [_P, _P, _F, _P, C.POINTER(_P), C.POINTER(C.c_float), _P, _P]),
@@ -187,7 +184,7 @@ def load():
         fn = getattr(lib, name)           # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.es_abi_version() != 3:
+    if lib.es_abi_version() != ABI_VERSION:
         raise EdgeStyleHipError("libedgestyle_hip.so ABI version mismatch")
     for i, st in enumerate((GemmDesc, AttnDesc, GnDesc, FusionDesc, LnDesc, XsDesc)):
         if lib.es_sizeof_desc(i) != C.sizeof(st):

@@ -656,11 +656,12 @@ class StepRunner:
         self.kmax = max(len(p) for _, p in self.groups)
         # execution of the four independent encoder chains of a step:
         #   "grouped" — one lockstep pass of grouped launches over the batch-concatenated activations (default)
-        #   "streams" — one HIP stream per chain (parallel hipGraph branches)
-        #   "serial"  — one chain after the other (profiling)
+        #   "serial"  — one chain after the other (profiling; also the fall-back for shapes whose groups do not tile)
+        # (a third mode, one HIP stream per chain, measured 15.2 vs 13.1 ms per step and was removed in round 3)
         self.mode = os.environ.get("ES_CHAIN_MODE", "serial" if os.environ.get("ES_SERIAL") == "1" else "grouped")
+        if self.mode not in ("grouped", "serial"):
+            raise ValueError(f"ES_CHAIN_MODE={self.mode!r}: 'grouped' or 'serial'")
         self._grouped = None
-        self._streams = None
         # every buffer a step reads between calls lives in a StepState; `state` is the one the next step() uses
         # (the pipeline switches it to the running loop's; stand-alone callers get this default one)
         self.state = StepState()
@@ -827,9 +828,7 @@ class StepRunner:
 
         The three batched ControlNet passes and the UNet's own down+mid path do not depend on each other (the
         residuals are only added after the UNet's down path, PL:500-510): by default they run in lockstep as grouped
-        launches (_step_grouped); ES_CHAIN_MODE=streams runs them as four concurrent chains on separate HIP streams
-        (forked from / joined into the current stream, hence capturable as parallel hipGraph branches), =serial one
-        after the other."""
+        launches (_step_grouped); ES_CHAIN_MODE=serial runs them one after the other."""
         st = self.state
         N = x.shape[0]
         if guess_mode:
@@ -852,19 +851,8 @@ class StepRunner:
             results["unet"] = (tproj, ue.encode(x, tproj, st.ctx_unet))
 
         chains = [lambda gi=gi: cn_chain(gi) for gi in range(len(self.groups))] + [unet_chain]
-        if self.mode == "streams":
-            main = torch.cuda.current_stream()
-            if self._streams is None:
-                self._streams = [torch.cuda.Stream(device=self.device) for _ in chains]
-            for i, (fn, stream) in enumerate(zip(chains, self._streams)):
-                stream.wait_stream(main)
-                with torch.cuda.stream(stream), ops.lane(i + 1):
-                    fn()
-            for stream in self._streams:
-                main.wait_stream(stream)
-        else:
-            for fn in chains:
-                fn()
+        for fn in chains:
+            fn()
         fused = self._fuse(results, N, scales, scales_dev)
         tproj, enc = results["unet"]
         if self.keep_debug:
@@ -922,20 +910,7 @@ class StepRunner:
             # the fusion kernel adds the UNet's own skip / mid tensors: its outputs ARE the decoder's inputs
             return self.controlnet.engine.forward(res_per_net, bs, N, scales, scales_dev, addends=addends, first_level=first_level)
 
-        # The zero-convs and fusion blocks of the two shallow resolution levels (7 of the 13 tensors, 92 % of their bytes)
-        # move ~0.4 GB per step and compute almost nothing; they run on a side stream as soon as level 1 is complete,
-        # beside the deep encoder levels whose split-K launches leave most of the memory system idle.
-        early = {}
-        n_blocks = len(ue.cfg.block_out_channels)
-
-        def after_block(i, skips):
-            if i == 1 and ops.SIDE_ENABLED and not self.single and n_blocks > 2:
-                ne = len(skips)
-                with ops.side_section():
-                    early["fused"] = zero_and_fuse(list(range(ne)), skips, [s[ncn:] for s in skips], 0)
-                early["n"] = ne
-
-        skips, h = ge.run(h0, tproj, st.ctx_grouped, after_block=after_block)
+        skips, h = ge.run(h0, tproj, st.ctx_grouped)
         enc = ([s[ncn:] for s in skips], h[ncn:])
         if self.single:
             # one ControlNet: skip + scale * zero_conv(cn_skip) straight out of the zero-conv epilogue (PL:500-510)
@@ -944,12 +919,8 @@ class StepRunner:
             fused = [ops.conv_gemm(s[:ncn], e.zero[i], residual=enc[0][i], **kw) for i, s in enumerate(skips)]
             fused.append(ops.conv_gemm(h[:ncn], e.zero_mid, residual=enc[1], **kw))
             return ue.forward(x, tproj[ncn:], st.ctx_unet, fused[:-1], fused[-1], out=out, encoded=enc, presummed=True)
-        ne = early.get("n", 0)
         srcs = skips + [h]
-        fused = zero_and_fuse(list(range(ne, len(srcs))), srcs[ne:], (enc[0] + [enc[1]])[ne:], ne)
-        if ne:
-            ops.join_side()
-            fused = early["fused"] + fused
+        fused = zero_and_fuse(list(range(len(srcs))), srcs, enc[0] + [enc[1]], 0)
         if self.keep_debug:
             self.debug = dict(presummed=[f.clone() for f in fused], skips=[e.clone() for e in enc[0] + [enc[1]]])
         return ue.forward(x, tproj[ncn:], st.ctx_unet, fused[:-1], fused[-1], out=out, encoded=enc, presummed=True)

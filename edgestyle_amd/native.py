@@ -54,8 +54,6 @@ class NativeEngine:
         pipe(output_type="pt", **kw)
         loop = self.loop = pipe._loops[(B, guidance, h, w, False)]
         runner = self.runner = pipe._runner
-        if runner.mode == "streams":
-            raise EdgeStyleHipError("ES_CHAIN_MODE=streams forks HIP streams inside a step: not expressible as one launch list")
         N = loop.N
         self.B, self.N, self.T, self.h, self.w, self.nn = B, N, T, h, w, nn
         self.dtype = pipe.dtype
@@ -95,7 +93,7 @@ class NativeEngine:
                             latent_pad=pipe.unet.engine.in_pad, n_conds=nn, n_steps=T, dtype=L.ES_F16 if self.dtype == torch.float16 else L.ES_BF16)
         L.check(self.lib.es_ctx_set_geometry(ctx, C.byref(geo)), "es_ctx_set_geometry")
         self._geo = geo
-        self.plan_sizes, self.plan_forks = {}, {}
+        self.plan_sizes = {}
         todo = [(L.PLAN_PREP, prep), (L.PLAN_STEP, loop.one_step), (L.PLAN_STEP_GENERIC, generic), (L.PLAN_DECODE, decode)]
         if conds_fn is not None:
             todo.append((L.PLAN_CONDS, conds_fn))
@@ -112,7 +110,6 @@ class NativeEngine:
                 L.check(self.lib.es_plan_end_record(plan), "es_plan_end_record")
             self._keep.append(graph)                 # owns the memory the plan's pointers refer to
             self.plan_sizes[which] = self.lib.es_plan_size(plan)
-            self.plan_forks[which] = self.lib.es_plan_count(plan, L.PLAN_SIDE_BEGIN)
             L.check(self.lib.es_ctx_set_plan(ctx, which, plan), "es_ctx_set_plan")
         self.image = out["img"]
         binds = {L.BUF_SAMPLE: loop.model_in, L.BUF_T_ROWS: loop.t_rows, L.BUF_EHS: loop.ehs, L.BUF_SCALES: loop.scales_cur,
@@ -284,36 +281,57 @@ class NativeEngine:
 
     # -- context image: everything es_ctx_load needs to run this context without Python ---------------------------------
     def save(self, path: str) -> dict:
-        """Write a context image for es_ctx_load (include/edgestyle_hip.h).  Every 8-byte word of the recorded launch lists
-        that falls inside a device segment of the allocator is a recorded pointer: it is replaced by an offset into one arena
-        that holds a copy of each segment referenced (packed weights, norm parameters, tables, static buffers, activation
-        scratch - the activations' contents do not matter but their space does).  Returns a summary dict."""
+        """Write a context image for es_ctx_load (include/edgestyle_hip.h).
+
+        Relocation is TYPED: the library names the pointer fields of every recorded call (es_plan_pointer_fields) and exactly
+        those 8-byte words are rewritten as offsets into one arena; a non-null pointer that is not inside a live allocator
+        segment of this device is an error here, not a fault at load time.  The arena keeps the layout of every referenced
+        allocator segment (an activation freed during a capture is an inactive block the captured kernels still write, and
+        may straddle today's block boundaries), but only memory that the plans READ and never WRITE - packed weights, norm
+        and fusion parameters, tables built at load time - is stored in the file; everything some call writes (activations,
+        split-K slabs, scratch, static input slots) is produced at run time and travels as zero-filled space."""
         import struct
         import numpy as np
         torch.cuda.synchronize()
         hip = C.CDLL("libamdhip64.so")
         hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        # the caching allocator's segments (hipMalloc granules; graph-private pools included), sorted by address.  Whole
-        # segments, not blocks: an activation freed DURING a capture is an inactive block of its private pool, and the
-        # captured kernels still write there at every replay
-        starts, sizes = [], []
         dev_index = self.pipe.device.index or 0
+        segs, blks = [], []
         for seg in torch.cuda.memory_snapshot():
             if seg.get("device", dev_index) != dev_index:
                 continue
-            starts.append(seg["address"])
-            sizes.append(seg["total_size"])
-        order = np.argsort(np.array(starts, dtype=np.uint64))
-        starts = np.array(starts, dtype=np.uint64)[order]
-        ends = starts + np.array(sizes, dtype=np.uint64)[order]
+            segs.append((seg["address"], seg["total_size"]))
+            a = seg["address"]
+            for bk in seg.get("blocks", []):
+                blks.append((bk.get("address", a), bk["size"]))
+                a = bk.get("address", a) + bk["size"]
+        segs.sort()
+        blks.sort()
+        starts = np.array([a for a, _ in segs], dtype=np.uint64)
+        ends = starts + np.array([n for _, n in segs], dtype=np.uint64)
+        bstarts = np.array([a for a, _ in blks], dtype=np.uint64)
+        bends = bstarts + np.array([n for _, n in blks], dtype=np.uint64)
 
-        def locate(addrs):
-            """block index of every address (or -1)"""
-            idx = np.searchsorted(starts, addrs, side="right").astype(np.int64) - 1
-            ok = (idx >= 0) & (addrs < ends[np.clip(idx, 0, len(ends) - 1)])
+        def locate(addrs, st, en):
+            idx = np.searchsorted(st, addrs, side="right").astype(np.int64) - 1
+            ok = (idx >= 0) & (addrs < en[np.clip(idx, 0, len(en) - 1)])
             return np.where(ok, idx, -1)
 
+        # pointer-field tables of the library, by op kind
+        fields = {}
+
+        def fields_of(kind):
+            if kind not in fields:
+                offs, uses = (C.c_int32 * 64)(), (C.c_int32 * 64)()
+                elem = C.c_int32(0)
+                n = self.lib.es_plan_pointer_fields(kind, offs, uses, 64, C.byref(elem))
+                if n > 64:
+                    raise EdgeStyleHipError("save: pointer-field table overflow")
+                fields[kind] = ([(offs[i], uses[i]) for i in range(n)], elem.value)
+            return fields[kind]
+
         plans, used = {}, set()
+        blk_use = {}                                   # block index -> OR of the uses of every pointer into it
         for which in range(5):
             pl = self.lib.es_ctx_plan(self.ctx, which)
             if not pl:
@@ -323,36 +341,69 @@ class NativeEngine:
             self.lib.es_plan_export(pl, raw, n)
             img = np.frombuffer(raw, dtype=np.uint8).copy()
             n_ops = int(img[:8].view(np.uint64)[0])
+            table = img[16:16 + 24 * n_ops].view(np.uint64).reshape(n_ops, 3)
             blob0 = 16 + 24 * n_ops
-            words = img[blob0:blob0 + (len(img) - blob0) // 8 * 8].view(np.uint64)
-            blk = locate(words)
-            hit = np.nonzero(blk >= 0)[0]
-            rel = [(int(i) * 8, int(blk[i]), int(words[i] - starts[blk[i]])) for i in hit]
-            used.update(b for _, b, _ in rel)
+            rel = []
+            for kind, off, nbytes in table.tolist():
+                kind = int(np.int64(kind))
+                fl, elem = fields_of(kind)
+                if not fl:
+                    continue
+                reps = max(1, nbytes // elem) if elem else 1
+                for r in range(reps):
+                    for fo, use in fl:
+                        pos = int(off) + r * elem + fo
+                        if pos + 8 > int(off) + int(nbytes):
+                            raise EdgeStyleHipError("save: a pointer field lies outside its record (ABI mismatch)")
+                        addr = int(img[blob0 + pos:blob0 + pos + 8].view(np.uint64)[0])
+                        if addr == 0:
+                            continue
+                        a1 = np.array([addr], dtype=np.uint64)
+                        si = int(locate(a1, starts, ends)[0])
+                        if si < 0:
+                            raise EdgeStyleHipError(f"save: op kind {kind} holds a device pointer {addr:#x} outside every allocator "
+                                                    "segment of this device - it cannot be relocated")
+                        rel.append((pos, si, addr - int(starts[si])))
+                        used.add(si)
+                        bi = int(locate(a1, bstarts, bends)[0])
+                        if bi >= 0:
+                            blk_use[bi] = blk_use.get(bi, 0) | use
             plans[which] = (img, rel)
         binds = {}
         for slot, t in self._binds.items():
-            b = int(locate(np.array([t.data_ptr()], dtype=np.uint64))[0])
-            if b < 0:
+            a1 = np.array([t.data_ptr()], dtype=np.uint64)
+            si = int(locate(a1, starts, ends)[0])
+            if si < 0:
                 raise EdgeStyleHipError("save: a bound buffer is not a live allocation")
-            used.add(b)
-            binds[slot] = (b, t.data_ptr() - int(starts[b]), t.numel() * t.element_size())
-        # arena layout
+            used.add(si)
+            binds[slot] = (si, t.data_ptr() - int(starts[si]), t.numel() * t.element_size())
+            bi = int(locate(a1, bstarts, bends)[0])
+            if bi >= 0:
+                blk_use[bi] = blk_use.get(bi, 0) | 2          # filled by the host entry points at run time
+        # arena layout: one slot per referenced segment
         off, arena = {}, 0
-        for b in sorted(used):
-            off[b] = arena
-            arena += (int(ends[b] - starts[b]) + 255) // 256 * 256
+        for si in sorted(used):
+            off[si] = arena
+            arena += (int(ends[si] - starts[si]) + 255) // 256 * 256
+        # data extents: blocks that are only ever read (small blocks travel in any case: tables / flags a few KB large)
+        extents = []
+        for bi, use in sorted(blk_use.items()):
+            nb = int(bends[bi] - bstarts[bi])
+            if (use & 2) and nb > (64 << 10):
+                continue
+            si = int(locate(np.array([bstarts[bi]], dtype=np.uint64), starts, ends)[0])
+            extents.append((int(bstarts[bi]), off[si] + int(bstarts[bi]) - int(starts[si]), nb))
         g = self._geo
         ac = self.pipe.scheduler.alphas_cumprod.float().contiguous().numpy()
         with open(path, "wb") as f:
-            f.write(b"ESCTX\x01\x00\x00" + struct.pack("<IIQ", 3, len(used), arena))
+            f.write(b"ESCTX\x02\x00\x00" + struct.pack("<IIQ", L.ABI_VERSION, len(used), arena))
             f.write(bytes(g))
             f.write(struct.pack("<6fffiI", *self._cond_scales, self._cg[0], self._cg[1], int(self._use_graphs), len(ac)))
             f.write(ac.tobytes())
             if len(ac) & 1:
                 f.write(b"\0" * 4)
-            for b in sorted(used):
-                f.write(struct.pack("<QQ", off[b], int(ends[b] - starts[b])))
+            for si in sorted(used):
+                f.write(struct.pack("<QQ", off[si], int(ends[si] - starts[si])))
             for which in range(5):
                 if which not in plans:
                     f.write(struct.pack("<Q", 0))
@@ -361,26 +412,32 @@ class NativeEngine:
                 f.write(struct.pack("<Q", len(img)))
                 f.write(img.tobytes())
                 f.write(struct.pack("<Q", len(rel)))
-                for blob_off, b, o in rel:
-                    f.write(struct.pack("<QQ", blob_off, off[b] + o))
+                for blob_off, si, o in rel:
+                    f.write(struct.pack("<QQ", blob_off, off[si] + o))
             nslots = L.BUF_COND_NOISE0 + 6
             for slot in range(nslots):
                 if slot in binds:
-                    b, o, nb = binds[slot]
-                    f.write(struct.pack("<qQ", off[b] + o, nb))
+                    si, o, nb = binds[slot]
+                    f.write(struct.pack("<qQ", off[si] + o, nb))
                 else:
                     f.write(struct.pack("<qQ", -1, 0))
+            f.write(struct.pack("<Q", len(extents)))
+            for _, ao, nb in extents:
+                f.write(struct.pack("<QQ", ao, nb))
             host = np.empty(64 << 20, dtype=np.uint8)
-            for b in sorted(used):
-                nb, done = int(ends[b] - starts[b]), 0
+            data_bytes = 0
+            for src, _, nb in extents:
+                done = 0
                 while done < nb:
                     n = min(nb - done, host.nbytes)
-                    rc = hip.hipMemcpy(host.ctypes.data, C.c_void_p(int(starts[b]) + done), n, 2)
+                    rc = hip.hipMemcpy(host.ctypes.data, C.c_void_p(src + done), n, 2)
                     if rc != 0:
                         raise EdgeStyleHipError(f"save: hipMemcpy failed ({rc})")
                     f.write(host[:n].tobytes())
                     done += n
-        return dict(blocks=len(used), arena_bytes=arena, relocations={w: len(r) for w, (_, r) in plans.items()})
+                data_bytes += nb
+        return dict(blocks=len(used), arena_bytes=arena, data_bytes=data_bytes, extents=len(extents),
+                    relocations={w: len(r) for w, (_, r) in plans.items()})
 
     def close(self):
         if self.ctx:

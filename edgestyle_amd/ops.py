@@ -33,56 +33,11 @@ class lane:
         LANE = self.prev
 
 
-# opt-in (ES_SIDE_FUSION=1): measured 484.1 vs 476.2 ms per image at batch 1 - the memory-bound side work takes CUs and power
-# from the GEMMs it runs beside, which costs more than the serial 0.3 ms it hides
-SIDE_ENABLED = _os.environ.get("ES_SIDE_FUSION", "0") == "1"
-_side_streams = {}
-
-
-class side_section:
-    """with ops.side_section(): ... — the launches inside go to a second HIP stream forked behind everything issued so far
-    on the current stream, and run beside what the current stream is given next; ops.join_side() makes the current stream
-    wait for them.  A recording plan gets the matching markers (es_plan_mark), torch's graph capture follows the fork
-    through the stream waits.  Scratch buffers come from lane 1."""
-
-    def __enter__(self):
-        main = torch.cuda.current_stream()
-        key = main.device
-        side = _side_streams.get(key)
-        if side is None:
-            side = _side_streams[key] = torch.cuda.Stream(device=main.device)
-        self.side = side
-        L.check(L.load().es_plan_mark(L.PLAN_SIDE_BEGIN), "es_plan_mark")
-        side.wait_stream(main)
-        self._ctx = torch.cuda.stream(side)
-        self._ctx.__enter__()
-        self._lane = lane(1)
-        self._lane.__enter__()
-        return self
-
-    def __exit__(self, *a):
-        self._lane.__exit__(*a)
-        self._ctx.__exit__(*a)
-        L.check(L.load().es_plan_mark(L.PLAN_SIDE_END), "es_plan_mark")
-
-
-def join_side():
-    """The current stream waits for the side section opened (and closed) before."""
-    main = torch.cuda.current_stream()
-    side = _side_streams.get(main.device)
-    if side is None:
-        return
-    L.check(L.load().es_plan_mark(L.PLAN_SIDE_JOIN), "es_plan_mark")
-    main.wait_stream(side)
-
-
 XCD_ORDER = -1      # tuning knob: -1 auto, 0 tile_n fastest, 1 tile_m fastest
 DEEP_RING = _os.environ.get("ES_DEEP_RING", "1") == "1"     # 4-stage LDS ring for launches of <= 1 workgroup per CU
 FORCE_BN = 0        # tuning knob: 0 = per-launch choice between the legal N tiles
-FORCE_BM = 0        # tuning knob: 0 = kernel picks the pixel tile (128 / 256)
 FORCE_STAGES = 0    # tuning knob (tools/gemm_bench.py): 0 = kernel picks the LDS ring depth
 FORCE_WAVES = 0     # tuning knob: 0 = planner picks 4 or 8 waves per 128-pixel workgroup
-FORCE_BK = 0        # tuning knob: 32 = half-depth LDS stages (three workgroups per CU)
 EIGHT_WAVES = _os.environ.get("ES_EIGHT_WAVES", "1") == "1"
 SMALL_TILE = _os.environ.get("ES_SMALL_TILE", "1") == "1"    # 64x64 tile for tiny launches
 PROFILE = None      # set to a Profiler by bench.py: every es_conv_gemm launch gets an in-kernel timing slot
@@ -358,31 +313,8 @@ def plan_launch(M: int, pw: "PackedWeight", bn: int):
     return sk, st
 
 
-@dataclass
-class SplitKPartial:
-    """What conv_gemm(..., defer_reduce=True) returns when the launch was split along K: the fp32 partial slabs stay in
-    the split-K workspace and the next op (group_norm) sums them itself - no reduce launch.  Must be consumed before the
-    next split-K launch on the same lane overwrites the workspace."""
-    ws: torch.Tensor
-    splitk: int
-    rows_padded: int
-    bias: object                  # fp32 tensor, list of tensors (grouped launch) or None
-    temb: Optional[torch.Tensor]
-    shape: tuple                  # (N, H, W, C) of the tensor the reduce would have produced
-    dtype: torch.dtype
-    device: torch.device
-
-
-# split-K reduce folded into the one-launch GroupNorm that follows conv1 (bit-identical, 15 launches less per batch-1 step):
-# opt-in - measured 0.8 % SLOWER per image (493 vs 489 ms, same box, alternating runs): the GroupNorm grid is a few dozen
-# workgroups and reads the 28-B-per-element slabs with far fewer loads in flight than the 2048-block reduce kernel
-SK_DEFER = _os.environ.get("ES_SK_DEFER", "0") == "1"
 XS_ENABLED = _os.environ.get("ES_XS", "1") == "1"      # row-stationary short-K linear kernel (csrc/linear_xs.hip)
 XS_TARGET_WGS = 256
-# "1": every linear_xs launch on 32x32x16 MFMAs, "geglu": the GEGLU ones, "0" (default): none.  Built on the expectation that
-# a 32x32x16 MFMA stream leaves the partner wave's epilogue more vector-issue slots; measured 5-9 % SLOWER on every shape
-# (tools/xs_bench.py: level-0 GEGLU 149 vs 137 us, to_q|k|v 60 vs 54 us) - kept selectable, tested, not used
-XS_MFMA32 = _os.environ.get("ES_XS_MFMA32", "0")
 XS_MIN_M = int(_os.environ.get("ES_XS_MIN_M", "8192"))   # 0: no size policy (tests exercise every shape)
 _zero_bias = {}
 
@@ -438,7 +370,6 @@ def linear_xs(x: torch.Tensor, pw, M: int, out: torch.Tensor, group_rows=None) -
     d.ldo = out.shape[-1]
     d.geglu, d.ln, d.ln_eps = int(pw.geglu), int(pw.ln_colsum is not None), pw.ln_eps
     d.nslices, d.chunks_per_slice, d.dtype = nslices, lps * pline, _dt(x)
-    d.mfma32 = 1 if (XS_MFMA32 == "1" or (XS_MFMA32 == "geglu" and pw.geglu)) else 0
     if pws is not None:
         d.ngroups = len(pws)
         acc = 0
@@ -469,7 +400,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
               out_scale_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
               out_hw=None, splitk: Optional[int] = None, stages: int = 0,
               group_n: Optional[Sequence[int]] = None, tail: Optional[Sequence[torch.Tensor]] = None,
-              x_rep: int = 1, defer_reduce: bool = False):
+              x_rep: int = 1):
     """x: [N,H,W,C1] (+ x2 [N,H,W,C2]); returns [N,Hout,Wout,Cout] (Cout/2 for GEGLU).
 
     x_rep > 1: the launch covers x_rep * N samples, sample n reading x[n % N] (es_gemm_desc.x_nmod): one sample tensor
@@ -516,10 +447,9 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         linear_xs(x.reshape(M, C1), pws if pws is not None else pw, M, out.reshape(M, cstore),
                   None if pws is None else [n * Hout * Wout for n in group_n])
         return out
-    big_ok = BIG_TILE and C1 % BK == 0 and C2 % BK == 0 and not pw.geglu and \
+    big_ok = BIG_TILE and C1 % BK == 0 and C2 % BK == 0 and not pw.geglu and pw.ln_colsum is None and \
         (group_n is None or all((n * Hout * Wout) % 256 == 0 for n in group_n))
-    small_ok = SMALL_TILE and C1 % BK == 0 and C2 % BK == 0 and not pw.geglu and FORCE_WAVES != 8 and FORCE_BM in (0, 64) \
-        and FORCE_BK != 32
+    small_ok = SMALL_TILE and C1 % BK == 0 and C2 % BK == 0 and not pw.geglu and FORCE_WAVES != 8
     cand = ((320,) if big_ok else ()) + (160, 128) + ((64,) if small_ok else ())
     bn, auto_splitk, auto_stages = plan_gemm(M, pw.rows_padded, pw.kpad, pw.geglu,
                                              bns=cand if FORCE_BN == 0 else (FORCE_BN,), allow_split=pw.ln_colsum is None)
@@ -544,23 +474,18 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     # XCD chunk order: keep the larger operand's tiles together on one XCD (see conv_gemm_kernel)
     d.xcd_m_fastest = (1 if (pws is None and splitk == 1 and M <= 2048 and pw.w.numel() > x.numel() * x_rep + (x2.numel() if x2 is not None else 0)) else 0) \
         if XCD_ORDER < 0 else XCD_ORDER
-    d.bm = FORCE_BM
-    d.bk = FORCE_BK
     d.x_nmod = nsrc if x_rep > 1 else 0
     if FORCE_WAVES:
         d.waves = FORCE_WAVES
-    elif EIGHT_WAVES and FORCE_BK != 32 and k == 1 and M <= 65536 and C1 % BK == 0 and C2 % BK == 0 and bn not in (64, 320) and FORCE_BM != 256 \
+    elif EIGHT_WAVES and k == 1 and M <= 65536 and C1 % BK == 0 and C2 % BK == 0 and bn not in (64, 320) \
             and not (int(d.stages) == 4 and bn != 128) and int(d.stages) != 3:
         # 1x1 convs / linears are short-K, latency-bound launches: two waves per SIMD on the same 128-pixel tile overlap
         # DMA issue, fragment reads and MFMAs (tools/gemm_tune.py: 3-15 % on every 1x1 shape of a batch-1 step, none on 3x3 or on the
         # memory-bound 1x1 launches of large batches)
         d.waves = 8
-    defer = defer_reduce and SK_DEFER and splitk > 1 and residual is None and act_i == L.ACT_NONE and out_scale == 1.0 \
-        and out_scale_dev is None
     if splitk > 1:
         ws = _get_workspace(splitk * M * pw.rows_padded * 4, x.device)
         d.workspace = ws.data_ptr()
-        d.no_reduce = 1 if defer else 0
     if pw.ln_colsum is not None:
         if (pws is not None and any(q.ln_colsum is None for q in pws)) or x2 is not None or k != 1:
             raise L.EdgeStyleHipError("LayerNorm-folded weights need a plain linear launch (all groups folded)")
@@ -601,9 +526,6 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         dd.prof = None
         PROFILE.descs.append(dd)
     L.check(L.load().es_conv_gemm(C.byref(d), _stream()), "es_conv_gemm")
-    if defer:
-        return SplitKPartial(ws, splitk, pw.rows_padded, [q.bias for q in pws] if pws is not None else pw.bias, temb,
-                             (N, Hout, Wout, cstore), x.dtype, x.device)
     return out
 
 
@@ -663,9 +585,6 @@ def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu: bool
                x2: Optional[torch.Tensor] = None, group_n: Optional[Sequence[int]] = None) -> torch.Tensor:
     """x: [N,H,W,C1] (+x2 [N,H,W,C2]) -> normalised [N,H,W,C1+C2].  gamma/beta may be lists (one per group of
     `group_n` consecutive samples): one launch for several nets' GroupNorms."""
-    part_in = x if isinstance(x, SplitKPartial) else None
-    if part_in is not None and x2 is not None:
-        raise L.EdgeStyleHipError("group_norm: a split-K source cannot be concatenated with a second tensor")
     N, H, W, C1 = x.shape
     C2 = 0 if x2 is None else x2.shape[3]
     out = torch.empty((N, H, W, C1 + C2), dtype=x.dtype, device=x.device)
@@ -675,16 +594,7 @@ def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu: bool
         part = torch.empty(L.load().es_group_norm_partials_bytes(N, groups) // 4, dtype=torch.float32, device=x.device)
         _gn_partials[key] = part
     d = L.GnDesc()
-    d.x, d.x2, d.out = (None if part_in is not None else x.data_ptr()), (x2.data_ptr() if x2 is not None else None), out.data_ptr()
-    if part_in is not None:
-        d.sk_ws, d.sk_n, d.sk_rows = part_in.ws.data_ptr(), part_in.splitk, part_in.rows_padded
-        if isinstance(part_in.bias, (list, tuple)):
-            for g, b in enumerate(part_in.bias):
-                d.sk_bias_g[g] = None if b is None else b.data_ptr()
-        elif part_in.bias is not None:
-            d.sk_bias = part_in.bias.data_ptr()
-        if part_in.temb is not None:
-            d.sk_temb, d.sk_temb_stride = part_in.temb.data_ptr(), part_in.temb.stride(0)
+    d.x, d.x2, d.out = x.data_ptr(), (x2.data_ptr() if x2 is not None else None), out.data_ptr()
     if isinstance(gamma, (list, tuple)) and len(gamma) > 1:
         if len(gamma) > 4 or len(group_n) != len(gamma) or sum(group_n) != N:
             raise L.EdgeStyleHipError("grouped group_norm: bad group table")
@@ -704,11 +614,6 @@ def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu: bool
     d.eps, d.silu, d.dtype = eps, 1 if silu else 0, _dt(x)
     L.check(L.load().es_group_norm(C.byref(d), _stream()), "es_group_norm")
     return out
-
-
-def gn_is_slab(hw: int, c: int, groups: int) -> bool:
-    """True when GroupNorm of this geometry runs as one launch - the form that can read a split-K source."""
-    return bool(L.load().es_group_norm_is_slab(hw, c, groups))
 
 
 def layer_norm(x: torch.Tensor, gamma, beta, eps: float = 1e-5, group_rows: Optional[Sequence[int]] = None) -> torch.Tensor:

@@ -590,9 +590,6 @@ class StableDiffusionControlNetPipeline:
         prof = ops.Profiler(self.device)
         torch.cuda.synchronize()
         ops.PROFILE = prof
-        was = self._runner.mode
-        if was == "streams":
-            self._runner.mode = "serial"     # no overlapping chains: each launch is timed with the GPU to itself
         try:
             loop.step_idx.zero_()
             loop.one_step()                  # eager serial warm-up: sizes lane-0 scratch outside the capture
@@ -604,7 +601,6 @@ class StableDiffusionControlNetPipeline:
                 loop.one_step()
         finally:
             ops.PROFILE = None
-            self._runner.mode = was
         prof.reset()
         loop.step_idx.zero_()
         torch.cuda.synchronize()

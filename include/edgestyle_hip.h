@@ -23,7 +23,7 @@ extern "C" {
 enum { ES_F16 = 0, ES_BF16 = 1 };
 enum { ES_ACT_NONE = 0, ES_ACT_SILU = 1, ES_ACT_GEGLU = 2 };
 
-#define ES_ABI_VERSION 3
+#define ES_ABI_VERSION 4
 int es_abi_version(void);
 /* sizeof the descriptor structs as compiled (0 gemm, 1 attn, 2 gn, 3 fusion, 4 ln, 5 xs): lets a binding verify its mirror */
 size_t es_sizeof_desc(int which);
@@ -59,7 +59,8 @@ typedef struct {
   int32_t temb_stride;
   int32_t act;                /* ES_ACT_* ; GEGLU halves the stored width (weights packed interleaved) */
   int32_t splitk;
-  int32_t bn;                 /* N tile the weights were packed for: 128 or 160 */
+  int32_t bn;                 /* N tile: 128 | 160 (128-pixel tile), 64 (64 x 64 tile, tiny launches), 320 (256 x 320 phase-interleaved
+                               * tile, csrc/gemm_conv8p.hip: large launches with 64-aligned channels); rows_padded % bn == 0 */
   int32_t dtype;
   /* Grouped launch: ngroups (<= 4) problems of identical geometry but different weights run as ONE launch over the
    * batch-concatenated activations (the 3 batched ControlNet passes + the UNet encoder of a denoising step): M tiles
@@ -70,19 +71,16 @@ typedef struct {
   const float* bias_g[4];
   int32_t stages;             /* LDS ring depth: 0 = auto, 2 (2 workgroups/CU), 3 or 4 (1 workgroup/CU) */
   int32_t xcd_m_fastest;      /* tile order inside an XCD's chunk: 1 = tile_m fastest (weights are the larger operand) */
-  int32_t bm;                 /* pixel tile: 0 = auto, 64 (with bn = 64), 128 (4 waves) or 256 (8 waves, large M only) */
   int32_t waves;              /* waves per 128-pixel workgroup: 0 / 4 = default, 8 = two per SIMD (launches that leave
                                * a workgroup alone on its CU: one wave per SIMD cannot overlap DMA issue, LDS reads and
                                * MFMAs with itself) */
-  int32_t bk;                 /* K depth of an LDS stage: 0 / 64 = default, 32 = half-depth stages, three workgroups per CU
-                               * (short-K launches of many tiles: workgroup turnover bound) */
   float out_scale;
   /* LayerNorm folded into a linear layer (the three LayerNorms of a BasicTransformerBlock feed exactly one Linear
    * each): x is the RAW residual stream, w holds W * gamma (per input channel), bias holds W beta + b, and
    * ln_colsum[j] = sum_k w[j][k] (fp32, of the rounded packed weights).  The kernel accumulates every row's sum and
    * sum of squares from the activation tiles it stages anyway and applies
    *   out[m][j] = rstd_m * (acc[m][j] - mean_m * ln_colsum[j]) + bias[j]
-   * in the epilogue.  Needs ksize 1, one source, K == C1 (a multiple of 64), splitk 1, bn 64|128|160, bk 64. */
+   * in the epilogue.  Needs ksize 1, one source, K == C1 (a multiple of 64), splitk 1, bn 64|128|160. */
   const float* ln_colsum;     /* NULL: plain launch */
   const float* ln_colsum_g[4];
   float ln_eps;
@@ -98,10 +96,6 @@ typedef struct {
    * CL:197-203; text states shared by the nets of a weight-sharing group) without a replicated copy.  0 = off.
    * Needs one source (no x2), no tail sources. */
   int32_t x_nmod;
-  /* splitk > 1 only: 1 = leave the fp32 partial slabs in `workspace` and launch no reduce kernel; the consumer sums them
-   * (es_group_norm with sk_ws: the GroupNorm that follows conv1 of a ResnetBlock2D reads the slabs directly - one launch
-   * and one fp16 round trip less).  Needs act NONE, out_scale 1, no residual, no out_scale_dev. */
-  int32_t no_reduce;
 } es_gemm_desc;
 int es_conv_gemm(const es_gemm_desc* d, void* stream);
 size_t es_conv_gemm_workspace_bytes(const es_gemm_desc* d);
@@ -131,8 +125,6 @@ typedef struct {
   float ln_eps;
   int32_t nslices, chunks_per_slice;
   int32_t dtype;
-  int32_t mfma32;             /* 1: 32x32x16 MFMAs (leaves the partner wave 75 % of the SIMD's vector issue: the GEGLU
-                               * launches are bound by it), 0: 16x16x32 */
 } es_xs_desc;
 int es_linear_xs(const es_xs_desc* d, void* stream);
 
@@ -163,15 +155,6 @@ typedef struct {
   int32_t n_end[4];
   const float* gamma_g[4];
   const float* beta_g[4];
-  /* split-K source: x = round_to_dtype( sum_z sk_ws[z][m][c] + sk_bias[c] + sk_temb[n][c] ), m = n*HW + pixel, the
-   * partial slabs of an es_conv_gemm launched with no_reduce (row pitch sk_rows = its rows_padded) - exactly what its
-   * reduce kernel would have stored.  One-launch (slab) form only: es_group_norm_is_slab(HW, C, groups) != 0; C2 = 0;
-   * x may be NULL.  sk_ws NULL: off. */
-  const float* sk_ws;
-  const float* sk_bias;            /* or NULL */
-  const float* sk_bias_g[4];       /* grouped launches: per sample group, like gamma_g */
-  const void* sk_temb;             /* or NULL: dtype [N, sk_temb_stride] */
-  int32_t sk_n, sk_rows, sk_temb_stride;
 } es_gn_desc;
 int es_group_norm(const es_gn_desc* d, void* stream);
 size_t es_group_norm_partials_bytes(int N, int groups);
@@ -288,22 +271,17 @@ es_plan* es_plan_create(void);
 void es_plan_destroy(es_plan* p);
 int es_plan_begin_record(es_plan* p);
 int es_plan_end_record(es_plan* p);
-/* Stream markers of a recording plan (no-ops when none records): the calls recorded between ES_PLAN_SIDE_BEGIN and
- * ES_PLAN_SIDE_END are re-issued on a second stream of the plan's own, forked behind everything recorded before and running
- * beside what is recorded after ES_PLAN_SIDE_END; ES_PLAN_SIDE_JOIN makes the launching stream wait for them.  The host that
- * builds the plan issues the same calls on a side stream of its own at that point (edgestyle_amd/ops.py side_section).
- * Used for the shallow-level zero-convs + fusion blocks of a step (models.py), which are memory-bound and overlap the
- * under-filled launches of the deep encoder levels. */
-#define ES_PLAN_SIDE_BEGIN 64
-#define ES_PLAN_SIDE_END 65
-#define ES_PLAN_SIDE_JOIN 66
-int es_plan_mark(int kind);
-int es_plan_size(const es_plan* p);                    /* number of recorded calls (markers included) */
+int es_plan_size(const es_plan* p);                    /* number of recorded calls */
 int es_plan_count(const es_plan* p, int kind);         /* ... of one kind (csrc/plan.h: 1 = es_conv_gemm, 2 = es_linear_xs, ...) */
 int es_plan_launch(const es_plan* p, void* stream);
 /* flat image of a plan: returns the bytes needed; writes them when cap suffices.  The recorded device addresses inside
  * are NOT relocated (edgestyle_amd/native.py save() builds the relocation tables es_ctx_load applies) */
 size_t es_plan_export(const es_plan* p, void* out, size_t cap);
+/* The pointer fields of a recorded call, by op kind (csrc/plan.h es_op_kind): byte offsets inside the argument record and how
+ * the op uses the memory behind each (1 = reads, 2 = writes, 3 = both); *elem_bytes != 0: the record is an array of elements
+ * of that size (es_fusion_blocks).  Returns the field count and fills at most `cap` entries.  This is what relocates a plan:
+ * exactly these words are device addresses (NativeEngine.save), nothing is guessed from bit patterns. */
+int es_plan_pointer_fields(int kind, int32_t* offsets, int32_t* uses, int cap, int32_t* elem_bytes);
 es_plan* es_plan_import(const void* data, size_t size);
 
 enum { ES_PLAN_STEP_GENERIC = 0,   /* es_denoise_step: text K/V projections + condition slots + time embedding + step */

@@ -232,23 +232,21 @@ def test_full_size_pipeline_768_bf16_config4_vs_oracle(full96):
 
 
 def test_full_width_chain_modes_agree(full):
-    """ES_CHAIN_MODE: the grouped lockstep pass (default, what the bench replays), the four chains one after the other and the
-    four chains on four HIP streams do the same arithmetic with different tile plans / launch groupings: at SD1.5 width
-    they agree to 5e-3 of the tensor's max (the tiny-width tests compare each with the oracle)."""
+    """ES_CHAIN_MODE: the grouped lockstep pass (default, what the bench replays) and the four chains one after the other do
+    the same arithmetic with different tile plans / launch groupings: at SD1.5 width they agree to 5e-3 of the tensor's max
+    (the tiny-width tests compare each with the oracle)."""
     from edgestyle_amd.models import StepRunner
     pipe = full["pipe"]
     x, ehs, conds = H.full_step_inputs()
     runner = StepRunner(pipe.unet, pipe.controlnet)
     outs = {}
-    for mode in ("grouped", "serial", "streams"):
+    for mode in ("grouped", "serial"):
         runner.mode = mode
         o = runner.step_nchw(x.to(DEV), H.FULL_STEP_T, ehs.to(DEV), [c.to(DEV) for c in conds], H.FULL_STEP_SCALES)
         torch.cuda.synchronize()
         outs[mode] = o.float().cpu()
-    record("full_step_chain_modes", serial_vs_grouped=H.rel_err(outs["serial"], outs["grouped"]),
-           streams_vs_serial=H.rel_err(outs["streams"], outs["serial"]))
+    record("full_step_chain_modes", serial_vs_grouped=H.rel_err(outs["serial"], outs["grouped"]))
     assert H.rel_err(outs["serial"], outs["grouped"]) <= 5e-3
-    assert H.rel_err(outs["streams"], outs["serial"]) <= 5e-3
 
 
 def test_full_size_guess_mode_and_unipc_vs_oracle(full):

@@ -28,7 +28,7 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert getattr(h, name) is not None
     L = lib.load()
-    assert L.es_abi_version() == 3
+    assert L.es_abi_version() == 4
     # struct layouts agree with the C side (sizes are what the kernels index with)
     for i, st in enumerate((lib.GemmDesc, lib.AttnDesc, lib.GnDesc, lib.FusionDesc, lib.LnDesc, lib.XsDesc)):
         assert L.es_sizeof_desc(i) == ctypes.sizeof(st)
@@ -55,25 +55,25 @@ def test_plan_records_nothing_and_launches_nothing_without_a_gpu():
 
 
 def test_plan_image_round_trip_markers_and_context_image_errors(tmp_path):
-    """Host-only parts of the context-image machinery: es_plan_export / es_plan_import round trip (stream markers recorded
-    through es_plan_mark included), refusal of truncated images, and es_ctx_load's errors on a missing / foreign file
-    (nothing touches a GPU: the file is rejected before any HIP call)."""
+    """Host-only parts of the context-image machinery: es_plan_import / es_plan_export round trip of a hand-made launch
+    list, refusal of truncated or inconsistent images, and es_ctx_load's errors on a missing / foreign file (nothing touches
+    a GPU: the file is rejected before any HIP call)."""
+    import struct
     L = lib.load()
-    p = ctypes.c_void_p(L.es_plan_create())
-    assert L.es_plan_mark(lib.PLAN_SIDE_BEGIN) == 0 and L.es_plan_size(p) == 0      # nothing records: a no-op
-    assert L.es_plan_mark(7) != 0 and b"marker" in L.es_last_error()
-    assert L.es_plan_begin_record(p) == 0
-    for k in (lib.PLAN_SIDE_BEGIN, lib.PLAN_SIDE_END, lib.PLAN_SIDE_JOIN):
-        assert L.es_plan_mark(k) == 0
-    assert L.es_plan_end_record(p) == 0 and L.es_plan_size(p) == 3
-    n = L.es_plan_export(p, None, 0)
-    assert n == 16 + 3 * 24
-    buf = (ctypes.c_char * n)()
-    assert L.es_plan_export(p, buf, n) == n
-    q = ctypes.c_void_p(L.es_plan_import(buf, n))
-    assert q.value and L.es_plan_size(q) == 3 and L.es_plan_count(q, lib.PLAN_SIDE_JOIN) == 1
-    assert not L.es_plan_import(buf, n - 8) and b"truncated" in L.es_last_error()
-    L.es_plan_destroy(p)
+    # a hand-made image of two recorded calls (csrc/plan.h: 18 = es_memcpy {dst, src, bytes}, 16 = es_incr {ctr}); nothing
+    # can RECORD on a CPU-only host (every entry point validates and launches), but import / export are host-only
+    blob = struct.pack("<QQQ", 0x1000, 0x2000, 64) + b"\0" * 8 + struct.pack("<Q", 0x3000)
+    img = struct.pack("<QQ", 2, len(blob)) + struct.pack("<qQQ", 18, 0, 24) + struct.pack("<qQQ", 16, 32, 8) + blob
+    buf = (ctypes.c_char * len(img)).from_buffer_copy(img)
+    q = ctypes.c_void_p(L.es_plan_import(buf, len(img)))
+    assert q.value and L.es_plan_size(q) == 2 and L.es_plan_count(q, 18) == 1 and L.es_plan_count(q, 16) == 1
+    n = L.es_plan_export(q, None, 0)
+    assert n == len(img)
+    out = (ctypes.c_char * n)()
+    assert L.es_plan_export(q, out, n) == n and bytes(out) == img
+    assert not L.es_plan_import(buf, len(img) - 8) and b"truncated" in L.es_last_error()
+    bad_op = struct.pack("<QQ", 1, 8) + struct.pack("<qQQ", 16, 4, 8) + b"\0" * 8          # record runs past the blob
+    assert not L.es_plan_import((ctypes.c_char * len(bad_op)).from_buffer_copy(bad_op), len(bad_op))
     L.es_plan_destroy(q)
     ctx = ctypes.c_void_p()
     assert L.es_ctx_load(str(tmp_path / "missing.esctx").encode(), 0, ctypes.byref(ctx)) != 0 and b"open" in L.es_last_error()
@@ -446,3 +446,40 @@ def test_best_embeddings_prompt_picker():
     assert be([object(), object()]) == ["edgestyle, red, green, dress, shirt", "edgestyle, green, blue, shirt, coat"]
     assert BestEmbeddings(Model(), Proc()).colors == DEFAULT_COLORS
     assert be.find_best(colors, [object()], n=3) == [["red", "green", "blue"]]
+
+
+def test_pointer_field_tables_match_the_descriptor_structs():
+    """es_plan_pointer_fields (what NativeEngine.save relocates by, instead of guessing pointers from bit patterns): for every
+    descriptor struct mirrored in edgestyle_amd/lib.py, the library's table names exactly the pointer-typed fields of the
+    struct - no more, no fewer -, each 8-byte aligned and inside the record, each with a use (1 reads, 2 writes, 3 both)."""
+    L = lib.load()
+
+    def table(kind):
+        offs, uses = (ctypes.c_int32 * 64)(), (ctypes.c_int32 * 64)()
+        elem = ctypes.c_int32(-1)
+        n = L.es_plan_pointer_fields(kind, offs, uses, 64, ctypes.byref(elem))
+        assert 0 <= n <= 64
+        return [(offs[i], uses[i]) for i in range(n)], elem.value
+
+    def struct_ptr_offsets(st):
+        out = set()
+        for name, tp in st._fields_:
+            f = getattr(st, name)
+            if tp is ctypes.c_void_p or (isinstance(tp, type) and issubclass(tp, ctypes._Pointer)):
+                out.add(f.offset)
+            elif isinstance(tp, type) and issubclass(tp, ctypes.Array) and (tp._type_ is ctypes.c_void_p):
+                out.update(f.offset + 8 * i for i in range(tp._length_))
+        return out
+
+    # op kinds of csrc/plan.h: 1 conv_gemm, 2 linear_xs, 3 attention, 4 group_norm, 6 layer_norm_grouped, 7 / 8 fusion block(s)
+    for kind, st in ((1, lib.GemmDesc), (2, lib.XsDesc), (3, lib.AttnDesc), (4, lib.GnDesc), (6, lib.LnDesc), (7, lib.FusionDesc),
+                     (8, lib.FusionDesc)):
+        fl, elem = table(kind)
+        assert elem == (ctypes.sizeof(st) if kind == 8 else 0)
+        assert {o for o, _ in fl} == struct_ptr_offsets(st), (kind, sorted(o for o, _ in fl), sorted(struct_ptr_offsets(st)))
+        assert len({o for o, _ in fl}) == len(fl) and all(o % 8 == 0 and o + 8 <= ctypes.sizeof(st) and u in (1, 2, 3) for o, u in fl)
+    # the outputs are marked as written
+    g = dict(table(1)[0])
+    assert g[lib.GemmDesc.out.offset] == 2 and g[lib.GemmDesc.w.offset] == 1 and g[lib.GemmDesc.workspace.offset] == 3
+    # small argument records (memcpy, incr, ...) and markers / unknown kinds
+    assert len(table(18)[0]) == 2 and len(table(16)[0]) == 1 and table(64) == ([], 0) and table(999) == ([], 0)

@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from edgestyle_amd import ops  # noqa: E402
 
-SHAPES = [(2, 8, 4096, 4096, 40), (6, 8, 4096, 4096, 40), (14, 8, 4096, 4096, 40), (16, 8, 4096, 4096, 40), (14, 8, 1024, 1024, 80), (14, 8, 4096, 77, 40), (2, 8, 1024, 1024, 80),
+SHAPES = [(2, 8, 4096, 4096, 40), (6, 8, 4096, 4096, 40), (14, 8, 4096, 4096, 40), (16, 8, 4096, 4096, 40), (112, 8, 4096, 4096, 40), (14, 8, 1024, 1024, 80), (14, 8, 4096, 77, 40), (2, 8, 1024, 1024, 80),
           (16, 8, 1024, 1024, 80), (2, 8, 256, 256, 160), (16, 8, 256, 256, 160), (2, 8, 4096, 77, 40),
           (16, 8, 4096, 77, 40), (16, 8, 1024, 77, 80), (1, 1, 4096, 4096, 512)]
 

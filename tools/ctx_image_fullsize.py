@@ -37,7 +37,8 @@ def main():
     info = eng.save(path)
     t_save = time.time() - t0
     size = os.path.getsize(path)
-    print(f"saved {path}: {size / 2**30:.2f} GiB, arena {info['arena_bytes'] / 2**30:.2f} GiB in {info['blocks']} segments, "
+    print(f"saved {path}: {size / 2**30:.2f} GiB ({info['data_bytes'] / 2**30:.2f} GiB of read-only data in {info['extents']} extents), "
+          f"arena {info['arena_bytes'] / 2**30:.2f} GiB in {info['blocks']} segments, "
           f"relocations per plan {info['relocations']}, {t_save:.1f} s", flush=True)
     arrs = dict(n_conds=np.int64(6), latents=lat.permute(0, 2, 3, 1).contiguous().cpu().numpy(),
                 ehs=torch.cat([ne, pe]).half().cpu().numpy(), guidance_scale=np.float32(7.5),

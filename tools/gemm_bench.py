@@ -24,7 +24,7 @@ SHAPES_B8 = [(16, 64, 320, 320, 3), (48, 64, 320, 320, 3), (16, 32, 640, 640, 3)
              (16, 16, 1280, 10240, 1)]
 
 
-def bench(shape, stages, R=8, dtype=torch.float16, splitk=None, bm=0):
+def bench(shape, stages, R=8, dtype=torch.float16, splitk=None, bn=0):
     N, H, Cin, Cout, k = shape
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
@@ -34,7 +34,7 @@ def bench(shape, stages, R=8, dtype=torch.float16, splitk=None, bm=0):
                            torch.randn(Cout, generator=g, device=dev) * 0.1, dtype, dev, geglu=geglu) for _ in range(R)]
     outs = [None] * R
     ops.FORCE_STAGES = stages
-    ops.FORCE_BM = bm
+    ops.FORCE_BN = bn
     try:
         for i in range(R):
             outs[i] = ops.conv_gemm(x, pws[i], splitk=splitk)
@@ -50,7 +50,7 @@ def bench(shape, stages, R=8, dtype=torch.float16, splitk=None, bm=0):
             best = min(best, e0.elapsed_time(e1) / R)
     finally:
         ops.FORCE_STAGES = 0
-        ops.FORCE_BM = 0
+        ops.FORCE_BN = 0
     M = N * H * H
     flops = 2.0 * M * Cout * k * k * Cin
     sk = splitk or (1 if geglu else ops.choose_splitk(M, pws[0].rows_padded, pws[0].bn, pws[0].kpad))
