@@ -61,20 +61,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stages", default="2,3,4")
     ap.add_argument("--shapes", default="b1")
-    ap.add_argument("--bm", default="0")
+    ap.add_argument("--bn", default="0", help="comma list of forced N tiles: 0 = planner, 64 | 128 | 160 | 320")
     ap.add_argument("--xcd", default="-1")
     a = ap.parse_args()
     st = [int(s) for s in a.stages.split(",")]
     shapes = SHAPES_B1 if a.shapes == "b1" else SHAPES_B8
-    bms = [int(b) for b in a.bm.split(",")]
+    bms = [int(b) for b in a.bn.split(",")]
     ops.XCD_ORDER = int(a.xcd)
-    print("shape(N,H,Cin,Cout,k)  M  splitk | " + " | ".join(f"st{s}/bm{b}: us TF/s" for s in st for b in bms), flush=True)
+    print("shape(N,H,Cin,Cout,k)  M  splitk | " + " | ".join(f"st{s}/bn{b}: us TF/s" for s in st for b in bms), flush=True)
     for shp in shapes:
         cells = []
         for s in st:
           for b in bms:
             try:
-                us, tf, sk = bench(shp, s, bm=b, splitk=1 if b == 256 else None)
+                us, tf, sk = bench(shp, s, bn=b)
                 cells.append(f"{us:7.1f} {tf:5.0f}")
             except Exception as e:
                 cells.append(f"  n/a ({str(e)[:30]})")
