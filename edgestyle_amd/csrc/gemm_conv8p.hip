@@ -38,7 +38,7 @@
 
 // Tool-only builds (tools/ab8p.sh): ES8P_SCHED picks the DMA issue schedule, ES8P_ABL removes one ingredient (results
 // are wrong by construction).  ABL bits: 1 = every DMA out of range (issued, zero-filled, no memory traffic),
-// 2 = no MFMAs, 4 = no barrier stagger.  The product library is built with ES8P_ABL == 0.
+// 2 = no MFMAs, 4 = no barrier stagger, 8 = activation DMAs out of range only, 16 = weight DMAs out of range only.  The product library is built with ES8P_ABL == 0.
 #ifndef ES8P_SCHED
 #define ES8P_SCHED 3
 #endif
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
     for (int i = 0; i < WI; ++i)
       if (i >= i0 && i < i1)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(smem + boff + XT + (wave * WI + i) * 1024), 16,
-                                                 (ES8P_ABL & 1) ? (int)OOB : (int)woff[i], soff_w, 0, 0);
+                                                 (ES8P_ABL & (1 | 16)) ? (int)OOB : (int)woff[i], soff_w, 0, 0);
   };
   // source of the K-tile `ks` (wave-uniform): base pointer, records, channel stride, scalar channel offset
   const void* xbase = px;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
       if ((i >> 1) == h)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             rS, (lptr_t)(smem + boff + (grp8 * 16 + (i >> 1) * 8 + wn * 2 + (i & 1)) * 1024), 16,
-            (ES8P_ABL & 1) ? (int)OOB : (int)voff[i], soff_x, 0, 0);
+            (ES8P_ABL & (1 | 8)) ? (int)OOB : (int)voff[i], soff_x, 0, 0);
   };
 
   f32x4 acc[FN][FM];

@@ -66,11 +66,14 @@ class Profiler:
         self.meta.append(meta)
         return self.slots[i].data_ptr() if self.stamps else 0
 
-    def replay_gemms(self):
+    def replay_gemms(self, only_ksize: int = 0):
         """Launch the recorded es_conv_gemm descriptors again on the current stream, un-instrumented (the production
-        kernel: no stamp atomics).  The buffers they point at must still be alive (keep the graph that owns them)."""
+        kernel: no stamp atomics).  The buffers they point at must still be alive (keep the graph that owns them).
+        only_ksize = 3: only the 3x3 convolutions."""
         lib = L.load()
         for d in self.descs:
+            if only_ksize and (isinstance(d, L.XsDesc) or int(d.ksize) != only_ksize):
+                continue
             fn = lib.es_linear_xs if isinstance(d, L.XsDesc) else lib.es_conv_gemm
             L.check(fn(C.byref(d), _stream()), "GEMM replay")
 
@@ -237,7 +240,7 @@ def _get_workspace(nbytes: int, device) -> torch.Tensor:
 #   * the big tile (256 px x 320 couts, one workgroup per CU) does the work of two 160-wide workgroups in ~4 % less
 #     time (half the L2->LDS bytes); it only pays on launches of many rounds, so it is offered from 32k pixels up.
 PLAN_T160, PLAN_ALONE, PLAN_TFIX, PLAN_RED_FIX, PLAN_SLAB_BYTES_PER_UNIT = 1.25, 0.9, 2.0, 12.0, 4.0e6
-PLAN_T320, PLAN_BIG_MIN_M, PLAN_T320_FIX, PLAN_BIG_MIN_NK = 2.15, 16384, 4.0, 16
+PLAN_T320, PLAN_BIG_MIN_M, PLAN_T320_FIX, PLAN_BIG_MIN_NK = 2.3, 16384, 4.0, 16
 #   * the 64x64 tile (tiny launches): a K-step costs 0.5 units with the CU to itself and 0.5 + 0.16 (w - 1)^2 with w
 #     workgroups per CU (measured 0.87 at w = 2.5, 2.0 at w = 3.75); x1.5 for K > 2560, where MFMA throughput starts to
 #     matter and the small tile reads LDS twice as often per FLOP;

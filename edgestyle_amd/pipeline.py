@@ -607,23 +607,25 @@ class StableDiffusionControlNetPipeline:
         g.replay()
         torch.cuda.synchronize()
         res = prof.results()
-        self.last_gemm_replay_ms = None
+        self.last_gemm_replay_ms = self.last_conv3_replay_ms = None
         if gemm_replay_iters > 0:
-            prof.replay_gemms()              # eager once (same workspace sizes as the step: nothing grows)
-            torch.cuda.synchronize()
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2):
-                prof.replay_gemms()
-            for _ in range(3):
-                g2.replay()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(gemm_replay_iters):
-                g2.replay()
-            e1.record()
-            torch.cuda.synchronize()
-            self.last_gemm_replay_ms = e0.elapsed_time(e1) / gemm_replay_iters
-            del g2
+            def timed(only):
+                prof.replay_gemms(only)      # eager once (same workspace sizes as the step: nothing grows)
+                torch.cuda.synchronize()
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2):
+                    prof.replay_gemms(only)
+                for _ in range(3):
+                    g2.replay()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(gemm_replay_iters):
+                    g2.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / gemm_replay_iters
+            self.last_gemm_replay_ms = timed(0)
+            self.last_conv3_replay_ms = timed(3)     # the 3x3 convolutions alone (with their split-K reduces)
         loop.step_idx.zero_()
         del g
         return res

@@ -17,10 +17,11 @@ import sys
 def short(name):
     m = re.match(r"_ZN12_GLOBAL__N_1\d+([a-z_0-9]+?)I", name)
     if m:
-        return m.group(1)
+        return "conv_gemm_kernel" if m.group(1) == "conv_gemm8p_kernel" else m.group(1)
     n = name[5:] if name.startswith("void ") else name
     n = n.replace("(anonymous namespace)::", "")
-    return re.split(r"[<(]", n, 1)[0][:40]
+    n = re.split(r"[<(]", n, 1)[0][:40]
+    return "conv_gemm_kernel" if n == "conv_gemm8p_kernel" else n      # the 256 x 320 tile counts as the GEMM kernel
 
 
 def per_step(path, counter):
