@@ -691,6 +691,18 @@ def test_conv_gemm_big_tile_equals_small_tile():
                            torch.float16, DEV) for _ in counts]
     big, small = both(lambda: ops.conv_gemm(xg, pws, group_n=counts))
     assert torch.equal(big, small)
+    # tail sources (conv2 + conv_shortcut as one launch) on the big tile, slices that start inside the tail
+    Ct1, Ct2 = 64, 128
+    t1 = q16(torch.randn(N, Ct1, H, H, generator=g))
+    t2 = q16(torch.randn(N, Ct2, H, H, generator=g))
+    wc = q16(torch.randn(320, C1, 3, 3, generator=g) / math.sqrt(9 * C1))
+    wt = q16(torch.randn(320, Ct1 + Ct2, generator=g) / math.sqrt(Ct1 + Ct2))
+    pwt = ops.pack_weight_tail(wc, wt, b[:320], torch.float16, DEV)
+    reft = F.conv2d(x1, wc, b[:320], padding=1) + F.conv2d(torch.cat([t1, t2], 1), wt[:, :, None, None])
+    for splitk in (1, 7, 21):                             # K = 9 * 128 + 192 = 21 K-tiles: one per slice at 21
+        big, small = both(lambda: ops.conv_gemm(nhwc(x1), pwt, tail=(nhwc(t1), nhwc(t2)), splitk=splitk))
+        assert torch.equal(big, small), splitk
+        assert rel_err(big.permute(0, 3, 1, 2), reft) < 3e-3, splitk
     with pytest.raises(Exception):                        # 128-pixel group boundaries cannot use 256-pixel tiles
         ops.FORCE_BN = 320
         try:
