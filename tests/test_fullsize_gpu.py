@@ -163,6 +163,16 @@ def test_batch8_graph_matches_batch1_requests(full):
         ps.append(H.psnr(img8[i:i + 1], img1))
     record("batch8_vs_batch1", psnr_min=min(ps), psnr=[round(p, 2) for p in ps])
     assert min(ps) >= 45.0, ps
+    # ... and against the ORACLE: the request of the committed 4-step fixture served as element 3 of a batch of 8
+    lat4, pe4, ne4, pc4 = H.full_pipeline_inputs()
+    lat_b, pe_b, ne_b = lat.clone(), pe.clone(), ne.clone()
+    lat_b[3], pe_b[3], ne_b[3] = lat4[0], pe4[0], ne4[0]
+    img_b = pipe(prompt_embeds=pe_b, negative_prompt_embeds=ne_b, image=pc4, latents=lat_b, guidance_scale=7.5,
+                 num_inference_steps=4, output_type="pt").images.float().cpu()
+    gold = load_file(os.path.join(GOLD, "full_pipeline4.safetensors"))
+    p_gold = H.psnr(img_b[3:4], gold["image"].float())
+    record("batch8_vs_oracle_fixture", psnr_vs_golden=p_gold)
+    assert p_gold >= 40.0, p_gold
 
 
 @pytest.fixture(scope="module")
