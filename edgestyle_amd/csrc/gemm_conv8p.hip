@@ -16,10 +16,13 @@
 //     and group 1 runs ONE BARRIER behind group 0, so on every SIMD one wave issues its MFMAs while its partner
 //     issues reads and DMAs: the matrix pipe sees a continuous MFMA stream from alternating waves;
 //   * LDS ring of two K-tiles (2 x 72 KB); the 9 DMA pieces (1 KB each) a wave issues per K-tile are spread over the
-//     four phases 3 | 2 | 2 | 2 in the order they are needed (weights, first pixel quarter, second pixel quarter) and
+//     four phases 2 | 3 | 2 | 2 in the order they are needed (weights, first pixel quarter, second pixel quarter) and
 //     retired by COUNTED s_waitcnt vmcnt: vmcnt(2) in phase 3 (weights + first quarter of the next tile landed, the
-//     second quarter stays in flight across the tile boundary), vmcnt(3) in phase 0 (second quarter landed, the three
-//     pieces just issued stay in flight).  Never vmcnt(0) inside the loop.
+//     second quarter stays in flight across the tile boundary), vmcnt(2) in phase 0 (second quarter landed, the two
+//     pieces just issued stay in flight).  Never vmcnt(0) inside the loop.  (Tried and measured within +-2 % of this:
+//     3 | 2 | 2 | 2, everything in phases 0-1, weights first / pixels second, no s_setprio, lgkmcnt(0) before the barrier.
+//     A chunk-major K order - the nine taps of a 64-channel chunk back to back, for L2 hits on the activation re-reads -
+//     measured 5-12 % SLOWER: consecutive K-tiles then read weight lines Cin * 2 bytes apart.)
 // Hazards (slots = intervals between consecutive workgroup barriers; group 0 reads in even slots and computes in
 // odd ones, group 1 the other way round):
 //   RAW  a wave's counted wait sits BEFORE the first barrier of its phase; the reads of the data it retires sit at
@@ -36,20 +39,10 @@
 #include "common.h"
 #include "../../include/edgestyle_hip.h"
 
-// Tool-only builds (tools/ab8p.sh): ES8P_SCHED picks the DMA issue schedule, ES8P_ABL removes one ingredient (results
-// are wrong by construction).  ABL bits: 1 = every DMA out of range (issued, zero-filled, no memory traffic),
+// Tool-only builds (tools/ab8p.sh): ES8P_ABL removes one ingredient (results are wrong by construction).  ABL bits: 1 = every DMA out of range (issued, zero-filled, no memory traffic),
 // 2 = no MFMAs, 4 = no barrier stagger, 8 = activation DMAs out of range only, 16 = weight DMAs out of range only.  The product library is built with ES8P_ABL == 0.
-#ifndef ES8P_SCHED
-#define ES8P_SCHED 3
-#endif
 #ifndef ES8P_ABL
 #define ES8P_ABL 0
-#endif
-#ifndef ES8P_PRIO
-#define ES8P_PRIO 1
-#endif
-#ifndef ES8P_LGKM_EARLY
-#define ES8P_LGKM_EARLY 0
 #endif
 
 namespace {
@@ -259,11 +252,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
     const char* xs = smem + boff;
 #define ES_RD(off) as_vec8<T>(*(const u32x4*)(xs + (off)))
 #define ES_MFMA(H)                                                                    \
-    if (ES8P_LGKM_EARLY) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           \
     __builtin_amdgcn_s_barrier();                                                     \
-    if (!ES8P_LGKM_EARLY) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                \
     __builtin_amdgcn_sched_barrier(0);                                                \
-    __builtin_amdgcn_s_setprio(ES8P_PRIO);                                            \
+    __builtin_amdgcn_s_setprio(1);                                                    \
     if constexpr ((ES8P_ABL & 2) != 0) {                                              \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(xa[j]));    \
       _Pragma("unroll") for (int i = 0; i < FN; ++i) asm volatile("" ::"v"(wa[i]));   \
@@ -280,74 +272,32 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
     for (int j = 0; j < 4; ++j) xa[j] = ES_RD(xrow + xo0 + (0 * 64 + j * 16) * RB);
 #pragma unroll
     for (int i = 0; i < FN; ++i) wa[i] = ES_RD(wrow + xo0 + i * 16 * RB);
-#if ES8P_SCHED == 0
-    if (nxt) {
-      issue_w(ksn, nboff, 0, 3);
-      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");    // the second pixel quarter of THIS tile has landed
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-#elif ES8P_SCHED == 3
     if (nxt) {
       issue_w(ksn, nboff, 0, 2);
-      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");    // the second pixel quarter of THIS tile has landed
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-#elif ES8P_SCHED == 1
-    // front-loaded: everything of the next tile is issued in phases 0 and 1 (at least two phases of flight)
-    if (nxt) {
-      issue_w(ksn, nboff, 0, 3);
-      select_x(ksn);
-      issue_x(nboff, 0);
-      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-#else
-    if (nxt) {
-      issue_w(ksn, nboff, 0, 5);
-      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-#endif
     ES_MFMA(0)
     // ---- phase 1: (h 1, kk 0) ----
 #pragma unroll
     for (int j = 0; j < 4; ++j) xa[j] = ES_RD(xrow + xo0 + (1 * 64 + j * 16) * RB);
-#if ES8P_SCHED == 0
-    if (nxt) issue_w(ksn, nboff, 3, WI);
-#elif ES8P_SCHED == 3
     if (nxt) { issue_w(ksn, nboff, 2, WI); select_x(ksn); }
-#elif ES8P_SCHED == 1
-    if (nxt) { issue_w(ksn, nboff, 3, WI); issue_x(nboff, 1); }
-#else
-    if (nxt) { select_x(ksn); issue_x(nboff, 0); issue_x(nboff, 1); }
-#endif
     ES_MFMA(1)
     // ---- phase 2: (h 0, kk 1) ----
 #pragma unroll
     for (int j = 0; j < 4; ++j) xa[j] = ES_RD(xrow + xo1 + (0 * 64 + j * 16) * RB);
 #pragma unroll
     for (int i = 0; i < FN; ++i) wa[i] = ES_RD(wrow + xo1 + i * 16 * RB);
-#if ES8P_SCHED == 0
-    if (nxt) { select_x(ksn); issue_x(nboff, 0); }
-#elif ES8P_SCHED == 3
     if (nxt) issue_x(nboff, 0);
-#endif
     ES_MFMA(0)
     // ---- phase 3: (h 1, kk 1) ----
 #pragma unroll
     for (int j = 0; j < 4; ++j) xa[j] = ES_RD(xrow + xo1 + (1 * 64 + j * 16) * RB);
-#if ES8P_SCHED == 0 || ES8P_SCHED == 3
     if (nxt) {
       issue_x(nboff, 1);
       asm volatile("s_waitcnt vmcnt(2)" ::: "memory");    // weights + first pixel quarter of the next tile have landed
     }
-#else
-    if (nxt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-#endif
     ES_MFMA(1)
 #undef ES_MFMA
 #undef ES_RD

@@ -1,8 +1,8 @@
 #!/bin/bash
 # On the GPU box: everything profiles/ holds for a round, into gpurun_out/final/ (copy what is to be judged to profiles/).
-#   bash tools/collect_profiles.sh r02
+#   bash tools/collect_profiles.sh r03
 cd "$(dirname "$0")/.."
-R=${1:-r02}
+R=${1:-r03}
 out=gpurun_out/final
 rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp

@@ -59,7 +59,7 @@ def main(fetch_csv, write_csv, launches_json, out_json):
     rd = 2 * 1024 * (F["conv_gemm_kernel"]["KiB_per_step"] + F["linear_xs_kernel"]["KiB_per_step"])
     wr = 1024 * (W["conv_gemm_kernel"]["KiB_per_step"] + W["linear_xs_kernel"]["KiB_per_step"])
     out = {
-        "round": 2,
+        "round": 3,
         "workload": "the GEMM launches (conv_gemm_kernel + linear_xs_kernel) of one batch-1 denoising step of the REAL "
                     "pipeline (bench.py --no-graph: same launch list as the captured step, eager so that counters can be "
                     f"collected per dispatch), steps averaged: {nf} (FETCH pass) / {nw} (WRITE pass)",
