@@ -26,8 +26,45 @@ ES_DEVICE float block_sum(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// The per-channel parameters of one 8-channel chunk: w1 [8][3][2], b1 [8][3], w2 [8][3], b2 [8] - 104 floats.  Loading them
+// per item element by element (26 loads beside the 12 that move data) made the passes instruction-bound: 2.7 TB/s of moved
+// bytes against 4.8 with the parameters replaced by constants (tools/fusion_bench.py).  The grids are chosen so that the grid
+// stride is a multiple of C / 8: a thread's chunk column then never changes and its parameters are loaded ONCE, ahead of its
+// loop (`fixc`); any other geometry reloads them per item, as 16-byte loads.
+struct ChunkParams {
+  float w1[8][3][2], b1[8][3], w2[8][3], b2[8];
+};
+ES_DEVICE void load_chunk_params(const es_fusion_desc& p, int c, ChunkParams& cp, bool second) {
+  const f32x4* w = (const f32x4*)(p.w1 + (size_t)c * 6);       // c % 8 == 0: 16-byte aligned
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    const f32x4 v = w[k];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) (&cp.w1[0][0][0])[k * 4 + r] = v[r];
+  }
+  const f32x4* b = (const f32x4*)(p.b1 + (size_t)c * 3);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const f32x4 v = b[k];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) (&cp.b1[0][0])[k * 4 + r] = v[r];
+  }
+  if (second) {
+    const f32x4* w2 = (const f32x4*)(p.w2 + (size_t)c * 3);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const f32x4 v = w2[k];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) (&cp.w2[0][0])[k * 4 + r] = v[r];
+    }
+    const f32x4 b0 = *(const f32x4*)(p.b2 + c), b1v = *(const f32x4*)(p.b2 + c + 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { cp.b2[r] = b0[r]; cp.b2[4 + r] = b1v[r]; }
+  }
+}
+
 template <typename T>
-ES_DEVICE void load_z(const es_fusion_desc& p, int n, size_t off, int c, float z[3][8]) {
+ES_DEVICE void load_z(const es_fusion_desc& p, int n, size_t off, const ChunkParams& cp, float z[3][8]) {
   // off = pix*C + c  (element offset inside one sample of one net)
   float r[6][8];
 #pragma unroll
@@ -41,10 +78,7 @@ ES_DEVICE void load_z(const es_fusion_desc& p, int n, size_t off, int c, float z
 #pragma unroll
   for (int e = 0; e < 8; ++e)
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const float* w = p.w1 + ((size_t)(c + e) * 3 + q) * 2;
-      z[q][e] = w[0] * r[2 * q][e] + w[1] * r[2 * q + 1][e] + p.b1[(c + e) * 3 + q];
-    }
+    for (int q = 0; q < 3; ++q) z[q][e] = cp.w1[e][q][0] * r[2 * q][e] + cp.w1[e][q][1] * r[2 * q + 1][e] + cp.b1[e][q];
 }
 
 ES_DEVICE void reduce_partials(const float* part, int nchunk, float cnt, float eps, float& mean, float& rstd,
@@ -93,10 +127,14 @@ ES_DEVICE void fusion_a_body(const es_fusion_desc& p, const int bx, const int nb
   const bool small = items < (1 << 24);
   const float inv_ch8 = 1.0f / (float)CH8;
   float s = 0.f, ss = 0.f;
-  for (int i = bx * 256 + threadIdx.x; i < items; i += nb * 256) {
-    const int c = (i - div_any(i, CH8, inv_ch8, small) * CH8) * 8;
+  const int i0 = bx * 256 + threadIdx.x;
+  const bool fixc = (nb * 256) % CH8 == 0;               // the thread's chunk column is the same for every item
+  ChunkParams cp;
+  if (fixc && i0 < items) load_chunk_params(p, (i0 - div_any(i0, CH8, inv_ch8, small) * CH8) * 8, cp, false);
+  for (int i = i0; i < items; i += nb * 256) {
+    if (!fixc) load_chunk_params(p, (i - div_any(i, CH8, inv_ch8, small) * CH8) * 8, cp, false);
     float z[3][8];
-    load_z<T>(p, n, (size_t)i * 8, c, z);
+    load_z<T>(p, n, (size_t)i * 8, cp, z);
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -122,10 +160,14 @@ ES_DEVICE void fusion_b_body(const es_fusion_desc& p, const int bx, const int nc
                   p.eps, mean1, rstd1, red);
   float s = 0.f, ss = 0.f;
   T* U = (T*)p.u + (size_t)n * p.HW * p.C;
-  for (int i = bx * 256 + threadIdx.x; i < items; i += nchunk * 256) {
-    const int c = (i - div_any(i, CH8, inv_ch8, small) * CH8) * 8;
+  const int i0 = bx * 256 + threadIdx.x;
+  const bool fixc = (nchunk * 256) % CH8 == 0;
+  ChunkParams cp;
+  if (fixc && i0 < items) load_chunk_params(p, (i0 - div_any(i0, CH8, inv_ch8, small) * CH8) * 8, cp, true);
+  for (int i = i0; i < items; i += nchunk * 256) {
+    if (!fixc) load_chunk_params(p, (i - div_any(i, CH8, inv_ch8, small) * CH8) * 8, cp, true);
     float z[3][8];
-    load_z<T>(p, n, (size_t)i * 8, c, z);
+    load_z<T>(p, n, (size_t)i * 8, cp, z);
     // affine planes: [(pix*C + c)*3 + q], 24 contiguous values for this thread
     const T* g1 = (const T*)p.g1 + (size_t)i * 24;
     const T* be1 = (const T*)p.be1 + (size_t)i * 24;
@@ -140,11 +182,11 @@ ES_DEVICE void fusion_b_body(const es_fusion_desc& p, const int bx, const int nc
     typename Traits<T>::vec8 uo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float u = p.b2[c + e];
+      float u = cp.b2[e];
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         const float y = silu_f((z[q][e] - mean1) * rstd1 * gv[e * 3 + q] + bv[e * 3 + q]);
-        u += p.w2[(c + e) * 3 + q] * y;
+        u += cp.w2[e][q] * y;
       }
       uo[e] = from_f32<T>(u);
       const float ur = to_f32(uo[e]);      // statistics of the value pass C will actually read
@@ -172,8 +214,18 @@ ES_DEVICE void fusion_c_body(const es_fusion_desc& p, const int bx, const int nb
                   mean2, rstd2, red);
   const T* U = (const T*)p.u + (size_t)n * p.HW * p.C;
   T* O = (T*)p.out + (size_t)n * p.HW * p.C;
-  for (int i = bx * 256 + threadIdx.x; i < items; i += nb * 256) {
-    const int c = (i - div_any(i, CH8, inv_ch8, small) * CH8) * 8;
+  const int i0 = bx * 256 + threadIdx.x;
+  const bool fixc = (nb * 256) % CH8 == 0;
+  float w3v[8], b3v[8];
+  auto load_w3 = [&](int c) __attribute__((always_inline)) {
+    const f32x4 wa = *(const f32x4*)(p.w3 + c), wb = *(const f32x4*)(p.w3 + c + 4);
+    const f32x4 ba = *(const f32x4*)(p.b3 + c), bb = *(const f32x4*)(p.b3 + c + 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { w3v[r] = wa[r]; w3v[4 + r] = wb[r]; b3v[r] = ba[r]; b3v[4 + r] = bb[r]; }
+  };
+  if (fixc && i0 < items) load_w3((i0 - div_any(i0, CH8, inv_ch8, small) * CH8) * 8);
+  for (int i = i0; i < items; i += nb * 256) {
+    if (!fixc) load_w3((i - div_any(i, CH8, inv_ch8, small) * CH8) * 8);
     const auto u = as_vec8<T>(*(const u32x4*)(U + (size_t)i * 8));
     const auto g = as_vec8<T>(*(const u32x4*)((const T*)p.g2 + (size_t)i * 8));
     const auto b = as_vec8<T>(*(const u32x4*)((const T*)p.be2 + (size_t)i * 8));
@@ -184,7 +236,7 @@ ES_DEVICE void fusion_c_body(const es_fusion_desc& p, const int bx, const int nb
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float v = silu_f((to_f32(u[e]) - mean2) * rstd2 * to_f32(g[e]) + to_f32(b[e]));
-      r[e] = from_f32<T>(p.w3[c + e] * v + p.b3[c + e]);
+      r[e] = from_f32<T>(w3v[e] * v + b3v[e]);
       if (p.addend) r[e] = from_f32<T>(to_f32(r[e]) + to_f32(a[e]));      // == es_add(out, addend)
     }
     store16(O + (size_t)i * 8, __builtin_bit_cast(u32x4, r));
@@ -219,13 +271,23 @@ __global__ __launch_bounds__(256) void fusion_batch_c(const FusionBatch b) {
   fusion_c_body<T>(b.d[k], bx, nb, b.ab_end[k] - (k ? b.ab_end[k - 1] : 0), blockIdx.y);
 }
 
+int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+
+// Workgroups per sample of passes A / B (nchunk: also the number of partial sums) and C (cb).  Both are multiples of
+// q = (C / 8) / gcd(C / 8, 256) - 5 for SD1.5's 320 | 640 | 1280 channels - so that the grid stride (256 threads x workgroups)
+// is a multiple of C / 8 and every thread keeps ONE chunk column: its per-channel parameters are loaded once.  ~8 items per
+// thread in A / B (the 104 parameter floats amortise), ~4 in C.
 void fusion_grids(const es_fusion_desc& d, int& nchunk, int& cb) {
   const long long items = (long long)d.HW * (d.C / 8);
-  nchunk = (int)(items / 512);
-  if (nchunk < 1) nchunk = 1;
-  if (nchunk > FU_MAX_CHUNK) nchunk = FU_MAX_CHUNK;
-  cb = (int)((items + 255) / 256);
-  if (cb > 512) cb = 512;
+  const int q = (d.C / 8) / gcd_i(d.C / 8, 256);
+  auto pick = [&](long long want, int cap) {
+    int n = (int)(want / q) * q;
+    if (n < q) n = q;
+    while (n > cap) n -= q;
+    return n < 1 ? (int)(want < 1 ? 1 : (want > cap ? cap : want)) : n;      // q > cap: no fixed column (per-item reloads)
+  };
+  nchunk = pick(items / 2048, FU_MAX_CHUNK);
+  cb = pick(items / 1024, 512);
 }
 
 template <typename T>
