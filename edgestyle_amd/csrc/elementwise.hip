@@ -200,7 +200,7 @@ extern "C" int es_abi_version(void) { return ES_ABI_VERSION; }
 
 extern "C" int es_timestep_embedding(const float* t, void* out, int N, int dim, int dtype, void* stream) {
   if (!t || !out || dim % 2 || N < 1) { es_set_error("es_timestep_embedding: bad arguments"); return -1; }
-  if (es_plan_recording()) { const es_op_timestep a{t, out, N, dim, dtype}; es_plan_record(ES_OP_TIMESTEP_EMBEDDING, &a, sizeof(a)); }
+  if (es_plan_recording()) { const es_op_timestep a{t, out, N, dim, dtype}; es_plan_record(ES_OP_TIMESTEP_EMBEDDING, &a, sizeof(a)); ES_PLAN_DRY_RETURN(); }
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)N * (dim / 2);
   if (dtype == ES_F16) hipLaunchKernelGGL(timestep_kernel<f16>, dim3(nblk(n)), dim3(256), 0, st, t, (f16*)out, N, dim);
@@ -216,7 +216,7 @@ extern "C" int es_cfg_ddim_step(const void* noise, float* latents, void* model_i
   }
   if (es_plan_recording()) {
     const es_op_cfg_ddim a{noise, latents, model_in, coef, step_idx, guidance_scale, B, HW, L, Lstride, cfg, nsteps, dtype};
-    es_plan_record(ES_OP_CFG_DDIM, &a, sizeof(a));
+    es_plan_record(ES_OP_CFG_DDIM, &a, sizeof(a)); ES_PLAN_DRY_RETURN();
   }
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)B * HW * L;
@@ -238,7 +238,7 @@ extern "C" int es_cfg_unipc_step(const void* noise, float* latents, float* last_
   }
   if (es_plan_recording()) {
     const es_op_cfg_unipc a{noise, latents, last_sample, m0, m1, model_in, coef, step_idx, guidance_scale, B, HW, L, Lstride, cfg, nsteps, dtype};
-    es_plan_record(ES_OP_CFG_UNIPC, &a, sizeof(a));
+    es_plan_record(ES_OP_CFG_UNIPC, &a, sizeof(a)); ES_PLAN_DRY_RETURN();
   }
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)B * HW * L;
@@ -254,7 +254,7 @@ extern "C" int es_cfg_unipc_step(const void* noise, float* latents, float* last_
 extern "C" int es_nchw_f32_to_nhwc(const float* in, void* out, int N, int C, int HW, int Cpad, int dtype,
                                    void* stream) {
   if (!in || !out || Cpad < C || N < 1) { es_set_error("es_nchw_f32_to_nhwc: bad arguments"); return -1; }
-  if (es_plan_recording()) { const es_op_nchw_to_nhwc a{in, out, N, C, HW, Cpad, dtype}; es_plan_record(ES_OP_NCHW_TO_NHWC, &a, sizeof(a)); }
+  if (es_plan_recording()) { const es_op_nchw_to_nhwc a{in, out, N, C, HW, Cpad, dtype}; es_plan_record(ES_OP_NCHW_TO_NHWC, &a, sizeof(a)); ES_PLAN_DRY_RETURN(); }
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)N * HW * Cpad;
   if (dtype == ES_F16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16>, dim3(nblk(n)), dim3(256), 0, st, in, (f16*)out, N, C, HW, Cpad);
@@ -265,7 +265,7 @@ extern "C" int es_nchw_f32_to_nhwc(const float* in, void* out, int N, int C, int
 extern "C" int es_nhwc_to_nchw_f32(const void* in, float* out, int N, int C, int HW, int Cstride, float scale,
                                    float shift, int clamp01, int dtype, void* stream) {
   if (!in || !out || Cstride < C || N < 1) { es_set_error("es_nhwc_to_nchw_f32: bad arguments"); return -1; }
-  if (es_plan_recording()) { const es_op_nhwc_to_nchw a{in, out, N, C, HW, Cstride, scale, shift, clamp01, dtype}; es_plan_record(ES_OP_NHWC_TO_NCHW, &a, sizeof(a)); }
+  if (es_plan_recording()) { const es_op_nhwc_to_nchw a{in, out, N, C, HW, Cstride, scale, shift, clamp01, dtype}; es_plan_record(ES_OP_NHWC_TO_NCHW, &a, sizeof(a)); ES_PLAN_DRY_RETURN(); }
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)N * C * HW;
   if (dtype == ES_F16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<f16>, dim3(nblk(n)), dim3(256), 0, st, (const f16*)in, out, N, C, HW, Cstride, scale, shift, clamp01);
@@ -275,7 +275,7 @@ extern "C" int es_nhwc_to_nchw_f32(const void* in, float* out, int N, int C, int
 
 extern "C" int es_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream) {
   if (!a || !b || !y || n < 8 || n % 8) { es_set_error("es_add: n must be a positive multiple of 8"); return -1; }
-  if (es_plan_recording()) { const es_op_add rec{a, b, y, n, dtype}; es_plan_record(ES_OP_ADD, &rec, sizeof(rec)); }
+  if (es_plan_recording()) { const es_op_add rec{a, b, y, n, dtype}; es_plan_record(ES_OP_ADD, &rec, sizeof(rec)); ES_PLAN_DRY_RETURN(); }
   hipStream_t st = (hipStream_t)stream;
   const long long n8 = n / 8;
   unsigned blocks = nblk(n8);
@@ -288,7 +288,7 @@ extern "C" int es_add(const void* a, const void* b, void* y, int64_t n, int dtyp
 extern "C" int es_vae_sample(const void* moments, const float* noise_nchw, void* z, int N, int HW, int L, int Lpad,
                              float scaling, int dtype, void* stream) {
   if (!moments || !noise_nchw || !z || Lpad < L || N < 1) { es_set_error("es_vae_sample: bad arguments"); return -1; }
-  if (es_plan_recording()) { const es_op_vae_sample a{moments, noise_nchw, z, N, HW, L, Lpad, scaling, dtype}; es_plan_record(ES_OP_VAE_SAMPLE, &a, sizeof(a)); }
+  if (es_plan_recording()) { const es_op_vae_sample a{moments, noise_nchw, z, N, HW, L, Lpad, scaling, dtype}; es_plan_record(ES_OP_VAE_SAMPLE, &a, sizeof(a)); ES_PLAN_DRY_RETURN(); }
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)N * HW * Lpad;
   if (dtype == ES_F16) hipLaunchKernelGGL(vae_sample_kernel<f16>, dim3(nblk(n)), dim3(256), 0, st, (const f16*)moments, noise_nchw, (f16*)z, N, HW, L, Lpad, scaling);
@@ -298,7 +298,7 @@ extern "C" int es_vae_sample(const void* moments, const float* noise_nchw, void*
 
 extern "C" int es_incr(int32_t* ctr, void* stream) {
   if (!ctr) { es_set_error("es_incr: null pointer"); return -1; }
-  if (es_plan_recording()) { const es_op_incr a{ctr}; es_plan_record(ES_OP_INCR, &a, sizeof(a)); }
+  if (es_plan_recording()) { const es_op_incr a{ctr}; es_plan_record(ES_OP_INCR, &a, sizeof(a)); ES_PLAN_DRY_RETURN(); }
   hipLaunchKernelGGL(incr_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ctr);
   ES_RET("es_incr");
 }
@@ -306,7 +306,7 @@ extern "C" int es_incr(int32_t* ctr, void* stream) {
 extern "C" int es_gather_row(const float* table, const int32_t* idx, float* out, int row_len, int nrows,
                              void* stream) {
   if (!table || !idx || !out || row_len < 1 || nrows < 1) { es_set_error("es_gather_row: bad arguments"); return -1; }
-  if (es_plan_recording()) { const es_op_gather_row a{table, idx, out, row_len, nrows}; es_plan_record(ES_OP_GATHER_ROW, &a, sizeof(a)); }
+  if (es_plan_recording()) { const es_op_gather_row a{table, idx, out, row_len, nrows}; es_plan_record(ES_OP_GATHER_ROW, &a, sizeof(a)); ES_PLAN_DRY_RETURN(); }
   hipLaunchKernelGGL(gather_row_kernel, dim3(nblk(row_len)), dim3(256), 0, (hipStream_t)stream, table, idx, out,
                      row_len, nrows);
   ES_RET("es_gather_row");
@@ -315,7 +315,7 @@ extern "C" int es_gather_row(const float* table, const int32_t* idx, float* out,
 extern "C" int es_latents_to_input(const float* latents, void* model_in, int B, int HW, int L, int Lstride, int cfg,
                                    int dtype, void* stream) {
   if (!latents || !model_in || B < 1 || HW < 1 || L < 1 || Lstride < L) { es_set_error("es_latents_to_input: bad arguments"); return -1; }
-  if (es_plan_recording()) { const es_op_latents_to_input a{latents, model_in, B, HW, L, Lstride, cfg, dtype}; es_plan_record(ES_OP_LATENTS_TO_INPUT, &a, sizeof(a)); }
+  if (es_plan_recording()) { const es_op_latents_to_input a{latents, model_in, B, HW, L, Lstride, cfg, dtype}; es_plan_record(ES_OP_LATENTS_TO_INPUT, &a, sizeof(a)); ES_PLAN_DRY_RETURN(); }
   const long long n = (long long)B * HW * Lstride;
   if (dtype == ES_F16) hipLaunchKernelGGL(latents_to_input_kernel<f16>, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, latents, (f16*)model_in, B, HW, L, Lstride, cfg);
   else hipLaunchKernelGGL(latents_to_input_kernel<bf16>, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, latents, (bf16*)model_in, B, HW, L, Lstride, cfg);
@@ -325,21 +325,21 @@ extern "C" int es_latents_to_input(const float* latents, void* model_in, int B, 
 /* device-to-device copies and fills as C-ABI calls, so that the data movement of a step is part of a recorded plan */
 extern "C" int es_memcpy(void* dst, const void* src, size_t bytes, void* stream) {
   if (!dst || !src || !bytes) { es_set_error("es_memcpy: bad arguments"); return -1; }
-  if (es_plan_recording()) { const es_op_memcpy a{dst, src, bytes}; es_plan_record(ES_OP_MEMCPY, &a, sizeof(a)); }
+  if (es_plan_recording()) { const es_op_memcpy a{dst, src, bytes}; es_plan_record(ES_OP_MEMCPY, &a, sizeof(a)); ES_PLAN_DRY_RETURN(); }
   if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) { es_set_error("es_memcpy: hipMemcpyAsync failed"); return -2; }
   return 0;
 }
 
 extern "C" int es_memcpy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, void* stream) {
   if (!dst || !src || !width || !height || dpitch < width || spitch < width) { es_set_error("es_memcpy2d: bad arguments"); return -1; }
-  if (es_plan_recording()) { const es_op_memcpy2d a{dst, dpitch, src, spitch, width, height}; es_plan_record(ES_OP_MEMCPY2D, &a, sizeof(a)); }
+  if (es_plan_recording()) { const es_op_memcpy2d a{dst, dpitch, src, spitch, width, height}; es_plan_record(ES_OP_MEMCPY2D, &a, sizeof(a)); ES_PLAN_DRY_RETURN(); }
   if (hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) { es_set_error("es_memcpy2d: hipMemcpy2DAsync failed"); return -2; }
   return 0;
 }
 
 extern "C" int es_fill_f32(float* dst, float value, size_t n, void* stream) {
   if (!dst || !n) { es_set_error("es_fill_f32: bad arguments"); return -1; }
-  if (es_plan_recording()) { const es_op_fill_f32 a{dst, value, n}; es_plan_record(ES_OP_FILL_F32, &a, sizeof(a)); }
+  if (es_plan_recording()) { const es_op_fill_f32 a{dst, n, value}; es_plan_record(ES_OP_FILL_F32, &a, sizeof(a)); ES_PLAN_DRY_RETURN(); }
   if (hipMemsetD32Async((hipDeviceptr_t)dst, __builtin_bit_cast(int, value), n, (hipStream_t)stream) != hipSuccess) { es_set_error("es_fill_f32: hipMemsetD32Async failed"); return -2; }
   return 0;
 }

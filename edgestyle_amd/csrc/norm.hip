@@ -462,6 +462,7 @@ extern "C" int es_layer_norm(const void* x, void* out, const float* gamma, const
   if (es_plan_recording()) {
     const es_op_layer_norm a{x, out, gamma, beta, M, C, eps, dtype};
     es_plan_record(ES_OP_LAYER_NORM, &a, sizeof(a));
+    ES_PLAN_DRY_RETURN();
   }
   hipStream_t st = (hipStream_t)stream;
   int rc = dtype == ES_F16 ? launch_ln<f16>(x, out, gamma, beta, M, C, eps, st)

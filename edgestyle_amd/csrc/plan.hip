@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -27,6 +28,7 @@ struct es_plan {
 namespace {
 thread_local es_plan* g_rec = nullptr;
 thread_local bool g_replaying = false;
+thread_local bool g_dry = false;
 
 int launch_op(const es_plan* p, const es_plan::Op& op, hipStream_t st, const float* guidance_override) {
   const char* a = p->blob.data() + op.off;
@@ -81,6 +83,8 @@ extern "C" void es_plan_record(int kind, const void* args, size_t bytes) {
   p->ops.push_back({kind, off, bytes});
 }
 
+extern "C" int es_plan_dry(void) { return g_dry && g_rec != nullptr && !g_replaying; }
+extern "C" int es_plan_set_dry(int on) { const int was = g_dry; g_dry = on != 0; return was; }
 extern "C" es_plan* es_plan_create(void) { return new es_plan(); }
 extern "C" void es_plan_destroy(es_plan* p) { if (g_rec == p) g_rec = nullptr; delete p; }
 extern "C" int es_plan_begin_record(es_plan* p) {
@@ -183,6 +187,24 @@ extern "C" int es_plan_pointer_fields(int kind, int32_t* offsets, int32_t* uses,
   return (int)f.size();
 }
 
+int es_plan_relocate(es_plan* p, unsigned long long (*map)(unsigned long long, int, void*), void* user) {
+  for (const auto& op : p->ops) {
+    int elem = 0;
+    const auto& f = ptr_fields(op.kind, elem);
+    const size_t reps = elem ? op.bytes / (size_t)elem : 1;
+    for (size_t r = 0; r < reps; ++r)
+      for (const auto& pf : f) {
+        const size_t pos = op.off + r * (size_t)elem + (size_t)pf.off;
+        if (pos + 8 > op.off + op.bytes) { es_set_error("es_plan_relocate: pointer field outside its record"); return -1; }
+        unsigned long long a;
+        memcpy(&a, p->blob.data() + pos, 8);
+        if (!a) continue;
+        a = map(a, pf.use, user);
+        memcpy(p->blob.data() + pos, &a, 8);
+      }
+  }
+  return 0;
+}
 // Flat image of a plan (es_ctx_save / es_ctx_load): u64 n_ops, u64 blob bytes, n_ops x {i64 kind, u64 off, u64 bytes}, blob.
 // The blob still holds the RECORDED device addresses: whoever moves it relocates them (edgestyle_amd/native.py save()).
 extern "C" size_t es_plan_export(const es_plan* p, void* out, size_t cap) {
@@ -229,7 +251,8 @@ struct es_ctx {
   size_t host_cap = 0;              // asynchronous, so the buffer is only rewritten after `staged` - recorded behind the
   hipEvent_t staged = nullptr;      // previous call's copies - has completed
   std::vector<float> alphas_cumprod;   // the scheduler's schedule (es_ctx_set_alphas_cumprod; SD1.5 default otherwise)
-  void* arena = nullptr;               // es_ctx_load: the one device allocation every recorded pointer was relocated into
+  void* arena = nullptr;               // es_ctx_load / es_load_weights: the one allocation every recorded pointer was relocated into
+  bool arena_on_host = false;          // es_load_weights(device -2): an inspection build in host memory
   hipGraphExec_t loop_exec = nullptr;  // use_graphs == 2: preparation + all steps of es_denoise_loop as one graph
   int loop_steps = 0;
   float loop_guidance = 0.f;
@@ -347,9 +370,10 @@ extern "C" void es_ctx_destroy(es_ctx* c) {
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   if (c->staged) { (void)hipEventSynchronize(c->staged); (void)hipEventDestroy(c->staged); }
   if (c->host) (void)hipHostFree(c->host);
-  if (c->arena) (void)hipFree(c->arena);
+  if (c->arena) { if (c->arena_on_host) free(c->arena); else (void)hipFree(c->arena); }
   delete c;
 }
+void es_ctx_adopt_arena(es_ctx* c, void* arena, bool on_host) { c->arena = arena; c->arena_on_host = on_host; }
 extern "C" int es_ctx_set_geometry(es_ctx* c, const es_ctx_geometry* g) {
   if (!c || !g || g->B < 1 || g->h < 1 || g->w < 1 || g->n_steps < 1 || g->n_conds < 1 || g->n_conds > 6) { es_set_error("es_ctx_set_geometry: bad geometry"); return -1; }
   c->g = *g;
@@ -368,6 +392,11 @@ extern "C" int es_ctx_bind(es_ctx* c, int slot, void* dev, size_t nbytes) {
   c->buf[slot] = dev;
   c->bytes[slot] = nbytes;
   return 0;
+}
+extern "C" void* es_ctx_buffer(const es_ctx* c, int slot, size_t* bytes) {      // borrowed: the slot's device memory
+  if (!c || slot < 0 || slot >= ES_BUF_COUNT) return nullptr;
+  if (bytes) *bytes = c->bytes[slot];
+  return c->buf[slot];
 }
 extern "C" int es_ctx_set_options(es_ctx* c, const float* cond_scales, float control_guidance_start, float control_guidance_end, int use_graphs) {
   if (!c) { es_set_error("es_ctx_set_options: null ctx"); return -1; }

@@ -30,8 +30,10 @@ def fold_lora(sd: SD) -> SD:
     for k in sd:
         if k.endswith(".lora_layer.down.weight"):
             base = k[: -len(".lora_layer.down.weight")]
-            up = sd[base + ".lora_layer.up.weight"].float()
-            out[base + ".weight"] = sd[base + ".weight"].float() + up @ sd[k].float()
+            # in double, rounded once: the result does not depend on the summation order of whoever folds (this host or
+            # es_load_weights, csrc/builder.hip)
+            up = sd[base + ".lora_layer.up.weight"].double()
+            out[base + ".weight"] = (sd[base + ".weight"].double() + up @ sd[k].double()).float()
     return out
 
 
@@ -427,7 +429,7 @@ class VAE:
             # decode(latents / scaling_factor) (PL:552-557) with the division folded into the 1x1 weights
             b = sd.get("post_quant_conv.bias")
             self.post_quant_scaled = ops.pack_weight(
-                pk.t("post_quant_conv.weight") / cfg.scaling_factor, None if b is None else b.to(device), dtype,
+                (pk.t("post_quant_conv.weight").double() / cfg.scaling_factor).float(), None if b is None else b.to(device), dtype,
                 device, cin_pad=self.lat_pad, cout_pad=8)
             self.d_in = pk.conv("decoder.conv_in", cin_pad=8)
             self.d_mid = mid("decoder")

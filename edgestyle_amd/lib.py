@@ -9,8 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ES_HIP_LIB: tools only (ablation / experimental kernel builds); the product always loads the in-tree library
 LIB_PATH = os.environ.get("ES_HIP_LIB") or os.path.join(_HERE, "lib", "libedgestyle_hip.so")
 
-ES_F16, ES_BF16 = 0, 1
-ABI_VERSION = 4          # include/edgestyle_hip.h ES_ABI_VERSION
+ES_F16, ES_BF16, ES_F32 = 0, 1, 2
+ABI_VERSION = 5          # include/edgestyle_hip.h ES_ABI_VERSION
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
 
 
@@ -101,6 +101,34 @@ class FusionDesc(C.Structure):
     ]
 
 
+class Tensor(C.Structure):          # es_tensor
+    _fields_ = [("key", C.c_char_p), ("data", C.c_void_p), ("shape", C.c_int64 * 4), ("ndim", C.c_int32), ("dtype", C.c_int32)]
+
+
+class StateDict(C.Structure):       # es_state_dict
+    _fields_ = [("tensors", C.POINTER(Tensor)), ("count", C.c_int32)]
+
+
+NET_CONTROLNET, NET_CONTROL_LORA_VAE, NET_CONTROL_LORA = 0, 1, 2
+
+
+class Weights(C.Structure):         # es_weights
+    _fields_ = [("unet", StateDict), ("vae", StateDict), ("fusion", StateDict), ("controlnet", StateDict * 6),
+                ("controlnet_kind", C.c_int32 * 6), ("n_controlnets", C.c_int32), ("net_of_cond", C.c_int32 * 6)]
+
+
+class ModelConfig(C.Structure):     # es_model_config
+    _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32),
+                ("n_blocks", C.c_int32), ("block_out_channels", C.c_int32 * 4), ("down_has_attn", C.c_int32 * 4),
+                ("layers_per_block", C.c_int32), ("num_heads", C.c_int32), ("cross_attention_dim", C.c_int32),
+                ("norm_num_groups", C.c_int32), ("norm_eps", C.c_float),
+                ("n_cond_embed", C.c_int32), ("cond_embed_channels", C.c_int32 * 4), ("conditioning_channels", C.c_int32),
+                ("text_tokens", C.c_int32),
+                ("vae_n_blocks", C.c_int32), ("vae_block_out_channels", C.c_int32 * 4), ("vae_layers_per_block", C.c_int32),
+                ("vae_latent_channels", C.c_int32), ("vae_norm_num_groups", C.c_int32),
+                ("vae_norm_eps", C.c_float), ("vae_scaling_factor", C.c_float)]
+
+
 # every symbol include/edgestyle_hip.h declares: (name, restype, argtypes)
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
 SYMBOLS = {
@@ -144,6 +172,7 @@ SYMBOLS = {
     "es_ctx_set_geometry": (C.c_int, [_P, C.POINTER(CtxGeometry)]),
     "es_ctx_set_plan": (C.c_int, [_P, _I, _P]),
     "es_ctx_bind": (C.c_int, [_P, _I, _P, C.c_size_t]),
+    "es_ctx_buffer": (_P, [_P, _I, C.POINTER(C.c_size_t)]),
     "es_ctx_set_options": (C.c_int, [_P, C.POINTER(C.c_float), _F, _F, _I]),
     "es_ctx_set_alphas_cumprod": (C.c_int, [_P, C.POINTER(C.c_float), _I]),
     "es_ctx_plan_size": (C.c_int, [_P, _I]),
@@ -158,6 +187,11 @@ SYMBOLS = {
     "es_denoise_loop": (C.c_int, [_P, _P, _P, _F, C.POINTER(C.c_float), _I, _P]),
     "es_vae_decode": (C.c_int, [_P, _P, _P, _P]),
     "es_prepare_conds": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), _P]),
+    "es_load_weights": (C.c_int, [C.POINTER(Weights), C.POINTER(ModelConfig), C.POINTER(CtxGeometry), _I, C.POINTER(_P)]),
+    "es_plan_gemm_choice": (C.c_int, [C.c_longlong, _I, _I, _I, C.POINTER(C.c_int), _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int)]),
+    "es_linear_xs_eligible": (C.c_int, [C.c_longlong, _I, _I, _I, _I, _I, _I]),
+    "es_plan_set_dry": (C.c_int, [_I]),
 }
 
 _lib = None

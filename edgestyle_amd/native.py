@@ -450,3 +450,185 @@ class NativeEngine:
             self.close()
         except Exception:
             pass
+
+
+# ======================================================================================================================
+# es_load_weights: the same context, built by the library itself from raw tensors (no model walk in Python)
+# ======================================================================================================================
+def model_config(ucfg, vcfg, text_tokens: int = 77) -> "L.ModelConfig":
+    """es_model_config of a UNetConfig / VAEConfig pair (edgestyle_amd/config.py)."""
+    m = L.ModelConfig()
+    m.in_channels, m.out_channels = ucfg.in_channels, ucfg.out_channels
+    m.n_blocks = len(ucfg.block_out_channels)
+    for i, c in enumerate(ucfg.block_out_channels):
+        m.block_out_channels[i] = c
+        m.down_has_attn[i] = int(ucfg.down_has_attn[i])
+    m.layers_per_block, m.num_heads = ucfg.layers_per_block, ucfg.num_heads
+    m.cross_attention_dim, m.norm_num_groups, m.norm_eps = ucfg.cross_attention_dim, ucfg.norm_num_groups, ucfg.norm_eps
+    m.n_cond_embed = len(ucfg.conditioning_embedding_out_channels)
+    for i, c in enumerate(ucfg.conditioning_embedding_out_channels):
+        m.cond_embed_channels[i] = c
+    m.conditioning_channels, m.text_tokens = ucfg.conditioning_channels, text_tokens
+    m.vae_n_blocks = len(vcfg.block_out_channels)
+    for i, c in enumerate(vcfg.block_out_channels):
+        m.vae_block_out_channels[i] = c
+    m.vae_layers_per_block, m.vae_latent_channels = vcfg.layers_per_block, vcfg.latent_channels
+    m.vae_norm_num_groups, m.vae_norm_eps, m.vae_scaling_factor = vcfg.norm_num_groups, vcfg.norm_eps, vcfg.scaling_factor
+    return m
+
+
+_TENSOR_DT = {torch.float32: L.ES_F32, torch.float16: L.ES_F16, torch.bfloat16: L.ES_BF16}
+
+
+def state_dict_descriptors(sd):
+    """{key: CPU tensor} -> (es_state_dict, keep-alive list): descriptors only, the data is not copied."""
+    arr = (L.Tensor * max(len(sd), 1))()
+    keep = [arr]
+    for i, (k, v) in enumerate(sd.items()):
+        if v.device.type != "cpu" or v.dtype not in _TENSOR_DT:
+            raise EdgeStyleHipError(f"es_load_weights takes host tensors in fp32 / fp16 / bf16: {k} is {v.dtype} on {v.device}")
+        v = v.contiguous()
+        kb = k.encode()
+        keep += [v, kb]
+        arr[i].key, arr[i].data, arr[i].ndim, arr[i].dtype = kb, v.data_ptr(), v.dim(), _TENSOR_DT[v.dtype]
+        if v.dim() < 1 or v.dim() > 4:
+            raise EdgeStyleHipError(f"{k}: tensors of 1..4 dimensions")
+        for j, s in enumerate(v.shape):
+            arr[i].shape[j] = s
+    return L.StateDict(arr, len(sd)), keep
+
+
+class NativeContext:
+    """A context built by es_load_weights (include/edgestyle_hip.h) from state dicts in the reference's key layout, and thin
+    ctypes drivers of the step-level entry points on raw device pointers.  Nothing of edgestyle_amd's model code (models.py,
+    engine.py, ops.py) is involved: torch only hands over host pointers at build time and device pointers at run time.
+
+    ws: {"unet", "vae", "fusion", <controlnet names>} state dicts; `controlnets`: [(name in ws, L.NET_*)] the distinct nets;
+    net_of_cond: which of them serves each of the six condition slots (TT:252-258).  device < 0: dry build (no GPU)."""
+
+    def __init__(self, ws, ucfg, vcfg, batch_size: int = 1, guidance: bool = True, num_inference_steps: int = 50,
+                 height: Optional[int] = None, width: Optional[int] = None, dtype=torch.float16, device: int = 0,
+                 controlnets=(("lora0", L.NET_CONTROL_LORA_VAE), ("openpose", L.NET_CONTROLNET), ("lora1", L.NET_CONTROL_LORA_VAE)),
+                 net_of_cond=(0, 1, 2, 1, 2, 1)):
+        self.lib = L.load()
+        self.ucfg, self.vcfg = ucfg, vcfg
+        h = (height // vcfg.scale) if height else ucfg.sample_size
+        w = (width // vcfg.scale) if width else ucfg.sample_size
+        self.B, self.N, self.T, self.h, self.w, self.nn = batch_size, batch_size * (2 if guidance else 1), num_inference_steps, h, w, 6
+        self.dtype, self.device = dtype, device
+        wts = L.Weights()
+        keep = []
+        for name in ("unet", "vae", "fusion"):
+            d, k = state_dict_descriptors(ws[name])
+            setattr(wts, name, d)
+            keep.append(k)
+        for i, (name, kind) in enumerate(controlnets):
+            d, k = state_dict_descriptors(ws[name])
+            wts.controlnet[i], wts.controlnet_kind[i] = d, kind
+            keep.append(k)
+        wts.n_controlnets = len(controlnets)
+        for i, n in enumerate(net_of_cond):
+            wts.net_of_cond[i] = n
+        geo = L.CtxGeometry(B=batch_size, cfg=int(guidance), h=h, w=w, latent_channels=ucfg.in_channels,
+                            latent_pad=(ucfg.in_channels + 7) // 8 * 8, n_conds=6, n_steps=num_inference_steps,
+                            dtype=L.ES_F16 if dtype == torch.float16 else L.ES_BF16)
+        mc = model_config(ucfg, vcfg)
+        ctx = C.c_void_p()
+        L.check(self.lib.es_load_weights(C.byref(wts), C.byref(mc), C.byref(geo), device, C.byref(ctx)), "es_load_weights")
+        self.ctx = ctx
+        self.uses_noise = [controlnets[n][1] == L.NET_CONTROL_LORA_VAE for n in net_of_cond]
+        del keep
+
+    def plan_size(self, which: int) -> int:
+        return self.lib.es_ctx_plan_size(self.ctx, which)
+
+    def set_options(self, cond_scales: Optional[Sequence[float]] = None, control_guidance_start: float = 0.0,
+                    control_guidance_end: float = 1.0, use_graphs=True):
+        arr = None if cond_scales is None else (C.c_float * 6)(*([float(s) for s in cond_scales] + [1.0] * (6 - len(cond_scales))))
+        L.check(self.lib.es_ctx_set_options(self.ctx, arr, control_guidance_start, control_guidance_end, int(use_graphs)),
+                "es_ctx_set_options")
+
+    def set_alphas_cumprod(self, alphas_cumprod):
+        """The scheduler's schedule (default: the library's own SD1.5 table, which equals torch's cumprod to 1e-6 only - hand
+        over the scheduler's tensor where the DDIM coefficients must match a Python host's bit for bit)."""
+        ac = alphas_cumprod.float().contiguous()
+        L.check(self.lib.es_ctx_set_alphas_cumprod(self.ctx, ac.numpy().ctypes.data_as(C.POINTER(C.c_float)), ac.numel()),
+                "es_ctx_set_alphas_cumprod")
+
+    @staticmethod
+    def _stream():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def denoise_step(self, sample, t: float, ehs, cond_embeds, scales=None, out=None):
+        """sample [N,h,w,latent_pad], ehs [N,77,D], cond_embeds 6 x [N,h,w,C0] (compute dtype, contiguous, device) -> [N,h,w,4]"""
+        if out is None:
+            out = torch.empty((self.N, self.h, self.w, self.ucfg.out_channels), dtype=self.dtype, device=sample.device)
+        ptrs = (C.c_void_p * 6)(*[c.data_ptr() for c in cond_embeds])
+        sc = None if scales is None else (C.c_float * 6)(*[float(s) for s in scales])
+        L.check(self.lib.es_denoise_step(self.ctx, _p(sample), float(t), _p(ehs), ptrs, sc, _p(out), self._stream()), "es_denoise_step")
+        return out
+
+    def prepare_conds(self, images, noise=None):
+        """images: 6 x device fp32 [B,3,H,W]; noise: per slot None or device fp32 [N,L,h,w]"""
+        self._live = ([im.contiguous() for im in images], [None if (noise is None or z is None) else z.contiguous() for z in (noise or [None] * 6)])
+        ip = (C.c_void_p * 6)(*[im.data_ptr() for im in self._live[0]])
+        npz = (C.c_void_p * 6)(*[None if z is None else z.data_ptr() for z in self._live[1]])
+        L.check(self.lib.es_prepare_conds(self.ctx, ip, npz, self._stream()), "es_prepare_conds")
+
+    def denoise_loop(self, latents, ehs, guidance_scale: float, timesteps):
+        """latents fp32 [B,h,w,L] NHWC device (in place); timesteps: host list of length n_steps"""
+        ts = (C.c_float * len(timesteps))(*[float(t) for t in timesteps])
+        L.check(self.lib.es_denoise_loop(self.ctx, _p(latents), _p(ehs), float(guidance_scale), ts, len(timesteps), self._stream()),
+                "es_denoise_loop")
+        return latents
+
+    def vae_decode(self, latents, out=None):
+        if out is None:
+            s = self.vcfg.scale
+            out = torch.empty((self.B, 3, self.h * s, self.w * s), dtype=torch.float32, device=latents.device)
+        L.check(self.lib.es_vae_decode(self.ctx, _p(latents), _p(out), self._stream()), "es_vae_decode")
+        return out
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.es_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def plan_records(lib, ctx, which: int):
+    """[(op kind, argument record with every pointer field replaced by 0 / 1 = null / set)] of one plan of a context: what two
+    builders must agree on call by call (the addresses themselves belong to each builder's allocator)."""
+    import numpy as np
+    pl = lib.es_ctx_plan(ctx, which)
+    if not pl:
+        return []
+    n = lib.es_plan_export(pl, None, 0)
+    raw = (C.c_char * n)()
+    lib.es_plan_export(pl, raw, n)
+    img = np.frombuffer(raw, dtype=np.uint8).copy()
+    n_ops = int(img[:8].view(np.uint64)[0])
+    table = img[16:16 + 24 * n_ops].view(np.uint64).reshape(n_ops, 3)
+    blob0 = 16 + 24 * n_ops
+    out, fields = [], {}
+    for kind, off, nbytes in table.tolist():
+        kind = int(np.int64(kind))
+        if kind not in fields:
+            offs, uses, elem = (C.c_int32 * 64)(), (C.c_int32 * 64)(), C.c_int32(0)
+            k = lib.es_plan_pointer_fields(kind, offs, uses, 64, C.byref(elem))
+            fields[kind] = ([offs[i] for i in range(k)], elem.value)
+        fl, elem = fields[kind]
+        rec = img[blob0 + int(off):blob0 + int(off) + int(nbytes)].copy()
+        for r in range(max(1, int(nbytes) // elem) if elem else 1):
+            for fo in fl:
+                pos = r * elem + fo
+                v = int(rec[pos:pos + 8].view(np.uint64)[0])
+                rec[pos:pos + 8] = 0
+                rec[pos] = 1 if v else 0
+        out.append((kind, rec.tobytes()))
+    return out

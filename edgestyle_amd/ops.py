@@ -200,11 +200,12 @@ def pack_weight_ln(weight: torch.Tensor, bias: Optional[torch.Tensor], gamma: to
         w = w[:, :, 0, 0]
     g = gamma.to(device=device, dtype=torch.float32)
     b = beta.to(device=device, dtype=torch.float32)
-    fb = w @ b
+    # the two reductions in double, rounded once (order-independent: es_load_weights computes the same values on the host)
+    fb = w.double() @ b.double()
     if bias is not None:
-        fb = fb + bias.to(device=device, dtype=torch.float32)
-    pw = pack_weight(w * g[None, :], fb, dtype, device, geglu=geglu)
-    pw.ln_colsum = pw.w.float().sum(dim=1).contiguous()          # of the ROUNDED weights the MFMAs multiply
+        fb = fb + bias.to(device=device, dtype=torch.float64)
+    pw = pack_weight(w * g[None, :], fb.float(), dtype, device, geglu=geglu)
+    pw.ln_colsum = pw.w.double().sum(dim=1).float().contiguous()          # of the ROUNDED weights the MFMAs multiply
     pw.ln_eps = float(eps)
     return pw
 

@@ -20,10 +20,10 @@
 extern "C" {
 #endif
 
-enum { ES_F16 = 0, ES_BF16 = 1 };
+enum { ES_F16 = 0, ES_BF16 = 1, ES_F32 = 2 /* es_tensor sources only: the kernels compute in ES_F16 / ES_BF16 */ };
 enum { ES_ACT_NONE = 0, ES_ACT_SILU = 1, ES_ACT_GEGLU = 2 };
 
-#define ES_ABI_VERSION 4
+#define ES_ABI_VERSION 5
 int es_abi_version(void);
 /* sizeof the descriptor structs as compiled (0 gemm, 1 attn, 2 gn, 3 fusion, 4 ln, 5 xs): lets a binding verify its mirror */
 size_t es_sizeof_desc(int which);
@@ -318,6 +318,7 @@ void es_ctx_destroy(es_ctx* c);                         /* destroys its plans to
 int es_ctx_set_geometry(es_ctx* c, const es_ctx_geometry* g);
 int es_ctx_set_plan(es_ctx* c, int which, es_plan* p);  /* the context takes ownership of the plan */
 int es_ctx_bind(es_ctx* c, int slot, void* dev, size_t bytes);
+void* es_ctx_buffer(const es_ctx* c, int slot, size_t* bytes);   /* the memory bound to a slot (borrowed; NULL if unbound) */
 /* cond_scales: float[6] or NULL (keep); control guidance window (PL:419-427); use_graphs: 0 = re-issue launch by launch,
  * 1 = one hipGraph per plan (es_denoise_loop launches the step graph n times), 2 = additionally the preparation and all n
  * steps of es_denoise_loop as ONE graph (instantiated on first use per (n_steps, guidance scale)) */
@@ -330,6 +331,67 @@ es_plan* es_ctx_plan(es_ctx* c, int which);             /* borrowed */
  * the five launch lists and their pointer relocations.  No Python, torch or model code is needed to load or run it - this is
  * what stands in for SURVEY 8b's es_load_weights when the host cannot walk the model itself: build once, ship the image. */
 int es_ctx_load(const char* path, int device, es_ctx** out);
+/* ---------------------------------------------------------------------------------------------------------
+ * es_load_weights - build a context from the reference's state dicts, natively.
+ * Replaces, on the loading side: EdgeStyleMultiControlNetModel.from_pretrained + load_state_dict
+ * (model/edgestyle_multicontrolnet.py:173-211, 289-430), ControlLoRAModel.tie_weights / load_state_dict / fuse
+ * (model/controllora.py:600-632, 728-777) and the module construction of the diffusers UNet / ControlNet / AutoencoderKL
+ * the reference instantiates (test_text2image_pretrained_openpose.py:224-261): everything between "tensors of a
+ * checkpoint in host memory" and "a context es_denoise_loop can run".
+ * Tensors are described, not copied: `key` is the state-dict key exactly as the reference's checkpoints spell it
+ * (diffusers UNet2DConditionModel / ControlNetModel / AutoencoderKL names; `<linear>.lora_layer.{down,up}.weight` and
+ * `controlnet_down_blocks.*` / `controlnet_mid_block.*` for a ControlLoRA net, CL:600-606; `multi_controlnet_down_blocks.{i}.*`
+ * / `multi_controlnet_mid_block.*` for the fusion blocks, MC:173-193), `data` a HOST pointer to a C-contiguous tensor of
+ * `dtype` (ES_F32 / ES_F16 / ES_BF16) that stays valid during the call.  A safetensors file maps onto this directly.
+ * The builder folds W + B.A into private copies (the UNet's tensors are never modified), folds every LayerNorm into the Linear
+ * it feeds, ff.net.2 into proj_out and conv_shortcut behind conv2, packs everything into the kernels' layouts, lays out ONE
+ * device arena (weights, static buffers, activations with lifetime-based reuse, split-K workspace), records the five launch
+ * lists and binds the slots.  A missing key or a tensor of the wrong shape is an error naming the key.
+ * Scope: the reference's fused configuration (six condition slots over 1..3 distinct ControlNets + the UNet, 64-aligned
+ * channel widths, DDIM).  device -1: dry build - everything but the device allocation and the upload (plans keep
+ * arena-relative addresses; for inspection with es_ctx_plan / es_plan_export on a host without a GPU); device -2: the same
+ * with the arena in host memory, contents included (what tests read the packed weights from).  Neither can launch.
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct {
+  const char* key;
+  const void* data;                /* host memory, C-contiguous */
+  int64_t shape[4];
+  int32_t ndim;                    /* 1..4 */
+  int32_t dtype;                   /* ES_F32 | ES_F16 | ES_BF16 */
+} es_tensor;
+typedef struct { const es_tensor* tensors; int32_t count; } es_state_dict;
+enum { ES_NET_CONTROLNET = 0,        /* ControlNetModel: its own encoder + conv-stack conditioning embedding (the openpose net, TT:247-250) */
+       ES_NET_CONTROL_LORA_VAE = 1,  /* ControlLoRAModel(uses_vae): LoRA + zero-convs, encoder tied to the UNet, conditioned through the VAE (CL:28-42) */
+       ES_NET_CONTROL_LORA = 2 };    /* ControlLoRAModel with its own conv-stack conditioning embedding */
+typedef struct {
+  es_state_dict unet, vae, fusion;
+  es_state_dict controlnet[6];     /* the distinct nets */
+  int32_t controlnet_kind[6];      /* ES_NET_* */
+  int32_t n_controlnets;
+  int32_t net_of_cond[6];          /* which net serves condition slot i (TT:252-258: {0, 1, 2, 1, 2, 1}) */
+} es_weights;
+typedef struct {                   /* config.json of the SD1.5 checkpoints (README.md:131-135; MC:73-102 hard-codes their consequences) */
+  int32_t in_channels, out_channels;
+  int32_t n_blocks, block_out_channels[4], down_has_attn[4];
+  int32_t layers_per_block, num_heads, cross_attention_dim, norm_num_groups;
+  float norm_eps;
+  int32_t n_cond_embed, cond_embed_channels[4], conditioning_channels;
+  int32_t text_tokens;             /* 77 */
+  int32_t vae_n_blocks, vae_block_out_channels[4], vae_layers_per_block, vae_latent_channels, vae_norm_num_groups;
+  float vae_norm_eps, vae_scaling_factor;
+} es_model_config;
+/* g: B, cfg, h, w, n_conds (6), n_steps, dtype are read; latent_channels / latent_pad are derived from the config */
+int es_load_weights(const es_weights* w, const es_model_config* cfg, const es_ctx_geometry* g, int device, es_ctx** out);
+/* The launch planner the builders share (host-only): the N tile (bn), split-K factor and LDS ring depth es_load_weights picks for
+ * an es_conv_gemm launch of M output pixels among the candidate tiles `bns` (edgestyle_amd/ops.py plan_gemm makes the same
+ * choice for the Python host; tests hold the two against each other), and whether a plain linear layer takes es_linear_xs. */
+int es_plan_gemm_choice(long long M, int rows_padded, int kpad, int geglu, const int* bns, int n_bns, int allow_split,
+                        int* bn, int* splitk, int* stages);
+int es_linear_xs_eligible(long long M, int ksize, int kpad, int cin, int ctail, int cout, int geglu);
+/* es_plan_set_dry(1): while a plan records on this thread, calls are validated and recorded but nothing is launched (the
+ * pointers need not exist yet).  Returns the previous setting. */
+int es_plan_set_dry(int on);
+
 /* run ONE plan of the context on `stream` (guidance_scale: pointer to the CFG scale for the scheduler call of
  * ES_PLAN_STEP, or NULL = as recorded): single-stepping a prepared loop */
 int es_ctx_launch_plan(es_ctx* c, int which, const float* guidance_scale, void* stream);

@@ -155,3 +155,160 @@ def psnr(a, b, peak=1.0):
     import math
     mse = float(((a.float().cpu() - b.float().cpu()) ** 2).mean())
     return 10 * math.log10(peak * peak / max(mse, 1e-20))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# The Python builder's launch lists WITHOUT a GPU: the library's dry recorder (es_plan_set_dry) validates and records
+# every C-ABI call and launches nothing, so the model walk of edgestyle_amd (engine.py / models.py / pipeline._Loop /
+# native.py) can run on host tensors.  Used to hold es_load_weights' plans against the Python host's, call by call.
+# ----------------------------------------------------------------------------------------------------------------
+def python_dry_context(ws, ucfg, vcfg, B=1, guidance=True, T=6, dtype=torch.float16):
+    """-> (lib, es_ctx) holding the five plans the Python host records for this configuration (addresses are host
+    addresses of scratch tensors: only good for plan_records)."""
+    import ctypes as Ct
+    from types import SimpleNamespace
+    from edgestyle_amd import lib as L, ops, models as M, native as Nat
+    from edgestyle_amd.pipeline import EdgeStyleStableDiffusionControlNetPipeline, _Loop
+    lib = L.load()
+    saved = (ops._stream, M._HipModel._require_gpu, ops._get_workspace)
+    ops._stream = lambda: None
+    M._HipModel._require_gpu = lambda self: None
+    wsb = {}
+
+    def get_ws(nbytes, device):
+        t = wsb.get("t")
+        if t is None or t.numel() * 4 < nbytes:
+            t = wsb["t"] = torch.empty(max(nbytes // 4, 1), dtype=torch.float32)
+        return t
+    ops._get_workspace = get_ws
+    try:
+        runner = M.StepRunner.from_state_dicts(ws, ucfg, dtype, "cpu")
+        vae = M.AutoencoderKL(ws["vae"], vcfg, dtype)
+        for n in runner.controlnet.nets:
+            if isinstance(n, M.ControlLoRAModel):
+                n.set_autoencoder(vae)
+        pipe = EdgeStyleStableDiffusionControlNetPipeline(vae=vae, unet=runner.unet, controlnet=runner.controlnet)
+        pipe._runner = runner
+        h = w = ucfg.sample_size
+        loop = _Loop(pipe, B, guidance, h, w)
+        N, k, nn = loop.N, runner.kmax, 6
+        loop.t_table = torch.zeros((T, k * N)); loop.scale_table = torch.zeros((T, nn)); loop.coef = torch.zeros((T, 4))
+        loop.ts_dev = torch.zeros((T,)); loop.guidance_scale, loop.steps = (7.5 if guidance else 1.0), T
+        eng = SimpleNamespace(cond_img=[None] * nn, cond_noise=[None] * nn, dtype=dtype)
+        conds_fn = Nat.NativeEngine._conds_fn(eng, pipe, loop, B, guidance, h, w)
+        image = {}
+
+        def prep():
+            runner.state = loop.state
+            runner.set_context(loop.ehs)
+            runner.set_conds(loop.conds)
+            runner.set_time_table(loop.ts_dev, N)
+
+        def generic():
+            runner.state = loop.state
+            runner.set_context(loop.ehs)
+            runner.set_conds(loop.conds)
+            runner.step(loop.model_in, loop.t_rows, loop.conds, [1.0] * nn, loop.scales_cur, out=loop.noise, step_idx=None)
+
+        def decode():
+            dec = vae.decode_nhwc(loop.model_in[:B], unscaled_latents=True)
+            image["t"] = ops.nhwc_to_nchw(dec, channels=3, scale=0.5, shift=0.5, clamp01=True)
+        ctx = Ct.c_void_p()
+        L.check(lib.es_ctx_create(0, Ct.byref(ctx)), "es_ctx_create")
+        keep = [runner, vae, pipe, loop, eng, image, wsb]
+        for which, fn in ((L.PLAN_PREP, prep), (L.PLAN_STEP, loop.one_step), (L.PLAN_STEP_GENERIC, generic), (L.PLAN_DECODE, decode),
+                          (L.PLAN_CONDS, conds_fn)):
+            plan = Ct.c_void_p(lib.es_plan_create())
+            L.check(lib.es_plan_begin_record(plan), "begin")
+            lib.es_plan_set_dry(1)
+            try:
+                fn()
+            finally:
+                lib.es_plan_set_dry(0)
+                lib.es_plan_end_record(plan)
+            L.check(lib.es_ctx_set_plan(ctx, which, plan), "set_plan")
+        return lib, ctx, keep
+    finally:
+        ops._stream, M._HipModel._require_gpu, ops._get_workspace = saved
+
+
+def describe_record(kind, rec):
+    """A recorded call as text (diagnostics of a plan mismatch)."""
+    import ctypes as Ct
+    from edgestyle_amd import lib as L
+    st = {1: L.GemmDesc, 2: L.XsDesc, 3: L.AttnDesc, 4: L.GnDesc, 6: L.LnDesc, 7: L.FusionDesc, 8: L.FusionDesc}.get(kind)
+    if st is None or len(rec) < Ct.sizeof(st):
+        return f"kind {kind}: {rec.hex()}"
+    d = st.from_buffer_copy(rec[:Ct.sizeof(st)])
+    out = []
+    for name, tp in st._fields_:
+        v = getattr(d, name)
+        if hasattr(v, "__len__"):
+            v = list(v)
+        out.append(f"{name}={v}")
+    return f"kind {kind}: " + " ".join(out)
+
+
+def diff_plans(lib, ctx_a, ctx_b, which):
+    """None if the two contexts hold the same calls in plan `which` (pointer fields compared as null / set), else a text."""
+    from edgestyle_amd.native import plan_records
+    a, b = plan_records(lib, ctx_a, which), plan_records(lib, ctx_b, which)
+    for i, (ra, rb) in enumerate(zip(a, b)):
+        if ra != rb:
+            return f"plan {which}: call {i} of {len(a)} / {len(b)} differs\n  A {describe_record(*ra)}\n  B {describe_record(*rb)}"
+    if len(a) != len(b):
+        return f"plan {which}: {len(a)} vs {len(b)} calls"
+    return None
+
+
+def plan_constants(lib, ctx, which):
+    """The persistent data every call of a plan reads - packed weights, biases, LayerNorm column sums, GroupNorm / fusion
+    parameters - as host bytes, in call order.  Only for contexts whose recorded addresses are HOST addresses
+    (python_dry_context, es_load_weights(device=-2))."""
+    import ctypes as Ct
+    import numpy as np
+    from edgestyle_amd import lib as L
+    pl = lib.es_ctx_plan(ctx, which)
+    n = lib.es_plan_export(pl, None, 0)
+    raw = (Ct.c_char * n)()
+    lib.es_plan_export(pl, raw, n)
+    img = bytes(raw)
+    n_ops = int.from_bytes(img[:8], "little")
+    blob0 = 16 + 24 * n_ops
+    out = []
+
+    def rd(addr, nbytes):
+        if addr:
+            out.append(Ct.string_at(addr, nbytes))
+    for i in range(n_ops):
+        kind, off, nb = (int.from_bytes(img[16 + 24 * i + 8 * j:24 + 24 * i + 8 * j], "little", signed=True) for j in range(3))
+        rec = img[blob0 + off:blob0 + off + nb]
+        if kind == 1:
+            d = L.GemmDesc.from_buffer_copy(rec)
+            ws_ = [d.w] if d.ngroups <= 1 else list(d.w_g)[:d.ngroups]
+            bs_ = [d.bias] if d.ngroups <= 1 else list(d.bias_g)[:d.ngroups]
+            cs_ = [d.ln_colsum] if d.ngroups <= 1 else list(d.ln_colsum_g)[:d.ngroups]
+            for w in ws_:
+                rd(w, d.rows_padded * d.Kpad * 2)
+            for b in bs_ + cs_:
+                rd(b, d.rows_padded * 4)
+        elif kind == 2:
+            d = L.XsDesc.from_buffer_copy(rec)
+            for w in ([d.w] if d.ngroups <= 1 else list(d.w_g)[:d.ngroups]):
+                rd(w, d.rows_padded * d.K * 2)
+            for b in ([d.bias] if d.ngroups <= 1 else list(d.bias_g)[:d.ngroups]):
+                rd(b, d.rows_padded * 4)
+        elif kind == 4:
+            d = L.GnDesc.from_buffer_copy(rec)
+            gs = [d.gamma, d.beta] if d.ngroups <= 1 else list(d.gamma_g)[:d.ngroups] + list(d.beta_g)[:d.ngroups]
+            for g in gs:
+                rd(g, (d.C1 + d.C2) * 4)
+        elif kind == 8:
+            sz = Ct.sizeof(L.FusionDesc)
+            for k in range(nb // sz):
+                d = L.FusionDesc.from_buffer_copy(rec[k * sz:(k + 1) * sz])
+                c, hw = d.C, d.HW
+                for p, nbytes in ((d.w1, c * 24), (d.b1, c * 12), (d.g1, hw * c * 6), (d.be1, hw * c * 6), (d.w2, c * 12), (d.b2, c * 4),
+                                  (d.g2, hw * c * 2), (d.be2, hw * c * 2), (d.w3, c * 4), (d.b3, c * 4)):
+                    rd(p, nbytes)
+    return out

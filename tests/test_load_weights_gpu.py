@@ -1,0 +1,140 @@
+"""es_load_weights (include/edgestyle_hip.h): a context built by the library itself from raw state-dict tensors -
+no model walk in Python - driven through ctypes with raw device pointers, against the context the Python host builds
+(NativeEngine) and the pipeline: bit for bit.  What is replaced on the loading side: MC:173-211, 289-430 (fusion weights,
+per-net directories), CL:600-632, 728-777 (tie_weights, LoRA state dict, fuse) and the diffusers module construction of
+TT:224-261."""
+import ctypes as C
+import dataclasses
+
+import pytest
+import torch
+
+from edgestyle_amd import config as Cfg, lib as L
+from tests.helpers import make_weights, quantize, diff_plans
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def both():
+    from edgestyle_amd.models import StepRunner, AutoencoderKL
+    from edgestyle_amd.pipeline import EdgeStyleStableDiffusionControlNetPipeline
+    from edgestyle_amd.native import NativeEngine, NativeContext
+    ucfg, vcfg = dataclasses.replace(Cfg.tiny_unet(), sample_size=64), Cfg.tiny_vae()
+    ws = {k: quantize(v) for k, v in make_weights(ucfg, vcfg, seed=5).items()}
+    runner = StepRunner.from_state_dicts(ws, ucfg, torch.float16, DEV)
+    vae = AutoencoderKL(ws["vae"], vcfg).to(DEV)
+    for n in runner.controlnet.nets:
+        if getattr(n.config, "uses_vae", False):
+            n.set_autoencoder(vae)
+    pipe = EdgeStyleStableDiffusionControlNetPipeline(vae=vae, unet=runner.unet, controlnet=runner.controlnet).to(DEV)
+    T = 5
+    eng = NativeEngine(pipe, batch_size=1, num_inference_steps=T)
+    nat = NativeContext(ws, ucfg, vcfg, batch_size=1, guidance=True, num_inference_steps=T, device=0)
+    nat.set_alphas_cumprod(pipe.scheduler.alphas_cumprod)      # torch's cumprod bits (the library's own table is equal to 1e-6)
+    yield pipe, eng, nat, ws, ucfg, vcfg, T
+    nat.close()
+    eng.close()
+
+
+def _inputs(ucfg, vcfg, seed):
+    g = torch.Generator().manual_seed(seed)
+    s, c0 = ucfg.sample_size, ucfg.block_out_channels[0]
+    px = s * vcfg.scale
+    lat = torch.randn(1, 4, s, s, generator=g)
+    pe = (torch.randn(1, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+    ne = (torch.randn(1, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+    conds = [(torch.randn(1, c0, s, s, generator=g) * 0.3).half().float() for _ in range(6)]
+    imgs = [(torch.rand(1, 3, px, px, generator=g) * (2 if i % 2 == 0 else 1) - (1 if i % 2 == 0 else 0)).half().float() for i in range(6)]
+    noise = [torch.randn(2, vcfg.latent_channels, s, s, generator=g).half().float() if i % 2 == 0 else None for i in range(6)]
+    return lat, pe, ne, conds, imgs, noise
+
+
+def test_the_two_builders_record_the_same_calls(both):
+    pipe, eng, nat, ws, ucfg, vcfg, T = both
+    lib = L.load()
+    for which in range(5):
+        assert diff_plans(lib, eng.ctx, nat.ctx, which) is None
+
+
+def test_es_denoise_step_of_a_natively_built_context_equals_the_python_step_bitwise(both):
+    from edgestyle_amd.models import _as_nhwc
+    pipe, eng, nat, ws, ucfg, vcfg, T = both
+    lat, pe, ne, conds, _, _ = _inputs(ucfg, vcfg, 31)
+    x = torch.cat([lat, lat]).half().float()
+    ehs = torch.cat([ne, pe])
+    sample = _as_nhwc(x, torch.float16, DEV, pipe.unet.engine.in_pad).contiguous()
+    ehs_d = ehs.to(DEV, torch.float16).contiguous()
+    cond_d = [_as_nhwc(c.repeat(2, 1, 1, 1), torch.float16, DEV).contiguous() for c in conds]
+    scales = [1.0, 0.8, 1.0, 1.0, 0.5, 1.0]
+    want = eng.denoise_step(sample, 441.0, ehs_d, cond_d, scales).clone()
+    for use_graphs in (True, False):
+        nat.set_options(use_graphs=use_graphs)
+        got = nat.denoise_step(sample, 441.0, ehs_d, cond_d, scales)
+        torch.cuda.synchronize()
+        assert torch.isfinite(got.float()).all() and float(got.float().abs().max()) > 1e-3
+        assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+
+
+def test_rgb_images_to_decoded_image_through_the_native_context_equal_the_pipeline_bitwise(both):
+    """es_prepare_conds -> es_denoise_loop -> es_vae_decode of the natively built context == pipe(image=rgb, cond_noise=...)."""
+    pipe, eng, nat, ws, ucfg, vcfg, T = both
+    lat, pe, ne, _, imgs, noise = _inputs(ucfg, vcfg, 37)
+    gs = 6.0
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=imgs, latents=lat, guidance_scale=gs, num_inference_steps=T,
+              cond_noise=noise)
+    want_lat = pipe(output_type="latent", **kw).images.clone()
+    want_img = pipe(output_type="pt", **kw).images.clone()
+    ehs = torch.cat([ne, pe]).to(DEV, torch.float16).contiguous()
+    x = lat.permute(0, 2, 3, 1).contiguous().to(DEV)
+    ts = pipe.scheduler.set_timesteps(T).tolist()
+    for use_graphs in (True, False, 2):
+        nat.set_options(use_graphs=use_graphs)
+        nat.prepare_conds([im.to(DEV) for im in imgs], [None if z is None else z.to(DEV) for z in noise])
+        got = nat.denoise_loop(x.clone(), ehs, gs, ts)
+        img = nat.vae_decode(got)
+        torch.cuda.synchronize()
+        assert torch.equal(got.permute(0, 3, 1, 2), want_lat), float((got.permute(0, 3, 1, 2) - want_lat).abs().max())
+        assert torch.equal(img, want_img)
+    # the condition embeddings themselves, slot by slot, against the Python host's context
+    eng.prepare_conds([im.to(DEV) for im in imgs], [None if z is None else z.to(DEV) for z in noise])
+    torch.cuda.synchronize()
+    lib = L.load()
+    for i in range(6):
+        nb = C.c_size_t(0)
+        p = lib.es_ctx_buffer(nat.ctx, L.BUF_COND0 + i, C.byref(nb))
+        mine = torch.empty(nb.value // 2, dtype=torch.float16, device=DEV)
+        L.check(lib.es_memcpy(C.c_void_p(mine.data_ptr()), C.c_void_p(p), nb.value, None), "es_memcpy")
+        torch.cuda.synchronize()
+        assert torch.equal(mine, eng.loop.conds[i].reshape(-1))
+
+
+def test_a_context_without_guidance_and_two_images_per_call(both):
+    """B = 2, no classifier-free guidance: another geometry through both builders."""
+    from edgestyle_amd.native import NativeContext
+    pipe, eng, nat, ws, ucfg, vcfg, T = both
+    g = torch.Generator().manual_seed(41)
+    s, c0 = ucfg.sample_size, ucfg.block_out_channels[0]
+    lat = torch.randn(2, 4, s, s, generator=g)
+    pe = (torch.randn(2, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+    conds = [(torch.randn(1, c0, s, s, generator=g) * 0.3).half().float() for _ in range(6)]
+    want = pipe(prompt_embeds=pe, image=conds, latents=lat, guidance_scale=1.0, num_inference_steps=3, output_type="latent").images.clone()
+    n2 = NativeContext(ws, ucfg, vcfg, batch_size=2, guidance=False, num_inference_steps=3, device=0)
+    n2.set_alphas_cumprod(pipe.scheduler.alphas_cumprod)
+    try:
+        from edgestyle_amd.models import _as_nhwc
+        lib = L.load()
+        for i, c in enumerate(conds):                          # pre-embedded conditions straight into the slots
+            src = _as_nhwc(c.repeat(2, 1, 1, 1), torch.float16, DEV).contiguous()
+            nb = C.c_size_t(0)
+            p = lib.es_ctx_buffer(n2.ctx, L.BUF_COND0 + i, C.byref(nb))
+            assert nb.value == src.numel() * 2
+            L.check(lib.es_memcpy(C.c_void_p(p), C.c_void_p(src.data_ptr()), nb.value, None), "es_memcpy")
+        torch.cuda.synchronize()
+        x = lat.permute(0, 2, 3, 1).contiguous().to(DEV)
+        got = n2.denoise_loop(x, pe.to(DEV, torch.float16).contiguous(), 1.0, pipe.scheduler.set_timesteps(3).tolist())
+        torch.cuda.synchronize()
+        assert torch.equal(got.permute(0, 3, 1, 2), want)
+    finally:
+        n2.close()
