@@ -1290,6 +1290,19 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
     B.dt = g->dtype;
     M.B_ = g->B; M.N = g->cfg ? 2 * g->B : g->B; M.T_ = g->n_steps; M.h = g->h; M.w = g->w; M.nn = 6;
     const int N = M.N, TS = M.T_, h = g->h, w = g->w, Bn = g->B;
+    {   // the groups of the lockstep pass: nets that share weights run as one batched chain; every group must tile
+      int cnt[6] = {};
+      for (int p = 0; p < 6; ++p) {
+        const int ni = wts->net_of_cond[p];
+        if (ni < 0 || ni >= wts->n_controlnets) fail("es_load_weights: net_of_cond names a ControlNet that was not given");
+        ++cnt[ni];
+      }
+      const int hw_min = (h >> (u.nb - 1)) * (w >> (u.nb - 1));
+      for (int i = 0; i <= wts->n_controlnets; ++i) {
+        const long long n = (i < wts->n_controlnets ? (long long)cnt[i] : 1) * N;
+        if (n && (n * hw_min) % BM) fail("es_load_weights: the groups of the lockstep pass do not tile in 128-pixel units at this latent size (the Python host falls back to serial chains; this builder does not)");
+      }
+    }
     // ---- state dicts
     M.d_unet.init(wts->unet, "UNet"); M.d_vae.init(wts->vae, "VAE"); M.d_fusion.init(wts->fusion, "fusion");
     for (int i = 0; i < wts->n_controlnets; ++i) M.d_cn[i].init(wts->controlnet[i], ("ControlNet " + std::to_string(i)).c_str());
@@ -1337,10 +1350,6 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
     M.ntot = 0; M.width = 0;
     for (size_t e = 0; e < M.encs.size(); ++e) { M.ntot += M.counts[e]; M.width = std::max(M.width, M.encs[e]->tproj_width()); }
     M.ncn = M.ntot - N;
-    {
-      const int hw_min = (h >> (u.nb - 1)) * (w >> (u.nb - 1));
-      for (int n : M.counts) if (((long long)n * hw_min) % BM) fail("es_load_weights: the groups of the lockstep pass do not tile in 128-pixel units at this latent size (the Python host falls back to serial chains; this builder does not)");
-    }
     // ---- static buffers
     const int Lc = u.in_ch, Lp = M.unet.in_pad, c0 = u.ch[0], sc = v.scale();
     M.latents = B.persistent_t(Bn, h, w, Lc, 4);

@@ -398,6 +398,45 @@ def test_native_abi_full_width_rgb_to_image_equals_pipeline_bitwise(full):
         eng.close()
 
 
+def test_es_load_weights_full_width_context_equals_pipeline_bitwise(full):
+    """SURVEY 8b's es_load_weights at SD1.5 width: the library builds the context itself from the raw state dicts (1.3 G
+    parameters: rank-32 LoRA folds, LayerNorm / proj_out / shortcut folds, packing, arena layout, five launch lists - no model
+    walk in Python) and RGB condition images -> es_prepare_conds -> es_denoise_loop -> es_vae_decode through it reproduce
+    pipe(image=rgb, cond_noise=...) bit for bit.  The golden fixture of the same call (oracle, 50 steps) is covered through the
+    pipeline above; this ties the natively built context to it."""
+    import time
+    from edgestyle_amd.native import NativeContext
+    pipe = full["pipe"]
+    for net in pipe.controlnet.nets:
+        if getattr(net.config, "uses_vae", False):
+            net.set_autoencoder(pipe.vae)
+    imgs, noise, lat, pe, ne = H.full_rgb_inputs(seed=52)
+    T, gs = 3, 7.5
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=imgs, latents=lat, guidance_scale=gs, num_inference_steps=T,
+              cond_noise=noise)
+    want_lat = pipe(output_type="latent", **kw).images.clone()
+    want_img = pipe(output_type="pt", **kw).images.clone()
+    t0 = time.time()
+    nat = NativeContext(full["ws"], full["ucfg"], full["vcfg"], batch_size=1, guidance=True, num_inference_steps=T, device=0)
+    build_s = time.time() - t0
+    try:
+        nat.set_alphas_cumprod(pipe.scheduler.alphas_cumprod)
+        ehs = torch.cat([ne, pe]).to(DEV, torch.float16).contiguous()
+        x = lat.permute(0, 2, 3, 1).contiguous().to(DEV)
+        ts = pipe.scheduler.set_timesteps(T).tolist()
+        for use_graphs in (True, 2):
+            nat.set_options(use_graphs=use_graphs)
+            nat.prepare_conds([im.to(DEV) for im in imgs], [None if z is None else z.to(DEV) for z in noise])
+            got = nat.denoise_loop(x.clone(), ehs, gs, ts)
+            img = nat.vae_decode(got)
+            torch.cuda.synchronize()
+            assert torch.equal(got.permute(0, 3, 1, 2), want_lat), float((got.permute(0, 3, 1, 2) - want_lat).abs().max())
+            assert torch.equal(img, want_img)
+        record("es_load_weights_full_width", build_seconds=round(build_s, 1), plan_step_calls=nat.plan_size(2), bitwise_equal_to_pipeline=True)
+    finally:
+        nat.close()
+
+
 def test_config4_batch4_768_bf16_vs_oracle(full96):
     """BASELINE configs[4] at ITS batch size: 768x768, bf16, batch 4, CFG 7.5, 2 DDIM steps, graph-replayed, VAE decode
     included - every image against the fp32 oracle pipeline of the same request (the oracle runs the four requests one by

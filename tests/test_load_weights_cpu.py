@@ -1,0 +1,148 @@
+"""es_load_weights without a GPU (include/edgestyle_hip.h; csrc/builder.hip): the native builder's host logic - key lookup and
+shape checks, LoRA / LayerNorm / proj_out / shortcut folds, weight packing, the launch planner, the model walk - against the
+Python host (edgestyle_amd/engine.py, models.py, ops.py) run on the library's dry recorder: the same calls in the same order
+with the same arguments, and the same bytes behind every weight pointer.  (The GPU side of the same comparison - outputs bit for
+bit - is tests/test_load_weights_gpu.py.)"""
+import ctypes as C
+import dataclasses
+import itertools
+
+import pytest
+import torch
+
+from edgestyle_amd import config as Cfg, lib as L, ops
+from edgestyle_amd.native import NativeContext
+from tests.helpers import make_weights, quantize, python_dry_context, diff_plans, plan_constants
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    ucfg, vcfg = dataclasses.replace(Cfg.tiny_unet(), sample_size=64), Cfg.tiny_vae()
+    ws = {k: quantize(v) for k, v in make_weights(ucfg, vcfg, seed=3).items()}
+    return ucfg, vcfg, ws
+
+
+def test_launch_planner_of_the_library_equals_the_python_hosts():
+    """es_plan_gemm_choice == ops.plan_gemm over the GEMM shapes of the model (all levels, batch 1..8, every candidate set)."""
+    lib = L.load()
+    bn, sk, st = C.c_int(), C.c_int(), C.c_int()
+    n = 0
+    Ms = [77 * 2, 154 * 3, 64, 256, 1024, 2048, 4096, 8192, 12288, 16384, 24576, 32768, 57344, 65536, 131072, 229376, 458752, 1 << 20]
+    rows = [128, 256, 320, 384, 640, 1280, 1920, 2560, 3840, 5120, 10240]
+    ks = [64, 320, 640, 1280, 2880, 3200, 5760, 6400, 8640, 11520, 17280, 23040]
+    cands = [(160, 128), (320, 160, 128, 64), (160, 128, 64), (320, 160, 128)]
+    for M, r, k, cand, split in itertools.product(Ms, rows, ks, cands, (True, False)):
+        try:
+            want = ops.plan_gemm(M, r, k, False, bns=cand, allow_split=split)
+        except L.EdgeStyleHipError:
+            want = None
+        arr = (C.c_int * len(cand))(*cand)
+        rc = lib.es_plan_gemm_choice(M, r, k, 0, arr, len(cand), int(split), C.byref(bn), C.byref(sk), C.byref(st))
+        got = None if rc else (bn.value, sk.value, st.value)
+        assert got == want, (M, r, k, cand, split, got, want)
+        n += 1
+    assert n > 10000
+    arr = (C.c_int * 2)(160, 128)
+    assert lib.es_plan_gemm_choice(4096, 2560, 320, 1, arr, 2, 1, C.byref(bn), C.byref(sk), C.byref(st)) == 0
+    assert (bn.value, sk.value, st.value) == ops.plan_gemm(4096, 2560, 320, True)
+
+
+def test_short_k_kernel_policy_of_the_library_equals_the_python_hosts():
+    lib = L.load()
+    for M, K, cout, geglu in itertools.product([1024, 8192, 16384, 32768, 57344, 458752], [320, 640, 1280, 768], [320, 640, 960, 1920, 2560, 5120],
+                                               [False, True]):
+        pw = ops.PackedWeight(w=torch.empty(0, K), bias=None, cout=cout, cin=K, ksize=1, bn=128, geglu=geglu)
+        assert bool(lib.es_linear_xs_eligible(M, 1, K, K, 0, cout, int(geglu))) == ops.xs_eligible(M, pw, None, None, 1), (M, K, cout, geglu)
+
+
+@pytest.mark.parametrize("B,guidance,T", [(1, True, 6), (2, False, 3)])
+def test_native_builder_records_the_python_hosts_calls_on_the_same_weight_bytes(tiny, B, guidance, T):
+    ucfg, vcfg, ws = tiny
+    lib, pctx, keep = python_dry_context(ws, ucfg, vcfg, B, guidance, T)
+    nat = NativeContext(ws, ucfg, vcfg, batch_size=B, guidance=guidance, num_inference_steps=T, device=-2)
+    try:
+        for which in range(5):
+            assert lib.es_ctx_plan_size(pctx, which) == nat.plan_size(which) > 20
+            assert diff_plans(lib, pctx, nat.ctx, which) is None
+            a, b = plan_constants(lib, pctx, which), plan_constants(lib, nat.ctx, which)
+            assert len(a) == len(b) and sum(map(len, a)) > 1 << 20
+            assert all(x == y for x, y in zip(a, b)), [i for i, (x, y) in enumerate(zip(a, b)) if x != y][:8]
+        assert lib.es_plan_count(lib.es_ctx_plan(nat.ctx, L.PLAN_STEP), 8) == 1          # ONE es_fusion_blocks call per step
+    finally:
+        nat.close()
+        lib.es_ctx_destroy(pctx)
+
+
+def test_sources_in_fp16_and_bf16_compute_type(tiny):
+    """Checkpoints stored in fp16 (the usual case) describe the same values; a bf16 context builds too."""
+    ucfg, vcfg, ws = tiny
+    lib = L.load()
+    a = NativeContext(ws, ucfg, vcfg, num_inference_steps=4, device=-2)
+    ws16 = {k: {kk: vv.half() for kk, vv in v.items()} for k, v in ws.items()}         # exact: the fixture is fp16-rounded
+    b = NativeContext(ws16, ucfg, vcfg, num_inference_steps=4, device=-2)
+    c = NativeContext(ws, ucfg, vcfg, num_inference_steps=4, device=-1, dtype=torch.bfloat16)
+    try:
+        assert plan_constants(lib, a.ctx, L.PLAN_STEP) == plan_constants(lib, b.ctx, L.PLAN_STEP)
+        assert c.plan_size(L.PLAN_STEP) == a.plan_size(L.PLAN_STEP)
+    finally:
+        for x in (a, b, c):
+            x.close()
+
+
+def test_missing_keys_wrong_shapes_and_unsupported_requests_are_named(tiny):
+    ucfg, vcfg, ws = tiny
+
+    def build(ws_, **kw):
+        return NativeContext(ws_, ucfg, vcfg, num_inference_steps=3, device=-1, **kw)
+
+    def without(name, key):
+        d = dict(ws)
+        d[name] = {k: v for k, v in ws[name].items() if k != key}
+        return d
+    with pytest.raises(L.EdgeStyleHipError, match="missing key 'mid_block.resnets.1.conv2.weight' in the UNet state dict"):
+        build(without("unet", "mid_block.resnets.1.conv2.weight"))
+    with pytest.raises(L.EdgeStyleHipError, match="missing key 'controlnet_mid_block.weight' in the ControlNet 2"):
+        build(without("lora1", "controlnet_mid_block.weight"))
+    with pytest.raises(L.EdgeStyleHipError, match="missing key 'multi_controlnet_mid_block.third_conv.bias' in the fusion"):
+        build(without("fusion", "multi_controlnet_mid_block.third_conv.bias"))
+    with pytest.raises(L.EdgeStyleHipError, match="missing key 'decoder.conv_out.weight' in the VAE"):
+        build(without("vae", "decoder.conv_out.weight"))
+    # a LoRA pair with only one half
+    with pytest.raises(L.EdgeStyleHipError, match="lora_layer.up.weight"):
+        build(without("lora0", "time_embedding.linear_1.lora_layer.up.weight"))
+    bad = dict(ws)
+    bad["fusion"] = dict(ws["fusion"])
+    k = "multi_controlnet_down_blocks.0.first_normalization.weight"
+    bad["fusion"][k] = ws["fusion"][k][:, :32]
+    with pytest.raises(L.EdgeStyleHipError, match="size mismatch for 'multi_controlnet_down_blocks.0.first_normalization.weight'"):
+        build(bad)
+    bad = dict(ws)
+    bad["unet"] = dict(ws["unet"])
+    bad["unet"]["conv_norm_out.weight"] = ws["unet"]["conv_norm_out.weight"][:32]
+    with pytest.raises(L.EdgeStyleHipError, match="size mismatch for 'conv_norm_out.weight'"):
+        build(bad)
+    with pytest.raises(L.EdgeStyleHipError, match="net_of_cond"):
+        build(ws, net_of_cond=(0, 1, 2, 1, 3, 1))
+    # 16x16 latents: the groups of the lockstep pass do not tile in 128-pixel units (the Python host falls back to serial chains)
+    with pytest.raises(L.EdgeStyleHipError, match="do not tile"):
+        NativeContext(ws, dataclasses.replace(ucfg, sample_size=16), vcfg, num_inference_steps=3, device=-1)
+    with pytest.raises(L.EdgeStyleHipError, match="host tensors"):
+        build(dict(ws, unet={k: v.double() for k, v in ws["unet"].items()}))
+
+
+def test_dry_recording_validates_but_does_not_launch():
+    """es_plan_set_dry: a recording thread's calls are checked and recorded, nothing runs (no GPU here) - and a call the
+    kernel would reject is rejected and NOT recorded."""
+    lib = L.load()
+    plan = C.c_void_p(lib.es_plan_create())
+    assert lib.es_plan_begin_record(plan) == 0
+    lib.es_plan_set_dry(1)
+    try:
+        buf = torch.zeros(64)
+        assert lib.es_fill_f32(C.c_void_p(buf.data_ptr()), 1.0, 64, None) == 0
+        assert lib.es_add(C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr()), 7, L.ES_F16, None) != 0
+        assert lib.es_plan_size(plan) == 1 and float(buf.sum()) == 0.0
+    finally:
+        assert lib.es_plan_set_dry(0) == 1
+        lib.es_plan_end_record(plan)
+        lib.es_plan_destroy(plan)
