@@ -138,3 +138,61 @@ def test_a_context_without_guidance_and_two_images_per_call(both):
         assert torch.equal(got.permute(0, 3, 1, 2), want)
     finally:
         n2.close()
+
+
+def test_compiled_host_from_checkpoint_directories_to_image(both, tmp_path):
+    """examples/checkpoint_host.cpp: a C++ program that memory-maps safetensors files in the reference's directory layout
+    (MC:213-282, 380-398: fusion blocks + controlnet_{0,1}/ of LoRA nets; diffusers dirs for UNet / VAE / openpose), hands the
+    tensors to es_load_weights and runs conditions -> loop -> decode.  No Python in that process; its output equals the
+    pipeline's here bit for bit."""
+    import os
+    import shutil
+    import subprocess
+    import numpy as np
+    from edgestyle_amd import weights as W
+    pipe, eng, nat, ws, ucfg, vcfg, T = both
+    lat, pe, ne, _, imgs, noise = _inputs(ucfg, vcfg, 43)
+    gs = 5.5
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=imgs, latents=lat, guidance_scale=gs, num_inference_steps=T,
+              cond_noise=noise)
+    want_lat = pipe(output_type="latent", **kw).images.float().cpu()
+    want_img = pipe(output_type="pt", **kw).images.float().cpu()
+    # the checkpoint directories, written the way the reference's save_pretrained methods lay them out
+    d = {k: str(tmp_path / k) for k in ("unet", "vae", "multi", "openpose")}
+    W.save_model_dir(d["unet"], ws["unet"], ucfg.to_dict())
+    W.save_model_dir(d["vae"], {k: v.half() for k, v in ws["vae"].items()}, vcfg.to_dict())          # an fp16 checkpoint
+    W.save_model_dir(d["openpose"], ws["openpose"], ucfg.to_dict())
+    W.save_model_dir(d["multi"], ws["fusion"])
+    W.save_model_dir(os.path.join(d["multi"], "controlnet_0"), ws["lora0"], dict(ucfg.to_dict(), uses_vae=True, lora_linear_rank=4))
+    W.save_model_dir(os.path.join(d["multi"], "controlnet_1"), ws["lora1"], dict(ucfg.to_dict(), uses_vae=True, lora_linear_rank=4))
+    s = ucfg.sample_size
+    Hpx = s * vcfg.scale
+    with open(str(tmp_path / "in.bin"), "wb") as f:
+        f.write(np.array([1, s, s, 4, ucfg.cross_attention_dim, 6, T] + [int(z is not None) for z in noise], dtype=np.int32).tobytes())
+        f.write(np.float32(gs).tobytes())
+        f.write(pipe.scheduler.set_timesteps(T).float().numpy().tobytes())
+        f.write(lat.permute(0, 2, 3, 1).contiguous().numpy().astype(np.float32).tobytes())
+        f.write(torch.cat([ne, pe]).half().numpy().tobytes())
+        for im, nz in zip(imgs, noise):
+            f.write(im.numpy().astype(np.float32).tobytes())
+            if nz is not None:
+                f.write(nz.numpy().astype(np.float32).tobytes())
+        ac = pipe.scheduler.alphas_cumprod.float().numpy()
+        f.write(np.int32(len(ac)).tobytes())
+        f.write(ac.tobytes())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "checkpoint_host")
+    libdir = os.path.join(root, "edgestyle_amd", "lib")
+    c = subprocess.run([hipcc, "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "checkpoint_host.cpp"),
+                        "-L" + libdir, "-ledgestyle_hip", "-Wl,-rpath," + libdir, "-o", exe], capture_output=True, text=True, timeout=600)
+    assert c.returncode == 0, c.stderr[-2000:]
+    r = subprocess.run([exe, d["unet"], d["vae"], d["multi"], d["openpose"], str(tmp_path / "in.bin"), str(tmp_path / "out.bin")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = np.fromfile(str(tmp_path / "out.bin"), dtype=np.float32)
+    nl = s * s * 4
+    got_lat = torch.from_numpy(raw[:nl].reshape(1, s, s, 4).copy()).permute(0, 3, 1, 2)
+    got_img = torch.from_numpy(raw[nl:].reshape(1, 3, Hpx, Hpx).copy())
+    assert torch.equal(got_lat, want_lat), float((got_lat - want_lat).abs().max())
+    assert torch.equal(got_img, want_img)
