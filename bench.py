@@ -252,6 +252,54 @@ def cpu_baseline_and_parity(pipe, ws, ucfg, B, steps_total, tiny):
     return base, parity
 
 
+def native_abi_leg(pipe, ws, ucfg, vcfg, B, T, dtype, dev_index, lat, pe, ne, imgs, cn, want_img, iters=3):
+    """The benchmarked request served through the C ABI alone: es_load_weights builds the context from the raw
+    state dicts (no model walk in Python), then es_prepare_conds + es_denoise_loop + es_vae_decode on raw device pointers,
+    the whole loop as one hipGraph.  Reported beside the headline value (same kernels, same launch lists: what changes is who
+    issues them); `bitwise_equal_to_pipeline` compares its image with the timed region's."""
+    from edgestyle_amd.native import NativeContext
+    dev = torch.device("cuda", dev_index)
+    t0 = time.perf_counter()
+    host = {k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in ws.items()}
+    t_copy = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    nat = NativeContext(host, ucfg, vcfg, batch_size=B, guidance=True, num_inference_steps=T, dtype=dtype, device=dev_index)
+    t_build = time.perf_counter() - t0
+    del host
+    try:
+        nat.set_alphas_cumprod(pipe.scheduler.alphas_cumprod)
+        nat.set_options(use_graphs=2)
+        im = [i.to(dev, torch.float32).repeat_interleave(B, dim=0).contiguous() if i.shape[0] == 1 else i.to(dev, torch.float32) for i in imgs]
+        nz = [None if z is None else z.to(dev, torch.float32).contiguous() for z in cn]
+        ehs = torch.cat([ne, pe]).to(dev, dtype).contiguous()
+        x0 = lat.permute(0, 2, 3, 1).contiguous().to(dev, torch.float32)
+        ts = pipe.scheduler.set_timesteps(T).tolist()
+        out = torch.empty((B, 3, ucfg.sample_size * vcfg.scale, ucfg.sample_size * vcfg.scale), dtype=torch.float32, device=dev)
+
+        def one():
+            x = x0.clone()
+            nat.prepare_conds(im, nz)
+            nat.denoise_loop(x, ehs, 7.5, ts)
+            nat.vae_decode(x, out)
+        one()
+        one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            one()
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) / iters
+        return {"workload": "the same request through the C ABI alone: context built by es_load_weights from raw state dicts, "
+                            "es_prepare_conds + es_denoise_loop (whole loop as one hipGraph) + es_vae_decode on raw device pointers",
+                "value": round(B / t, 4), "unit": "images/s", "ms_per_step": round(t * 1e3, 1), "steps": iters, "warmup": 2,
+                "build_s": round(t_build, 1), "weights_to_host_s": round(t_copy, 1),
+                "arena_gib": round(nat.lib.es_ctx_arena_bytes(nat.ctx) / 2 ** 30, 2),
+                "calls_per_denoising_step": nat.plan_size(2),
+                "bitwise_equal_to_pipeline": bool(torch.equal(out, want_img.to(dev, torch.float32)[:B]))}
+    finally:
+        nat.close()
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,6 +320,8 @@ def main(argv=None):
                     help="skip the extra 768x768 bf16 batch-4 (BASELINE configs[4]) measurement")
     ap.add_argument("--no-throughput-mode", action="store_true",
                     help="skip the extra batch-8 (BASELINE configs[2]) measurement reported beside the headline value")
+    ap.add_argument("--no-native-abi", action="store_true",
+                    help="skip the extra leg that serves the same request through the C ABI alone (es_load_weights context)")
     ap.add_argument("--fake-pipeline", action="store_true",
                     help="CPU rehearsal of the multi-rank control flow (gloo, no GPU, no kernels): NOT a measurement")
     args = ap.parse_args(argv)
@@ -302,7 +352,7 @@ def main(argv=None):
         from edgestyle_amd import config as C
         ucfg, vcfg = C.tiny_unet(), C.tiny_vae()
         pipe, ws = _FakePipeline(ucfg, vcfg), None
-        args.no_roofline = args.no_cpu_baseline = args.no_throughput_mode = args.no_stress_mode = True
+        args.no_roofline = args.no_cpu_baseline = args.no_throughput_mode = args.no_stress_mode = args.no_native_abi = True
     else:
         pipe, ws, ucfg, vcfg = build_pipeline(device, dtype, tiny=args.tiny, resolution=args.resolution)
     B = args.batch
@@ -376,6 +426,9 @@ def main(argv=None):
             # before the batch-8 leg: the parity step must run the very configuration the timed region replayed
             line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(pipe, ws, ucfg, B, args.ddim_steps, args.tiny)
             log(f"cpu baseline + parity done: {line['parity']}")
+        if not args.no_native_abi and world == 1 and not args.tiny and args.resolution == 512 and not args.no_graph:
+            line["native_abi"] = native_abi_leg(pipe, ws, ucfg, vcfg, B, args.ddim_steps, dtype, dev_index, lat, pe, ne, imgs, cn, img)
+            log(f"native ABI leg done: {line['native_abi']}")
         if not args.no_throughput_mode and world == 1 and B != 8 and not args.tiny and args.resolution == 512:
             # BASELINE configs[2]: same path, 8 images per step (hipGraph-captured, throughput mode); reported beside
             # the headline value, never instead of it

@@ -1443,7 +1443,7 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
     if (device == -2)
       for (auto& up : B.uploads) memcpy((void*)(mp.heap_base + (up.first - FAKE_HEAP)), up.second.data(), up.second.size());
     if (es_ctx_create(device < 0 ? 0 : device, &ctx)) fail("es_load_weights: es_ctx_create failed");
-    es_ctx_adopt_arena(ctx, arena, device == -2);
+    es_ctx_adopt_arena(ctx, arena, (size_t)total, device == -2);
     arena = nullptr;
     es_ctx_geometry geo = *g;
     geo.latent_channels = Lc; geo.latent_pad = Lp;

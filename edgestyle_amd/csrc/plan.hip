@@ -252,6 +252,7 @@ struct es_ctx {
   hipEvent_t staged = nullptr;      // previous call's copies - has completed
   std::vector<float> alphas_cumprod;   // the scheduler's schedule (es_ctx_set_alphas_cumprod; SD1.5 default otherwise)
   void* arena = nullptr;               // es_ctx_load / es_load_weights: the one allocation every recorded pointer was relocated into
+  size_t arena_bytes = 0;
   bool arena_on_host = false;          // es_load_weights(device -2): an inspection build in host memory
   hipGraphExec_t loop_exec = nullptr;  // use_graphs == 2: preparation + all steps of es_denoise_loop as one graph
   int loop_steps = 0;
@@ -373,7 +374,8 @@ extern "C" void es_ctx_destroy(es_ctx* c) {
   if (c->arena) { if (c->arena_on_host) free(c->arena); else (void)hipFree(c->arena); }
   delete c;
 }
-void es_ctx_adopt_arena(es_ctx* c, void* arena, bool on_host) { c->arena = arena; c->arena_on_host = on_host; }
+void es_ctx_adopt_arena(es_ctx* c, void* arena, size_t bytes, bool on_host) { c->arena = arena; c->arena_bytes = bytes; c->arena_on_host = on_host; }
+extern "C" size_t es_ctx_arena_bytes(const es_ctx* c) { return c ? c->arena_bytes : 0; }
 extern "C" int es_ctx_set_geometry(es_ctx* c, const es_ctx_geometry* g) {
   if (!c || !g || g->B < 1 || g->h < 1 || g->w < 1 || g->n_steps < 1 || g->n_conds < 1 || g->n_conds > 6) { es_set_error("es_ctx_set_geometry: bad geometry"); return -1; }
   c->g = *g;
@@ -465,6 +467,7 @@ extern "C" int es_ctx_load(const char* path, int device, es_ctx** out) {
   if (h.n_blocks && !rd(blocks.data(), h.n_blocks * sizeof(Blk))) return fail("es_ctx_load: truncated block table");
   for (const auto& b : blocks) if (!inside(b.off, b.bytes)) return fail("es_ctx_load: block outside the arena");
   if (hipMalloc(&c->arena, h.arena_bytes ? h.arena_bytes : 256) != hipSuccess) return fail("es_ctx_load: hipMalloc of the arena failed");
+  c->arena_bytes = (size_t)h.arena_bytes;
   // run-time-produced memory (activations, split-K slabs, scratch) travels as space only: zero it once
   if (hipMemset(c->arena, 0, h.arena_bytes ? h.arena_bytes : 256) != hipSuccess) return fail("es_ctx_load: hipMemset of the arena failed");
   char* base = (char*)c->arena;

@@ -173,6 +173,7 @@ SYMBOLS = {
     "es_ctx_set_plan": (C.c_int, [_P, _I, _P]),
     "es_ctx_bind": (C.c_int, [_P, _I, _P, C.c_size_t]),
     "es_ctx_buffer": (_P, [_P, _I, C.POINTER(C.c_size_t)]),
+    "es_ctx_arena_bytes": (C.c_size_t, [_P]),
     "es_ctx_set_options": (C.c_int, [_P, C.POINTER(C.c_float), _F, _F, _I]),
     "es_ctx_set_alphas_cumprod": (C.c_int, [_P, C.POINTER(C.c_float), _I]),
     "es_ctx_plan_size": (C.c_int, [_P, _I]),

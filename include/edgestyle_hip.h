@@ -318,7 +318,8 @@ void es_ctx_destroy(es_ctx* c);                         /* destroys its plans to
 int es_ctx_set_geometry(es_ctx* c, const es_ctx_geometry* g);
 int es_ctx_set_plan(es_ctx* c, int which, es_plan* p);  /* the context takes ownership of the plan */
 int es_ctx_bind(es_ctx* c, int slot, void* dev, size_t bytes);
-void* es_ctx_buffer(const es_ctx* c, int slot, size_t* bytes);   /* the memory bound to a slot (borrowed; NULL if unbound) */
+void* es_ctx_buffer(const es_ctx* c, int slot, size_t* bytes);
+size_t es_ctx_arena_bytes(const es_ctx* c);   /* size of the context's own arena (es_load_weights / es_ctx_load; a dry build reports what it would be) */   /* the memory bound to a slot (borrowed; NULL if unbound) */
 /* cond_scales: float[6] or NULL (keep); control guidance window (PL:419-427); use_graphs: 0 = re-issue launch by launch,
  * 1 = one hipGraph per plan (es_denoise_loop launches the step graph n times), 2 = additionally the preparation and all n
  * steps of es_denoise_loop as ONE graph (instantiated on first use per (n_steps, guidance scale)) */
