@@ -1,4 +1,6 @@
-"""Builder of a native execution context (es_ctx, include/edgestyle_hip.h) from a loaded pipeline.
+"""Builders of a native execution context (es_ctx, include/edgestyle_hip.h): NativeEngine records one from a loaded pipeline
+(this host walks the model); NativeContext, at the end of the file, has the library build it from raw state dicts
+(es_load_weights: no model walk in Python at all).
 
 The C ABI's step-level entry points — es_denoise_step (== OnnxUNetAndControlnets.forward, export_onnx.py:43-74),
 es_denoise_loop (== the loop of model/edgestyle_pipeline.py:435-543) and es_vae_decode (PL:552-572) — execute recorded

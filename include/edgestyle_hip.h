@@ -262,8 +262,9 @@ int es_fill_f32(float* dst, float value, size_t n, void* stream);
  *   es_denoise_loop  == the loop of EdgeStyleStableDiffusionControlNetPipeline.__call__   model/edgestyle_pipeline.py:435-543
  *   es_vae_decode    == vae.decode(latents / scaling_factor) + postprocess               model/edgestyle_pipeline.py:552-572
  *   es_prepare_conds == prepare_image + CachedControlNetModel.preprocess_image            model/edgestyle_pipeline.py:629-664, controllora.py:289-290
- * A context is BUILT by a host that can walk the model (edgestyle_amd/native.py does: it packs the weights, allocates
- * the static buffers, records the plans); after that no interpreter is involved in these calls.
+ * A context is BUILT either by es_load_weights below (natively, from raw state-dict tensors) or by a host that walks the model
+ * itself (edgestyle_amd/native.py NativeEngine: packs the weights, allocates the static buffers, records the plans); after that
+ * no interpreter is involved in these calls.
  * ========================================================================================================= */
 typedef struct es_plan es_plan;
 typedef struct es_ctx es_ctx;
@@ -329,8 +330,8 @@ int es_ctx_set_alphas_cumprod(es_ctx* c, const float* alphas_cumprod, int n);   
 int es_ctx_plan_size(const es_ctx* c, int which);
 es_plan* es_ctx_plan(es_ctx* c, int which);             /* borrowed */
 /* Load a context image written by NativeEngine.save(path) (edgestyle_amd/native.py): packed weights, tables, static buffers,
- * the five launch lists and their pointer relocations.  No Python, torch or model code is needed to load or run it - this is
- * what stands in for SURVEY 8b's es_load_weights when the host cannot walk the model itself: build once, ship the image. */
+ * the five launch lists and their pointer relocations.  No Python, torch or model code is needed to load or run it: build once
+ * (es_load_weights or a Python host), ship the image, start in under a second. */
 int es_ctx_load(const char* path, int device, es_ctx** out);
 /* ---------------------------------------------------------------------------------------------------------
  * es_load_weights - build a context from the reference's state dicts, natively.

@@ -248,7 +248,7 @@ def test_context_image_saved_here_runs_in_a_process_without_torch(built, tmp_pat
     """NativeEngine.save(path) -> es_ctx_load(path) in a child process that imports neither torch nor this package
     (tests/run_ctx_image.py: ctypes on the library and the HIP runtime only), and in a compiled C++ host
     (examples/tryon_host.cpp): RGB condition images -> es_prepare_conds -> es_denoise_loop -> es_vae_decode there equals the
-    pipeline here, bit for bit.  This is the stand-in for SURVEY 8b's es_load_weights: the image carries the packed weights,
+    pipeline here, bit for bit.  The image carries the packed weights,
     the static buffers and the relocated launch lists."""
     import os
     import subprocess
