@@ -79,12 +79,26 @@ struct Dict {
   const es_tensor* find(const std::string& k) const { auto it = m.find(k); return it == m.end() ? nullptr : it->second; }
 };
 long long numel(const es_tensor* t) { long long n = 1; for (int i = 0; i < t->ndim; ++i) n *= t->shape[i]; return n; }
+// the source tensors may live on a device as well (a host that already holds the checkpoint there): copied to the host first
+bool on_device(const void* p) {
+  hipPointerAttribute_t a;
+  const bool dev = hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeDevice;
+  (void)hipGetLastError();
+  return dev;
+}
 std::vector<float> to_f32(const es_tensor* t) {
   const long long n = numel(t);
   std::vector<float> v((size_t)n);
-  if (t->dtype == ES_F32) memcpy(v.data(), t->data, (size_t)n * 4);
-  else if (t->dtype == ES_F16) { const uint16_t* s = (const uint16_t*)t->data; for (long long i = 0; i < n; ++i) v[i] = f16_to_f32(s[i]); }
-  else { const uint16_t* s = (const uint16_t*)t->data; for (long long i = 0; i < n; ++i) v[i] = bf16_to_f32(s[i]); }
+  const void* src = t->data;
+  std::vector<char> tmp;
+  if (on_device(src)) {
+    tmp.resize((size_t)n * (t->dtype == ES_F32 ? 4 : 2));
+    if (hipMemcpy(tmp.data(), src, tmp.size(), hipMemcpyDeviceToHost) != hipSuccess) fail(std::string("es_load_weights: cannot read '") + t->key + "' from the device");
+    src = tmp.data();
+  }
+  if (t->dtype == ES_F32) memcpy(v.data(), src, (size_t)n * 4);
+  else if (t->dtype == ES_F16) { const uint16_t* s = (const uint16_t*)src; for (long long i = 0; i < n; ++i) v[i] = f16_to_f32(s[i]); }
+  else { const uint16_t* s = (const uint16_t*)src; for (long long i = 0; i < n; ++i) v[i] = bf16_to_f32(s[i]); }
   return v;
 }
 

@@ -483,11 +483,11 @@ _TENSOR_DT = {torch.float32: L.ES_F32, torch.float16: L.ES_F16, torch.bfloat16: 
 
 
 def state_dict_descriptors(sd):
-    """{key: CPU tensor} -> (es_state_dict, keep-alive list): descriptors only, the data is not copied."""
+    """{key: tensor (host, or on the GPU the context is built for)} -> (es_state_dict, keep-alive list): descriptors only."""
     arr = (L.Tensor * max(len(sd), 1))()
     keep = [arr]
     for i, (k, v) in enumerate(sd.items()):
-        if v.device.type != "cpu" or v.dtype not in _TENSOR_DT:
+        if v.device.type not in ("cpu", "cuda") or v.dtype not in _TENSOR_DT:
             raise EdgeStyleHipError(f"es_load_weights takes host tensors in fp32 / fp16 / bf16: {k} is {v.dtype} on {v.device}")
         v = v.contiguous()
         kb = k.encode()

@@ -343,8 +343,9 @@ int es_ctx_load(const char* path, int device, es_ctx** out);
  * Tensors are described, not copied: `key` is the state-dict key exactly as the reference's checkpoints spell it
  * (diffusers UNet2DConditionModel / ControlNetModel / AutoencoderKL names; `<linear>.lora_layer.{down,up}.weight` and
  * `controlnet_down_blocks.*` / `controlnet_mid_block.*` for a ControlLoRA net, CL:600-606; `multi_controlnet_down_blocks.{i}.*`
- * / `multi_controlnet_mid_block.*` for the fusion blocks, MC:173-193), `data` a HOST pointer to a C-contiguous tensor of
- * `dtype` (ES_F32 / ES_F16 / ES_BF16) that stays valid during the call.  A safetensors file maps onto this directly.
+ * / `multi_controlnet_mid_block.*` for the fusion blocks, MC:173-193), `data` a pointer (host memory, or device memory of
+ * `device`: read back first) to a C-contiguous tensor of `dtype` (ES_F32 / ES_F16 / ES_BF16) that stays valid during the call;
+ * nothing is kept: the caller keeps ownership.  A safetensors file maps onto this directly.
  * The builder folds W + B.A into private copies (the UNet's tensors are never modified), folds every LayerNorm into the Linear
  * it feeds, ff.net.2 into proj_out and conv_shortcut behind conv2, packs everything into the kernels' layouts, lays out ONE
  * device arena (weights, static buffers, activations with lifetime-based reuse, split-K workspace), records the five launch
@@ -356,7 +357,7 @@ int es_ctx_load(const char* path, int device, es_ctx** out);
  * --------------------------------------------------------------------------------------------------------- */
 typedef struct {
   const char* key;
-  const void* data;                /* host memory, C-contiguous */
+  const void* data;                /* host (or device) memory, C-contiguous; borrowed for the duration of the call */
   int64_t shape[4];
   int32_t ndim;                    /* 1..4 */
   int32_t dtype;                   /* ES_F32 | ES_F16 | ES_BF16 */

@@ -162,7 +162,8 @@ def psnr(a, b, peak=1.0):
 # every C-ABI call and launches nothing, so the model walk of edgestyle_amd (engine.py / models.py / pipeline._Loop /
 # native.py) can run on host tensors.  Used to hold es_load_weights' plans against the Python host's, call by call.
 # ----------------------------------------------------------------------------------------------------------------
-def python_dry_context(ws, ucfg, vcfg, B=1, guidance=True, T=6, dtype=torch.float16):
+def python_dry_context(ws, ucfg, vcfg, B=1, guidance=True, T=6, dtype=torch.float16,
+                       controlnets=(("lora0", 1), ("openpose", 0), ("lora1", 1)), net_of_cond=(0, 1, 2, 1, 2, 1), rank=4):
     """-> (lib, es_ctx) holding the five plans the Python host records for this configuration (addresses are host
     addresses of scratch tensors: only good for plan_records)."""
     import ctypes as Ct
@@ -182,11 +183,23 @@ def python_dry_context(ws, ucfg, vcfg, B=1, guidance=True, T=6, dtype=torch.floa
         return t
     ops._get_workspace = get_ws
     try:
-        runner = M.StepRunner.from_state_dicts(ws, ucfg, dtype, "cpu")
+        # controlnets: (name in ws, kind) with kind as include/edgestyle_hip.h ES_NET_*: 0 ControlNetModel, 1 ControlLoRA through
+        # the VAE, 2 ControlLoRA with its own conv-stack embedding
+        unet = M.UNet2DConditionModel(ws["unet"], ucfg, dtype).to("cpu")
         vae = M.AutoencoderKL(ws["vae"], vcfg, dtype)
-        for n in runner.controlnet.nets:
-            if isinstance(n, M.ControlLoRAModel):
-                n.set_autoencoder(vae)
+        distinct = []
+        for name, kind in controlnets:
+            if kind == 0:
+                net = M.ControlNetModel(ws[name], ucfg, dtype)
+            else:
+                net = M.ControlLoRAModel(ws[name], ucfg, dtype, lora_linear_rank=rank, uses_vae=kind == 1)
+                net.tie_weights(unet)
+                if kind == 1:
+                    net.set_autoencoder(vae)
+            distinct.append(net)
+        mc = M.EdgeStyleMultiControlNetModel([distinct[i] for i in net_of_cond], ucfg, None)
+        mc.load_state_dict(ws["fusion"])
+        runner = M.StepRunner(unet, mc)
         pipe = EdgeStyleStableDiffusionControlNetPipeline(vae=vae, unet=runner.unet, controlnet=runner.controlnet)
         pipe._runner = runner
         h = w = ucfg.sample_size
