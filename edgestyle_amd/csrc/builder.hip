@@ -990,7 +990,7 @@ struct Model {
   // static buffers (pipeline._Loop + StepState + NativeEngine)
   int B_ = 1, N = 2, T_ = 50, h = 64, w = 64, nn = 6, kmax = 3;
   T latents, model_in, noise, ehs, step_idx, t_rows, scales_cur, t_table, scale_table, coef, ts_dev, image;
-  std::vector<T> conds, cond_img, cond_noise, gbufs;
+  std::vector<T> conds, cond_img, cond_noise, gbufs, hist;
   std::vector<T> ctx_grouped, ctx_unet; std::vector<std::vector<T>> ctx_nets;
   T cond_cat, tproj_table, tproj_cur, tproj_gen;
 
@@ -1376,7 +1376,8 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
     M.scales_cur = B.persistent_t(1, 1, 1, 6, 4);
     M.t_table = B.persistent_t(TS, 1, 1, M.kmax * N, 4);
     M.scale_table = B.persistent_t(TS, 1, 1, 6, 4);
-    M.coef = B.persistent_t(TS, 1, 1, 4, 4);
+    M.coef = B.persistent_t(TS, 1, 1, 12, 4);                       // T x 4 (DDIM) or T x 12 (UniPC) rows
+    for (int i = 0; i < 3; ++i) M.hist.push_back(B.persistent_t(Bn, h, w, Lc, 4));   // UniPC multistep state
     M.ts_dev = B.persistent_t(1, 1, 1, TS, 4);
     M.image = B.persistent_t(Bn, h * sc, w * sc, 3, 4);            // NCHW fp32 (the T fields only carry the size)
     {   // text K/V projections, batch-concatenated in group order [net groups..., UNet] (StepRunner.set_context)
@@ -1467,6 +1468,7 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
     bind(ES_BUF_SAMPLE, M.model_in); bind(ES_BUF_T_ROWS, M.t_rows); bind(ES_BUF_EHS, M.ehs); bind(ES_BUF_SCALES, M.scales_cur);
     bind(ES_BUF_NOISE, M.noise); bind(ES_BUF_LATENTS, M.latents); bind(ES_BUF_STEP_IDX, M.step_idx); bind(ES_BUF_T_TABLE, M.t_table);
     bind(ES_BUF_SCALE_TABLE, M.scale_table); bind(ES_BUF_COEF, M.coef); bind(ES_BUF_TIMESTEPS, M.ts_dev); bind(ES_BUF_IMAGE, M.image);
+    for (int i = 0; i < 3; ++i) bind(ES_BUF_HIST0 + i, M.hist[i]);
     for (int i = 0; i < 6; ++i) {
       bind(ES_BUF_COND0 + i, M.conds[i]);
       bind(ES_BUF_COND_IMG0 + i, M.cond_img[i]);

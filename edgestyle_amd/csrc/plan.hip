@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/edgestyle_hip.h"
@@ -30,7 +31,13 @@ thread_local es_plan* g_rec = nullptr;
 thread_local bool g_replaying = false;
 thread_local bool g_dry = false;
 
-int launch_op(const es_plan* p, const es_plan::Op& op, hipStream_t st, const float* guidance_override) {
+// what a context may change about a recorded list when it re-issues it: the CFG scale of the scheduler call, and the scheduler
+// itself (the recorded call is the DDIM update; a context switched to UniPC issues es_cfg_unipc_step on its state slots instead)
+struct RunOpts { const float* guidance = nullptr; const es_ctx* unipc = nullptr; };
+int unipc_step(const es_ctx* c, const es_op_cfg_ddim* r, float guidance, void* s);
+
+int launch_op(const es_plan* p, const es_plan::Op& op, hipStream_t st, const RunOpts& ro) {
+  const float* guidance_override = ro.guidance;
   const char* a = p->blob.data() + op.off;
   void* s = (void*)st;
   switch (op.kind) {
@@ -44,6 +51,7 @@ int launch_op(const es_plan* p, const es_plan::Op& op, hipStream_t st, const flo
     case ES_OP_FUSION_BLOCKS: return es_fusion_blocks((const es_fusion_desc*)a, (int)(op.bytes / sizeof(es_fusion_desc)), s);
     case ES_OP_TIMESTEP_EMBEDDING: { auto* r = (const es_op_timestep*)a; return es_timestep_embedding(r->t, r->out, r->N, r->dim, r->dtype, s); }
     case ES_OP_CFG_DDIM: { auto* r = (const es_op_cfg_ddim*)a;
+      if (ro.unipc) return unipc_step(ro.unipc, r, guidance_override ? *guidance_override : r->guidance_scale, s);
       return es_cfg_ddim_step(r->noise, r->latents, r->model_in, r->coef, r->step_idx, guidance_override ? *guidance_override : r->guidance_scale,
                               r->B, r->HW, r->L, r->Lstride, r->cfg, r->nsteps, r->dtype, s); }
     case ES_OP_CFG_UNIPC: { auto* r = (const es_op_cfg_unipc*)a;
@@ -63,12 +71,12 @@ int launch_op(const es_plan* p, const es_plan::Op& op, hipStream_t st, const flo
   }
 }
 
-int run_plan(const es_plan* p, hipStream_t st, const float* guidance_override) {
+int run_plan(const es_plan* p, hipStream_t st, const RunOpts& ro) {
   if (g_rec) { es_set_error("es_plan_launch: a plan is recording on this thread"); return -1; }
   g_replaying = true;
   int rc = 0;
   for (const auto& op : p->ops)
-    if ((rc = launch_op(p, op, st, guidance_override)) != 0) break;
+    if ((rc = launch_op(p, op, st, ro)) != 0) break;
   g_replaying = false;
   return rc;
 }
@@ -106,7 +114,7 @@ extern "C" int es_plan_count(const es_plan* p, int kind) {
 }
 extern "C" int es_plan_launch(const es_plan* p, void* stream) {
   if (!p) { es_set_error("es_plan_launch: null plan"); return -1; }
-  return run_plan(p, (hipStream_t)stream, nullptr);
+  return run_plan(p, (hipStream_t)stream, RunOpts{});
 }
 
 // Pointer fields of a recorded call, by op kind: byte offset inside the argument record and how the op uses the memory
@@ -250,6 +258,8 @@ struct es_ctx {
   float* host = nullptr;            // PINNED staging for the per-call tables (hipHostMalloc): the H2D copies are truly
   size_t host_cap = 0;              // asynchronous, so the buffer is only rewritten after `staged` - recorded behind the
   hipEvent_t staged = nullptr;      // previous call's copies - has completed
+  int scheduler = ES_SCHED_DDIM;       // es_ctx_set_scheduler
+  std::vector<double> alphas_cumprod_f64;   // UniPC derives its sigmas in double (es_ctx_set_alphas_cumprod_f64; SD1.5 default otherwise)
   std::vector<float> alphas_cumprod;   // the scheduler's schedule (es_ctx_set_alphas_cumprod; SD1.5 default otherwise)
   void* arena = nullptr;               // es_ctx_load / es_load_weights: the one allocation every recorded pointer was relocated into
   size_t arena_bytes = 0;
@@ -298,14 +308,17 @@ int run(es_ctx* c, int which, hipStream_t st, const float* guidance) {
   if (!p) { es_set_error("es_ctx: plan not set"); return -1; }
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &cs);
-  if (!c->use_graphs || cs != hipStreamCaptureStatusNone) return run_plan(p, st, guidance);
+  RunOpts ro;
+  ro.guidance = guidance;
+  ro.unipc = c->scheduler == ES_SCHED_UNIPC ? c : nullptr;
+  if (!c->use_graphs || cs != hipStreamCaptureStatusNone) return run_plan(p, st, ro);
   const float gs = guidance ? *guidance : 0.f;
   if (c->exec[which] && c->exec_guidance[which] != gs) { (void)hipGraphExecDestroy(c->exec[which]); c->exec[which] = nullptr; }
   if (!c->exec[which]) {
     hipGraph_t graph = nullptr;
     if (!c->cap_stream && hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking) != hipSuccess) { es_set_error("es_ctx: hipStreamCreate failed"); return -2; }
     if (hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { es_set_error("es_ctx: hipStreamBeginCapture failed"); return -2; }
-    const int rc = run_plan(p, c->cap_stream, guidance);
+    const int rc = run_plan(p, c->cap_stream, ro);
     const hipError_t e = hipStreamEndCapture(c->cap_stream, &graph);
     if (rc || e != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); if (!rc) es_set_error("es_ctx: hipStreamEndCapture failed"); return rc ? rc : -2; }
     const hipError_t ei = hipGraphInstantiate(&c->exec[which], graph, nullptr, nullptr, 0);
@@ -352,7 +365,123 @@ void ddim_coef(es_ctx* c, const float* ts, int n, float* out) {
   if (c->alphas_cumprod.empty()) default_alphas(c->alphas_cumprod);
   ddim_coef_from(c->alphas_cumprod, ts, n, out);
 }
+
+// UniPCMultistepScheduler (the scheduler the reference's callers assign: TT:273, APP:118) with the SD1.5 scheduler config it
+// inherits - bh2, solver_order <= 2, predict_x0, lower_order_final, epsilon prediction.  Every update of the multistep
+// predictor / corrector is linear in {last_sample, m0, m1, x0}: per step 12 scalars {alpha_t, sigma_t, use_c, c_last, c_m0, c_m1,
+// c_x0, p_x, p_x0, p_m0, 0, 0}, derived here in double exactly as edgestyle_amd/schedulers.py does (same formulas, same order of
+// operations; the 2 x 2 system of the second-order corrector is solved in closed form), consumed by es_cfg_unipc_step.
+void default_alphas_f64(std::vector<double>& ac) {
+  // torch.linspace(sqrt(b0), sqrt(b1), 1000, float64) ** 2 -> cumprod(1 - betas)
+  ac.resize(1000);
+  const double b0 = sqrt(0.00085), b1 = sqrt(0.012), step = (b1 - b0) / 999.0;
+  double prod = 1.0;
+  for (int i = 0; i < 1000; ++i) {
+    const double b = i < 500 ? b0 + step * (double)i : b1 - step * (double)(999 - i);
+    prod *= 1.0 - b * b;
+    ac[i] = prod;
+  }
+}
+void unipc_coef_from(const std::vector<double>& ac, const float* ts, int T, int solver_order, float* out) {
+  const int n = (int)ac.size();
+  auto sig_at = [&](double t) {                       // np.interp(t, arange(n), sqrt((1 - ac) / ac))
+    auto sg = [&](int i) { return sqrt((1.0 - ac[i]) / ac[i]); };
+    if (t <= 0) return sg(0);
+    if (t >= n - 1) return sg(n - 1);
+    const int i = (int)t;
+    const double f = t - (double)i;
+    return f == 0.0 ? sg(i) : sg(i) + (sg(i + 1) - sg(i)) * f;
+  };
+  std::vector<double> sigmas((size_t)T + 1);
+  for (int i = 0; i < T; ++i) sigmas[i] = sig_at((double)ts[i]);
+  sigmas[T] = sqrt((1.0 - ac[0]) / ac[0]);
+  struct Asl { double a, s, l; };
+  auto asl = [&](int idx) { const double s = sigmas[idx]; const double a = 1.0 / sqrt(s * s + 1.0); return Asl{a, s * a, log(a) - log(s * a)}; };
+  // rhos of the B(h) = e^h - 1 variant: corrector (order 1: 1/2; order 2: 2 x 2 solve), predictor (order 2: 1/2)
+  auto rhos = [&](const double* rks, double hh, int order, bool corrector, double* rho, double& h_phi_1, double& B_h) {
+    h_phi_1 = expm1(hh);
+    double h_phi_k = h_phi_1 / hh - 1.0;
+    B_h = expm1(hh);
+    double fact = 1.0, b[2] = {0, 0};
+    for (int i = 1; i <= order; ++i) {
+      b[i - 1] = h_phi_k * fact / B_h;
+      fact *= (double)(i + 1);
+      h_phi_k = h_phi_k / hh - 1.0 / fact;
+    }
+    rho[0] = rho[1] = 0.0;
+    if (corrector) {
+      if (order == 1) rho[0] = 0.5;
+      else { rho[0] = (b[0] - b[1]) / (1.0 - rks[0]); rho[1] = b[0] - rho[0]; }      // [[1, 1], [rk0, 1]] rho = b
+    } else if (order == 2) rho[0] = 0.5;
+  };
+  int lower_order_nums = 0, this_order = 1;
+  for (int i = 0; i < T; ++i) {
+    const Asl ci = asl(i);
+    double row[12] = {ci.a, ci.s, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (i > 0) {                                      // corrector with the order of the previous predictor
+      const int order = this_order;
+      const Asl c0 = asl(i - 1);
+      const double h = ci.l - c0.l;
+      double rks[2] = {1.0, 1.0};
+      if (order == 2) rks[0] = (asl(i - 2).l - c0.l) / h;
+      double rho[2], h_phi_1, B_h;
+      rhos(rks, -h, order, true, rho, h_phi_1, B_h);
+      const double A = ci.s / c0.s, Hh = ci.a * h_phi_1, Bc = ci.a * B_h;
+      row[2] = 1.0; row[3] = A;
+      if (order == 1) { row[4] = -Hh + Bc * rho[0]; row[5] = 0.0; row[6] = -Bc * rho[0]; }
+      else { row[4] = -Hh + Bc * (rho[0] / rks[0] + rho[1]); row[5] = -Bc * rho[0] / rks[0]; row[6] = -Bc * rho[1]; }
+    }
+    this_order = std::min(std::min(solver_order, T - i), lower_order_nums + 1);        // lower_order_final + warm-up
+    const Asl ct = asl(i + 1);
+    const double h = ct.l - ci.l;
+    double rks[2] = {1.0, 1.0};
+    if (this_order == 2) rks[0] = (asl(i - 1).l - ci.l) / h;
+    double rho[2], h_phi_1, B_h;
+    rhos(rks, -h, this_order, false, rho, h_phi_1, B_h);
+    const double A = ct.s / ci.s, Hh = ct.a * h_phi_1, Bp = ct.a * B_h;
+    row[7] = A;
+    if (this_order == 1) { row[8] = -Hh; row[9] = 0.0; }
+    else { row[8] = -Hh + Bp * rho[0] / rks[0]; row[9] = -Bp * rho[0] / rks[0]; }
+    if (lower_order_nums < solver_order) ++lower_order_nums;
+    for (int k = 0; k < 12; ++k) out[i * 12 + k] = (float)row[k];
+  }
+}
+void unipc_coef(const es_ctx* c, const float* ts, int T, float* out) {
+  std::vector<double> ac = c->alphas_cumprod_f64;
+  if (ac.empty()) default_alphas_f64(ac);
+  unipc_coef_from(ac, ts, T, 2, out);
+}
+// the scheduler call of a recorded step, re-issued as the UniPC update on the context's state slots
+int unipc_step(const es_ctx* c, const es_op_cfg_ddim* r, float guidance, void* s) {
+  return es_cfg_unipc_step(r->noise, r->latents, (float*)c->buf[ES_BUF_HIST0], (float*)c->buf[ES_BUF_HIST1], (float*)c->buf[ES_BUF_HIST2],
+                           r->model_in, (const float*)c->buf[ES_BUF_COEF], r->step_idx, guidance, r->B, r->HW, r->L, r->Lstride, r->cfg,
+                           r->nsteps, r->dtype, s);
+}
 }  // namespace
+
+extern "C" int es_ctx_set_scheduler(es_ctx* c, int scheduler) {
+  if (!c || (scheduler != ES_SCHED_DDIM && scheduler != ES_SCHED_UNIPC)) { es_set_error("es_ctx_set_scheduler: ES_SCHED_DDIM or ES_SCHED_UNIPC"); return -1; }
+  if (scheduler == ES_SCHED_UNIPC) {
+    for (int i = 0; i < 3; ++i)
+      if (!c->buf[ES_BUF_HIST0 + i] || c->bytes[ES_BUF_HIST0 + i] != c->bytes[ES_BUF_LATENTS]) { es_set_error("es_ctx_set_scheduler: UniPC needs the three ES_BUF_HIST slots bound (fp32, the size of the latents)"); return -1; }
+    if (c->bytes[ES_BUF_COEF] < (size_t)c->g.n_steps * 12 * sizeof(float)) { es_set_error("es_ctx_set_scheduler: UniPC needs ES_BUF_COEF of n_steps x 12 floats"); return -1; }
+  }
+  if (c->scheduler != scheduler) {                     // the scheduler node of every instantiated graph changes
+    for (int i = 0; i < ES_PLAN_COUNT; ++i) if (c->exec[i]) { (void)hipGraphExecDestroy(c->exec[i]); c->exec[i] = nullptr; }
+    if (c->loop_exec) { (void)hipGraphExecDestroy(c->loop_exec); c->loop_exec = nullptr; }
+  }
+  c->scheduler = scheduler;
+  return 0;
+}
+/* host-only: the per-step UniPC coefficient rows es_denoise_loop derives from `timesteps` (alphas_cumprod NULL: SD1.5's schedule in double) */
+extern "C" int es_unipc_coef_table(const double* alphas_cumprod, int n_alphas, const float* timesteps, int n, float* out) {
+  if (!timesteps || !out || n < 1) { es_set_error("es_unipc_coef_table: bad arguments"); return -1; }
+  std::vector<double> ac;
+  if (alphas_cumprod && n_alphas > 0) ac.assign(alphas_cumprod, alphas_cumprod + n_alphas);
+  else default_alphas_f64(ac);
+  unipc_coef_from(ac, timesteps, n, 2, out);
+  return 0;
+}
 
 extern "C" int es_ctx_create(int device, es_ctx** out) {
   if (!out) { es_set_error("es_ctx_create: null out"); return -1; }
@@ -411,6 +540,11 @@ extern "C" int es_ctx_set_options(es_ctx* c, const float* cond_scales, float con
 extern "C" int es_ctx_set_alphas_cumprod(es_ctx* c, const float* alphas_cumprod, int n) {
   if (!c || !alphas_cumprod || n < 1) { es_set_error("es_ctx_set_alphas_cumprod: bad arguments"); return -1; }
   c->alphas_cumprod.assign(alphas_cumprod, alphas_cumprod + n);
+  return 0;
+}
+extern "C" int es_ctx_set_alphas_cumprod_f64(es_ctx* c, const double* alphas_cumprod, int n) {
+  if (!c || !alphas_cumprod || n < 1) { es_set_error("es_ctx_set_alphas_cumprod_f64: bad arguments"); return -1; }
+  c->alphas_cumprod_f64.assign(alphas_cumprod, alphas_cumprod + n);
   return 0;
 }
 /* one plan of the context on `stream` (what es_denoise_loop does n_steps times with ES_PLAN_STEP): lets a host single-step
@@ -562,22 +696,30 @@ extern "C" int es_denoise_loop(es_ctx* c, float* latents_inout, const void* ehs,
   const es_ctx_geometry& g = c->g;
   const int T = n_steps, nc = g.n_conds;
   const size_t trow = c->bytes[ES_BUF_T_TABLE] / 4 / T;          // kmax * N timestep copies per step
-  float* tt = staging(c, (size_t)T * (trow + nc + 4 + 1));
+  const bool unipc = c->scheduler == ES_SCHED_UNIPC;
+  const int cw = unipc ? 12 : 4;
+  if (unipc && (c->bytes[ES_BUF_COEF] < (size_t)T * 48 || !c->buf[ES_BUF_HIST0] || !c->buf[ES_BUF_HIST1] || !c->buf[ES_BUF_HIST2])) {
+    es_set_error("es_denoise_loop: the context's slots do not hold a UniPC state (ES_BUF_HIST*, ES_BUF_COEF of n_steps x 12)"); return -1; }
+  float* tt = staging(c, (size_t)T * (trow + nc + cw + 1));
   if (!tt) { es_set_error("es_denoise_loop: pinned staging allocation failed"); return -2; }
   float* sc = tt + (size_t)T * trow;
   float* cf = sc + (size_t)T * nc;
-  float* tsd = cf + (size_t)T * 4;
+  float* tsd = cf + (size_t)T * cw;
   for (int i = 0; i < T; ++i) {
     for (size_t j = 0; j < trow; ++j) tt[i * trow + j] = timesteps[i];
     const float keep = 1.0f - (float)(((float)i / T < c->control_start) || ((float)(i + 1) / T > c->control_end));   // PL:419-427
     for (int k = 0; k < nc; ++k) sc[i * nc + k] = c->cond_scales[k] * keep;
     tsd[i] = timesteps[i];
   }
-  ddim_coef(c, timesteps, T, cf);
+  if (unipc) unipc_coef(c, timesteps, T, cf);
+  else ddim_coef(c, timesteps, T, cf);
   int rc;
   if ((rc = h2d(c->buf[ES_BUF_T_TABLE], tt, (size_t)T * trow * 4, st))) return rc;
   if ((rc = h2d(c->buf[ES_BUF_SCALE_TABLE], sc, (size_t)T * nc * 4, st))) return rc;
-  if ((rc = h2d(c->buf[ES_BUF_COEF], cf, (size_t)T * 16, st))) return rc;
+  if ((rc = h2d(c->buf[ES_BUF_COEF], cf, (size_t)T * cw * 4, st))) return rc;
+  if (unipc)                                                            // multistep history: zero before the first step
+    for (int i = 0; i < 3; ++i)
+      if (hipMemsetAsync(c->buf[ES_BUF_HIST0 + i], 0, c->bytes[ES_BUF_HIST0 + i], st) != hipSuccess) { es_set_error("es_denoise_loop: memset failed"); return -2; }
   if ((rc = h2d(c->buf[ES_BUF_TIMESTEPS], tsd, (size_t)T * 4, st))) return rc;
   if (hipEventRecord(c->staged, st) != hipSuccess) { es_set_error("es_denoise_loop: hipEventRecord failed"); return -2; }
   if (hipMemsetAsync(c->buf[ES_BUF_STEP_IDX], 0, 4, st) != hipSuccess) { es_set_error("es_denoise_loop: memset failed"); return -2; }
@@ -594,8 +736,11 @@ extern "C" int es_denoise_loop(es_ctx* c, float* latents_inout, const void* ehs,
       hipGraph_t graph = nullptr;
       if (!c->cap_stream && hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking) != hipSuccess) { es_set_error("es_ctx: hipStreamCreate failed"); return -2; }
       if (hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { es_set_error("es_ctx: hipStreamBeginCapture failed"); return -2; }
-      rc = run_plan(c->plan[ES_PLAN_PREP], c->cap_stream, nullptr);
-      for (int i = 0; i < T && !rc; ++i) rc = run_plan(c->plan[ES_PLAN_STEP], c->cap_stream, &guidance_scale);
+      RunOpts ro;
+      ro.unipc = c->scheduler == ES_SCHED_UNIPC ? c : nullptr;
+      rc = run_plan(c->plan[ES_PLAN_PREP], c->cap_stream, ro);
+      ro.guidance = &guidance_scale;
+      for (int i = 0; i < T && !rc; ++i) rc = run_plan(c->plan[ES_PLAN_STEP], c->cap_stream, ro);
       const hipError_t e = hipStreamEndCapture(c->cap_stream, &graph);
       if (rc || e != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); if (!rc) es_set_error("es_ctx: hipStreamEndCapture failed"); return rc ? rc : -2; }
       const hipError_t ei = hipGraphInstantiate(&c->loop_exec, graph, nullptr, nullptr, 0);

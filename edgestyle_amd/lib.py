@@ -56,6 +56,8 @@ PLAN_STEP_GENERIC, PLAN_PREP, PLAN_STEP, PLAN_DECODE, PLAN_CONDS = 0, 1, 2, 3, 4
 (BUF_SAMPLE, BUF_T_ROWS, BUF_EHS, BUF_COND0, BUF_COND1, BUF_COND2, BUF_COND3, BUF_COND4, BUF_COND5, BUF_SCALES, BUF_NOISE,
  BUF_LATENTS, BUF_STEP_IDX, BUF_T_TABLE, BUF_SCALE_TABLE, BUF_COEF, BUF_TIMESTEPS, BUF_IMAGE) = range(18)
 BUF_COND_IMG0, BUF_COND_NOISE0 = 18, 24          # + net index
+BUF_HIST0, BUF_COUNT = 30, 33                    # UniPC state slots (+ 0..2)
+SCHED_DDIM, SCHED_UNIPC = 0, 1
 OP_CONV_GEMM, OP_LINEAR_XS, OP_ATTENTION = 1, 2, 3      # csrc/plan.h es_op_kind (es_plan_count)
 
 
@@ -175,6 +177,9 @@ SYMBOLS = {
     "es_ctx_buffer": (_P, [_P, _I, C.POINTER(C.c_size_t)]),
     "es_ctx_arena_bytes": (C.c_size_t, [_P]),
     "es_ctx_set_options": (C.c_int, [_P, C.POINTER(C.c_float), _F, _F, _I]),
+    "es_ctx_set_scheduler": (C.c_int, [_P, _I]),
+    "es_ctx_set_alphas_cumprod_f64": (C.c_int, [_P, C.POINTER(C.c_double), _I]),
+    "es_unipc_coef_table": (C.c_int, [C.POINTER(C.c_double), _I, C.POINTER(C.c_float), _I, C.POINTER(C.c_float)]),
     "es_ctx_set_alphas_cumprod": (C.c_int, [_P, C.POINTER(C.c_float), _I]),
     "es_ctx_plan_size": (C.c_int, [_P, _I]),
     "es_ctx_plan": (_P, [_P, _I]),

@@ -57,6 +57,11 @@ class NativeEngine:
         loop = self.loop = pipe._loops[(B, guidance, h, w, False)]
         runner = self.runner = pipe._runner
         N = loop.N
+        # the coefficient table the recorded scheduler call reads: room for UniPC's 12 columns (es_ctx_set_scheduler), the DDIM
+        # rows the pipeline call left there in front
+        self._coef = torch.zeros((T * 12,), dtype=torch.float32, device=dev)
+        self._coef[:T * 4].copy_(loop.coef.reshape(-1))
+        loop.coef = self._coef[:T * 4].view(T, 4)
         self.B, self.N, self.T, self.h, self.w, self.nn = B, N, T, h, w, nn
         self.dtype = pipe.dtype
         self.ts_dev = torch.zeros((T,), dtype=torch.float32, device=dev)
@@ -116,7 +121,9 @@ class NativeEngine:
         self.image = out["img"]
         binds = {L.BUF_SAMPLE: loop.model_in, L.BUF_T_ROWS: loop.t_rows, L.BUF_EHS: loop.ehs, L.BUF_SCALES: loop.scales_cur,
                  L.BUF_NOISE: loop.noise, L.BUF_LATENTS: loop.latents, L.BUF_STEP_IDX: loop.step_idx, L.BUF_T_TABLE: loop.t_table,
-                 L.BUF_SCALE_TABLE: loop.scale_table, L.BUF_COEF: loop.coef, L.BUF_TIMESTEPS: self.ts_dev, L.BUF_IMAGE: self.image}
+                 L.BUF_SCALE_TABLE: loop.scale_table, L.BUF_COEF: self._coef, L.BUF_TIMESTEPS: self.ts_dev, L.BUF_IMAGE: self.image}
+        for i in range(3):
+            binds[L.BUF_HIST0 + i] = loop.hist[i]
         for i, c in enumerate(loop.conds):
             binds[L.BUF_COND0 + i] = c
             if conds_fn is not None:
@@ -222,6 +229,10 @@ class NativeEngine:
         self._cg, self._use_graphs = (float(control_guidance_start), float(control_guidance_end)), int(use_graphs)
         L.check(self.lib.es_ctx_set_options(self.ctx, arr, control_guidance_start, control_guidance_end, int(use_graphs)),
                 "es_ctx_set_options")
+
+    def set_scheduler(self, scheduler: int):
+        """L.SCHED_DDIM | L.SCHED_UNIPC: the update es_denoise_loop applies (the recorded step list is the same)."""
+        L.check(self.lib.es_ctx_set_scheduler(self.ctx, int(scheduler)), "es_ctx_set_scheduler")
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -416,7 +427,7 @@ class NativeEngine:
                 f.write(struct.pack("<Q", len(rel)))
                 for blob_off, si, o in rel:
                     f.write(struct.pack("<QQ", blob_off, off[si] + o))
-            nslots = L.BUF_COND_NOISE0 + 6
+            nslots = L.BUF_COUNT
             for slot in range(nslots):
                 if slot in binds:
                     si, o, nb = binds[slot]
@@ -549,6 +560,10 @@ class NativeContext:
         arr = None if cond_scales is None else (C.c_float * 6)(*([float(s) for s in cond_scales] + [1.0] * (6 - len(cond_scales))))
         L.check(self.lib.es_ctx_set_options(self.ctx, arr, control_guidance_start, control_guidance_end, int(use_graphs)),
                 "es_ctx_set_options")
+
+    def set_scheduler(self, scheduler: int):
+        """L.SCHED_DDIM | L.SCHED_UNIPC (UniPCMultistepScheduler with the SD1.5 config, TT:273)."""
+        L.check(self.lib.es_ctx_set_scheduler(self.ctx, int(scheduler)), "es_ctx_set_scheduler")
 
     def set_alphas_cumprod(self, alphas_cumprod):
         """The scheduler's schedule (default: the library's own SD1.5 table, which equals torch's cumprod to 1e-6 only - hand

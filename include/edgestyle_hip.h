@@ -305,7 +305,9 @@ enum { ES_BUF_SAMPLE = 0,          /* dtype [N,h,w,latent_pad]: the networks' in
         * latent_dist.sample() noise of CL:39 for the CFG-duplicated batch, fp32 [N,latent_channels,h,w] */
        ES_BUF_COND_IMG0, ES_BUF_COND_IMG1, ES_BUF_COND_IMG2, ES_BUF_COND_IMG3, ES_BUF_COND_IMG4, ES_BUF_COND_IMG5,
        ES_BUF_COND_NOISE0, ES_BUF_COND_NOISE1, ES_BUF_COND_NOISE2, ES_BUF_COND_NOISE3, ES_BUF_COND_NOISE4, ES_BUF_COND_NOISE5,
+       ES_BUF_HIST0, ES_BUF_HIST1, ES_BUF_HIST2,   /* UniPC multistep state: last_sample, m0, m1 - fp32 [B,h,w,L] each (es_ctx_set_scheduler) */
        ES_BUF_COUNT };
+enum { ES_SCHED_DDIM = 0, ES_SCHED_UNIPC = 1 };
 typedef struct {
   int32_t B, cfg;                  /* images per call; 1 = classifier-free guidance (N = 2B) */
   int32_t h, w;                    /* latent size */
@@ -327,6 +329,18 @@ size_t es_ctx_arena_bytes(const es_ctx* c);   /* size of the context's own arena
 int es_ctx_set_options(es_ctx* c, const float* cond_scales, float control_guidance_start, float control_guidance_end,
                        int use_graphs);
 int es_ctx_set_alphas_cumprod(es_ctx* c, const float* alphas_cumprod, int n);   /* scheduler schedule (default: SD1.5's) */
+/* The update es_denoise_loop applies after each step's noise prediction: ES_SCHED_DDIM (eta 0; the BASELINE metric's scheduler,
+ * model/edgestyle_pipeline.py:520-522 with the pipeline's default) or ES_SCHED_UNIPC - UniPCMultistepScheduler with the SD1.5
+ * scheduler config, bh2, order 2, the scheduler the reference's callers assign (test_text2image_pretrained_openpose.py:273,
+ * app.py:118); its timesteps come from the caller like DDIM's (UniPC spaces them over n + 1 intervals: 951, 901, ... for 20
+ * steps).  The recorded step list is the same: the context re-issues its scheduler call as es_cfg_unipc_step on the
+ * ES_BUF_HIST* slots with a n_steps x 12 coefficient table in ES_BUF_COEF (contexts of es_load_weights and NativeEngine bind both). */
+int es_ctx_set_scheduler(es_ctx* c, int scheduler);
+/* UniPC works from a double-precision schedule like the Python scheduler (default: SD1.5's scaled_linear betas, derived in double;
+ * the fp32 table of es_ctx_set_alphas_cumprod is the DDIM update's) */
+int es_ctx_set_alphas_cumprod_f64(es_ctx* c, const double* alphas_cumprod, int n);
+/* host-only: out[n][12], the UniPC coefficient rows of a timestep list (alphas_cumprod NULL = SD1.5's schedule, in double) */
+int es_unipc_coef_table(const double* alphas_cumprod, int n_alphas, const float* timesteps, int n, float* out);
 int es_ctx_plan_size(const es_ctx* c, int which);
 es_plan* es_ctx_plan(es_ctx* c, int which);             /* borrowed */
 /* Load a context image written by NativeEngine.save(path) (edgestyle_amd/native.py): packed weights, tables, static buffers,

@@ -100,6 +100,25 @@ def test_native_ddim_coefficients_match_the_host_scheduler():
         assert np.abs(out - want).max() < 1e-6
 
 
+def test_native_unipc_coefficients_match_the_host_scheduler_bitwise():
+    """es_unipc_coef_table (what es_denoise_loop derives from `timesteps` under ES_SCHED_UNIPC; csrc/plan.hip) ==
+    UniPCMultistepScheduler.coef_table(), with the library's own double-precision SD1.5 schedule and with the scheduler's."""
+    import numpy as np
+    from edgestyle_amd.schedulers import UniPCMultistepScheduler
+    L = lib.load()
+    fp = ctypes.POINTER(ctypes.c_float)
+    for T in (2, 3, 4, 20, 50):
+        s = UniPCMultistepScheduler()
+        ts = s.set_timesteps(T).float().numpy().astype(np.float32)
+        want = s.coef_table().numpy()
+        out = np.zeros((T, 12), dtype=np.float32)
+        assert L.es_unipc_coef_table(None, 0, ts.ctypes.data_as(fp), T, out.ctypes.data_as(fp)) == 0
+        assert np.array_equal(out, want)
+        ac = s.alphas_cumprod.numpy().astype(np.float64)
+        assert L.es_unipc_coef_table(ac.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), len(ac), ts.ctypes.data_as(fp), T, out.ctypes.data_as(fp)) == 0
+        assert np.array_equal(out, want)
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(lib, "_lib", None)
     monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libedgestyle_hip.so")

@@ -110,6 +110,52 @@ def test_rgb_images_to_decoded_image_through_the_native_context_equal_the_pipeli
         assert torch.equal(mine, eng.loop.conds[i].reshape(-1))
 
 
+def test_unipc_through_the_native_loop_equals_the_pipeline_bitwise(both):
+    """es_ctx_set_scheduler(ES_SCHED_UNIPC): the scheduler the reference's callers assign (TT:273, APP:118).  The coefficient
+    rows are derived in C (csrc/plan.hip) exactly as schedulers.UniPCMultistepScheduler derives them; the recorded step list is
+    the DDIM one with its scheduler call re-issued as es_cfg_unipc_step.  Both contexts (es_load_weights', the Python host's)
+    against pipe.scheduler = UniPCMultistepScheduler, graphs and launch by launch, and back to DDIM."""
+    from edgestyle_amd.schedulers import UniPCMultistepScheduler
+    from edgestyle_amd.models import _as_nhwc
+    pipe, eng, nat, ws, ucfg, vcfg, T = both
+    lat, pe, ne, conds, _, _ = _inputs(ucfg, vcfg, 47)
+    gs = 4.0
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, latents=lat, guidance_scale=gs, num_inference_steps=T)
+    want_ddim = pipe(output_type="latent", **kw).images.clone()
+    old = pipe.scheduler
+    pipe.scheduler = UniPCMultistepScheduler.from_config(old.config)
+    try:
+        want = pipe(output_type="latent", **kw).images.clone()
+        ts = pipe.scheduler.set_timesteps(T).tolist()
+    finally:
+        pipe.scheduler = old
+    assert not torch.equal(want, want_ddim)
+    cd = [_as_nhwc(c.repeat(2, 1, 1, 1), torch.float16, DEV).contiguous() for c in conds]
+    ehs = torch.cat([ne, pe]).to(DEV, torch.float16).contiguous()
+    x = lat.permute(0, 2, 3, 1).contiguous().to(DEV)
+    lib = L.load()
+    for i in range(6):
+        nb = C.c_size_t(0)
+        p = lib.es_ctx_buffer(nat.ctx, L.BUF_COND0 + i, C.byref(nb))
+        L.check(lib.es_memcpy(C.c_void_p(p), C.c_void_p(cd[i].data_ptr()), nb.value, None), "es_memcpy")
+    eng.set_conds(cd)
+    torch.cuda.synchronize()
+    for ctx in (nat, eng):
+        ctx.set_scheduler(L.SCHED_UNIPC)
+        try:
+            for use_graphs in (True, False, 2):
+                ctx.set_options(use_graphs=use_graphs)
+                got = ctx.denoise_loop(x.clone(), ehs, gs, ts)
+                torch.cuda.synchronize()
+                assert torch.equal(got.permute(0, 3, 1, 2), want), (type(ctx).__name__, use_graphs, float((got.permute(0, 3, 1, 2) - want).abs().max()))
+        finally:
+            ctx.set_scheduler(L.SCHED_DDIM)
+            ctx.set_options(use_graphs=True)
+        got = ctx.denoise_loop(x.clone(), ehs, gs, old.set_timesteps(T).tolist())
+        torch.cuda.synchronize()
+        assert torch.equal(got.permute(0, 3, 1, 2), want_ddim)
+
+
 def test_a_context_without_guidance_and_two_images_per_call(both):
     """B = 2, no classifier-free guidance: another geometry through both builders."""
     from edgestyle_amd.native import NativeContext
