@@ -70,9 +70,13 @@ struct Dict {
   std::string name;
   void init(const es_state_dict& sd, const char* nm) {
     name = nm;
+    if (sd.count < 0 || (sd.count > 0 && !sd.tensors)) fail(std::string("es_load_weights: the ") + nm + " state dict has a count but no tensors");
     for (int i = 0; i < sd.count; ++i) {
       const es_tensor& t = sd.tensors[i];
-      if (!t.key || !t.data || t.ndim < 1 || t.ndim > 4 || t.dtype < 0 || t.dtype > ES_F32) fail(name + ": malformed tensor descriptor #" + std::to_string(i));
+      if (!t.key || !t.data || t.ndim < 1 || t.ndim > 4 || t.dtype < 0 || t.dtype > ES_F32) fail("es_load_weights: malformed tensor descriptor #" + std::to_string(i) + " in the " + name + " state dict");
+      long long n = 1;
+      for (int d = 0; d < t.ndim; ++d) { if (t.shape[d] < 1 || t.shape[d] > (1ll << 31)) n = -1; else if (n > 0) n *= t.shape[d]; if (n > (1ll << 33)) n = -1; }
+      if (n < 0) fail(std::string("es_load_weights: implausible shape of '") + t.key + "' in the " + name + " state dict");
       m[t.key] = &t;
     }
   }
@@ -381,6 +385,7 @@ struct Builder {
                  const std::vector<float>* tail = nullptr, int ctail = 0) {
     if ((long long)w.size() != (long long)cout * cin * k * k) fail("builder: weight size does not match its shape");
     const int cp = cin_pad ? cin_pad : round_up(cin, 8);
+    if (cp < cin || cp % 8 || (cout_pad && cout_pad < cout)) fail("builder: channel padding smaller than the tensor");
     const int ktrue = k * k * cp + ctail;
     const int cout_eff = cout_pad ? cout_pad : cout;
     const int bn = geglu ? 128 : choose_bn(cout_eff);
@@ -719,6 +724,10 @@ struct Resnet {
   Resnet(Builder& B, const Weights& W, const std::string& p, int groups_, float eps_, int temb_off_) : groups(groups_), eps(eps_), temb_off(temb_off_) {
     const es_tensor* w1 = W.get(p + ".conv1.weight");
     const int cin = (int)w1->shape[1], cout = (int)w1->shape[0];
+    W.shaped(p + ".conv1.weight", {cout, cin, 3, 3}); W.shaped(p + ".conv2.weight", {cout, cout, 3, 3});
+    if (W.has(p + ".conv_shortcut.weight")) W.shaped(p + ".conv_shortcut.weight", {cout, cin, 1, 1});
+    else if (cin != cout) fail("es_load_weights: '" + p + "' changes the channel count but has no conv_shortcut");
+    if (temb_off_ >= 0) W.shaped(p + ".time_emb_proj.weight", {cout, -1});
     n1 = B.norm(W, p + ".norm1", cin); n2 = B.norm(W, p + ".norm2", cout);
     conv1 = B.conv(W, p + ".conv1");
     const bool has_short = W.has(p + ".conv_shortcut.weight");
@@ -754,6 +763,12 @@ struct Transformer {               // Transformer2DModel(use_linear_projection F
     const es_tensor* pi = W.get(p + ".proj_in.weight");
     c = (int)pi->shape[0];
     if (c % 64) fail("es_load_weights: transformer width " + std::to_string(c) + " ('" + p + "') is not a multiple of 64: the LayerNorm / proj_out folds of this builder need it");
+    const int cross = (int)W.get(tb + ".attn2.to_k.weight")->shape[1];
+    W.shaped(p + ".proj_in.weight", {c, c, 1, 1}); W.shaped(p + ".proj_out.weight", {c, c, 1, 1});
+    for (const char* q : {".attn1.to_q", ".attn1.to_k", ".attn1.to_v", ".attn1.to_out.0", ".attn2.to_q", ".attn2.to_out.0"}) W.shaped(tb + q + ".weight", {c, c});
+    W.shaped(tb + ".attn2.to_k.weight", {c, cross}); W.shaped(tb + ".attn2.to_v.weight", {c, cross});
+    W.shaped(tb + ".ff.net.0.proj.weight", {8 * c, c}); W.shaped(tb + ".ff.net.2.weight", {c, 4 * c});
+    if (c % heads_) fail("es_load_weights: transformer width of '" + p + "' is not a multiple of the head count");
     norm = B.norm(W, p + ".norm", c);
     proj_in = B.conv(W, p + ".proj_in");
     qkv_ln = B.cat_ln(W, {tb + ".attn1.to_q", tb + ".attn1.to_k", tb + ".attn1.to_v"}, false, tb + ".norm1");
@@ -800,6 +815,8 @@ struct Encoder {                   // conv_in + time_embedding + down_blocks + m
   void init(Builder& B, const Weights& W, const UCfg& c, const std::vector<std::string>& extra_resnets) {
     cfg = c;
     in_pad = round_up(c.in_ch, 8);
+    W.shaped("conv_in.weight", {c.ch[0], c.in_ch, 3, 3});
+    W.shaped("time_embedding.linear_1.weight", {4 * c.ch[0], c.ch[0]}); W.shaped("time_embedding.linear_2.weight", {4 * c.ch[0], 4 * c.ch[0]});
     conv_in = B.conv(W, "conv_in", in_pad);
     t1 = B.conv(W, "time_embedding.linear_1"); t2 = B.conv(W, "time_embedding.linear_2");
     std::vector<std::string> names;
@@ -808,7 +825,7 @@ struct Encoder {                   // conv_in + time_embedding + down_blocks + m
     names.insert(names.end(), extra_resnets.begin(), extra_resnets.end());
     int o = 0;
     std::vector<std::string> tp;
-    for (const auto& nm : names) { temb_offs[nm] = o; o += (int)W.get(nm + ".time_emb_proj.weight")->shape[0]; tp.push_back(nm + ".time_emb_proj"); }
+    for (const auto& nm : names) { temb_offs[nm] = o; o += (int)W.shaped(nm + ".time_emb_proj.weight", {-1, 4 * c.ch[0]})->shape[0]; tp.push_back(nm + ".time_emb_proj"); }
     tproj = B.cat(W, tp, true);
     for (int i = 0; i < c.nb; ++i) {
       down.emplace_back();
@@ -856,6 +873,7 @@ struct UNet : Encoder {
       }
       upsample.push_back(i != c.nb - 1 ? B.conv(W, "up_blocks." + std::to_string(i) + ".upsamplers.0.conv") : nullptr);
     }
+    W.shaped("conv_out.weight", {c.out_ch, c.ch[0], 3, 3});
     norm_out = B.norm(W, "conv_norm_out", c.ch[0]);
     conv_out = B.conv(W, "conv_out");
   }
@@ -868,11 +886,18 @@ struct ControlNet : Encoder {
   void init(Builder& B, const Weights& W, const UCfg& c, bool uses_vae_) {
     Encoder::init(B, W, c, {});
     uses_vae = uses_vae_;
-    const int nres = 1 + c.nb * c.lpb + (c.nb - 1);
-    for (int i = 0; i < nres; ++i) zero.push_back(B.conv(W, "controlnet_down_blocks." + std::to_string(i)));
+    std::vector<int> rc{c.ch[0]};                      // channels of the 12 down residuals (MC:73-102)
+    for (int i = 0; i < c.nb; ++i) { for (int j = 0; j < c.lpb; ++j) rc.push_back(c.ch[i]); if (i != c.nb - 1) rc.push_back(c.ch[i]); }
+    for (size_t i = 0; i < rc.size(); ++i) {
+      W.shaped("controlnet_down_blocks." + std::to_string(i) + ".weight", {rc[i], rc[i], 1, 1});
+      zero.push_back(B.conv(W, "controlnet_down_blocks." + std::to_string(i)));
+    }
+    W.shaped("controlnet_mid_block.weight", {c.ch[c.nb - 1], c.ch[c.nb - 1], 1, 1});
     zero_mid = B.conv(W, "controlnet_mid_block");
     if (!uses_vae) {
       const std::string p = "controlnet_cond_embedding";
+      W.shaped(p + ".conv_in.weight", {c.ce[0], c.cond_ch, 3, 3});
+      W.shaped(p + ".conv_out.weight", {c.ch[0], c.ce[c.nce - 1], 3, 3});
       cond.push_back(B.conv(W, p + ".conv_in", 8));
       for (int i = 0; i < 2 * (c.nce - 1); ++i) cond.push_back(B.conv(W, p + ".blocks." + std::to_string(i)));
       cond.push_back(B.conv(W, p + ".conv_out"));
@@ -909,6 +934,11 @@ struct VAE {
     cfg = c;
     lat_pad = round_up(c.latent, 8);
     const int n = c.nb;
+    W.shaped("encoder.conv_in.weight", {c.ch[0], 3, 3, 3}); W.shaped("encoder.conv_out.weight", {2 * c.latent, c.ch[n - 1], 3, 3});
+    W.shaped("quant_conv.weight", {2 * c.latent, 2 * c.latent, 1, 1}); W.shaped("post_quant_conv.weight", {c.latent, c.latent, 1, 1});
+    W.shaped("decoder.conv_in.weight", {c.ch[n - 1], c.latent, 3, 3}); W.shaped("decoder.conv_out.weight", {3, c.ch[0], 3, 3});
+    for (const char* side : {"encoder", "decoder"})
+      for (const char* q : {".to_q", ".to_k", ".to_v", ".to_out.0"}) W.shaped(std::string(side) + ".mid_block.attentions.0" + q + ".weight", {c.ch[n - 1], c.ch[n - 1]});
     e_in = B.conv(W, "encoder.conv_in", 8);
     for (int i = 0; i < n; ++i) {
       std::vector<Resnet> rs;

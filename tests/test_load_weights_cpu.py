@@ -142,6 +142,17 @@ def test_missing_keys_wrong_shapes_and_unsupported_requests_are_named(tiny):
     bad["unet"]["conv_norm_out.weight"] = ws["unet"]["conv_norm_out.weight"][:32]
     with pytest.raises(L.EdgeStyleHipError, match="size mismatch for 'conv_norm_out.weight'"):
         build(bad)
+    bad = dict(ws)
+    bad["openpose"] = dict(ws["openpose"])
+    k = "down_blocks.1.attentions.0.transformer_blocks.0.attn2.to_v.weight"
+    bad["openpose"][k] = ws["openpose"][k][:64]                                           # a K/V projection of the wrong width
+    with pytest.raises(L.EdgeStyleHipError, match="size mismatch for 'down_blocks.1.attentions.0.transformer_blocks.0.attn2.to_v.weight' in the ControlNet 1"):
+        build(bad)
+    bad = dict(ws)
+    bad["vae"] = dict(ws["vae"])
+    bad["vae"]["decoder.conv_out.weight"] = ws["vae"]["decoder.conv_out.weight"][:, :16]
+    with pytest.raises(L.EdgeStyleHipError, match="size mismatch for 'decoder.conv_out.weight' in the VAE"):
+        build(bad)
     with pytest.raises(L.EdgeStyleHipError, match="net_of_cond"):
         build(ws, net_of_cond=(0, 1, 2, 1, 3, 1))
     # 16x16 latents: the groups of the lockstep pass do not tile in 128-pixel units (the Python host falls back to serial chains)
