@@ -154,6 +154,48 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const es_gn_desc p, const
   T* out = (T*)p.out + (size_t)n * p.HW * C;
   // grid-stride loop, four items' loads in flight per thread
   const int gstride = gridDim.x * 256;
+  if (gstride % CH8 == 0) {
+    // The launcher makes the grid stride a multiple of the chunks per pixel: a thread then stays on ONE 16-byte channel chunk
+    // for all of its pixels, so its 8 scale / shift pairs live in registers (read from LDS once) and the pixel index advances
+    // by a constant - the loop is load, 8 FMA (+ SiLU), store.  (Per item the general loop below issues four LDS reads and an
+    // index division beside one 16-byte global load: instruction-bound at ~2.8 TB/s, like the fusion passes before they were
+    // given the same treatment.)  Same arithmetic on the same values: bit-identical results.
+    const int i0 = blockIdx.x * 256 + threadIdx.x;
+    const int px0 = div_any(i0, CH8, inv_ch8, small);
+    const int c = (i0 - px0 * CH8) * 8;
+    const int pstep = gstride / CH8;
+    const bool second = c >= p.C1;
+    const T* src = (second ? (const T*)p.x2 : (const T*)p.x) + (size_t)n * p.HW * (second ? p.C2 : p.C1) + (second ? c - p.C1 : c);
+    const int cs = second ? p.C2 : p.C1;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = scale[c + e]; sh[e] = shift[c + e]; }
+    T* o = out + c;
+    for (int px = px0; px < p.HW; px += GNU * pstep) {
+      u32x4 raw[GNU];
+#pragma unroll
+      for (int u = 0; u < GNU; ++u) {
+        const int q = px + u * pstep;
+        raw[u] = q < p.HW ? *(const u32x4*)(src + (size_t)q * cs) : u32x4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int u = 0; u < GNU; ++u) {
+        const int q = px + u * pstep;
+        if (q < p.HW) {
+          const auto v = as_vec8<T>(raw[u]);
+          typename Traits<T>::vec8 r;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float f = to_f32(v[e]) * sc[e] + sh[e];
+            if (p.silu) f = silu_f(f);
+            r[e] = from_f32<T>(f);
+          }
+          store16(o + (size_t)q * C, __builtin_bit_cast(u32x4, r));
+        }
+      }
+    }
+    return;
+  }
   for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += GNU * gstride) {
     u32x4 raw[GNU];
     int pxs[GNU], cs_[GNU];
@@ -392,9 +434,22 @@ int launch_gn(const es_gn_desc& d, hipStream_t st) {
   const size_t lds_stats = (size_t)2 * PS * C * sizeof(float);
   hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(nchunk, d.N), dim3(256), lds_stats, st, d);
   const long long total = (long long)d.HW * (C / 8);
-  int blocks = (int)((total + 256 * GNU - 1) / (256 * GNU));
+  // workgroups per sample: every workgroup first reduces the partials and builds the scale / shift tables (~2 us), so a thread
+  // should stream more than one round of loads behind that prologue - 16 items where that still leaves >= 1024 workgroups for the
+  // chip, else 8, else 4 (tools/norm_bench.py, 14 x 64^2 x 320: 32.1 / 27.7 / 28.5 us for 4 / 8 / 16; 112 samples: 215 / 188 / 180)
+  static const bool legacy = getenv("ES_GN_LEGACY") && getenv("ES_GN_LEGACY")[0] == '1';     // tool switch: the round-2 geometry
+  int ipt = GNU;
+  if (!legacy)
+    for (int cand : {16, 8}) if (((total + 256 * cand - 1) / (256 * cand)) * d.N >= 1024) { ipt = cand; break; }
+  int blocks = (int)((total + 256 * ipt - 1) / (256 * ipt));
   if (blocks < 1) blocks = 1;
   if (blocks > 1024) blocks = 1024;
+  if (!legacy) {   // a multiple of q = CH8 / gcd(CH8, 256) workgroups: the grid stride is then a multiple of the chunks per pixel (gn_apply_kernel)
+    int a = CH8, b = 256;
+    while (b) { const int t = a % b; a = b; b = t; }
+    const int q = CH8 / a;
+    if (q <= 64) blocks = blocks < q ? q : blocks / q * q;
+  }
   const size_t lds = (size_t)(2 * C + 2 * d.groups + 256) * sizeof(float);
   hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(blocks, d.N), dim3(256), lds, st, d, nchunk);
   return hipGetLastError() == hipSuccess ? 0 : -2;
