@@ -417,7 +417,10 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? (FM == 2 
       wa1[i] = as_vec8<T>(*(const u32x4*)(ws + row * 128 + (((4 + fq) ^ (row & 7)) << 4)));
     }
     }
-    if constexpr (LN) {
+#ifndef ES_LN_NOGRAM            // tool-only ablation: the row statistics' MFMAs removed (results are wrong by construction)
+#define ES_LN_NOGRAM 0
+#endif
+    if constexpr (LN && !ES_LN_NOGRAM) {
 #pragma unroll
       for (int jj = 0; jj < LNH; ++jj) {
         const auto f0 = wn ? xa0[LNH + jj] : xa0[jj];
