@@ -398,7 +398,8 @@ def test_native_abi_full_width_rgb_to_image_equals_pipeline_bitwise(full):
         eng.close()
 
 
-def test_es_load_weights_full_width_context_equals_pipeline_bitwise(full):
+@pytest.mark.parametrize("B,T", [(1, 3), (8, 2)])
+def test_es_load_weights_full_width_context_equals_pipeline_bitwise(full, B, T):
     """SURVEY 8b's es_load_weights at SD1.5 width: the library builds the context itself from the raw state dicts (1.3 G
     parameters: rank-32 LoRA folds, LayerNorm / proj_out / shortcut folds, packing, arena layout, five launch lists - no model
     walk in Python) and RGB condition images -> es_prepare_conds -> es_denoise_loop -> es_vae_decode through it reproduce
@@ -411,13 +412,20 @@ def test_es_load_weights_full_width_context_equals_pipeline_bitwise(full):
         if getattr(net.config, "uses_vae", False):
             net.set_autoencoder(pipe.vae)
     imgs, noise, lat, pe, ne = H.full_rgb_inputs(seed=52)
-    T, gs = 3, 7.5
+    gs = 7.5
+    if B > 1:                                  # batch 8 (BASELINE configs[2]): per-image latents / prompts / sampling noise, shared images
+        g = torch.Generator().manual_seed(53)
+        lat = torch.randn(B, *lat.shape[1:], generator=g)
+        pe = (torch.randn(B, *pe.shape[1:], generator=g) * 0.5).half().float()
+        ne = (torch.randn(B, *ne.shape[1:], generator=g) * 0.5).half().float()
+        noise = [None if z is None else torch.randn(2 * B, *z.shape[1:], generator=g).half().float() for z in noise]
     kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=imgs, latents=lat, guidance_scale=gs, num_inference_steps=T,
               cond_noise=noise)
     want_lat = pipe(output_type="latent", **kw).images.clone()
     want_img = pipe(output_type="pt", **kw).images.clone()
+    imgs = [im.repeat_interleave(B, dim=0) for im in imgs]         # the C ABI takes one image per request (PL:647-653 repeats them)
     t0 = time.time()
-    nat = NativeContext(full["ws"], full["ucfg"], full["vcfg"], batch_size=1, guidance=True, num_inference_steps=T, device=0)
+    nat = NativeContext(full["ws"], full["ucfg"], full["vcfg"], batch_size=B, guidance=True, num_inference_steps=T, device=0)
     build_s = time.time() - t0
     try:
         nat.set_alphas_cumprod(pipe.scheduler.alphas_cumprod)
@@ -432,7 +440,8 @@ def test_es_load_weights_full_width_context_equals_pipeline_bitwise(full):
             torch.cuda.synchronize()
             assert torch.equal(got.permute(0, 3, 1, 2), want_lat), float((got.permute(0, 3, 1, 2) - want_lat).abs().max())
             assert torch.equal(img, want_img)
-        record("es_load_weights_full_width", build_seconds=round(build_s, 1), plan_step_calls=nat.plan_size(2), bitwise_equal_to_pipeline=True)
+        record("es_load_weights_full_width", batch=B, build_seconds=round(build_s, 1), plan_step_calls=nat.plan_size(2),
+               arena_gib=round(nat.lib.es_ctx_arena_bytes(nat.ctx) / 2 ** 30, 2), bitwise_equal_to_pipeline=True)
     finally:
         nat.close()
 

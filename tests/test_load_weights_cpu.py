@@ -101,13 +101,19 @@ def test_sources_in_fp16_and_bf16_compute_type(tiny):
     a = NativeContext(ws, ucfg, vcfg, num_inference_steps=4, device=-2)
     ws16 = {k: {kk: vv.half() for kk, vv in v.items()} for k, v in ws.items()}         # exact: the fixture is fp16-rounded
     b = NativeContext(ws16, ucfg, vcfg, num_inference_steps=4, device=-2)
-    c = NativeContext(ws, ucfg, vcfg, num_inference_steps=4, device=-1, dtype=torch.bfloat16)
+    c = NativeContext(ws, ucfg, vcfg, num_inference_steps=4, device=-2, dtype=torch.bfloat16)
+    _, pctx, keep = python_dry_context(ws, ucfg, vcfg, 1, True, 4, dtype=torch.bfloat16)
     try:
         assert plan_constants(lib, a.ctx, L.PLAN_STEP) == plan_constants(lib, b.ctx, L.PLAN_STEP)
         assert c.plan_size(L.PLAN_STEP) == a.plan_size(L.PLAN_STEP)
+        for which in range(5):                                   # bf16: the same calls, the same rounding of every packed value
+            assert diff_plans(lib, pctx, c.ctx, which) is None
+            assert plan_constants(lib, pctx, which) == plan_constants(lib, c.ctx, which)
+        assert plan_constants(lib, c.ctx, L.PLAN_STEP) != plan_constants(lib, a.ctx, L.PLAN_STEP)
     finally:
         for x in (a, b, c):
             x.close()
+        lib.es_ctx_destroy(pctx)
 
 
 def test_missing_keys_wrong_shapes_and_unsupported_requests_are_named(tiny):
