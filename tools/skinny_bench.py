@@ -2,7 +2,8 @@
 """Weight-streaming-bound 3x3 convolutions of the deep levels at batch 1 (M = 128 ... 3584 output pixels, K = 11520 ... 23040,
 N = 1280): the planner's tile against a forced N tile / split-K, grouped like the step's launches.
 
-    python tools/skinny_bench.py [--bn 0,320] [--sk 0]          (ES_BN320_SKINNY=4|2: the 128 x 320 tile on 4 | 8 waves)
+    python tools/skinny_bench.py [--bn 0,128,160] [--sk 0,4,7]
+(this is the harness a 128 x 320 instantiation of conv_gemm_kernel was measured with - and lost.)
 """
 import argparse
 import os
