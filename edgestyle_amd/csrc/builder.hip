@@ -10,9 +10,10 @@
 // uploaded.  The walk is the one edgestyle_amd/engine.py + models.py (StepRunner, grouped lockstep mode) + native.py perform
 // through Python; tests/test_load_weights_*.py hold the two builders against each other call by call and bit by bit.
 //
-// Scope: the reference's configuration - the fused multi-ControlNet model with 64-aligned channel widths, DDIM, grouped
-// lockstep execution.  What the Python builder offers beyond that (single ControlNet, guess_mode, UniPC, tiny widths that do
-// not tile) is refused here with an error, never approximated.
+// Scope: the reference's configurations - the fused six-slot multi-ControlNet model (TT:252-258) or ONE ControlNet whose 13
+// residuals go to the UNet without fusion blocks (PL:338-351, BASELINE configs[0]) - with 64-aligned channel widths, grouped
+// lockstep execution, DDIM or UniPC (es_ctx_set_scheduler).  What the Python builder offers beyond that (guess_mode, latent
+// sizes whose groups do not tile) is refused here with an error, never approximated.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -1164,6 +1165,15 @@ struct Model {
     std::vector<T> srcs = skips; srcs.push_back(mid);
     std::vector<T> enc;
     for (const auto& s : srcs) enc.push_back(s.batch(ncn));
+    std::vector<T> fused;
+    if (nn == 1) {
+      // one ControlNet: skip + scale * zero_conv(cn_skip) straight out of the zero-conv epilogue (PL:500-510; CL:266-270)
+      const ControlNet* cn = (const ControlNet*)encs[0];
+      for (size_t lvl = 0; lvl < srcs.size(); ++lvl) {
+        CA a; a.residual = enc[lvl]; a.out_scale = 1.f; a.out_scale_dev = scales_cur.chan(0, 1);
+        fused.push_back(B.conv_gemm(srcs[lvl].batch(0, ncn), lvl + 1 < srcs.size() ? cn->zero[lvl] : cn->zero_mid, a));
+      }
+    } else {
     // zero-convs of all levels (grouped over the ControlNets) -> the fusion blocks, which also add the UNet's own tensors
     std::vector<int> cn_counts(counts.begin(), counts.end() - 1);
     std::vector<T> res;
@@ -1175,7 +1185,7 @@ struct Model {
     std::vector<int> first(nn, 0);
     { int a = 0; for (const auto& g : groups) for (int p : g.second) { first[p] = a; a += N; } }
     std::vector<es_fusion_desc> fd(srcs.size());
-    std::vector<T> us, fused;
+    std::vector<T> us;
     for (size_t k = 0; k < srcs.size(); ++k) {
       const FusionParams& fp = fusion[k];
       const int HW = fp.s * fp.s, Cc = fp.c;
@@ -1198,7 +1208,8 @@ struct Model {
       fused.push_back(out.view(N, fp.s, fp.s, Cc));
     }
     Builder::ok(es_fusion_blocks(fd.data(), (int)fd.size(), nullptr), "es_fusion_blocks");
-    us.clear(); res.clear(); srcs.clear(); skips.clear(); enc.clear(); mid = T();
+    }
+    srcs.clear(); skips.clear(); enc.clear(); mid = T();
     // the UNet decoder on the fused tensors (skip + residual already summed: PL:500-510)
     T tp = tproj.batch(ncn);
     T hh = fused.back();
@@ -1316,7 +1327,8 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
     Builder& B = M.B;
     // ---- configuration
     if (mc->n_blocks < 2 || mc->n_blocks > 4 || mc->vae_n_blocks < 2 || mc->vae_n_blocks > 4) fail("es_load_weights: 2..4 resolution levels");
-    if (g->n_conds != 6) fail("es_load_weights: the reference's fused configuration has six condition slots (MC:66-114); a single ControlNet is built by the Python host only");
+    if (g->n_conds != 6 && g->n_conds != 1) fail("es_load_weights: n_conds is 6 (the reference's fused multi-ControlNet model, MC:66-114) or 1 (a single ControlNet, PL:338-351)");
+    if (g->n_conds == 1 && wts->n_controlnets != 1) fail("es_load_weights: a single-ControlNet context takes exactly one ControlNet");
     if (g->dtype != ES_F16 && g->dtype != ES_BF16) fail("es_load_weights: dtype must be ES_F16 or ES_BF16");
     if (g->B < 1 || g->h < 1 || g->w < 1 || g->n_steps < 1) fail("es_load_weights: bad geometry");
     if (wts->n_controlnets < 1 || wts->n_controlnets > 6) fail("es_load_weights: 1..6 distinct ControlNets");
@@ -1332,11 +1344,11 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
     if (u.cond_ch != 3 || u.nce < 2 || u.nce > 4) fail("es_load_weights: conditioning embedding of 3 input channels, 2..4 widths");
     M.geo = *g;
     B.dt = g->dtype;
-    M.B_ = g->B; M.N = g->cfg ? 2 * g->B : g->B; M.T_ = g->n_steps; M.h = g->h; M.w = g->w; M.nn = 6;
-    const int N = M.N, TS = M.T_, h = g->h, w = g->w, Bn = g->B;
+    M.B_ = g->B; M.N = g->cfg ? 2 * g->B : g->B; M.T_ = g->n_steps; M.h = g->h; M.w = g->w; M.nn = g->n_conds;
+    const int N = M.N, TS = M.T_, h = g->h, w = g->w, Bn = g->B, NN = g->n_conds;
     {   // the groups of the lockstep pass: nets that share weights run as one batched chain; every group must tile
       int cnt[6] = {};
-      for (int p = 0; p < 6; ++p) {
+      for (int p = 0; p < NN; ++p) {
         const int ni = wts->net_of_cond[p];
         if (ni < 0 || ni >= wts->n_controlnets) fail("es_load_weights: net_of_cond names a ControlNet that was not given");
         ++cnt[ni];
@@ -1364,7 +1376,7 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
       M.nets.emplace_back(new ControlNet());
       M.nets.back()->init(B, Wc, u, kind == ES_NET_CONTROL_LORA_VAE);
     }
-    for (int p = 0; p < 6; ++p) {
+    for (int p = 0; p < NN; ++p) {
       const int ni = wts->net_of_cond[p];
       if (ni < 0 || ni >= wts->n_controlnets) fail("es_load_weights: net_of_cond names a ControlNet that was not given");
       M.net_of_cond.push_back(ni);
@@ -1387,7 +1399,7 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
       M.table.push_back({u.ch[u.nb - 1], s});
       if (M.table.size() > ES_FUSION_MAX_BATCH) fail("es_load_weights: more residual levels than es_fusion_blocks takes");
     }
-    M.pack_fusion(Wf);
+    if (NN > 1) M.pack_fusion(Wf);
     // ---- the grouped encoder
     for (const auto& gp : M.groups) { M.encs.push_back(M.nets[gp.first].get()); M.counts.push_back((int)gp.second.size() * N); }
     M.encs.push_back(&M.unet); M.counts.push_back(N);
@@ -1399,13 +1411,13 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
     M.latents = B.persistent_t(Bn, h, w, Lc, 4);
     M.model_in = B.persistent_t(N, h, w, Lp);
     M.noise = B.persistent_t(N, h, w, u.out_ch);
-    for (int i = 0; i < 6; ++i) M.conds.push_back(B.persistent_t(N, h, w, c0));
+    for (int i = 0; i < NN; ++i) M.conds.push_back(B.persistent_t(N, h, w, c0));
     M.ehs = B.persistent_t(N, mc->text_tokens > 0 ? mc->text_tokens : 77, 1, u.cross);
     M.step_idx = B.persistent_t(1, 1, 1, 1, 4);
     M.t_rows = B.persistent_t(1, 1, 1, M.kmax * N, 4);
-    M.scales_cur = B.persistent_t(1, 1, 1, 6, 4);
+    M.scales_cur = B.persistent_t(1, 1, 1, NN, 4);
     M.t_table = B.persistent_t(TS, 1, 1, M.kmax * N, 4);
-    M.scale_table = B.persistent_t(TS, 1, 1, 6, 4);
+    M.scale_table = B.persistent_t(TS, 1, 1, NN, 4);
     M.coef = B.persistent_t(TS, 1, 1, 12, 4);                       // T x 4 (DDIM) or T x 12 (UniPC) rows
     for (int i = 0; i < 3; ++i) M.hist.push_back(B.persistent_t(Bn, h, w, Lc, 4));   // UniPC multistep state
     M.ts_dev = B.persistent_t(1, 1, 1, TS, 4);
@@ -1428,13 +1440,13 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
     M.tproj_cur = B.persistent_t(M.ntot, 1, 1, M.width);
     M.tproj_gen = B.persistent_t(M.ntot, 1, 1, M.width);
     // es_prepare_conds inputs: one image batch per shared encoder (the VAE of the LoRA nets first, NativeEngine._conds_fn)
-    M.cond_img.resize(6); M.cond_noise.resize(6);
+    M.cond_img.resize(NN); M.cond_noise.resize(NN);
     {
       Model::CondGroup vg; vg.vae = true; vg.net = -1;
-      for (int i = 0; i < 6; ++i) if (M.nets[M.net_of_cond[i]]->uses_vae) vg.idx.push_back(i);
+      for (int i = 0; i < NN; ++i) if (M.nets[M.net_of_cond[i]]->uses_vae) vg.idx.push_back(i);
       std::vector<Model::CondGroup> order;
       bool vae_placed = false;
-      for (int i = 0; i < 6; ++i) {
+      for (int i = 0; i < NN; ++i) {
         const int ni = M.net_of_cond[i];
         if (M.nets[ni]->uses_vae) { if (!vae_placed) { order.push_back(vg); vae_placed = true; } continue; }
         bool found = false;
@@ -1499,7 +1511,7 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
     bind(ES_BUF_NOISE, M.noise); bind(ES_BUF_LATENTS, M.latents); bind(ES_BUF_STEP_IDX, M.step_idx); bind(ES_BUF_T_TABLE, M.t_table);
     bind(ES_BUF_SCALE_TABLE, M.scale_table); bind(ES_BUF_COEF, M.coef); bind(ES_BUF_TIMESTEPS, M.ts_dev); bind(ES_BUF_IMAGE, M.image);
     for (int i = 0; i < 3; ++i) bind(ES_BUF_HIST0 + i, M.hist[i]);
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < NN; ++i) {
       bind(ES_BUF_COND0 + i, M.conds[i]);
       bind(ES_BUF_COND_IMG0 + i, M.cond_img[i]);
       if (M.cond_noise[i]) bind(ES_BUF_COND_NOISE0 + i, M.cond_noise[i]);

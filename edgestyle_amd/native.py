@@ -517,7 +517,8 @@ class NativeContext:
     engine.py, ops.py) is involved: torch only hands over host pointers at build time and device pointers at run time.
 
     ws: {"unet", "vae", "fusion", <controlnet names>} state dicts; `controlnets`: [(name in ws, L.NET_*)] the distinct nets;
-    net_of_cond: which of them serves each of the six condition slots (TT:252-258).  device < 0: dry build (no GPU)."""
+    net_of_cond: which of them serves each of the six condition slots (TT:252-258) - or ONE entry for a single ControlNet whose
+    residuals go to the UNet without fusion blocks (PL:338-351; no "fusion" dict then).  device < 0: dry build (no GPU)."""
 
     def __init__(self, ws, ucfg, vcfg, batch_size: int = 1, guidance: bool = True, num_inference_steps: int = 50,
                  height: Optional[int] = None, width: Optional[int] = None, dtype=torch.float16, device: int = 0,
@@ -527,11 +528,14 @@ class NativeContext:
         self.ucfg, self.vcfg = ucfg, vcfg
         h = (height // vcfg.scale) if height else ucfg.sample_size
         w = (width // vcfg.scale) if width else ucfg.sample_size
-        self.B, self.N, self.T, self.h, self.w, self.nn = batch_size, batch_size * (2 if guidance else 1), num_inference_steps, h, w, 6
+        nn = len(net_of_cond)
+        self.B, self.N, self.T, self.h, self.w, self.nn = batch_size, batch_size * (2 if guidance else 1), num_inference_steps, h, w, nn
         self.dtype, self.device = dtype, device
         wts = L.Weights()
         keep = []
         for name in ("unet", "vae", "fusion"):
+            if name == "fusion" and nn == 1:
+                continue
             d, k = state_dict_descriptors(ws[name])
             setattr(wts, name, d)
             keep.append(k)
@@ -543,7 +547,7 @@ class NativeContext:
         for i, n in enumerate(net_of_cond):
             wts.net_of_cond[i] = n
         geo = L.CtxGeometry(B=batch_size, cfg=int(guidance), h=h, w=w, latent_channels=ucfg.in_channels,
-                            latent_pad=(ucfg.in_channels + 7) // 8 * 8, n_conds=6, n_steps=num_inference_steps,
+                            latent_pad=(ucfg.in_channels + 7) // 8 * 8, n_conds=nn, n_steps=num_inference_steps,
                             dtype=L.ES_F16 if dtype == torch.float16 else L.ES_BF16)
         mc = model_config(ucfg, vcfg)
         ctx = C.c_void_p()
@@ -580,16 +584,16 @@ class NativeContext:
         """sample [N,h,w,latent_pad], ehs [N,77,D], cond_embeds 6 x [N,h,w,C0] (compute dtype, contiguous, device) -> [N,h,w,4]"""
         if out is None:
             out = torch.empty((self.N, self.h, self.w, self.ucfg.out_channels), dtype=self.dtype, device=sample.device)
-        ptrs = (C.c_void_p * 6)(*[c.data_ptr() for c in cond_embeds])
-        sc = None if scales is None else (C.c_float * 6)(*[float(s) for s in scales])
+        ptrs = (C.c_void_p * self.nn)(*[c.data_ptr() for c in cond_embeds])
+        sc = None if scales is None else (C.c_float * self.nn)(*[float(s) for s in scales])
         L.check(self.lib.es_denoise_step(self.ctx, _p(sample), float(t), _p(ehs), ptrs, sc, _p(out), self._stream()), "es_denoise_step")
         return out
 
     def prepare_conds(self, images, noise=None):
         """images: 6 x device fp32 [B,3,H,W]; noise: per slot None or device fp32 [N,L,h,w]"""
-        self._live = ([im.contiguous() for im in images], [None if (noise is None or z is None) else z.contiguous() for z in (noise or [None] * 6)])
-        ip = (C.c_void_p * 6)(*[im.data_ptr() for im in self._live[0]])
-        npz = (C.c_void_p * 6)(*[None if z is None else z.data_ptr() for z in self._live[1]])
+        self._live = ([im.contiguous() for im in images], [None if (noise is None or z is None) else z.contiguous() for z in (noise or [None] * self.nn)])
+        ip = (C.c_void_p * self.nn)(*[im.data_ptr() for im in self._live[0]])
+        npz = (C.c_void_p * self.nn)(*[None if z is None else z.data_ptr() for z in self._live[1]])
         L.check(self.lib.es_prepare_conds(self.ctx, ip, npz, self._stream()), "es_prepare_conds")
 
     def denoise_loop(self, latents, ehs, guidance_scale: float, timesteps):

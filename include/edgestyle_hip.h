@@ -364,8 +364,9 @@ int es_ctx_load(const char* path, int device, es_ctx** out);
  * it feeds, ff.net.2 into proj_out and conv_shortcut behind conv2, packs everything into the kernels' layouts, lays out ONE
  * device arena (weights, static buffers, activations with lifetime-based reuse, split-K workspace), records the five launch
  * lists and binds the slots.  A missing key or a tensor of the wrong shape is an error naming the key.
- * Scope: the reference's fused configuration (six condition slots over 1..3 distinct ControlNets + the UNet, 64-aligned
- * channel widths, DDIM).  device -1: dry build - everything but the device allocation and the upload (plans keep
+ * Scope: the reference's configurations - six condition slots over 1..3 distinct ControlNets + the UNet through the fusion blocks
+ * (TT:252-258), or n_conds = 1: ONE ControlNet whose 13 residuals go to the UNet directly (PL:338-351; `fusion` is not read) -
+ * with 64-aligned channel widths; DDIM or UniPC (es_ctx_set_scheduler).  device -1: dry build - everything but the device allocation and the upload (plans keep
  * arena-relative addresses; for inspection with es_ctx_plan / es_plan_export on a host without a GPU); device -2: the same
  * with the arena in host memory, contents included (what tests read the packed weights from).  Neither can launch.
  * --------------------------------------------------------------------------------------------------------- */
@@ -385,7 +386,7 @@ typedef struct {
   es_state_dict controlnet[6];     /* the distinct nets */
   int32_t controlnet_kind[6];      /* ES_NET_* */
   int32_t n_controlnets;
-  int32_t net_of_cond[6];          /* which net serves condition slot i (TT:252-258: {0, 1, 2, 1, 2, 1}) */
+  int32_t net_of_cond[6];          /* which net serves condition slot i (TT:252-258: {0, 1, 2, 1, 2, 1}); n_conds entries are read */
 } es_weights;
 typedef struct {                   /* config.json of the SD1.5 checkpoints (README.md:131-135; MC:73-102 hard-codes their consequences) */
   int32_t in_channels, out_channels;
@@ -397,7 +398,7 @@ typedef struct {                   /* config.json of the SD1.5 checkpoints (READ
   int32_t vae_n_blocks, vae_block_out_channels[4], vae_layers_per_block, vae_latent_channels, vae_norm_num_groups;
   float vae_norm_eps, vae_scaling_factor;
 } es_model_config;
-/* g: B, cfg, h, w, n_conds (6), n_steps, dtype are read; latent_channels / latent_pad are derived from the config */
+/* g: B, cfg, h, w, n_conds (6 | 1), n_steps, dtype are read; latent_channels / latent_pad are derived from the config */
 int es_load_weights(const es_weights* w, const es_model_config* cfg, const es_ctx_geometry* g, int device, es_ctx** out);
 /* The launch planner the builders share (host-only): the N tile (bn), split-K factor and LDS ring depth es_load_weights picks for
  * an es_conv_gemm launch of M output pixels among the candidate tiles `bns` (edgestyle_amd/ops.py plan_gemm makes the same

@@ -197,14 +197,17 @@ def python_dry_context(ws, ucfg, vcfg, B=1, guidance=True, T=6, dtype=torch.floa
                 if kind == 1:
                     net.set_autoencoder(vae)
             distinct.append(net)
-        mc = M.EdgeStyleMultiControlNetModel([distinct[i] for i in net_of_cond], ucfg, None)
-        mc.load_state_dict(ws["fusion"])
+        if len(net_of_cond) == 1:                       # one ControlNet: 13 residuals straight to the UNet (PL:338-351)
+            mc = distinct[net_of_cond[0]]
+        else:
+            mc = M.EdgeStyleMultiControlNetModel([distinct[i] for i in net_of_cond], ucfg, None)
+            mc.load_state_dict(ws["fusion"])
         runner = M.StepRunner(unet, mc)
         pipe = EdgeStyleStableDiffusionControlNetPipeline(vae=vae, unet=runner.unet, controlnet=runner.controlnet)
         pipe._runner = runner
         h = w = ucfg.sample_size
         loop = _Loop(pipe, B, guidance, h, w)
-        N, k, nn = loop.N, runner.kmax, 6
+        N, k, nn = loop.N, runner.kmax, len(net_of_cond)
         loop.t_table = torch.zeros((T, k * N)); loop.scale_table = torch.zeros((T, nn)); loop.coef = torch.zeros((T, 4))
         loop.ts_dev = torch.zeros((T,)); loop.guidance_scale, loop.steps = (7.5 if guidance else 1.0), T
         eng = SimpleNamespace(cond_img=[None] * nn, cond_noise=[None] * nn, dtype=dtype)

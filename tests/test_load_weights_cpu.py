@@ -94,6 +94,26 @@ def test_other_net_patterns_two_nets_and_a_lora_net_with_its_own_conv_stack(tiny
             lib.es_ctx_destroy(pctx)
 
 
+def test_single_controlnet_context(tiny):
+    """n_conds = 1 (BASELINE configs[0]: the UNet + ONE openpose ControlNet, PL:338-351): 13 residuals scaled by the
+    conditioning scale and added to the UNet's skips straight out of the zero-conv epilogues, no fusion blocks."""
+    ucfg, vcfg, ws = tiny
+    lib = L.load()
+    nets, slots = (("openpose", 0),), (0,)
+    _, pctx, keep = python_dry_context(ws, ucfg, vcfg, 1, True, 4, controlnets=nets, net_of_cond=slots)
+    nat = NativeContext({k: v for k, v in ws.items() if k != "fusion"}, ucfg, vcfg, num_inference_steps=4, device=-2, controlnets=nets, net_of_cond=slots)
+    try:
+        for which in range(5):
+            assert diff_plans(lib, pctx, nat.ctx, which) is None
+            assert plan_constants(lib, pctx, which) == plan_constants(lib, nat.ctx, which)
+        assert lib.es_plan_count(lib.es_ctx_plan(nat.ctx, L.PLAN_STEP), 8) == 0            # no fusion blocks
+    finally:
+        nat.close()
+        lib.es_ctx_destroy(pctx)
+    with pytest.raises(L.EdgeStyleHipError, match="exactly one ControlNet"):
+        NativeContext(ws, ucfg, vcfg, num_inference_steps=4, device=-1, net_of_cond=(0,))
+
+
 def test_sources_in_fp16_and_bf16_compute_type(tiny):
     """Checkpoints stored in fp16 (the usual case) describe the same values; a bf16 context builds too."""
     ucfg, vcfg, ws = tiny

@@ -242,3 +242,37 @@ def test_compiled_host_from_checkpoint_directories_to_image(both, tmp_path):
     got_img = torch.from_numpy(raw[nl:].reshape(1, 3, Hpx, Hpx).copy())
     assert torch.equal(got_lat, want_lat), float((got_lat - want_lat).abs().max())
     assert torch.equal(got_img, want_img)
+
+
+def test_single_controlnet_context_equals_the_pipeline_bitwise(both):
+    """n_conds = 1 (BASELINE configs[0], PL:338-351): one openpose ControlNet, its RGB pose image embedded by the net's own
+    conv stack (es_prepare_conds), 13 residuals added to the UNet's skips without fusion blocks."""
+    from edgestyle_amd.native import NativeContext
+    from edgestyle_amd.pipeline import StableDiffusionControlNetPipeline
+    pipe, eng, nat, ws, ucfg, vcfg, T = both
+    pose = pipe.controlnet.nets[1]
+    p1 = StableDiffusionControlNetPipeline(vae=pipe.vae, unet=pipe.unet, controlnet=pose).to(DEV)
+    g = torch.Generator().manual_seed(59)
+    s = ucfg.sample_size
+    lat = torch.randn(1, 4, s, s, generator=g)
+    pe = (torch.randn(1, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+    ne = (torch.randn(1, 77, ucfg.cross_attention_dim, generator=g) * 0.5).half().float()
+    img = torch.rand(1, 3, s * vcfg.scale, s * vcfg.scale, generator=g).half().float()
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=img, latents=lat, guidance_scale=5.0, num_inference_steps=3,
+              controlnet_conditioning_scale=0.8)
+    want_lat = p1(output_type="latent", **kw).images.clone()
+    want_img = p1(output_type="pt", **kw).images.clone()
+    n1 = NativeContext({k: v for k, v in ws.items() if k != "fusion"}, ucfg, vcfg, num_inference_steps=3, device=0,
+                       controlnets=(("openpose", L.NET_CONTROLNET),), net_of_cond=(0,))
+    try:
+        n1.set_alphas_cumprod(p1.scheduler.alphas_cumprod)
+        n1.set_options(cond_scales=[0.8])
+        n1.prepare_conds([img.to(DEV)], [None])
+        x = lat.permute(0, 2, 3, 1).contiguous().to(DEV)
+        got = n1.denoise_loop(x, torch.cat([ne, pe]).to(DEV, torch.float16).contiguous(), 5.0, p1.scheduler.set_timesteps(3).tolist())
+        out = n1.vae_decode(got)
+        torch.cuda.synchronize()
+        assert torch.equal(got.permute(0, 3, 1, 2), want_lat), float((got.permute(0, 3, 1, 2) - want_lat).abs().max())
+        assert torch.equal(out, want_img)
+    finally:
+        n1.close()
