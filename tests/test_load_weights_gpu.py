@@ -276,3 +276,28 @@ def test_single_controlnet_context_equals_the_pipeline_bitwise(both):
         assert torch.equal(out, want_img)
     finally:
         n1.close()
+
+
+def test_bf16_context_equals_the_python_step_bitwise():
+    """Compute dtype bf16 (BASELINE configs[4]'s): weights packed as bf16 by both builders, one denoising step bit for bit."""
+    from edgestyle_amd.models import StepRunner, _as_nhwc, _as_nchw_view
+    from edgestyle_amd.native import NativeContext
+    ucfg, vcfg = dataclasses.replace(Cfg.tiny_unet(), sample_size=64), Cfg.tiny_vae()
+    ws = {k: {kk: vv.bfloat16().float() for kk, vv in v.items()} for k, v in make_weights(ucfg, vcfg, seed=7).items()}
+    runner = StepRunner.from_state_dicts(ws, ucfg, torch.bfloat16, DEV)
+    g = torch.Generator().manual_seed(61)
+    s, c0 = ucfg.sample_size, ucfg.block_out_channels[0]
+    x = torch.randn(2, 4, s, s, generator=g).bfloat16().float()
+    ehs = (torch.randn(2, 77, ucfg.cross_attention_dim, generator=g) * 0.5).bfloat16().float()
+    conds = [(torch.randn(2, c0, s, s, generator=g) * 0.3).bfloat16().float() for _ in range(6)]
+    scales = [1.0, 0.8, 1.0, 1.0, 0.5, 1.0]
+    want = runner.step_nchw(x.to(DEV), 301, ehs.to(DEV), [c.to(DEV) for c in conds], scales).clone()
+    assert want.dtype == torch.bfloat16 and runner.mode == "grouped"
+    nat = NativeContext(ws, ucfg, vcfg, batch_size=1, guidance=True, num_inference_steps=3, dtype=torch.bfloat16, device=0)
+    try:
+        got = nat.denoise_step(_as_nhwc(x, torch.bfloat16, DEV, 8).contiguous(), 301.0, ehs.to(DEV, torch.bfloat16).contiguous(),
+                               [_as_nhwc(c, torch.bfloat16, DEV).contiguous() for c in conds], scales)
+        torch.cuda.synchronize()
+        assert torch.equal(_as_nchw_view(got), want), float((_as_nchw_view(got).float() - want.float()).abs().max())
+    finally:
+        nat.close()
