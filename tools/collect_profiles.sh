@@ -19,6 +19,9 @@ cp gpurun_out/traffic_b1/traffic.json $out/${R}_gemm_pmc_traffic_b1.json
 cp gpurun_out/traffic_b1/launches.json $out/${R}_gemm_step_launches_b1.json
 cp gpurun_out/traffic_b8/traffic.json $out/${R}_gemm_pmc_traffic_b8.json
 cp gpurun_out/traffic_b8/launches.json $out/${R}_gemm_step_launches_b8.json
+# 3b. matrix-core utilisation of the step's kernels (PMC, real pipeline)
+bash tools/collect_mfma_util.sh 1 > $out/mfma_b1.log 2>&1; cp gpurun_out/mfma_b1/mfma_util.json $out/${R}_mfma_util_b1.json
+bash tools/collect_mfma_util.sh 8 > $out/mfma_b8.log 2>&1; cp gpurun_out/mfma_b8/mfma_util.json $out/${R}_mfma_util_b8.json
 # 4. clock / power while the loop runs
 python3 tools/clock_probe.py > $out/${R}_clock_power_probe.txt 2>&1 || true
 python3 tools/clock_probe.py --attn > $out/${R}_clock_power_probe_attention.txt 2>&1 || true
