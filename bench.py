@@ -174,6 +174,17 @@ def gemm_roofline(pipe, traffic_profile="r03_gemm_pmc_traffic_b1.json", replay_i
                 traffic_src = f"profiles/{traffic_profile} (builder-collected rocprofv3 --pmc passes, not measured in this run)"
         except Exception:
             traffic = None
+    # matrix-core utilisation of the GEMM kernels by PMC (SQ_VALU_MFMA_BUSY_CYCLES per dispatch, builder-collected on the same
+    # workload: tools/collect_mfma_util.sh); rides along like `traffic`, never measured inside this run
+    mfma_util = None
+    mp = os.path.join(ROOT, "profiles", traffic_profile.replace("gemm_pmc_traffic", "mfma_util"))
+    if traffic is not None and os.path.exists(mp):
+        try:
+            mk = json.load(open(mp)).get("kernels", {})
+            mfma_util = {k: mk[k]["mfma_util"] for k in ("conv_gemm_kernel", "conv_gemm8p_kernel", "linear_xs_kernel") if k in mk}
+            mfma_util["source"] = "profiles/" + os.path.basename(mp)
+        except Exception:
+            mfma_util = None
     n_xs = sum(1 for m, _ in res if m[3].get("kernel") == "linear_xs")
     stamped = {"achieved": round(ach, 2), "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "avg_launch_us": round(tot_t * 1e6 / max(n, 1), 2),
                "gemm_time_per_step_ms": round(tot_t * 1e3, 3),
@@ -184,7 +195,7 @@ def gemm_roofline(pipe, traffic_profile="r03_gemm_pmc_traffic_b1.json", replay_i
     out = {"bound": "mfma",
            "kernel": "conv_gemm_kernel / conv_gemm8p_kernel (implicit-GEMM conv3x3/1x1/linear) + linear_xs_kernel (row-stationary short-K linear)",
            "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": traffic, "traffic_source": traffic_src,
-           "launches_per_step": n, "linear_xs_launches": n_xs,
+           "mfma_util_pmc": mfma_util, "launches_per_step": n, "linear_xs_launches": n_xs,
            "algorithmic_gflop_per_launch": round(tot_f / max(n, 1) / 1e9, 3),
            "algorithmic_bytes_per_launch": int(sum(m[3].get("algorithmic_bytes", 0) for m, _ in res) / max(n, 1)),
            "conv3x3_only": ({"achieved": round(f3 / (rp3 * 1e-3) / 1e12, 2), "frac": round(f3 / (rp3 * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
@@ -448,7 +459,7 @@ def main(argv=None):
             if not args.no_roofline:
                 r8 = gemm_roofline(pipe, traffic_profile="r03_gemm_pmc_traffic_b8.json", replay_iters=5)
                 line["throughput_mode"]["roofline"] = {k: r8[k] for k in (
-                    "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "launches_per_step",
+                    "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "mfma_util_pmc", "launches_per_step",
                     "avg_launch_us", "gemm_time_per_step_ms", "conv3x3_only", "stamped", "how") if k in r8}
             log(f"throughput mode (batch 8): {8 / t8:.3f} images/s")
             del lat8, pe8, ne8, imgs8, cn8, img8
