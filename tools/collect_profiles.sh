@@ -22,6 +22,8 @@ cp gpurun_out/traffic_b8/launches.json $out/${R}_gemm_step_launches_b8.json
 # 3b. matrix-core utilisation of the step's kernels (PMC, real pipeline)
 bash tools/collect_mfma_util.sh 1 > $out/mfma_b1.log 2>&1; cp gpurun_out/mfma_b1/mfma_util.json $out/${R}_mfma_util_b1.json
 bash tools/collect_mfma_util.sh 8 > $out/mfma_b8.log 2>&1; cp gpurun_out/mfma_b8/mfma_util.json $out/${R}_mfma_util_b8.json
+bash tools/collect_wave_states.sh 1 > $out/waves_b1.log 2>&1; cp gpurun_out/waves_b1/wave_states.json $out/${R}_wave_states_b1.json
+bash tools/collect_wave_states.sh 8 > $out/waves_b8.log 2>&1; cp gpurun_out/waves_b8/wave_states.json $out/${R}_wave_states_b8.json
 # 4. clock / power while the loop runs
 python3 tools/clock_probe.py > $out/${R}_clock_power_probe.txt 2>&1 || true
 python3 tools/clock_probe.py --attn > $out/${R}_clock_power_probe_attention.txt 2>&1 || true
