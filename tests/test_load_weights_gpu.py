@@ -301,3 +301,36 @@ def test_bf16_context_equals_the_python_step_bitwise():
         assert torch.equal(_as_nchw_view(got), want), float((_as_nchw_view(got).float() - want.float()).abs().max())
     finally:
         nat.close()
+
+
+def test_contexts_release_their_arena_and_graphs(both):
+    """es_ctx_destroy frees the arena, the instantiated graphs and the pinned staging: building, running and destroying contexts
+    in a row leaves the device's free memory where it was."""
+    from edgestyle_amd.native import NativeContext
+    pipe, eng, nat, ws, ucfg, vcfg, T = both
+    lat, pe, ne, conds, imgs, noise = _inputs(ucfg, vcfg, 67)
+    ehs = torch.cat([ne, pe]).to(DEV, torch.float16).contiguous()
+    x = lat.permute(0, 2, 3, 1).contiguous().to(DEV)
+    ims = [im.to(DEV) for im in imgs]
+    nz = [None if z is None else z.to(DEV) for z in noise]
+    ts = pipe.scheduler.set_timesteps(3).tolist()
+    torch.cuda.synchronize()
+    free0 = None
+    outs = []
+    for it in range(4):
+        c = NativeContext(ws, ucfg, vcfg, batch_size=1, guidance=True, num_inference_steps=3, device=0)
+        for use_graphs in (True, 2):
+            c.set_options(use_graphs=use_graphs)
+            c.prepare_conds(ims, nz)
+            got = c.denoise_loop(x.clone(), ehs, 6.0, ts)
+            img = c.vae_decode(got)
+        torch.cuda.synchronize()
+        outs.append(img.clone())
+        c.close()
+        torch.cuda.synchronize()
+        free = torch.cuda.mem_get_info()[0]
+        if it == 0:
+            free0 = free                      # after the first round: allocator pools of this process are warm
+        else:
+            assert abs(free - free0) <= 64 << 20, (it, free0 - free)
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
