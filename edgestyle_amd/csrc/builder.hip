@@ -1492,6 +1492,8 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
     };
     for (int i = 0; i < ES_PLAN_COUNT; ++i) if (es_plan_relocate(plans[i], reloc, &mp) || mp.bad) fail("es_load_weights: a recorded pointer lies outside the arena");
     auto real = [&](const T& t) { return (void*)(mp.heap_base + (t.p - FAKE_HEAP)); };
+    std::vector<size_t> up_sizes;
+    for (const auto& up : B.uploads) up_sizes.push_back(up.second.size());
     if (device >= 0)
       for (auto& up : B.uploads) {
         if (hipMemcpy((void*)(mp.heap_base + (up.first - FAKE_HEAP)), up.second.data(), up.second.size(), hipMemcpyHostToDevice) != hipSuccess) fail("es_load_weights: copy to the device failed");
@@ -1502,6 +1504,7 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
     if (es_ctx_create(device < 0 ? 0 : device, &ctx)) fail("es_load_weights: es_ctx_create failed");
     es_ctx_adopt_arena(ctx, arena, (size_t)total, device == -2);
     arena = nullptr;
+    for (const auto& up : B.uploads) es_ctx_add_extent(ctx, up.first - FAKE_HEAP, up.second.size() ? up.second.size() : up_sizes[&up - &B.uploads[0]]);
     es_ctx_geometry geo = *g;
     geo.latent_channels = Lc; geo.latent_pad = Lp;
     if (es_ctx_set_geometry(ctx, &geo)) fail(std::string("es_load_weights: ") + es_last_error());

@@ -44,3 +44,4 @@ struct es_plan;
 struct es_ctx;
 int es_plan_relocate(es_plan* p, unsigned long long (*map)(unsigned long long addr, int use, void* user), void* user);
 void es_ctx_adopt_arena(es_ctx* c, void* arena, size_t bytes, bool on_host);
+void es_ctx_add_extent(es_ctx* c, unsigned long long off, unsigned long long bytes);   // persistent data inside the arena (es_ctx_save)

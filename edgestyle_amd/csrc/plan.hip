@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "../../include/edgestyle_hip.h"
@@ -263,7 +264,8 @@ struct es_ctx {
   std::vector<float> alphas_cumprod;   // the scheduler's schedule (es_ctx_set_alphas_cumprod; SD1.5 default otherwise)
   void* arena = nullptr;               // es_ctx_load / es_load_weights: the one allocation every recorded pointer was relocated into
   size_t arena_bytes = 0;
-  bool arena_on_host = false;          // es_load_weights(device -2): an inspection build in host memory
+  bool arena_on_host = false;
+  std::vector<std::pair<unsigned long long, unsigned long long>> extents;   // (offset, bytes) of the arena's persistent DATA (es_ctx_save)          // es_load_weights(device -2): an inspection build in host memory
   hipGraphExec_t loop_exec = nullptr;  // use_graphs == 2: preparation + all steps of es_denoise_loop as one graph
   int loop_steps = 0;
   float loop_guidance = 0.f;
@@ -504,6 +506,7 @@ extern "C" void es_ctx_destroy(es_ctx* c) {
   delete c;
 }
 void es_ctx_adopt_arena(es_ctx* c, void* arena, size_t bytes, bool on_host) { c->arena = arena; c->arena_bytes = bytes; c->arena_on_host = on_host; }
+void es_ctx_add_extent(es_ctx* c, unsigned long long off, unsigned long long bytes) { c->extents.emplace_back(off, bytes); }
 extern "C" size_t es_ctx_arena_bytes(const es_ctx* c) { return c ? c->arena_bytes : 0; }
 extern "C" int es_ctx_set_geometry(es_ctx* c, const es_ctx_geometry* g) {
   if (!c || !g || g->B < 1 || g->h < 1 || g->w < 1 || g->n_steps < 1 || g->n_conds < 1 || g->n_conds > 6) { es_set_error("es_ctx_set_geometry: bad geometry"); return -1; }
@@ -637,6 +640,7 @@ extern "C" int es_ctx_load(const char* path, int device, es_ctx** out) {
   std::vector<Blk> ext((size_t)n_ext);
   if (n_ext && !rd(ext.data(), (size_t)n_ext * sizeof(Blk))) return fail("es_ctx_load: truncated extent table");
   for (const auto& b : ext) if (!inside(b.off, b.bytes)) return fail("es_ctx_load: extent outside the arena");
+  for (const auto& b : ext) c->extents.emplace_back(b.off, b.bytes);
   buf.resize(64u << 20);
   for (const auto& b : ext) {
     for (unsigned long long done = 0; done < b.bytes;) {
@@ -648,6 +652,82 @@ extern "C" int es_ctx_load(const char* path, int device, es_ctx** out) {
   }
   fclose(f);
   *out = c;
+  return 0;
+}
+
+// Write a context that owns its arena (es_load_weights, es_ctx_load) as a context image es_ctx_load reads: the same format
+// NativeEngine.save (edgestyle_amd/native.py) writes for a Python-built context.  Every pointer field of every recorded call
+// (typed tables above) and every bound slot must lie inside the arena; only the persistent DATA extents travel as bytes, the rest
+// of the arena (activations, slabs, scratch, input slots) as zero-filled space.
+extern "C" int es_ctx_save(const es_ctx* c, const char* path) {
+  if (!c || !path) { es_set_error("es_ctx_save: null argument"); return -1; }
+  if (!c->arena || c->arena_on_host) { es_set_error("es_ctx_save: the context does not own a device arena (built by a Python host: use NativeEngine.save)"); return -1; }
+  const unsigned long long base = (unsigned long long)c->arena, size = c->arena_bytes;
+  auto inside = [&](unsigned long long a, unsigned long long n) { return a >= base && a - base <= size && n <= size - (a - base); };
+  FILE* f = fopen(path, "wb");
+  if (!f) { es_set_error("es_ctx_save: cannot open the file"); return -1; }
+  auto fail = [&](const char* msg) { es_set_error(msg); fclose(f); return -1; };
+  auto wr = [&](const void* p, size_t n) { return fwrite(p, 1, n, f) == n; };
+  struct { char magic[8]; unsigned abi, n_blocks; unsigned long long arena_bytes; } h = {{'E', 'S', 'C', 'T', 'X', 2, 0, 0}, ES_ABI_VERSION, 1, size};
+  struct { float cond_scales[6]; float start, end; int use_graphs; unsigned n_alphas; } o;
+  memcpy(o.cond_scales, c->cond_scales, sizeof(o.cond_scales));
+  o.start = c->control_start; o.end = c->control_end; o.use_graphs = c->use_graphs; o.n_alphas = (unsigned)c->alphas_cumprod.size();
+  if (!wr(&h, sizeof(h)) || !wr(&c->g, sizeof(c->g)) || !wr(&o, sizeof(o))) return fail("es_ctx_save: write failed");
+  if (o.n_alphas && !wr(c->alphas_cumprod.data(), o.n_alphas * sizeof(float))) return fail("es_ctx_save: write failed");
+  const unsigned zero4 = 0;
+  if ((o.n_alphas & 1) && !wr(&zero4, 4)) return fail("es_ctx_save: write failed");
+  const unsigned long long blk[2] = {0, size};
+  if (!wr(blk, 16)) return fail("es_ctx_save: write failed");
+  for (int which = 0; which < ES_PLAN_COUNT; ++which) {
+    const es_plan* p = c->plan[which];
+    unsigned long long pb = p ? es_plan_export(p, nullptr, 0) : 0;
+    if (!wr(&pb, 8)) return fail("es_ctx_save: write failed");
+    if (!p) continue;
+    std::vector<char> img((size_t)pb);
+    es_plan_export(p, img.data(), img.size());
+    const size_t blob0 = 16 + p->ops.size() * 24;
+    std::vector<unsigned long long> rel;
+    for (const auto& op : p->ops) {
+      int elem = 0;
+      const auto& fl = ptr_fields(op.kind, elem);
+      const size_t reps = elem ? op.bytes / (size_t)elem : 1;
+      for (size_t r = 0; r < reps; ++r)
+        for (const auto& pf : fl) {
+          const size_t pos = op.off + r * (size_t)elem + (size_t)pf.off;
+          unsigned long long a;
+          memcpy(&a, p->blob.data() + pos, 8);
+          if (!a) continue;
+          if (!inside(a, 1)) return fail("es_ctx_save: a recorded pointer lies outside the context's arena");
+          rel.push_back(pos); rel.push_back(a - base);
+          const unsigned long long off = a - base;          // the image holds no absolute address: the same context saves to the same bytes
+          memcpy(img.data() + blob0 + pos, &off, 8);
+        }
+    }
+    if (!wr(img.data(), img.size())) return fail("es_ctx_save: write failed");
+    const unsigned long long nrel = rel.size() / 2;
+    if (!wr(&nrel, 8) || (nrel && !wr(rel.data(), rel.size() * 8))) return fail("es_ctx_save: write failed");
+  }
+  for (int slot = 0; slot < ES_BUF_COUNT; ++slot) {
+    long long r[2] = {-1, 0};
+    if (c->buf[slot]) {
+      if (!inside((unsigned long long)c->buf[slot], c->bytes[slot])) return fail("es_ctx_save: a bound slot lies outside the context's arena");
+      r[0] = (long long)((unsigned long long)c->buf[slot] - base); r[1] = (long long)c->bytes[slot];
+    }
+    if (!wr(r, 16)) return fail("es_ctx_save: write failed");
+  }
+  const unsigned long long n_ext = c->extents.size();
+  if (!wr(&n_ext, 8)) return fail("es_ctx_save: write failed");
+  for (const auto& e : c->extents) { const unsigned long long r[2] = {e.first, e.second}; if (!wr(r, 16)) return fail("es_ctx_save: write failed"); }
+  if (hipSetDevice(c->device) != hipSuccess) return fail("es_ctx_save: hipSetDevice failed");
+  std::vector<char> buf(64u << 20);
+  for (const auto& e : c->extents)
+    for (unsigned long long done = 0; done < e.second;) {
+      const size_t n = (size_t)std::min<unsigned long long>(e.second - done, buf.size());
+      if (hipMemcpy(buf.data(), (const char*)c->arena + e.first + done, n, hipMemcpyDeviceToHost) != hipSuccess) return fail("es_ctx_save: copy from the device failed");
+      if (!wr(buf.data(), n)) return fail("es_ctx_save: write failed");
+      done += n;
+    }
+  if (fclose(f) != 0) { es_set_error("es_ctx_save: write failed"); return -1; }
   return 0;
 }
 

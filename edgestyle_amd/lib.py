@@ -184,6 +184,7 @@ SYMBOLS = {
     "es_ctx_plan_size": (C.c_int, [_P, _I]),
     "es_ctx_plan": (_P, [_P, _I]),
     "es_ctx_load": (C.c_int, [C.c_char_p, _I, C.POINTER(_P)]),
+    "es_ctx_save": (C.c_int, [_P, C.c_char_p]),
     "es_plan_export": (C.c_size_t, [_P, _P, C.c_size_t]),
     "es_plan_import": (_P, [_P, C.c_size_t]),
     "es_plan_pointer_fields": (C.c_int, [_I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, C.POINTER(C.c_int32)]),

@@ -4,7 +4,9 @@
 // es_prepare_conds / es_denoise_loop / es_vae_decode exactly like examples/tryon_host.cpp does for a context image.
 //
 //   hipcc -O2 -Iinclude examples/checkpoint_host.cpp -Ledgestyle_amd/lib -ledgestyle_hip -Wl,-rpath,$PWD/edgestyle_amd/lib -o checkpoint_host
-//   ./checkpoint_host <unet_dir> <vae_dir> <multi_controlnet_dir> <openpose_dir> inputs.bin outputs.bin
+//   ./checkpoint_host <unet_dir> <vae_dir> <multi_controlnet_dir> <openpose_dir> inputs.bin outputs.bin [context.esctx]
+// (the optional last argument: also write the built context as an image - es_ctx_save - that examples/tryon_host.cpp and
+//  es_ctx_load start from in under a second next time)
 //
 // Directory layout (what the reference reads and writes):
 //   <unet_dir>/, <vae_dir>/, <openpose_dir>/      config.json + diffusion_pytorch_model.safetensors (diffusers save_pretrained)
@@ -160,7 +162,7 @@ template <typename T>
 static bool rd(FILE* f, std::vector<T>& v, size_t n) { v.resize(n); return fread(v.data(), sizeof(T), n, f) == n; }
 
 int main(int argc, char** argv) {
-  if (argc != 7) { fprintf(stderr, "usage: %s unet_dir vae_dir multi_controlnet_dir openpose_dir inputs.bin outputs.bin\n", argv[0]); return 1; }
+  if (argc != 7 && argc != 8) { fprintf(stderr, "usage: %s unet_dir vae_dir multi_controlnet_dir openpose_dir inputs.bin outputs.bin [context.esctx]\n", argv[0]); return 1; }
   const std::string W = "/diffusion_pytorch_model.safetensors";
   SafeTensors unet, vae, fusion, lora0, lora1, pose;
   if (!unet.open(argv[1] + W) || !vae.open(argv[2] + W) || !fusion.open(argv[3] + W) || !lora0.open(std::string(argv[3]) + "/controlnet_0" + W) ||
@@ -240,6 +242,7 @@ int main(int argc, char** argv) {
     ES_OK(es_ctx_set_alphas_cumprod(ctx, ac.data(), n_alphas));
   }
   fclose(f);
+  if (argc == 8) ES_OK(es_ctx_save(ctx, argv[7]));
   float *d_lat = nullptr, *d_out = nullptr;
   void* d_ehs = nullptr;
   HIP_OK(hipMalloc(&d_lat, lat.size() * 4));

@@ -347,6 +347,10 @@ es_plan* es_ctx_plan(es_ctx* c, int which);             /* borrowed */
  * the five launch lists and their pointer relocations.  No Python, torch or model code is needed to load or run it: build once
  * (es_load_weights or a Python host), ship the image, start in under a second. */
 int es_ctx_load(const char* path, int device, es_ctx** out);
+/* Write a context that owns its arena - one built by es_load_weights, or loaded by es_ctx_load - as such an image (same format):
+ * build from checkpoints once (seconds), start from the image afterwards (one hipMalloc + copies).  Contexts of a Python host
+ * hold pointers into the host's allocator pools instead of one arena: NativeEngine.save writes those. */
+int es_ctx_save(const es_ctx* c, const char* path);
 /* ---------------------------------------------------------------------------------------------------------
  * es_load_weights - build a context from the reference's state dicts, natively.
  * Replaces, on the loading side: EdgeStyleMultiControlNetModel.from_pretrained + load_state_dict

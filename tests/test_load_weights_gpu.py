@@ -334,3 +334,67 @@ def test_contexts_release_their_arena_and_graphs(both):
         else:
             assert abs(free - free0) <= 64 << 20, (it, free0 - free)
     assert all(torch.equal(o, outs[0]) for o in outs[1:])
+
+
+def test_es_ctx_save_of_a_native_context_loads_in_a_torch_free_process(both, tmp_path):
+    """es_ctx_save (C, csrc/plan.hip) writes a natively built context as a context image: es_ctx_load brings it up again - here,
+    and in a child process that imports neither torch nor this package (tests/run_ctx_image.py: ctypes on the library and the HIP
+    runtime only) - and every output equals the pipeline's bit for bit.  Checkpoints -> es_load_weights -> es_ctx_save ->
+    es_ctx_load: no Python model code anywhere on that route."""
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    pipe, eng, nat, ws, ucfg, vcfg, T = both
+    lat, pe, ne, _, imgs, noise = _inputs(ucfg, vcfg, 71)
+    gs = 6.5
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=imgs, latents=lat, guidance_scale=gs, num_inference_steps=T,
+              cond_noise=noise)
+    want_lat = pipe(output_type="latent", **kw).images.float().cpu()
+    want_img = pipe(output_type="pt", **kw).images.float().cpu()
+    lib = L.load()
+    path = str(tmp_path / "native.esctx")
+    L.check(lib.es_ctx_save(nat.ctx, path.encode()), "es_ctx_save")
+    arena = lib.es_ctx_arena_bytes(nat.ctx)
+    assert 1 << 20 < os.path.getsize(path) < arena                 # weights and tables travel, activations / slabs / slots do not
+    assert lib.es_ctx_save(eng.ctx, str(tmp_path / "no.esctx").encode()) != 0 and b"does not own" in lib.es_last_error()
+    # in this process
+    ctx2 = C.c_void_p()
+    L.check(lib.es_ctx_load(path.encode(), 0, C.byref(ctx2)), "es_ctx_load")
+    try:
+        ims = [im.to(DEV) for im in imgs]
+        nz = [None if z is None else z.to(DEV) for z in noise]
+        ip = (C.c_void_p * 6)(*[im.data_ptr() for im in ims])
+        npz = (C.c_void_p * 6)(*[None if z is None else z.data_ptr() for z in nz])
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        x = lat.permute(0, 2, 3, 1).contiguous().to(DEV)
+        ehs = torch.cat([ne, pe]).to(DEV, torch.float16).contiguous()
+        ts = pipe.scheduler.set_timesteps(T).tolist()
+        tsa = (C.c_float * T)(*[float(t) for t in ts])
+        out = torch.empty_like(want_img, device=DEV)
+        L.check(lib.es_prepare_conds(ctx2, ip, npz, stream), "es_prepare_conds")
+        L.check(lib.es_denoise_loop(ctx2, C.c_void_p(x.data_ptr()), C.c_void_p(ehs.data_ptr()), gs, tsa, T, stream), "es_denoise_loop")
+        L.check(lib.es_vae_decode(ctx2, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), stream), "es_vae_decode")
+        torch.cuda.synchronize()
+        assert torch.equal(x.permute(0, 3, 1, 2).cpu(), want_lat) and torch.equal(out.cpu(), want_img)
+        # a loaded context can be saved again: same bytes
+        path2 = str(tmp_path / "again.esctx")
+        L.check(lib.es_ctx_save(ctx2, path2.encode()), "es_ctx_save")
+        assert open(path, "rb").read() == open(path2, "rb").read()
+    finally:
+        lib.es_ctx_destroy(ctx2)
+    # in a child process without torch
+    arrs = dict(n_conds=np.int64(6), latents=lat.permute(0, 2, 3, 1).contiguous().numpy(), ehs=torch.cat([ne, pe]).half().numpy(),
+                guidance_scale=np.float32(gs), timesteps=pipe.scheduler.set_timesteps(T).float().numpy())
+    for i, (im, z) in enumerate(zip(imgs, noise)):
+        arrs[f"img{i}"] = im.numpy()
+        if z is not None:
+            arrs[f"noise{i}"] = z.numpy()
+    np.savez(str(tmp_path / "in.npz"), **arrs)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "run_ctx_image.py"), path, str(tmp_path / "in.npz"), str(tmp_path / "out.npz")],
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    o = np.load(str(tmp_path / "out.npz"))
+    assert torch.equal(torch.from_numpy(o["latents"]).permute(0, 3, 1, 2), want_lat)
+    assert torch.equal(torch.from_numpy(o["image"]), want_img)
