@@ -188,6 +188,18 @@ def test_missing_keys_wrong_shapes_and_unsupported_requests_are_named(tiny):
         build(dict(ws, unet={k: v.double() for k, v in ws["unet"].items()}))
 
 
+def test_a_dry_context_cannot_be_saved_or_run(tiny, tmp_path):
+    """device = -1 / -2 builds are for inspection: no device arena, so es_ctx_save refuses them by name."""
+    ucfg, vcfg, ws = tiny
+    lib = L.load()
+    c = NativeContext(ws, ucfg, vcfg, num_inference_steps=3, device=-2)
+    try:
+        assert lib.es_ctx_arena_bytes(c.ctx) > 100 << 20
+        assert lib.es_ctx_save(c.ctx, str(tmp_path / "x.esctx").encode()) != 0 and b"does not own a device arena" in lib.es_last_error()
+    finally:
+        c.close()
+
+
 def test_dry_recording_validates_but_does_not_launch():
     """es_plan_set_dry: a recording thread's calls are checked and recorded, nothing runs (no GPU here) - and a call the
     kernel would reject is rejected and NOT recorded."""
