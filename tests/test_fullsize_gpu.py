@@ -399,7 +399,7 @@ def test_native_abi_full_width_rgb_to_image_equals_pipeline_bitwise(full):
 
 
 @pytest.mark.parametrize("B,T", [(1, 3), (8, 2)])
-def test_es_load_weights_full_width_context_equals_pipeline_bitwise(full, B, T):
+def test_es_load_weights_full_width_context_equals_pipeline_bitwise(full, B, T, tmp_path):
     """SURVEY 8b's es_load_weights at SD1.5 width: the library builds the context itself from the raw state dicts (1.3 G
     parameters: rank-32 LoRA folds, LayerNorm / proj_out / shortcut folds, packing, arena layout, five launch lists - no model
     walk in Python) and RGB condition images -> es_prepare_conds -> es_denoise_loop -> es_vae_decode through it reproduce
@@ -440,8 +440,40 @@ def test_es_load_weights_full_width_context_equals_pipeline_bitwise(full, B, T):
             torch.cuda.synchronize()
             assert torch.equal(got.permute(0, 3, 1, 2), want_lat), float((got.permute(0, 3, 1, 2) - want_lat).abs().max())
             assert torch.equal(img, want_img)
+        extra = {}
+        if B == 1:
+            # ... and as a context image written by the library itself: es_ctx_save -> es_ctx_load -> the same bits
+            import ctypes as C
+            from edgestyle_amd import lib as L
+            lib = L.load()
+            path = str(tmp_path / "full.esctx")
+            t0 = time.time()
+            L.check(lib.es_ctx_save(nat.ctx, path.encode()), "es_ctx_save")
+            t_save = time.time() - t0
+            ctx2 = C.c_void_p()
+            t0 = time.time()
+            L.check(lib.es_ctx_load(path.encode(), 0, C.byref(ctx2)), "es_ctx_load")
+            t_load = time.time() - t0
+            try:
+                stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                ims = [im.to(DEV).contiguous() for im in imgs]
+                nzs = [None if z is None else z.to(DEV).contiguous() for z in noise]
+                ip = (C.c_void_p * 6)(*[im.data_ptr() for im in ims])
+                npz = (C.c_void_p * 6)(*[None if z is None else z.data_ptr() for z in nzs])
+                x2 = x.clone()
+                tsa = (C.c_float * T)(*[float(t) for t in ts])
+                L.check(lib.es_prepare_conds(ctx2, ip, npz, stream), "es_prepare_conds")
+                L.check(lib.es_denoise_loop(ctx2, C.c_void_p(x2.data_ptr()), C.c_void_p(ehs.data_ptr()), gs, tsa, T, stream), "es_denoise_loop")
+                torch.cuda.synchronize()
+                assert torch.equal(x2.permute(0, 3, 1, 2), want_lat)
+            finally:
+                lib.es_ctx_destroy(ctx2)
+            size = os.path.getsize(path)
+            assert size <= 4 << 30                          # full-size image <= 4 GiB
+            extra = dict(image_gib=round(size / 2 ** 30, 2), save_seconds=round(t_save, 1), load_seconds=round(t_load, 1))
+            os.remove(path)
         record("es_load_weights_full_width", batch=B, build_seconds=round(build_s, 1), plan_step_calls=nat.plan_size(2),
-               arena_gib=round(nat.lib.es_ctx_arena_bytes(nat.ctx) / 2 ** 30, 2), bitwise_equal_to_pipeline=True)
+               arena_gib=round(nat.lib.es_ctx_arena_bytes(nat.ctx) / 2 ** 30, 2), bitwise_equal_to_pipeline=True, **extra)
     finally:
         nat.close()
 
