@@ -462,6 +462,11 @@ def main(argv=None):
                     "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "mfma_util_pmc", "launches_per_step",
                     "avg_launch_us", "gemm_time_per_step_ms", "conv3x3_only", "stamped", "how") if k in r8}
             log(f"throughput mode (batch 8): {8 / t8:.3f} images/s")
+            if not args.no_native_abi and not args.no_graph:
+                n8abi = native_abi_leg(pipe, ws, ucfg, vcfg, 8, args.ddim_steps, dtype, dev_index, lat8, pe8, ne8, imgs8, cn8, img8, iters=2)
+                line["throughput_mode"]["native_abi"] = {k: n8abi[k] for k in ("value", "unit", "ms_per_step", "build_s", "arena_gib",
+                                                                               "bitwise_equal_to_pipeline")}
+                log(f"throughput mode through the C ABI alone: {n8abi['value']:.3f} images/s")
             del lat8, pe8, ne8, imgs8, cn8, img8
         if not args.no_stress_mode and world == 1 and not args.tiny and args.resolution == 512 and dtype == torch.float16:
             # BASELINE configs[4]: bf16, 768x768, batch 4 (outside the reference's own domain): one warmed,
