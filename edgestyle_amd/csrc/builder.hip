@@ -262,7 +262,7 @@ struct T {
 
 struct PW {                       // ops.PackedWeight
   unsigned long long w = 0, bias = 0, ln_colsum = 0;
-  int cout = 0, cin = 0, ksize = 1, bn = 128, rows_padded = 0, kpad = 0, ctail = 0;
+  int cout = 0, cin = 0, ksize = 1, bn = 128, rows_padded = 0, kpad = 0, ctail = 0, korder = 0;
   bool geglu = false;
   float ln_eps = 1e-5f;
   const uint16_t* host_w = nullptr;      // the staged copy, until the upload
@@ -380,7 +380,7 @@ struct Builder {
   uint16_t enc(float f) const { return dt == ES_F16 ? f32_to_f16(f) : f32_to_bf16(f); }
   float dec(uint16_t u) const { return dt == ES_F16 ? f16_to_f32(u) : bf16_to_f32(u); }
 
-  // -- weight packing (ops.pack_weight*): [rows_padded][Kpad] K-contiguous, K = (ky, kx, c) tap-major
+  // -- weight packing (ops.pack_weight*): [rows_padded][Kpad] K-contiguous, K = (ky, kx, c) tap-major or (c / 64, ky, kx, c % 64) chunk-major
   // w: [cout][cin][k][k] fp32 (linear: k = 1)
   const PW* pack(const std::vector<float>& w, int cout, int cin, int k, const std::vector<float>* bias, bool geglu = false, int cin_pad = 0, int cout_pad = 0,
                  const std::vector<float>* tail = nullptr, int ctail = 0) {
@@ -397,6 +397,11 @@ struct Builder {
     pws.emplace_back();
     PW& p = pws.back();
     p.cout = cout_eff; p.cin = cp; p.ksize = k; p.bn = bn; p.rows_padded = rows; p.kpad = kpad; p.geglu = geglu; p.ctail = ctail;
+    // K order (ops.choose_korder): with ES_CHUNK_MAJOR=1 every 3x3 convolution over 64-aligned channels is packed chunk-major,
+    // k = (c / 64, tap, c % 64); the default is tap-major (the chunk-major order measured 5-10 % slower, ops.py)
+    static const bool chunk_major_on = [] { const char* e = getenv("ES_CHUNK_MAJOR"); return e && e[0] == '1' && !e[1]; }();
+    const bool chunk_major = chunk_major_on && k == 3 && cp % BK == 0;
+    p.korder = chunk_major ? 1 : 0;
     p.w = persistent((size_t)rows * kpad * 2);
     uint16_t* dst = (uint16_t*)staged(p.w, (size_t)rows * kpad * 2);
     p.host_w = dst;
@@ -406,7 +411,8 @@ struct Builder {
         const float* s = w.data() + (size_t)src_row((int)r) * cin * k * k;
         uint16_t* d = dst + (size_t)r * kpad;
         for (int t = 0; t < k * k; ++t)
-          for (int ci = 0; ci < cin; ++ci) d[t * cp + ci] = enc(s[(size_t)ci * k * k + t]);
+          for (int ci = 0; ci < cin; ++ci)
+            d[chunk_major ? ((ci / BK) * k * k + t) * BK + ci % BK : t * cp + ci] = enc(s[(size_t)ci * k * k + t]);
         if (tail) for (int j = 0; j < ctail; ++j) d[k * k * cp + j] = enc((*tail)[(size_t)r * ctail + j]);
       }
     });
@@ -608,6 +614,7 @@ struct Builder {
     const long long src_numel = x.numel() * a.x_rep + (a.x2 ? a.x2.numel() : 0);
     d.xcd_m_fastest = (!grouped && splitk == 1 && M <= 2048 && pw->w_numel() > src_numel) ? 1 : 0;
     d.x_nmod = a.x_rep > 1 ? nsrc : 0;
+    d.korder = pw->korder;
     if (k == 1 && M <= 65536 && C1 % BK == 0 && C2 % BK == 0 && bn != 64 && bn != 320 && !(stages == 4 && bn != 128) && stages != 3) d.waves = 8;
     if (splitk > 1) d.workspace = (float*)workspace((unsigned long long)splitk * M * pw->rows_padded * 4);
     if (pw->ln_colsum) {
@@ -630,7 +637,7 @@ struct Builder {
       for (size_t g = 0; g < pl.size(); ++g) {
         const PW* q = pl[g];
         if (q->rows_padded != pw->rows_padded || q->kpad != pw->kpad || q->cout != pw->cout || q->cin != pw->cin || q->ksize != pw->ksize ||
-            q->geglu != pw->geglu || q->ctail != pw->ctail) fail("grouped conv_gemm: weight geometry differs between groups");
+            q->geglu != pw->geglu || q->ctail != pw->ctail || q->korder != pw->korder) fail("grouped conv_gemm: weight geometry differs between groups");
         acc += a.group_n[g] * hw / BM;
         d.mt_end[g] = (int)acc; d.w_g[g] = (const void*)q->w; d.bias_g[g] = (const float*)q->bias; d.ln_colsum_g[g] = (const float*)q->ln_colsum;
       }

@@ -82,7 +82,8 @@ ES_DEVICE void row_offsets_fn(unsigned (&voff)[XI], const int (&iy0)[XI], const 
 }
 
 template <typename T, int BM, int BN, bool ALIGNED, int STAGES, int FM = 4 /* pixel fragments per wave */,
-          bool LN = false /* LayerNorm folded into this linear layer */>
+          bool LN = false /* LayerNorm folded into this linear layer */,
+          bool KO = false /* chunk-major K order (es_gemm_desc.korder == 1): 3x3, 64-aligned channels */>
 // (second launch bound = minimum waves per SIMD: 8-wave workgroups need 4 to keep two workgroups on a CU)
 __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? (FM == 2 ? 4 : 2) : 1) void conv_gemm_kernel(
     const es_gemm_desc p, const int M, const int nk, const void* const tail1, const void* const tail2, const int tailC1,
@@ -206,6 +207,30 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? (FM == 2 
       nb[i] = n * p.Hsrc * p.Wsrc;
     }
   }
+  // Chunk-major K order: the tap changes with EVERY K-step, so the im2col state of a row is kept as the source pixel
+  // of tap (0,0) plus a tap-validity mask (bits 0-8: taps, bit 9: the row exists = the tail tap, bits 10/11: the
+  // parities that place a nearest-2x upsampled tap) - a K-step's four offsets cost ~5 vector instructions each
+  // instead of the ~12 of row_offsets_fn (that difference, issued beside the partner wave's MFMAs every K-step, is
+  // what a first chunk-major attempt in round 3 lost 5-12 % to).
+  int pix0[KO ? XI : 1];
+  unsigned tmask[KO ? XI : 1];
+  if constexpr (KO) {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int ay = iy0[i], ax = ix0[i];
+      unsigned vy = 0, vx = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        vy |= ((unsigned)(ay + k) < (unsigned)Hin ? 1u : 0u) << k;
+        vx |= ((unsigned)(ax + k) < (unsigned)Win ? 1u : 0u) << k;
+      }
+      unsigned mk = ((vy & 1) ? vx : 0u) | ((vy & 2) ? vx << 3 : 0u) | ((vy & 4) ? vx << 6 : 0u);
+      mk |= ay > -(1 << 19) ? 1u << 9 : 0u;
+      mk |= (unsigned)(ay & p.upsample) << 10 | (unsigned)(ax & p.upsample) << 11;
+      tmask[i] = mk;
+      pix0[i] = nb[i] + (ay >> p.upsample) * p.Wsrc + (ax >> p.upsample);
+    }
+  }
   int grp = 0;
   if (p.ngroups > 1) {
     const int t128 = (tile_m * BM) / 128;               // group table is in 128-pixel units
@@ -240,6 +265,11 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? (FM == 2 
     tap = kg == 0 ? 0 : fast_div(kg, Ctot, __builtin_amdgcn_rcpf((float)Ctot));      // kg < Kpad < 2^24
     cpos = kg - tap * Ctot;
     if (ALIGNED && tap >= KK) { tap = KK; cpos = kg - KK * Ctot; }      // a split-K slice that starts inside the tail
+    if constexpr (KO) {                                                 // K-step = (64-channel chunk, tap), then the tail
+      const int kt = (KK * Ctot) / BKT;
+      if (ks0 >= kt) { tap = KK; cpos = (ks0 - kt) * BKT; }
+      else { const int ch = fast_div(ks0, 9, 1.0f / 9.0f); tap = ks0 - ch * 9; cpos = ch * BKT; }
+    }
   }
   unsigned voff[XI];
 #pragma unroll
@@ -270,7 +300,18 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? (FM == 2 
       const int second = cpos >= c1 ? 1 : 0;              // a K-step never straddles taps or sources
       const int cs = second ? (tail ? q3 : q1) : c1;
       const int cc = second ? cpos - c1 : cpos;
-      if (tap != cur_tap || second != cur_second) {
+      if constexpr (KO) {
+        int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+        if (tail) { ky = pk_pad; kx = pk_pad; }
+        const unsigned tb = 1u << tap, cs2 = (unsigned)cs * 2u;
+        const int dsc = ky * pk_wsrc + kx;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+          int pix = pix0[i] + dsc;
+          if (pk_up) pix = pix0[i] + ((int)(((tmask[i] >> 10) & 1) + ky) >> 1) * pk_wsrc + ((int)(((tmask[i] >> 11) & 1) + kx) >> 1);
+          voff[i] = (tmask[i] & tb) ? __umul24((unsigned)pix, cs2) + (unsigned)(kc * 16) : 0xFFFFFF00u;
+        }
+      } else if (tap != cur_tap || second != cur_second) {
         row_offsets(tap, cs, kc * 8);
         cur_tap = tap; cur_second = second;
       }
@@ -304,8 +345,16 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? (FM == 2 
       for (int i = 0; i < XI; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rX1, (lptr_t)(xs + (wave * XI + i) * 1024), 16, (int)voff[i], 0, 0, 0);
     }
-    cpos += BKT;
-    if (tap < KK) { while (cpos >= Ctot) { cpos -= Ctot; ++tap; } }      // (the tail is the last tap: cpos just runs on)
+    if constexpr (KO) {
+      if (tap < KK) {
+        if (++tap == KK) { cpos += BKT; if (cpos >= Ctot) cpos = 0; else tap = 0; }     // next chunk, or on to the tail
+      } else {
+        cpos += BKT;
+      }
+    } else {
+      cpos += BKT;
+      if (tap < KK) { while (cpos >= Ctot) { cpos -= Ctot; ++tap; } }      // (the tail is the last tap: cpos just runs on)
+    }
   };
 
 #undef row_offsets
@@ -711,7 +760,12 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
   if (stages == 0) stages = 2;   // measured (tools/gemm_bench.py): 2 stages x 2 workgroups/CU beats a 3-4 deep ring at 1/CU
 #define ES_LAUNCH_F(BMV, BNV, AL, ST, FMV)                                                                  \
   do {                                                                                                      \
-    auto kfn = conv_gemm_kernel<T, BMV, BNV, AL, ST, FMV>;                                                  \
+    if (AL && d.korder) ES_LAUNCH_K(BMV, BNV, AL, ST, FMV, AL);                                             \
+    else ES_LAUNCH_K(BMV, BNV, AL, ST, FMV, false);                                                         \
+  } while (0)
+#define ES_LAUNCH_K(BMV, BNV, AL, ST, FMV, KOV)                                                             \
+  do {                                                                                                      \
+    auto kfn = conv_gemm_kernel<T, BMV, BNV, AL, ST, FMV, false, KOV>;                                      \
     const size_t lds = (size_t)ST * (BMV + BNV) * BK * 2;                                                   \
     static bool attr_set = false;                                                                           \
     if (!attr_set) {                                                                                        \
@@ -756,6 +810,7 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
 #undef ES_LAUNCH_ST
 #undef ES_LAUNCH
 #undef ES_LAUNCH_F
+#undef ES_LAUNCH_K
 #undef ES_LAUNCH_LN
   if (d.splitk > 1) {
     const long long total = (long long)M * (d.rows_padded / 8);
@@ -805,6 +860,8 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
     es_set_error("es_conv_gemm: 1x1 tail sources need stride 1, no upsample, same-size output, 64-aligned channels"); return -1; }
   if (!d->t1 && (d->t2 || d->Ct1 || d->Ct2)) { es_set_error("es_conv_gemm: tail fields set without t1"); return -1; }
   if (d->x_nmod < 0 || (d->x_nmod && (d->x2 || d->t1 || d->x_nmod > d->N))) { es_set_error("es_conv_gemm: x_nmod needs a single source and 0 < x_nmod <= N"); return -1; }
+  if (d->korder != 0 && (d->korder != 1 || d->ksize != 3 || d->C1 % BK || d->C2 % BK || d->ln_colsum)) {
+    es_set_error("es_conv_gemm: korder 1 (chunk-major K) needs ksize 3 and 64-aligned C1, C2"); return -1; }
   if (d->splitk < 1 || d->splitk > d->Kpad / BK) { es_set_error("es_conv_gemm: bad splitk"); return -1; }
   if (d->splitk > 1 && (!d->workspace || d->act == ES_ACT_GEGLU)) { es_set_error("es_conv_gemm: splitk needs workspace and no GEGLU"); return -1; }
   if (d->splitk > 1 && (long long)d->N * d->Hout * d->Wout * (d->rows_padded / 8) >= (1ll << 31)) { es_set_error("es_conv_gemm: split-K output too large for 32-bit indices"); return -1; }

@@ -40,10 +40,13 @@
 #include "../../include/edgestyle_hip.h"
 
 // Tool-only builds (tools/ab8p.sh): ES8P_ABL removes one ingredient (results are wrong by construction).  ABL bits: 1 = every DMA out of range (issued, zero-filled, no memory traffic),
-// 2 = no MFMAs, 4 = no barrier stagger, 8 = activation DMAs out of range only, 16 = weight DMAs out of range only.  The product library is built with ES8P_ABL == 0.
+// 2 = no MFMAs, 4 = no barrier stagger, 8 = activation DMAs out of range only, 16 = weight DMAs out of range only, 32 = chunk-major order with the
+// activation tile staged on tap 0 of every 64-channel chunk ONLY (taps 1-8 multiply whatever the buffer holds: the DMA count and L2->LDS bytes of an
+// LDS-resident halo patch, on non-zero data - what that design could gain at most).  The product library is built with ES8P_ABL == 0.
 #ifndef ES8P_ABL
 #define ES8P_ABL 0
 #endif
+
 
 namespace {
 
@@ -71,7 +74,7 @@ ES_DEVICE void row_offsets4(unsigned (&voff)[XI], const int (&iy0)[XI], const in
   }
 }
 
-template <typename T>
+template <typename T, bool KO /* chunk-major K order, es_gemm_desc.korder == 1 */>
 __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc p, const int M, const int nk,
                                                              const void* const tail1, const void* const tail2,
                                                              const int tailC1, const int tailC2) {
@@ -139,6 +142,26 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
       nb[i] = n * p.Hsrc * p.Wsrc;
     }
   }
+  // chunk-major K order: per-row state = source pixel of tap (0,0) + tap-validity mask (see conv_gemm_kernel)
+  int pix0[KO ? XI : 1];
+  unsigned tmask[KO ? XI : 1];
+  if constexpr (KO) {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int ay = iy0[i], ax = ix0[i];
+      unsigned vy = 0, vx = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        vy |= ((unsigned)(ay + k) < (unsigned)Hin ? 1u : 0u) << k;
+        vx |= ((unsigned)(ax + k) < (unsigned)Win ? 1u : 0u) << k;
+      }
+      unsigned mk = ((vy & 1) ? vx : 0u) | ((vy & 2) ? vx << 3 : 0u) | ((vy & 4) ? vx << 6 : 0u);
+      mk |= ay > -(1 << 19) ? 1u << 9 : 0u;
+      mk |= (unsigned)(ay & p.upsample) << 10 | (unsigned)(ax & p.upsample) << 11;
+      tmask[i] = mk;
+      pix0[i] = nb[i] + (ay >> p.upsample) * p.Wsrc + (ax >> p.upsample);
+    }
+  }
   int grp = 0;
   if (p.ngroups > 1) {
     const int t128 = (tile_m * BM) / 128;               // group table is in 128-pixel units
@@ -167,6 +190,11 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
     tap = kg == 0 ? 0 : fast_div(kg, Ctot, __builtin_amdgcn_rcpf((float)Ctot));
     cpos = kg - tap * Ctot;
     if (tap >= KK) { tap = KK; cpos = kg - KK * Ctot; }
+    if constexpr (KO) {                                 // K-tile = (64-channel chunk, tap), then the tail
+      const int kt = (KK * Ctot) / 64;
+      if (ks0 >= kt) { tap = KK; cpos = (ks0 - kt) * 64; }
+      else { const int ch = fast_div(ks0, 9, 1.0f / 9.0f); tap = ks0 - ch * 9; cpos = ch * 64; }
+    }
   }
   unsigned voff[XI];
 #pragma unroll
@@ -187,15 +215,28 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
   // source of the K-tile `ks` (wave-uniform): base pointer, records, channel stride, scalar channel offset
   const void* xbase = px;
   int xrec = 0, soff_x = 0;
+  bool x_skip = false;                                  // ES8P_ABL & 32 only
   auto select_x = [&](int ks) __attribute__((always_inline)) {
     const bool tail = ks >= ks_tail;
+    if constexpr (KO && (ES8P_ABL & 32) != 0) x_skip = !tail && tap != 0;
     int q0 = pC1, q1 = pC2, q2 = pCt1, q3 = pCt2;
     asm("" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3));
     const int c1 = tail ? q2 : q0;
     const int second = cpos >= c1 ? 1 : 0;              // a K-tile never straddles taps or sources
     const int cs = second ? (tail ? q3 : q1) : c1;
     const int cc = second ? cpos - c1 : cpos;
-    if (tap != cur_tap || second != cur_second) {
+    if constexpr (KO) {
+      int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+      if (tail) { ky = pk_pad; kx = pk_pad; }
+      const unsigned tb = 1u << tap, cs2 = (unsigned)cs * 2u;
+      const int dsc = ky * pk_wsrc + kx;
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        int pix = pix0[i] + dsc;
+        if (pk_up) pix = pix0[i] + ((int)(((tmask[i] >> 10) & 1) + ky) >> 1) * pk_wsrc + ((int)(((tmask[i] >> 11) & 1) + kx) >> 1);
+        voff[i] = (tmask[i] & tb) ? __umul24((unsigned)pix, cs2) + (unsigned)(kc * 16) : OOB;
+      }
+    } else if (tap != cur_tap || second != cur_second) {
       row_offsets4(voff, iy0, ix0, nb, tap, cs, kc * 8, pk_ksize, KK, pk_pad, Hin, Win, pk_up, pk_wsrc);
       cur_tap = tap; cur_second = second;
     }
@@ -206,10 +247,19 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
     const int nrec = tail ? (second ? n3 : n2) : (second ? n1 : n0);
     xbase = base; xrec = nrec;
     soff_x = cc * 2;
-    cpos += 64;
-    if (tap < KK) { while (cpos >= Ctot) { cpos -= Ctot; ++tap; } }
+    if constexpr (KO) {
+      if (tap < KK) {
+        if (++tap == KK) { cpos += 64; if (cpos >= Ctot) cpos = 0; else tap = 0; }       // next chunk, or on to the tail
+      } else {
+        cpos += 64;
+      }
+    } else {
+      cpos += 64;
+      if (tap < KK) { while (cpos >= Ctot) { cpos -= Ctot; ++tap; } }
+    }
   };
   auto issue_x = [&](int boff, int h) __attribute__((always_inline)) {
+    if constexpr (KO && (ES8P_ABL & 32) != 0) { if (x_skip) return; }
     const auto rS = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, (short)0, xrec, 0x00020000);
 #pragma unroll
     for (int i = 0; i < XI; ++i)
@@ -296,6 +346,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
     for (int j = 0; j < 4; ++j) xa[j] = ES_RD(xrow + xo1 + (1 * 64 + j * 16) * RB);
     if (nxt) {
       issue_x(nboff, 1);
+      if (KO && (ES8P_ABL & 32) != 0 && x_skip) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else
       asm volatile("s_waitcnt vmcnt(2)" ::: "memory");    // weights + first pixel quarter of the next tile have landed
     }
     ES_MFMA(1)
@@ -426,13 +478,15 @@ int es_conv_gemm8p_launch(const es_gemm_desc& d, hipStream_t st) {
   constexpr size_t lds = 2 * (size_t)BUF;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_gemm8p_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)conv_gemm8p_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_gemm8p_kernel<f16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_gemm8p_kernel<bf16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_gemm8p_kernel<f16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_gemm8p_kernel<bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  if (d.dtype == ES_F16)
-    hipLaunchKernelGGL(conv_gemm8p_kernel<f16>, grid, dim3(512), lds, st, d, M, nk, d.t1, d.t2, d.Ct1, d.Ct2);
-  else
-    hipLaunchKernelGGL(conv_gemm8p_kernel<bf16>, grid, dim3(512), lds, st, d, M, nk, d.t1, d.t2, d.Ct1, d.Ct2);
+#define ES8P_LAUNCH(TT, KOV) hipLaunchKernelGGL((conv_gemm8p_kernel<TT, KOV>), grid, dim3(512), lds, st, d, M, nk, d.t1, d.t2, d.Ct1, d.Ct2)
+  if (d.dtype == ES_F16) { if (d.korder) ES8P_LAUNCH(f16, true); else ES8P_LAUNCH(f16, false); }
+  else                   { if (d.korder) ES8P_LAUNCH(bf16, true); else ES8P_LAUNCH(bf16, false); }
+#undef ES8P_LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ES_HIP_LIB") or os.path.join(_HERE, "lib", "libedgestyle_hip.so")
 
 ES_F16, ES_BF16, ES_F32 = 0, 1, 2
-ABI_VERSION = 5          # include/edgestyle_hip.h ES_ABI_VERSION
+ABI_VERSION = 6          # include/edgestyle_hip.h ES_ABI_VERSION
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
 
 
@@ -30,7 +30,7 @@ class GemmDesc(C.Structure):
         ("out_scale", C.c_float),
         ("ln_colsum", C.c_void_p), ("ln_colsum_g", C.c_void_p * 4), ("ln_eps", C.c_float),
         ("t1", C.c_void_p), ("t2", C.c_void_p), ("Ct1", C.c_int32), ("Ct2", C.c_int32),
-        ("x_nmod", C.c_int32),
+        ("x_nmod", C.c_int32), ("korder", C.c_int32),
     ]
 
 

@@ -114,6 +114,7 @@ class PackedWeight:
     ln_colsum: Optional[torch.Tensor] = None   # fp32 [rows_padded]: LayerNorm folded into this linear layer (pack_weight_ln)
     ln_eps: float = 1e-5
     ctail: int = 0                  # channels of the 1x1 tail sources appended along K (pack_weight_tail)
+    korder: int = 0                 # K order of the k*k*cin main part: 0 tap-major (ky,kx,c), 1 chunk-major (c/64,ky,kx,c%64)
 
     @property
     def rows_padded(self):
@@ -126,6 +127,25 @@ class PackedWeight:
 
 def choose_bn(cout: int) -> int:
     return 160 if (cout % 160 == 0 and cout % 128 != 0) else 128
+
+
+# K order of the 3x3 convolutions (es_gemm_desc.korder).  Chunk-major - the nine taps of a 64-channel chunk back to back - makes
+# eight of a workgroup's nine shifted reads of the same activation lines L2 hits: the level-0 batch-8 launch fetches 0.39 GB
+# through the fabric instead of 2.6 GB (FETCH_SIZE, profiles/r04_korder_pmc.txt).  It is nevertheless 5-10 % SLOWER in every
+# sustained A/B (profiles/r04_korder_bench.txt), even with eight of the nine activation DMAs removed altogether
+# (profiles/r04_patchsim_ablation.txt), so it is OFF by default: ES_CHUNK_MAJOR=1 (read by csrc/builder.hip too) turns it on.
+CHUNK_MAJOR = _os.environ.get("ES_CHUNK_MAJOR", "0") == "1"
+
+
+def choose_korder(k: int, cin_padded: int) -> int:
+    """es_gemm_desc.korder of a convolution's packed weights (csrc/builder.hip: the same rule)."""
+    return 1 if (CHUNK_MAJOR and k == 3 and cin_padded % BK == 0) else 0
+
+
+def _chunk_major(w: torch.Tensor, k: int, cin: int) -> torch.Tensor:
+    """[Cout, k*k*cin] tap-major -> chunk-major."""
+    cout = w.shape[0]
+    return w.reshape(cout, k * k, cin // BK, BK).permute(0, 2, 1, 3).reshape(cout, k * k * cin)
 
 
 def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype, device, geglu: bool = False,
@@ -145,6 +165,9 @@ def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype, devic
     if cp != cin:
         w = torch.nn.functional.pad(w, (0, cp - cin))
     w = w.reshape(cout, k * k * cp)
+    korder = choose_korder(k, cp)
+    if korder:
+        w = _chunk_major(w, k, cp)
     b = None if bias is None else bias.to(device=device, dtype=torch.float32)
     if geglu:
         inner = cout // 2
@@ -166,7 +189,7 @@ def pack_weight(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype, devic
     if b is not None:
         bp = torch.zeros(rows, dtype=torch.float32, device=device)
         bp[:cout] = b
-    return PackedWeight(wp, bp, cout_eff, cp, k, bn, geglu)
+    return PackedWeight(wp, bp, cout_eff, cp, k, bn, geglu, korder=korder)
 
 
 def pack_weight_tail(weight: torch.Tensor, tail_weight: torch.Tensor, bias: Optional[torch.Tensor], dtype, device) -> PackedWeight:
@@ -178,7 +201,9 @@ def pack_weight_tail(weight: torch.Tensor, tail_weight: torch.Tensor, bias: Opti
     cout, cin, k, _ = weight.shape
     if cin % BK or tw.shape[1] % BK or tw.shape[0] != cout:
         raise L.EdgeStyleHipError("pack_weight_tail: conv and tail channels must be multiples of 64, equal Cout")
-    w = torch.cat([weight.permute(0, 2, 3, 1).reshape(cout, k * k * cin), tw], 1)
+    korder = choose_korder(k, cin)
+    wm = weight.permute(0, 2, 3, 1).reshape(cout, k * k * cin)
+    w = torch.cat([_chunk_major(wm, k, cin) if korder else wm, tw], 1)
     bn = choose_bn(cout)
     rows = (cout + bn - 1) // bn * bn
     wp = torch.zeros(rows, w.shape[1], dtype=dtype, device=device)
@@ -187,7 +212,7 @@ def pack_weight_tail(weight: torch.Tensor, tail_weight: torch.Tensor, bias: Opti
     if bias is not None:
         bp = torch.zeros(rows, dtype=torch.float32, device=device)
         bp[:cout] = bias.to(device=device, dtype=torch.float32)
-    return PackedWeight(wp, bp, cout, cin, k, bn, False, ctail=tw.shape[1])
+    return PackedWeight(wp, bp, cout, cin, k, bn, False, ctail=tw.shape[1], korder=korder)
 
 
 def pack_weight_ln(weight: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
@@ -475,6 +500,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     d.temb_stride = temb.stride(0) if temb is not None else 0
     d.act, d.splitk, d.bn, d.dtype, d.out_scale = act_i, splitk, bn, _dt(x), out_scale
     d.stages = stages or FORCE_STAGES
+    d.korder = pw.korder
     # XCD chunk order: keep the larger operand's tiles together on one XCD (see conv_gemm_kernel)
     d.xcd_m_fastest = (1 if (pws is None and splitk == 1 and M <= 2048 and pw.w.numel() > x.numel() * x_rep + (x2.numel() if x2 is not None else 0)) else 0) \
         if XCD_ORDER < 0 else XCD_ORDER
@@ -508,7 +534,8 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
         d.ngroups = len(pws)
         acc = 0
         for g, (q, n) in enumerate(zip(pws, group_n)):
-            if (q.rows_padded, q.kpad, q.cout, q.cin, q.ksize, q.geglu, q.ctail) != (pw.rows_padded, pw.kpad, pw.cout, pw.cin, pw.ksize, pw.geglu, pw.ctail):
+            if (q.rows_padded, q.kpad, q.cout, q.cin, q.ksize, q.geglu, q.ctail, q.korder) != \
+                    (pw.rows_padded, pw.kpad, pw.cout, pw.cin, pw.ksize, pw.geglu, pw.ctail, pw.korder):
                 raise L.EdgeStyleHipError("grouped conv_gemm: weight geometry differs between groups")
             acc += n * hw // BM
             d.mt_end[g] = acc

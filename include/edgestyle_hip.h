@@ -23,7 +23,7 @@ extern "C" {
 enum { ES_F16 = 0, ES_BF16 = 1, ES_F32 = 2 /* es_tensor sources only: the kernels compute in ES_F16 / ES_BF16 */ };
 enum { ES_ACT_NONE = 0, ES_ACT_SILU = 1, ES_ACT_GEGLU = 2 };
 
-#define ES_ABI_VERSION 5
+#define ES_ABI_VERSION 6
 int es_abi_version(void);
 /* sizeof the descriptor structs as compiled (0 gemm, 1 attn, 2 gn, 3 fusion, 4 ln, 5 xs): lets a binding verify its mirror */
 size_t es_sizeof_desc(int which);
@@ -37,7 +37,7 @@ const char* es_last_error(void);
  * (model/controllora.py:197-254) and the skip-concat `torch.cat([h, res], 1)` of the UNet up blocks (x2).
  *   out[m, co] = act( sum_k A[m,k] * W[co,k] + bias[co] + temb[n(m), co] ) * out_scale (+ residual[m, co])
  * with m = (n, oy, ox), k = (ky, kx, c) tap-major over the channel-concatenated sources (x | x2).
- * W is pre-packed by es_pack_conv_weight layout rules: [rows_padded][Kpad] K-contiguous, dtype.
+ * W is pre-packed (ops.pack_weight / es_load_weights): [rows_padded][Kpad] K-contiguous, dtype; K order: `korder`.
  * --------------------------------------------------------------------------------------------------------- */
 typedef struct {
   const void* x;          /* [N, Hsrc, Wsrc, C1] */
@@ -96,6 +96,13 @@ typedef struct {
    * CL:197-203; text states shared by the nets of a weight-sharing group) without a replicated copy.  0 = off.
    * Needs one source (no x2), no tail sources. */
   int32_t x_nmod;
+  /* K order of the packed weights (and of the loader): 0 = tap-major, k = (ky, kx, c) over the channel concat;
+   * 1 = chunk-major, k = (c / 64, ky, kx, c % 64): the nine taps of one 64-channel chunk back to back, so that eight of
+   * the nine activation tiles a workgroup stages per chunk re-read lines it fetched one K-tile earlier (L2 hits instead
+   * of Infinity-Cache round trips: with tap-major order the 32 workgroups of an XCD sweep 5-10 MB of activations between
+   * two reads of the same line).  The 1x1 tail sources follow the k*k*Ctot main part in either order.
+   * 1 needs ksize 3 and 64-aligned C1, C2; ops.pack_weight / es_load_weights pack every such convolution this way. */
+  int32_t korder;
 } es_gemm_desc;
 int es_conv_gemm(const es_gemm_desc* d, void* stream);
 size_t es_conv_gemm_workspace_bytes(const es_gemm_desc* d);

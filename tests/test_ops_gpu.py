@@ -832,3 +832,50 @@ def test_linear_xs_row_stationary_kernel(dtype):
     assert rel_err(yg, torch.cat(refs)) < tol
     assert torch.equal(yg, again)                         # deterministic: same launch twice, bit for bit
     ops.XS_MIN_M = 8192
+
+
+@pytest.mark.parametrize("N,H,C1,C2,Cout,stride,up,Ct,splitk,bn", [
+    (2, 16, 128, 0, 256, 1, False, 0, None, 0),      # planner's choice, plain 3x3
+    (2, 16, 64, 128, 320, 1, False, 0, None, 160),   # skip concat: chunks run over (x | x2)
+    (1, 16, 128, 0, 256, 2, False, 0, None, 128),    # stride 2
+    (2, 8, 64, 0, 128, 1, True, 0, None, 128),       # nearest-2x upsample: per-row parities place the taps
+    (2, 8, 128, 0, 128, 1, False, 64, 5, 128),       # 1x1 tail behind the chunks, split-K slices that start mid-chunk / in the tail
+    (3, 5, 64, 0, 64, 1, False, 0, None, 64),        # ragged M on the 64 x 64 tile
+    (8, 32, 128, 0, 320, 1, False, 64, None, 320),   # the 256 x 320 tile, tail sources
+    (8, 32, 64, 64, 320, 2, False, 0, 3, 320),       # the 256 x 320 tile: concat, stride 2, split-K
+    (4, 16, 64, 0, 320, 1, True, 0, None, 320),      # the 256 x 320 tile with the fused upsample
+])
+def test_conv_gemm_chunk_major_k_order(N, H, C1, C2, Cout, stride, up, Ct, splitk, bn):
+    """es_gemm_desc.korder = 1 (opt-in, ES_CHUNK_MAJOR=1): weights packed k = (c / 64, ky, kx, c % 64) and the loaders of both
+    GEMM kernels walking K in that order - the same convolution as the tap-major default, to rounding (the fp32 accumulation
+    order differs), and each against torch's conv2d."""
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(N * 100 + C1 + C2 + Cout + stride)
+    C = C1 + C2
+    x = q16(torch.randn(N, C, H, H, generator=g))
+    w = q16(torch.randn(Cout, C, 3, 3, generator=g) / math.sqrt(9 * C))
+    b = torch.randn(Cout, generator=g) * 0.1
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    ref = F.conv2d(xin, w, b, stride=stride, padding=1)
+    t = wt = None
+    if Ct:
+        t = q16(torch.randn(N, Ct, H, H, generator=g))
+        wt = q16(torch.randn(Cout, Ct, 1, 1, generator=g) / math.sqrt(Ct))
+        ref = ref + F.conv2d(t, wt, None)
+    xs = nhwc(x)
+    x1, x2 = (xs[..., :C1].contiguous(), xs[..., C1:].contiguous()) if C2 else (xs, None)
+    outs = {}
+    prev = ops.CHUNK_MAJOR, ops.FORCE_BN
+    try:
+        ops.FORCE_BN = bn
+        for ko in (0, 1):
+            ops.CHUNK_MAJOR = bool(ko)
+            pw = ops.pack_weight_tail(w, wt, b, torch.float16, DEV) if Ct else ops.pack_weight(w, b, torch.float16, DEV)
+            assert pw.korder == ko
+            outs[ko] = ops.conv_gemm(x1, pw, x2=x2, stride=stride, upsample=up, splitk=splitk, tail=(nhwc(t),) if Ct else None)
+    finally:
+        ops.CHUNK_MAJOR, ops.FORCE_BN = prev
+    torch.cuda.synchronize()
+    for ko in (0, 1):
+        assert rel_err(outs[ko].permute(0, 3, 1, 2), ref) < 3e-3, ko
+    assert rel_err(outs[1], outs[0]) < 1e-3

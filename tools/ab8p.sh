@@ -7,6 +7,6 @@ NAME=$1; shift
 mkdir -p ../lib/ablate/obj_$NAME
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -ffp-contract=fast "$@" -c gemm_conv8p.hip -o ../lib/ablate/obj_$NAME/gemm_conv8p.o
 OBJS=""
-for f in gemm_conv linear_xs attention norm fusion elementwise plan; do OBJS="$OBJS ../lib/obj/$f.o"; done
+for f in gemm_conv linear_xs attention norm fusion elementwise plan builder; do OBJS="$OBJS ../lib/obj/$f.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/ablate/libes_8p_$NAME.so $OBJS ../lib/ablate/obj_$NAME/gemm_conv8p.o
 echo built ../lib/ablate/libes_8p_$NAME.so
