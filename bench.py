@@ -263,7 +263,7 @@ def cpu_baseline_and_parity(pipe, ws, ucfg, B, steps_total, tiny):
     return base, parity
 
 
-def native_abi_leg(pipe, ws, ucfg, vcfg, B, T, dtype, dev_index, lat, pe, ne, imgs, cn, want_img, iters=3):
+def native_abi_leg(pipe, ws, ucfg, vcfg, B, T, dtype, dev_index, lat, pe, ne, imgs, cn, want_img, iters=3, graphs=2):
     """The benchmarked request served through the C ABI alone: es_load_weights builds the context from the raw
     state dicts (no model walk in Python), then es_prepare_conds + es_denoise_loop + es_vae_decode on raw device pointers,
     the whole loop as one hipGraph.  Reported beside the headline value (same kernels, same launch lists: what changes is who
@@ -275,7 +275,7 @@ def native_abi_leg(pipe, ws, ucfg, vcfg, B, T, dtype, dev_index, lat, pe, ne, im
     t_build = time.perf_counter() - t0          # (the bench's weights live on the GPU: the builder reads them back itself)
     try:
         nat.set_alphas_cumprod(pipe.scheduler.alphas_cumprod)
-        nat.set_options(use_graphs=2)
+        nat.set_options(use_graphs=graphs)
         im = [i.to(dev, torch.float32).repeat_interleave(B, dim=0).contiguous() if i.shape[0] == 1 else i.to(dev, torch.float32) for i in imgs]
         nz = [None if z is None else z.to(dev, torch.float32).contiguous() for z in cn]
         ehs = torch.cat([ne, pe]).to(dev, dtype).contiguous()
@@ -297,7 +297,8 @@ def native_abi_leg(pipe, ws, ucfg, vcfg, B, T, dtype, dev_index, lat, pe, ne, im
         torch.cuda.synchronize()
         t = (time.perf_counter() - t0) / iters
         return {"workload": "the same request through the C ABI alone: context built by es_load_weights from raw state dicts, "
-                            "es_prepare_conds + es_denoise_loop (whole loop as one hipGraph) + es_vae_decode on raw device pointers",
+                            "es_prepare_conds + es_denoise_loop (" + {2: "whole loop as one hipGraph", 1: "one hipGraph per plan", 0: "launch by launch"}[graphs]
+                            + ") + es_vae_decode on raw device pointers",
                 "value": round(B / t, 4), "unit": "images/s", "ms_per_step": round(t * 1e3, 1), "steps": iters, "warmup": 2,
                 "build_s": round(t_build, 1),
                 "arena_gib": round(nat.lib.es_ctx_arena_bytes(nat.ctx) / 2 ** 30, 2),
@@ -329,6 +330,10 @@ def main(argv=None):
                     help="skip the extra batch-8 (BASELINE configs[2]) measurement reported beside the headline value")
     ap.add_argument("--no-native-abi", action="store_true",
                     help="skip the extra leg that serves the same request through the C ABI alone (es_load_weights context)")
+    ap.add_argument("--native-graphs", type=int, default=2, choices=(0, 1, 2),
+                    help="how the native-ABI leg replays its plans: 2 = the whole loop as ONE hipGraph (default), 1 = one hipGraph per "
+                         "plan (a step per launch), 0 = launch by launch.  Under rocprofv3 use 1: the profiler's queue interception "
+                         "cannot take one graph launch of ~14 k kernel nodes of a batch-8 loop (DESIGN.md, round-4 note)")
     ap.add_argument("--fake-pipeline", action="store_true",
                     help="CPU rehearsal of the multi-rank control flow (gloo, no GPU, no kernels): NOT a measurement")
     args = ap.parse_args(argv)
@@ -434,7 +439,8 @@ def main(argv=None):
             line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(pipe, ws, ucfg, B, args.ddim_steps, args.tiny)
             log(f"cpu baseline + parity done: {line['parity']}")
         if not args.no_native_abi and world == 1 and not args.tiny and args.resolution == 512 and not args.no_graph:
-            line["native_abi"] = native_abi_leg(pipe, ws, ucfg, vcfg, B, args.ddim_steps, dtype, dev_index, lat, pe, ne, imgs, cn, img)
+            line["native_abi"] = native_abi_leg(pipe, ws, ucfg, vcfg, B, args.ddim_steps, dtype, dev_index, lat, pe, ne, imgs, cn, img,
+                                                graphs=args.native_graphs)
             log(f"native ABI leg done: {line['native_abi']}")
         if not args.no_throughput_mode and world == 1 and B != 8 and not args.tiny and args.resolution == 512:
             # BASELINE configs[2]: same path, 8 images per step (hipGraph-captured, throughput mode); reported beside
@@ -463,7 +469,8 @@ def main(argv=None):
                     "avg_launch_us", "gemm_time_per_step_ms", "conv3x3_only", "stamped", "how") if k in r8}
             log(f"throughput mode (batch 8): {8 / t8:.3f} images/s")
             if not args.no_native_abi and not args.no_graph:
-                n8abi = native_abi_leg(pipe, ws, ucfg, vcfg, 8, args.ddim_steps, dtype, dev_index, lat8, pe8, ne8, imgs8, cn8, img8, iters=2)
+                n8abi = native_abi_leg(pipe, ws, ucfg, vcfg, 8, args.ddim_steps, dtype, dev_index, lat8, pe8, ne8, imgs8, cn8, img8, iters=2,
+                                       graphs=args.native_graphs)
                 line["throughput_mode"]["native_abi"] = {k: n8abi[k] for k in ("value", "unit", "ms_per_step", "build_s", "arena_gib",
                                                                                "bitwise_equal_to_pipeline")}
                 log(f"throughput mode through the C ABI alone: {n8abi['value']:.3f} images/s")

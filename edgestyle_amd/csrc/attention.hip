@@ -996,6 +996,12 @@ extern "C" int es_attention(const es_attn_desc* d, void* stream) {
   if (!d->q || !d->k || !d->v || !d->o) { es_set_error("es_attention: null pointer"); return -1; }
   if (d->d % 8 || d->ldq % 8 || d->ldk % 8 || d->ldv % 8 || d->ldo % 4) { es_set_error("es_attention: d and strides must be multiples of 8"); return -1; }
   if (d->Sq < 1 || d->Skv < 1 || d->N < 1 || d->heads < 1) { es_set_error("es_attention: empty problem"); return -1; }
+  {   // the head widths dispatch() has a kernel for - checked HERE so that a dry recording (es_load_weights) rejects what a launch would
+    static const int ok_d[] = {8, 16, 24, 32, 40, 48, 64, 80, 128, 160, 512};
+    bool ok = false;
+    for (int v : ok_d) ok = ok || d->d == v;
+    if (!ok) { es_set_error("es_attention: unsupported head_dim (8,16,24,32,40,48,64,80,128,160,512)"); return -3; }
+  }
   ES_PLAN_RECORD(ES_OP_ATTENTION, d, sizeof(*d));       // after validation: a rejected call never enters a recording plan
   hipStream_t st = (hipStream_t)stream;
   int rc = d->dtype == ES_F16 ? dispatch<f16>(*d, st) : dispatch<bf16>(*d, st);

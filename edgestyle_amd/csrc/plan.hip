@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -265,6 +266,7 @@ struct es_ctx {
   void* arena = nullptr;               // es_ctx_load / es_load_weights: the one allocation every recorded pointer was relocated into
   size_t arena_bytes = 0;
   bool arena_on_host = false;
+  bool launchable = true;              // false: an inspection build (es_load_weights device -1 / -2) whose recorded addresses are not device memory
   std::vector<std::pair<unsigned long long, unsigned long long>> extents;   // (offset, bytes) of the arena's persistent DATA (es_ctx_save)          // es_load_weights(device -2): an inspection build in host memory
   hipGraphExec_t loop_exec = nullptr;  // use_graphs == 2: preparation + all steps of es_denoise_loop as one graph
   int loop_steps = 0;
@@ -289,6 +291,15 @@ bool capturing(hipStream_t st) {
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
 }
+// the dry (-1) and host-arena (-2) builds of es_load_weights bind every slot and relocate every plan to addresses that are NOT
+// device memory: launching them would fault on the GPU, so every entry point that launches refuses them
+int can_launch(const es_ctx* c, const char* who) {
+  if (c->launchable) return 0;
+  static thread_local char msg[192];
+  snprintf(msg, sizeof(msg), "%s: this context is an inspection build (es_load_weights device -1 / -2): its plans hold no device addresses and cannot be launched", who);
+  es_set_error(msg);
+  return -1;
+}
 int need(const es_ctx* c, int slot, const char* what) {
   if (!c->buf[slot]) { es_set_error(what); return -1; }
   return 0;
@@ -305,9 +316,15 @@ int h2d(void* dst, const void* src, size_t n, hipStream_t st) {
 
 // one plan: as a hipGraph captured from the launch list (re-captured when the guidance scale baked into its scheduler
 // node changes), or - use_graphs 0, or while the caller's stream is itself capturing - re-issued launch by launch
+// ES_CTX_TRACE=1: one line on stderr ahead of every HIP graph call of a context (which call a host-side fault sits in when the
+// process runs under a tool that intercepts the HIP / HSA layers)
+bool ctx_trace() { static const bool on = [] { const char* e = getenv("ES_CTX_TRACE"); return e && e[0] == '1'; }(); return on; }
+#define ES_TRACE(...) do { if (ctx_trace()) { fprintf(stderr, "[es_ctx] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+
 int run(es_ctx* c, int which, hipStream_t st, const float* guidance) {
   es_plan* p = c->plan[which];
   if (!p) { es_set_error("es_ctx: plan not set"); return -1; }
+  if (can_launch(c, "es_ctx")) return -1;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &cs);
   RunOpts ro;
@@ -319,16 +336,21 @@ int run(es_ctx* c, int which, hipStream_t st, const float* guidance) {
   if (!c->exec[which]) {
     hipGraph_t graph = nullptr;
     if (!c->cap_stream && hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking) != hipSuccess) { es_set_error("es_ctx: hipStreamCreate failed"); return -2; }
+    ES_TRACE("plan %d: hipStreamBeginCapture (%zu calls)", which, p->ops.size());
     if (hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { es_set_error("es_ctx: hipStreamBeginCapture failed"); return -2; }
     const int rc = run_plan(p, c->cap_stream, ro);
+    ES_TRACE("plan %d: hipStreamEndCapture", which);
     const hipError_t e = hipStreamEndCapture(c->cap_stream, &graph);
     if (rc || e != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); if (!rc) es_set_error("es_ctx: hipStreamEndCapture failed"); return rc ? rc : -2; }
+    ES_TRACE("plan %d: hipGraphInstantiate", which);
     const hipError_t ei = hipGraphInstantiate(&c->exec[which], graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (ei != hipSuccess) { c->exec[which] = nullptr; es_set_error("es_ctx: hipGraphInstantiate failed"); return -2; }
     c->exec_guidance[which] = gs;
   }
+  ES_TRACE("plan %d: hipGraphLaunch", which);
   if (hipGraphLaunch(c->exec[which], st) != hipSuccess) { es_set_error("es_ctx: hipGraphLaunch failed"); return -2; }
+  ES_TRACE("plan %d: hipGraphLaunch returned", which);
   return 0;
 }
 
@@ -505,7 +527,10 @@ extern "C" void es_ctx_destroy(es_ctx* c) {
   if (c->arena) { if (c->arena_on_host) free(c->arena); else (void)hipFree(c->arena); }
   delete c;
 }
-void es_ctx_adopt_arena(es_ctx* c, void* arena, size_t bytes, bool on_host) { c->arena = arena; c->arena_bytes = bytes; c->arena_on_host = on_host; }
+void es_ctx_adopt_arena(es_ctx* c, void* arena, size_t bytes, bool on_host) {
+  c->arena = arena; c->arena_bytes = bytes; c->arena_on_host = on_host;
+  c->launchable = arena != nullptr && !on_host;
+}
 void es_ctx_add_extent(es_ctx* c, unsigned long long off, unsigned long long bytes) { c->extents.emplace_back(off, bytes); }
 extern "C" size_t es_ctx_arena_bytes(const es_ctx* c) { return c ? c->arena_bytes : 0; }
 extern "C" int es_ctx_set_geometry(es_ctx* c, const es_ctx_geometry* g) {
@@ -554,6 +579,7 @@ extern "C" int es_ctx_set_alphas_cumprod_f64(es_ctx* c, const double* alphas_cum
  * a loop it has prepared, e.g. to look at intermediate latents */
 extern "C" int es_ctx_launch_plan(es_ctx* c, int which, const float* guidance_scale, void* stream) {
   if (!c || which < 0 || which >= ES_PLAN_COUNT) { es_set_error("es_ctx_launch_plan: bad arguments"); return -1; }
+  if (can_launch(c, "es_ctx_launch_plan")) return -1;
   return run(c, which, (hipStream_t)stream, guidance_scale);
 }
 /* host-only: the per-step DDIM coefficient rows es_denoise_loop derives from `timesteps` (no GPU involved) */
@@ -583,20 +609,23 @@ extern "C" int es_ctx_load(const char* path, int device, es_ctx** out) {
   auto fail = [&](const char* msg) { es_set_error(msg); if (c) es_ctx_destroy(c); fclose(f); return -1; };
   auto rd = [&](void* dst, size_t n) { return fread(dst, 1, n, f) == n; };
   struct { char magic[8]; unsigned abi, n_blocks; unsigned long long arena_bytes; } h;
-  if (!rd(&h, sizeof(h)) || memcmp(h.magic, "ESCTX\2\0\0", 8) != 0) return fail("es_ctx_load: not a context image (or one of an older format: rebuild it)");
+  if (!rd(&h, sizeof(h)) || memcmp(h.magic, "ESCTX\3\0\0", 8) != 0) return fail("es_ctx_load: not a context image (or one of an older format: rebuild it)");
   if (h.abi != ES_ABI_VERSION) return fail("es_ctx_load: the image was written for another ABI version");
   if (h.arena_bytes > (1ull << 40) || h.n_blocks > (1u << 24)) return fail("es_ctx_load: implausible header");
   if (hipSetDevice(device) != hipSuccess) return fail("es_ctx_load: hipSetDevice failed");
   c = new es_ctx();
   c->device = device;
-  struct { float cond_scales[6]; float start, end; int use_graphs; unsigned n_alphas; } o;
+  struct { float cond_scales[6]; float start, end; int use_graphs; unsigned n_alphas; int scheduler; unsigned n_alphas_f64; } o;
   if (!rd(&c->g, sizeof(c->g)) || !rd(&o, sizeof(o))) return fail("es_ctx_load: truncated header");
-  if (o.n_alphas > (1u << 20)) return fail("es_ctx_load: implausible schedule length");
+  if (o.n_alphas > (1u << 20) || o.n_alphas_f64 > (1u << 20)) return fail("es_ctx_load: implausible schedule length");
+  if (o.scheduler != ES_SCHED_DDIM && o.scheduler != ES_SCHED_UNIPC) return fail("es_ctx_load: unknown scheduler in the image");
   memcpy(c->cond_scales, o.cond_scales, sizeof(o.cond_scales));
   c->control_start = o.start; c->control_end = o.end; c->use_graphs = o.use_graphs;
   c->alphas_cumprod.resize(o.n_alphas);
   if (o.n_alphas && !rd(c->alphas_cumprod.data(), o.n_alphas * sizeof(float))) return fail("es_ctx_load: truncated schedule");
   if ((o.n_alphas & 1) && fseek(f, 4, SEEK_CUR)) return fail("es_ctx_load: truncated schedule");
+  c->alphas_cumprod_f64.resize(o.n_alphas_f64);
+  if (o.n_alphas_f64 && !rd(c->alphas_cumprod_f64.data(), o.n_alphas_f64 * sizeof(double))) return fail("es_ctx_load: truncated schedule");
   struct Blk { unsigned long long off, bytes; };
   // (overflow-safe: off <= arena and bytes <= arena - off)
   auto inside = [&](unsigned long long off, unsigned long long bytes) { return off <= h.arena_bytes && bytes <= h.arena_bytes - off; };
@@ -618,11 +647,36 @@ extern "C" int es_ctx_load(const char* path, int device, es_ctx** out) {
     es_plan* p = es_plan_import(buf.data(), pb);
     if (!p) { if (c) es_ctx_destroy(c); fclose(f); return -1; }
     c->plan[which] = p;
+    // The stored relocation list is only trusted as far as the typed pointer-field tables agree with it: an entry must
+    // address a pointer field of a recorded call (nothing else in a record - sizes, strides - can be overwritten by a
+    // malformed image), and every non-null pointer field must have been relocated (none keeps a foreign address).
+    std::vector<size_t> legal;
+    for (const auto& op : p->ops) {
+      int elem = 0;
+      const auto& fl = ptr_fields(op.kind, elem);
+      const size_t reps = elem ? op.bytes / (size_t)elem : 1;
+      for (size_t r = 0; r < reps; ++r)
+        for (const auto& pf : fl) {
+          const size_t pos = op.off + r * (size_t)elem + (size_t)pf.off;
+          if (pos + 8 > op.off + op.bytes) return fail("es_ctx_load: a recorded call is shorter than its argument record");
+          legal.push_back(pos);
+        }
+    }
+    std::sort(legal.begin(), legal.end());
+    std::vector<char> done(legal.size(), 0);
     for (unsigned long long i = 0; i < nrel; ++i) {
       unsigned long long r[2];
-      if (!rd(r, 16) || r[0] > p->blob.size() || p->blob.size() - r[0] < 8 || r[1] >= h.arena_bytes) return fail("es_ctx_load: bad relocation");
+      if (!rd(r, 16) || r[1] >= h.arena_bytes) return fail("es_ctx_load: bad relocation");
+      const auto it = std::lower_bound(legal.begin(), legal.end(), (size_t)r[0]);
+      if (it == legal.end() || *it != (size_t)r[0]) return fail("es_ctx_load: a relocation does not address a pointer field of a recorded call");
       const unsigned long long addr = (unsigned long long)(base + r[1]);
       memcpy(p->blob.data() + r[0], &addr, 8);
+      done[(size_t)(it - legal.begin())] = 1;
+    }
+    for (size_t i = 0; i < legal.size(); ++i) {
+      unsigned long long a;
+      memcpy(&a, p->blob.data() + legal[i], 8);
+      if (a && !done[i]) return fail("es_ctx_load: a pointer field of a recorded call has no relocation");
     }
   }
   for (int slot = 0; slot < ES_BUF_COUNT; ++slot) {
@@ -651,6 +705,11 @@ extern "C" int es_ctx_load(const char* path, int device, es_ctx** out) {
     }
   }
   fclose(f);
+  c->scheduler = o.scheduler;          // (the graphs are instantiated lazily: nothing to rebuild)
+  if (o.scheduler == ES_SCHED_UNIPC) {
+    const int rc = es_ctx_set_scheduler(c, ES_SCHED_UNIPC);      // checks the state slots the image bound
+    if (rc) { es_ctx_destroy(c); return rc; }
+  }
   *out = c;
   return 0;
 }
@@ -664,18 +723,23 @@ extern "C" int es_ctx_save(const es_ctx* c, const char* path) {
   if (!c->arena || c->arena_on_host) { es_set_error("es_ctx_save: the context does not own a device arena (built by a Python host: use NativeEngine.save)"); return -1; }
   const unsigned long long base = (unsigned long long)c->arena, size = c->arena_bytes;
   auto inside = [&](unsigned long long a, unsigned long long n) { return a >= base && a - base <= size && n <= size - (a - base); };
-  FILE* f = fopen(path, "wb");
+  // written under a temporary name and renamed on success: a failure (a pointer outside the arena, a failed device copy, a full
+  // disk) never leaves a truncated image under the final name
+  const std::string tmp = std::string(path) + ".tmp";
+  FILE* f = fopen(tmp.c_str(), "wb");
   if (!f) { es_set_error("es_ctx_save: cannot open the file"); return -1; }
-  auto fail = [&](const char* msg) { es_set_error(msg); fclose(f); return -1; };
+  auto fail = [&](const char* msg) { es_set_error(msg); fclose(f); (void)remove(tmp.c_str()); return -1; };
   auto wr = [&](const void* p, size_t n) { return fwrite(p, 1, n, f) == n; };
-  struct { char magic[8]; unsigned abi, n_blocks; unsigned long long arena_bytes; } h = {{'E', 'S', 'C', 'T', 'X', 2, 0, 0}, ES_ABI_VERSION, 1, size};
-  struct { float cond_scales[6]; float start, end; int use_graphs; unsigned n_alphas; } o;
+  struct { char magic[8]; unsigned abi, n_blocks; unsigned long long arena_bytes; } h = {{'E', 'S', 'C', 'T', 'X', 3, 0, 0}, ES_ABI_VERSION, 1, size};
+  struct { float cond_scales[6]; float start, end; int use_graphs; unsigned n_alphas; int scheduler; unsigned n_alphas_f64; } o;
   memcpy(o.cond_scales, c->cond_scales, sizeof(o.cond_scales));
   o.start = c->control_start; o.end = c->control_end; o.use_graphs = c->use_graphs; o.n_alphas = (unsigned)c->alphas_cumprod.size();
+  o.scheduler = c->scheduler; o.n_alphas_f64 = (unsigned)c->alphas_cumprod_f64.size();
   if (!wr(&h, sizeof(h)) || !wr(&c->g, sizeof(c->g)) || !wr(&o, sizeof(o))) return fail("es_ctx_save: write failed");
   if (o.n_alphas && !wr(c->alphas_cumprod.data(), o.n_alphas * sizeof(float))) return fail("es_ctx_save: write failed");
   const unsigned zero4 = 0;
   if ((o.n_alphas & 1) && !wr(&zero4, 4)) return fail("es_ctx_save: write failed");
+  if (o.n_alphas_f64 && !wr(c->alphas_cumprod_f64.data(), o.n_alphas_f64 * sizeof(double))) return fail("es_ctx_save: write failed");
   const unsigned long long blk[2] = {0, size};
   if (!wr(blk, 16)) return fail("es_ctx_save: write failed");
   for (int which = 0; which < ES_PLAN_COUNT; ++which) {
@@ -727,7 +791,8 @@ extern "C" int es_ctx_save(const es_ctx* c, const char* path) {
       if (!wr(buf.data(), n)) return fail("es_ctx_save: write failed");
       done += n;
     }
-  if (fclose(f) != 0) { es_set_error("es_ctx_save: write failed"); return -1; }
+  if (fclose(f) != 0) { es_set_error("es_ctx_save: write failed"); (void)remove(tmp.c_str()); return -1; }
+  if (rename(tmp.c_str(), path) != 0) { es_set_error("es_ctx_save: cannot rename the finished image to its final name"); (void)remove(tmp.c_str()); return -1; }
   return 0;
 }
 
@@ -739,6 +804,7 @@ extern "C" int es_ctx_plan_size(const es_ctx* c, int which) {
 extern "C" int es_denoise_step(es_ctx* c, const void* sample, float t, const void* ehs, const void* const* cond_embeds,
                                const float* scales, void* out_noise, void* stream) {
   if (!c || !sample || !ehs || !cond_embeds || !out_noise) { es_set_error("es_denoise_step: null argument"); return -1; }
+  if (can_launch(c, "es_denoise_step")) return -1;
   hipStream_t st = (hipStream_t)stream;
   if (capturing(st)) { es_set_error("es_denoise_step: the stream is capturing; this entry point stages host values (timestep, scales) through pinned memory and cannot be captured - capture es_ctx_launch_plan(ES_PLAN_STEP_GENERIC) on buffers you fill yourself"); return -1; }
   if (!c->plan[ES_PLAN_STEP_GENERIC]) { es_set_error("es_denoise_step: the context has no ES_PLAN_STEP_GENERIC"); return -1; }
@@ -767,6 +833,7 @@ extern "C" int es_denoise_step(es_ctx* c, const void* sample, float t, const voi
 extern "C" int es_denoise_loop(es_ctx* c, float* latents_inout, const void* ehs, float guidance_scale, const float* timesteps,
                                int n_steps, void* stream) {
   if (!c || !latents_inout || !ehs || !timesteps) { es_set_error("es_denoise_loop: null argument"); return -1; }
+  if (can_launch(c, "es_denoise_loop")) return -1;
   if (n_steps != c->g.n_steps) { es_set_error("es_denoise_loop: the context was built for another number of steps"); return -1; }
   const int need_slots[] = {ES_BUF_LATENTS, ES_BUF_SAMPLE, ES_BUF_EHS, ES_BUF_STEP_IDX, ES_BUF_T_TABLE, ES_BUF_SCALE_TABLE, ES_BUF_COEF, ES_BUF_TIMESTEPS};
   for (int s : need_slots) if (need(c, s, "es_denoise_loop: a static buffer is not bound")) return -1;
@@ -840,6 +907,7 @@ extern "C" int es_denoise_loop(es_ctx* c, float* latents_inout, const void* ehs,
 // == prepare_image (PL:629-664) + the one-time conditioning embedding (CL:28-42, 289-290) for all nets of the context
 extern "C" int es_prepare_conds(es_ctx* c, const float* const* images, const float* const* noise, void* stream) {
   if (!c || !images) { es_set_error("es_prepare_conds: null argument"); return -1; }
+  if (can_launch(c, "es_prepare_conds")) return -1;
   if (!c->plan[ES_PLAN_CONDS]) { es_set_error("es_prepare_conds: the context has no ES_PLAN_CONDS (built from pre-embedded conditions)"); return -1; }
   hipStream_t st = (hipStream_t)stream;
   int rc;
@@ -858,6 +926,7 @@ extern "C" int es_prepare_conds(es_ctx* c, const float* const* images, const flo
 // latents fp32 [B,h,w,L] NHWC -> image fp32 [B,3,8h,8w] NCHW in [0,1]
 extern "C" int es_vae_decode(es_ctx* c, const float* latents, float* out_img, void* stream) {
   if (!c || !latents || !out_img) { es_set_error("es_vae_decode: null argument"); return -1; }
+  if (can_launch(c, "es_vae_decode")) return -1;
   if (need(c, ES_BUF_SAMPLE, "es_vae_decode: ES_BUF_SAMPLE not bound") || need(c, ES_BUF_IMAGE, "es_vae_decode: ES_BUF_IMAGE not bound")) return -1;
   const es_ctx_geometry& g = c->g;
   int rc;

@@ -233,6 +233,7 @@ class NativeEngine:
     def set_scheduler(self, scheduler: int):
         """L.SCHED_DDIM | L.SCHED_UNIPC: the update es_denoise_loop applies (the recorded step list is the same)."""
         L.check(self.lib.es_ctx_set_scheduler(self.ctx, int(scheduler)), "es_ctx_set_scheduler")
+        self._scheduler = int(scheduler)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -409,9 +410,12 @@ class NativeEngine:
         g = self._geo
         ac = self.pipe.scheduler.alphas_cumprod.float().contiguous().numpy()
         with open(path, "wb") as f:
-            f.write(b"ESCTX\x02\x00\x00" + struct.pack("<IIQ", L.ABI_VERSION, len(used), arena))
+            f.write(b"ESCTX\x03\x00\x00" + struct.pack("<IIQ", L.ABI_VERSION, len(used), arena))
             f.write(bytes(g))
-            f.write(struct.pack("<6fffiI", *self._cond_scales, self._cg[0], self._cg[1], int(self._use_graphs), len(ac)))
+            # options record of format 3: + the scheduler es_denoise_loop applies and the length of an f64 schedule (none from
+            # this host: a loaded UniPC context derives its sigmas from the library's own SD1.5 table in double, as this one does)
+            f.write(struct.pack("<6fffiIiI", *self._cond_scales, self._cg[0], self._cg[1], int(self._use_graphs), len(ac),
+                                int(getattr(self, "_scheduler", L.SCHED_DDIM)), 0))
             f.write(ac.tobytes())
             if len(ac) & 1:
                 f.write(b"\0" * 4)

@@ -379,7 +379,8 @@ int es_ctx_save(const es_ctx* c, const char* path);
  * (TT:252-258), or n_conds = 1: ONE ControlNet whose 13 residuals go to the UNet directly (PL:338-351; `fusion` is not read) -
  * with 64-aligned channel widths; DDIM or UniPC (es_ctx_set_scheduler).  device -1: dry build - everything but the device allocation and the upload (plans keep
  * arena-relative addresses; for inspection with es_ctx_plan / es_plan_export on a host without a GPU); device -2: the same
- * with the arena in host memory, contents included (what tests read the packed weights from).  Neither can launch.
+ * with the arena in host memory, contents included (what tests read the packed weights from).  Neither can launch: every entry point that would
+ * run one of their plans returns an error that says so.
  * --------------------------------------------------------------------------------------------------------- */
 typedef struct {
   const char* key;

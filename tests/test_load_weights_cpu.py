@@ -189,15 +189,32 @@ def test_missing_keys_wrong_shapes_and_unsupported_requests_are_named(tiny):
 
 
 def test_a_dry_context_cannot_be_saved_or_run(tiny, tmp_path):
-    """device = -1 / -2 builds are for inspection: no device arena, so es_ctx_save refuses them by name."""
+    """device = -1 / -2 builds are for inspection: no device arena, so es_ctx_save refuses them by name, and so does every
+    entry point that would launch their plans (their recorded addresses are arena-relative or host memory: launching them
+    was a GPU fault, not an error code - ADVICE r3)."""
     ucfg, vcfg, ws = tiny
     lib = L.load()
-    c = NativeContext(ws, ucfg, vcfg, num_inference_steps=3, device=-2)
-    try:
-        assert lib.es_ctx_arena_bytes(c.ctx) > 100 << 20
-        assert lib.es_ctx_save(c.ctx, str(tmp_path / "x.esctx").encode()) != 0 and b"does not own a device arena" in lib.es_last_error()
-    finally:
-        c.close()
+    for dev in (-2, -1):
+        c = NativeContext(ws, ucfg, vcfg, num_inference_steps=3, device=dev)
+        try:
+            assert lib.es_ctx_arena_bytes(c.ctx) > 100 << 20
+            assert lib.es_ctx_save(c.ctx, str(tmp_path / "x.esctx").encode()) != 0 and b"does not own a device arena" in lib.es_last_error()
+            host = torch.zeros(1 << 16)
+            hp = C.c_void_p(host.data_ptr())
+            six = (C.c_void_p * 6)(*([host.data_ptr()] * 6))
+            ts = (C.c_float * 3)(981.0, 641.0, 301.0)
+            calls = [
+                ("es_ctx_launch_plan", lambda: lib.es_ctx_launch_plan(c.ctx, L.PLAN_STEP, None, None)),
+                ("es_vae_decode", lambda: lib.es_vae_decode(c.ctx, hp, hp, None)),
+                ("es_denoise_loop", lambda: lib.es_denoise_loop(c.ctx, hp, hp, 7.5, ts, 3, None)),
+                ("es_denoise_step", lambda: lib.es_denoise_step(c.ctx, hp, 501.0, hp, six, None, hp, None)),
+                ("es_prepare_conds", lambda: lib.es_prepare_conds(c.ctx, six, six, None)),
+            ]
+            for name, call in calls:
+                assert call() != 0, name
+                assert b"inspection build" in lib.es_last_error(), (name, lib.es_last_error())
+        finally:
+            c.close()
 
 
 def test_dry_recording_validates_but_does_not_launch():
@@ -212,6 +229,19 @@ def test_dry_recording_validates_but_does_not_launch():
         assert lib.es_fill_f32(C.c_void_p(buf.data_ptr()), 1.0, 64, None) == 0
         assert lib.es_add(C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr()), 7, L.ES_F16, None) != 0
         assert lib.es_plan_size(plan) == 1 and float(buf.sum()) == 0.0
+        # a head width that passes d % 8 but has no kernel (e.g. block_out_channels / heads = 56) is refused while RECORDING,
+        # not at the first launch: es_load_weights therefore rejects such a config like the eager Python builder does
+        d = L.AttnDesc()
+        q = torch.zeros(4 * 64 * 56 * 2, dtype=torch.float16)
+        d.q = d.k = d.v = d.o = q.data_ptr()
+        d.N, d.heads, d.Sq, d.Skv, d.d = 1, 2, 64, 64, 56
+        d.ldq = d.ldk = d.ldv = d.ldo = 112
+        d.bsq = d.bsk = d.bsv = d.bso = 64 * 112
+        d.scale, d.dtype = 0.1, L.ES_F16
+        assert lib.es_attention(C.byref(d), None) != 0 and b"unsupported head_dim" in lib.es_last_error()
+        assert lib.es_plan_size(plan) == 1
+        d.d, d.ldq, d.ldk, d.ldv, d.ldo = 40, 80, 80, 80, 80
+        assert lib.es_attention(C.byref(d), None) == 0 and lib.es_plan_size(plan) == 2
     finally:
         assert lib.es_plan_set_dry(0) == 1
         lib.es_plan_end_record(plan)

@@ -2,6 +2,8 @@
 # On the GPU box: cache / traffic counters of one 3x3 convolution in both K orders.  bash tools/collect_korder_pmc.sh [bn] [N H Cin Cout]
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+# rocprofiler-sdk's queue interception faults on the HIP runtime's pre-built graph AQL packets: replay graphs packet by packet
+export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 out=gpurun_out/korder_pmc
 rm -rf $out; mkdir -p $out
 rocprofv3 -L > $out/counters_available.txt 2>&1

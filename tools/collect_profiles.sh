@@ -1,16 +1,16 @@
 #!/bin/bash
 # On the GPU box: everything profiles/ holds for a round, into gpurun_out/final/ (copy what is to be judged to profiles/).
-#   bash tools/collect_profiles.sh r03
+#   bash tools/collect_profiles.sh r04
 cd "$(dirname "$0")/.."
-R=${1:-r03}
+R=${1:-r04}
 out=gpurun_out/final
 rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp
 # 1. the default bench line (driver's flags)
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/${R}_bench_default_run.json 2> $out/${R}_bench_default_run.err
 # 2. rocprofv3 kernel stats at batch 1 and batch 8
-bash tools/prof_bench.sh ${R}_bench_b1 --steps 2 --warmup 1 --no-cpu-baseline --no-throughput-mode --no-stress-mode --no-roofline --no-native-abi
-bash tools/prof_bench.sh ${R}_bench_b8 --batch 8 --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode --no-stress-mode --no-roofline --no-native-abi
+bash tools/prof_bench.sh ${R}_bench_b1 --steps 2 --warmup 1 --no-cpu-baseline --no-throughput-mode --no-stress-mode --no-roofline
+bash tools/prof_bench.sh ${R}_bench_b8 --batch 8 --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode --no-stress-mode --no-roofline
 cp gpurun_out/${R}_bench_b1_kernel_stats.csv gpurun_out/${R}_bench_b8_kernel_stats.csv gpurun_out/${R}_bench_b1_under_rocprof.json gpurun_out/${R}_bench_b8_under_rocprof.json $out/ 2>/dev/null
 # 3. HBM-side traffic of the step's GEMM launches (PMC, real pipeline), batch 1 and 8
 bash tools/collect_traffic_pipeline.sh 1 > $out/traffic_b1.log 2>&1

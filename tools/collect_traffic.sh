@@ -4,6 +4,8 @@
 set -e
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+# rocprofiler-sdk's queue interception faults on the HIP runtime's pre-built graph AQL packets: replay graphs packet by packet
+export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 mkdir -p gpurun_out/traffic
 ES_DUMP_GEMM=1 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode > gpurun_out/traffic/dump.log 2>&1
 cp gpurun_out/gemm_step_launches.json gpurun_out/traffic/launches.json

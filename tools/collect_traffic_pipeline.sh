@@ -3,6 +3,8 @@
 # rocprofv3 --pmc, one counter per pass.   bash tools/collect_traffic_pipeline.sh [batch]
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+# rocprofiler-sdk's queue interception faults on the HIP runtime's pre-built graph AQL packets: replay graphs packet by packet
+export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 B=${1:-1}
 out=gpurun_out/traffic_b$B
 rm -rf $out; mkdir -p $out

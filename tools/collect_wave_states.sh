@@ -3,6 +3,8 @@
 # eager launches under rocprofv3 --pmc.   bash tools/collect_wave_states.sh [batch]   -> gpurun_out/waves_b<batch>/wave_states.json
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+# rocprofiler-sdk's queue interception faults on the HIP runtime's pre-built graph AQL packets: replay graphs packet by packet
+export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 B=${1:-1}
 out=gpurun_out/waves_b$B
 rm -rf $out; mkdir -p $out
