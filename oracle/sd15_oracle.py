@@ -1,4 +1,6 @@
-"""CPU ORACLE — test infrastructure only.  PARITY UNPINNED for the diffusers-owned blocks (see below).
+"""CPU ORACLE — test infrastructure only.  PINNED for the arithmetic the reference itself owns (ControlNetBlock, interleave_*:
+tests/golden/ref_fusion.safetensors holds outputs of the reference's OWN code, tests/golden/make_golden_ref_fusion.py);
+PARITY UNPINNED for the diffusers-owned blocks (see below).
 
 A plain-PyTorch fp32 restatement of EdgeStyle's 6-condition multi-ControlNet SD1.5 denoising path.  It is the
 checker for the HIP path: only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import

@@ -328,3 +328,48 @@ def plan_constants(lib, ctx, which):
                                   (d.g2, hw * c * 2), (d.be2, hw * c * 2), (d.w3, c * 4), (d.b3, c * 4)):
                     rd(p, nbytes)
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Inputs of tests/golden/ref_fusion.safetensors (make_golden_ref_fusion.py: outputs of the REFERENCE's own ControlNetBlock
+# and interleave functions): the 13 (channels, size) pairs of the reference's residual table (MC:73-102) at batch 2
+# ----------------------------------------------------------------------------------------------------------------
+REF_FUSION_LEVELS = [(320, 64)] * 3 + [(320, 32)] + [(640, 32)] * 2 + [(640, 16)] + [(1280, 16)] * 2 + [(1280, 8)] * 3 + [(1280, 8)]
+
+
+def ref_fusion_sample(y: torch.Tensor) -> torch.Tensor:
+    """the stored part of a block's output [N, C, S, S]: every 4th channel on an 8 x 8 pixel grid (the LayerNorms couple every
+    element of a sample, so an error anywhere shows everywhere; the full-tensor sum and abs-sum are stored beside it)"""
+    st = max(y.shape[-1] // 8, 1)
+    return y[:, ::4, ::st, ::st]
+
+
+def ref_fusion_case(i: int, N: int = 2):
+    """-> (state dict of ControlNetBlock(C, (S, S), 6) with the reference's parameter names, six residuals [N, C, S, S]);
+    parameters and residuals are rounded through fp16 so that the HIP path sees the same values."""
+    C, S = REF_FUSION_LEVELS[i]
+    g = torch.Generator().manual_seed(9000 + i)
+
+    def q(x):
+        return x.half().float()
+    sd = {
+        "first_conv.weight": q(torch.randn(3 * C, 2, 1, 1, generator=g) * 0.7),
+        "first_conv.bias": q(torch.randn(3 * C, generator=g) * 0.1),
+        "first_normalization.weight": q(1 + 0.1 * torch.randn(3 * C, S, S, generator=g)),
+        "first_normalization.bias": q(0.1 * torch.randn(3 * C, S, S, generator=g)),
+        "second_conv.weight": q(torch.randn(C, 3, 1, 1, generator=g) * 0.6),
+        "second_conv.bias": q(torch.randn(C, generator=g) * 0.1),
+        "second_normalization.weight": q(1 + 0.1 * torch.randn(C, S, S, generator=g)),
+        "second_normalization.bias": q(0.1 * torch.randn(C, S, S, generator=g)),
+        "third_conv.weight": q(torch.randn(C, 1, 1, 1, generator=g)),
+        "third_conv.bias": q(torch.randn(C, generator=g) * 0.1),
+    }
+    res = [q(torch.randn(N, C, S, S, generator=g) * (0.5 + 0.25 * k)) for k in range(6)]
+    return sd, res
+
+
+def ref_interleave_cases():
+    g = torch.Generator().manual_seed(9100)
+    a = [torch.randn(2, 8, 4, 4, generator=g) for _ in range(6)]
+    b = [torch.randn(1, 5, 3, 2, generator=g) for _ in range(3)]
+    return a, b

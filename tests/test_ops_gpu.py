@@ -367,6 +367,30 @@ def test_fusion_block_vs_reference_restatement(C, S, N):
     assert rel_err(y, ref) < 4e-3
 
 
+@pytest.mark.parametrize("level", list(range(13)))
+def test_fusion_block_vs_the_references_own_outputs(level):
+    """es_fusion_block against outputs of the REFERENCE's own ControlNetBlock(interleave_tensors(...)) (MC:23-63, 479-501):
+    tests/golden/ref_fusion.safetensors, written by tests/golden/make_golden_ref_fusion.py from the reference's source text -
+    all 13 (channels, size) pairs of MC:73-102 at batch 2.  PINNED parity for the kernel the reference owns: sampled elements
+    within 4e-3 of the tensor's scale (fp16 storage), full-tensor abs-sum within 1e-3."""
+    import os
+    from safetensors.torch import load_file
+    from edgestyle_amd import ops
+    from tests import helpers as H
+    gold = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_fusion.safetensors"))
+    C, S = H.REF_FUSION_LEVELS[level]
+    N = 2
+    sd, res = H.ref_fusion_case(level)
+    params = ops.pack_fusion_params({"b." + k: v for k, v in sd.items()}, "b", torch.float16, DEV)
+    r = [nhwc(x).reshape(N, S * S, C) for x in res]
+    y = ops.fusion_block(r, [S * S * C] * 6, params, N, S * S, C, [1.0] * 6)
+    y = y.reshape(N, S, S, C).permute(0, 3, 1, 2).float().cpu()
+    want = gold[f"level{level}_sample"]
+    assert float((H.ref_fusion_sample(y) - want).abs().max()) <= 4e-3 * float(want.abs().max())
+    sums = gold[f"level{level}_sums"]
+    assert abs(float(y.double().abs().sum()) - float(sums[1])) <= 1e-3 * float(sums[1])
+
+
 @pytest.mark.parametrize("C,S,N", [(320, 64, 2), (1280, 8, 2)])
 def test_fusion_block_residuals_with_a_large_common_mean(C, S, N):
     """Real zero-conv outputs carry offsets: residuals = randn * 0.3 + 5 and same-sign first_conv weights make the

@@ -84,6 +84,28 @@ def test_fusion_block_and_interleave_vs_module_restatement_and_closed_form():
     assert torch.allclose(y, out, atol=1e-4)
 
 
+def test_oracle_fusion_equals_the_references_own_code():
+    """PINNED: tests/golden/ref_fusion.safetensors holds outputs of the REFERENCE's own `ControlNetBlock`, `interleave_tensors`
+    and `interleave_tensors_from_list_of_lists` (model/edgestyle_multicontrolnet.py:23-63, 479-514; executed from its source text
+    by tests/golden/make_golden_ref_fusion.py in the build container - the three definitions use torch / torch.nn only).  The
+    oracle's restatement must reproduce them for all 13 (channels, size) pairs of MC:73-102 at batch 2: sampled elements to 2e-5
+    of the tensor's scale and the full-tensor sums (float64).  This pins the arithmetic the reference owns; the diffusers-owned
+    blocks stay unpinned."""
+    from safetensors.torch import load_file
+    from tests import helpers as H
+    gold = load_file(os.path.join(GOLD, "ref_fusion.safetensors"))
+    a, b = H.ref_interleave_cases()
+    assert torch.equal(O.interleave_tensors(a), gold["interleave_a"])
+    assert torch.equal(O.interleave_tensors(b), gold["interleave_lists_1"]) and torch.equal(gold["interleave_lists_0"], gold["interleave_a"])
+    for i in range(len(H.REF_FUSION_LEVELS)):
+        sd, res = H.ref_fusion_case(i)
+        y = O.controlnet_block({"b." + k: v for k, v in sd.items()}, "b", O.interleave_tensors(res)).double()
+        want = gold[f"level{i}_sample"].double()
+        assert float((H.ref_fusion_sample(y) - want).abs().max()) <= 2e-5 * float(want.abs().max()), i
+        sums = gold[f"level{i}_sums"]
+        assert abs(float(y.sum()) - float(sums[0])) <= 1e-6 * float(sums[1]) and abs(float(y.abs().sum()) - float(sums[1])) <= 1e-6 * float(sums[1]), i
+
+
 def test_ddim_known_answers():
     g = json.load(open(os.path.join(GOLD, "ddim.json")))
     s = O.DDIM()
