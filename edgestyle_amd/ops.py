@@ -280,8 +280,29 @@ PLAN_RED_FIX = float(_os.environ.get("ES_PLAN_REDFIX", PLAN_RED_FIX))
 PLAN_MIN_SLICE, PLAN_NK_NOSPLIT, PLAN_RESIDENT = 12, 10, 512
 
 
+_PLAN_TUNING = any(k in _os.environ for k in ("ES_PLAN_SLAB", "ES_PLAN_REDFIX"))
+
+
 def plan_gemm(M: int, rows_padded: int, kpad: int, geglu: bool = False, bns=(160, 128, 64), allow_split: bool = True):
-    """(bn, splitk, stages) with the lowest modelled time among the legal N tiles (ties go to the wider tile)."""
+    """(bn, splitk, stages) of an es_conv_gemm launch: ONE planner for both hosts - the library's (es_plan_gemm_choice,
+    csrc/builder.hip), which es_load_weights uses itself.  `plan_gemm_reference` below is the Python copy it replaced: kept for
+    the tuning tools (cost-model knobs from the environment) and as a guard - tests/test_load_weights_cpu.py sweeps both."""
+    if _PLAN_TUNING:
+        return plan_gemm_reference(M, rows_padded, kpad, geglu, bns, allow_split)
+    arr = (C.c_int * len(bns))(*[int(b) for b in bns])
+    bn, sk, st = C.c_int(), C.c_int(), C.c_int()
+    if L.load().es_plan_gemm_choice(int(M), int(rows_padded), int(kpad), int(bool(geglu)), arr, len(bns), int(bool(allow_split)),
+                                    C.byref(bn), C.byref(sk), C.byref(st)) != 0:
+        raise L.EdgeStyleHipError(f"plan_gemm: rows_padded {rows_padded} fits no N tile")
+    stages = st.value
+    if stages == 4 and not (DEEP_RING and LANE == 0):       # tool knobs: no 4-deep ring
+        stages = 2
+    return bn.value, sk.value, stages
+
+
+def plan_gemm_reference(M: int, rows_padded: int, kpad: int, geglu: bool = False, bns=(160, 128, 64), allow_split: bool = True):
+    """The Python copy of the library's planner (one more round as a guard; tuning tools): (bn, splitk, stages) with the
+    lowest modelled time among the legal N tiles (ties go to the wider tile)."""
     if geglu:
         return 128, 1, 2
     nk = kpad // BK
@@ -348,24 +369,35 @@ XS_MIN_M = int(_os.environ.get("ES_XS_MIN_M", "8192"))   # 0: no size policy (te
 _zero_bias = {}
 
 
-def xs_eligible(M: int, pw: "PackedWeight", pws, group_n, hw: int) -> bool:
-    """K = 320 | 640 linear layers with an output width of whole 128-byte lines: the to_q|k|v and GEGLU projections of
-    the 64x64 and 32x32 levels."""
-    if not XS_ENABLED or pw.ksize != 1 or pw.kpad not in (320, 640) or pw.cin != pw.kpad or pw.ctail:
+def xs_shape_reference(M: int, pw: "PackedWeight", min_m: int) -> bool:
+    """The Python copy of the library's es_linear_xs_eligible (kept one more round as a guard, and for min_m != the shipped 8192:
+    tests exercise every instantiation with min_m = 0).  K = 320 | 640 linear layers with an output width of whole 128-byte
+    lines: the to_q|k|v and GEGLU projections of the 64x64 and 32x32 levels."""
+    if pw.ksize != 1 or pw.kpad not in (320, 640) or pw.cin != pw.kpad or pw.ctail:
         return False
     ch = 64 if pw.kpad == 320 else 32
     line = ch * (128 // (ch if pw.geglu else 2 * ch))        # GEMM columns per 128-byte output line
     if pw.cout % line or pw.cout < 4 * line:
         return False
-    if pws is not None:
-        if len(pws) > 4 or any((n * hw) % 256 for n in group_n) or any((q.ln_colsum is None) != (pw.ln_colsum is None) for q in pws):
-            return False
     # where it wins (tools/xs_bench.py, batch-1 shapes): 1.4-1.6x on the 14-sample launches of both levels and 1.05-1.1x on
     # the decoder's wide K = 320 projections; it loses where a workgroup's share of N is a few chunks (the activation
     # rows are re-read per slice and the 40 KB stages no longer amortise): small M with K = 640, narrow N at small M
-    if XS_MIN_M and (M < XS_MIN_M or (M < 4 * XS_MIN_M and pw.cout < (960 if pw.kpad == 320 else 1920))):
+    if min_m and (M < min_m or (M < 4 * min_m and pw.cout < (960 if pw.kpad == 320 else 1920))):
         return False
     return True
+
+
+def xs_eligible(M: int, pw: "PackedWeight", pws, group_n, hw: int) -> bool:
+    """Does this plain linear launch go to es_linear_xs?  The shape / size rule is the library's (es_linear_xs_eligible: what
+    es_load_weights applies itself); the grouping conditions belong to the caller's launch."""
+    if not XS_ENABLED:
+        return False
+    if pws is not None:
+        if len(pws) > 4 or any((n * hw) % 256 for n in group_n) or any((q.ln_colsum is None) != (pw.ln_colsum is None) for q in pws):
+            return False
+    if XS_MIN_M != 8192:
+        return xs_shape_reference(M, pw, XS_MIN_M)
+    return bool(L.load().es_linear_xs_eligible(int(M), int(pw.ksize), int(pw.kpad), int(pw.cin), int(pw.ctail), int(pw.cout), int(pw.geglu)))
 
 
 def linear_xs(x: torch.Tensor, pw, M: int, out: torch.Tensor, group_rows=None) -> torch.Tensor:

@@ -33,7 +33,8 @@ def test_launch_planner_of_the_library_equals_the_python_hosts():
     cands = [(160, 128), (320, 160, 128, 64), (160, 128, 64), (320, 160, 128)]
     for M, r, k, cand, split in itertools.product(Ms, rows, ks, cands, (True, False)):
         try:
-            want = ops.plan_gemm(M, r, k, False, bns=cand, allow_split=split)
+            want = ops.plan_gemm_reference(M, r, k, False, bns=cand, allow_split=split)
+            assert ops.plan_gemm(M, r, k, False, bns=cand, allow_split=split) == want          # the Python host now asks the library
         except L.EdgeStyleHipError:
             want = None
         arr = (C.c_int * len(cand))(*cand)
@@ -44,7 +45,7 @@ def test_launch_planner_of_the_library_equals_the_python_hosts():
     assert n > 10000
     arr = (C.c_int * 2)(160, 128)
     assert lib.es_plan_gemm_choice(4096, 2560, 320, 1, arr, 2, 1, C.byref(bn), C.byref(sk), C.byref(st)) == 0
-    assert (bn.value, sk.value, st.value) == ops.plan_gemm(4096, 2560, 320, True)
+    assert (bn.value, sk.value, st.value) == ops.plan_gemm(4096, 2560, 320, True) == ops.plan_gemm_reference(4096, 2560, 320, True)
 
 
 def test_short_k_kernel_policy_of_the_library_equals_the_python_hosts():
@@ -52,7 +53,8 @@ def test_short_k_kernel_policy_of_the_library_equals_the_python_hosts():
     for M, K, cout, geglu in itertools.product([1024, 8192, 16384, 32768, 57344, 458752], [320, 640, 1280, 768], [320, 640, 960, 1920, 2560, 5120],
                                                [False, True]):
         pw = ops.PackedWeight(w=torch.empty(0, K), bias=None, cout=cout, cin=K, ksize=1, bn=128, geglu=geglu)
-        assert bool(lib.es_linear_xs_eligible(M, 1, K, K, 0, cout, int(geglu))) == ops.xs_eligible(M, pw, None, None, 1), (M, K, cout, geglu)
+        want = ops.xs_shape_reference(M, pw, 8192)
+        assert bool(lib.es_linear_xs_eligible(M, 1, K, K, 0, cout, int(geglu))) == want == ops.xs_eligible(M, pw, None, None, 1), (M, K, cout, geglu)
 
 
 @pytest.mark.parametrize("B,guidance,T", [(1, True, 6), (2, False, 3)])
