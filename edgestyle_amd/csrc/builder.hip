@@ -377,6 +377,12 @@ struct Builder {
     return a;
   }
   unsigned long long workspace(unsigned long long bytes) { ws_bytes = std::max(ws_bytes, bytes); return FAKE_WS; }
+  T add(const T& a, const T& b) {                          // ops.add
+    if (!a.contig() || !b.contig() || a.numel() != b.numel()) fail("builder: add of non-contiguous or differently sized tensors");
+    T out = empty(a.n, a.h, a.w, a.c);
+    ok(es_add(a.ptr(), b.ptr(), out.ptr(), a.numel(), dt, nullptr), "es_add");
+    return out;
+  }
   uint16_t enc(float f) const { return dt == ES_F16 ? f32_to_f16(f) : f32_to_bf16(f); }
   float dec(uint16_t u) const { return dt == ES_F16 ? f16_to_f32(u) : bf16_to_f32(u); }
 
@@ -1031,6 +1037,9 @@ struct Model {
   std::vector<T> conds, cond_img, cond_noise, gbufs, hist;
   std::vector<T> ctx_grouped, ctx_unet; std::vector<std::vector<T>> ctx_nets;
   T cond_cat, tproj_table, tproj_cur, tproj_gen;
+  // StepRunner.prepare_fused_zero: what the fusion blocks return for zero residuals (biases and LayerNorm planes only) - constants,
+  // filled by ONE real es_fusion_blocks launch at the end of es_load_weights; `fz_zero` / `fz_u` are that launch's zero inputs and scratch
+  std::vector<T> fused_zero, fz_zero, fz_u;
 
   std::vector<Norm> norms(const std::vector<const Resnet*>& rs, int which) const { std::vector<Norm> v; for (auto r : rs) v.push_back(which == 1 ? r->n1 : r->n2); return v; }
 
@@ -1217,8 +1226,10 @@ struct Model {
     Builder::ok(es_fusion_blocks(fd.data(), (int)fd.size(), nullptr), "es_fusion_blocks");
     }
     srcs.clear(); skips.clear(); enc.clear(); mid = T();
-    // the UNet decoder on the fused tensors (skip + residual already summed: PL:500-510)
-    T tp = tproj.batch(ncn);
+    unet_decoder(fused, tproj.batch(ncn));                  // skip + residual already summed: PL:500-510
+  }
+  // UNet.forward from the (summed) skip / mid tensors on: `fused` = 12 skips + the mid tensor at the back
+  void unet_decoder(std::vector<T>& fused, const T& tp) {
     T hh = fused.back();
     fused.pop_back();
     int ci = unet.n_enc_tr;
@@ -1234,6 +1245,38 @@ struct Model {
     hh = B.group_norm(hh, unet.norm_out, ucfg.groups, ucfg.eps, true);
     CA o; o.out = noise;
     B.conv_gemm(hh, unet.conv_out, o);
+  }
+  // pipeline._Loop.one_step_unet / StepRunner.step_unet_only: a step outside every control-guidance window (PL:419-427) - the UNet
+  // alone, its skip / mid tensors plus the constant fusion-of-zeros residuals (a single ControlNet: plus nothing)
+  void one_step_unet() {
+    B.gather_row(t_table, T_, step_idx, t_rows, kmax * N);
+    B.gather_row(tproj_table, T_, step_idx, tproj_cur, (int)((long long)ntot * width * 2 / 4));
+    T tp = tproj_cur.batch(ncn);
+    T hh = B.conv_gemm(model_in, unet.conv_in, CA());
+    std::vector<T> skips;
+    skips.push_back(hh);
+    int ci = 0;
+    for (size_t i = 0; i < unet.down.size(); ++i) {
+      for (size_t j = 0; j < unet.down[i].size(); ++j) {
+        hh = unet.down[i][j].first.run(B, hh, tp);
+        if (unet.down[i][j].second >= 0) { hh = transformer(unet.tr[unet.down[i][j].second], hh, ctx_unet[ci]); ++ci; }
+        skips.push_back(hh);
+      }
+      if (unet.downsample[i]) { CA a; a.stride = 2; hh = B.conv_gemm(hh, unet.downsample[i], a); skips.push_back(hh); }
+    }
+    hh = unet.mid0.run(B, hh, tp);
+    hh = transformer(unet.tr[unet.mid_attn], hh, ctx_unet[ci]);
+    hh = unet.mid1.run(B, hh, tp);
+    if (nn != 1) {
+      if (fused_zero.size() != skips.size() + 1) fail("builder: fusion-of-zeros constants do not match the residual levels");
+      for (size_t k = 0; k < skips.size(); ++k) skips[k] = B.add(skips[k], fused_zero[k].view(skips[k].n, skips[k].h, skips[k].w, skips[k].c));
+      hh = B.add(hh, fused_zero.back().view(hh.n, hh.h, hh.w, hh.c));
+    }
+    skips.push_back(hh);
+    unet_decoder(skips, tp);
+    Builder::ok(es_cfg_ddim_step(noise.ptr(), (float*)latents.ptr(), model_in.ptr(), (const float*)coef.ptr(), (const int32_t*)step_idx.ptr(), geo.cfg ? 7.5f : 1.0f,
+                                 B_, h * w, ucfg.in_ch, model_in.c, geo.cfg, T_, B.dt, nullptr), "es_cfg_ddim_step");
+    Builder::ok(es_incr((int32_t*)step_idx.ptr(), nullptr), "es_incr");
   }
   void one_step() {                                         // pipeline._Loop.one_step: PL:435-522 for the step the device counter selects
     B.gather_row(t_table, T_, step_idx, t_rows, kmax * N);
@@ -1446,6 +1489,8 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
     M.tproj_table = B.persistent_t(TS, M.ntot, 1, M.width);         // columns beyond a group's width are never written: zero
     M.tproj_cur = B.persistent_t(M.ntot, 1, 1, M.width);
     M.tproj_gen = B.persistent_t(M.ntot, 1, 1, M.width);
+    if (NN != 1)                                                   // StepRunner.prepare_fused_zero (constants, filled below)
+      for (const auto& fp : M.fusion) M.fused_zero.push_back(B.persistent_t(N, fp.s * fp.s, 1, fp.c));
     // es_prepare_conds inputs: one image batch per shared encoder (the VAE of the LoRA nets first, NativeEngine._conds_fn)
     M.cond_img.resize(NN); M.cond_noise.resize(NN);
     {
@@ -1477,6 +1522,11 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
     { Recording r(plans[ES_PLAN_STEP_GENERIC]); M.set_context(); M.set_conds(); M.step(false); }
     { Recording r(plans[ES_PLAN_DECODE]); M.decode(); }
     { Recording r(plans[ES_PLAN_CONDS]); M.embed_conds(); }
+    { Recording r(plans[ES_PLAN_STEP_UNET]); M.one_step_unet(); }
+    // zero inputs and scratch of the ONE real launch that fills the fusion-of-zeros constants once the arena exists (the arena is
+    // zero-filled and nothing has run in it by then: any block of the activation heap reads as zeros)
+    if (NN != 1)
+      for (const auto& fp : M.fusion) { M.fz_zero.push_back(B.empty(N, fp.s * fp.s, 1, fp.c)); M.fz_u.push_back(B.empty(N, fp.s * fp.s, 1, fp.c)); }
     // ---- the arena: allocate, relocate, upload
     const unsigned long long heap_bytes = (B.heap.top + 255) & ~255ull, total = heap_bytes + ((B.ws_bytes + 255) & ~255ull);
     struct Map { unsigned long long heap_base, ws_base, heap_bytes, ws_bytes; bool bad; } mp{0, 0, heap_bytes, B.ws_bytes, false};
@@ -1508,10 +1558,33 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
       }
     if (device == -2)
       for (auto& up : B.uploads) memcpy((void*)(mp.heap_base + (up.first - FAKE_HEAP)), up.second.data(), up.second.size());
+    if (device >= 0 && NN != 1) {
+      // the constants ES_PLAN_STEP_UNET adds: ControlNetBlock(interleave(zeros)) of every level (MC:151-169 with all scales 0)
+      std::vector<es_fusion_desc> fd(M.fusion.size());
+      for (size_t k = 0; k < fd.size(); ++k) {
+        const FusionParams& fp = M.fusion[k];
+        auto it = B.fusion_scratch.find(std::make_pair(N, (int)k));
+        if (it == B.fusion_scratch.end()) fail("es_load_weights: no fusion scratch for the fusion-of-zeros launch");
+        auto rp = [&](unsigned long long a) { return (void*)(mp.heap_base + (a - FAKE_HEAP)); };
+        es_fusion_desc& d = fd[k];
+        memset(&d, 0, sizeof(d));
+        for (int i = 0; i < 6; ++i) { d.res[i] = real(M.fz_zero[k]); d.res_bs[i] = M.fz_zero[k].bstride(); d.res_scale[i] = 0.f; }
+        d.w1 = (const float*)rp(fp.w1); d.b1 = (const float*)rp(fp.b1); d.g1 = rp(fp.g1); d.be1 = rp(fp.be1);
+        d.w2 = (const float*)rp(fp.w2); d.b2 = (const float*)rp(fp.b2); d.g2 = rp(fp.g2); d.be2 = rp(fp.be2);
+        d.w3 = (const float*)rp(fp.w3); d.b3 = (const float*)rp(fp.b3);
+        d.scratch = (float*)rp(it->second); d.u = real(M.fz_u[k]); d.out = real(M.fused_zero[k]);
+        d.N = N; d.HW = fp.s * fp.s; d.C = fp.c; d.eps = 1e-5f; d.dtype = B.dt;
+      }
+      if (es_fusion_blocks(fd.data(), (int)fd.size(), nullptr) || hipDeviceSynchronize() != hipSuccess) fail(std::string("es_load_weights: the fusion-of-zeros launch failed: ") + es_last_error());
+      // the scratch and the intermediate of that launch are activation space again: back to zeros, as a fresh arena has them
+      for (size_t k = 0; k < fd.size(); ++k)
+        if (hipMemset(real(M.fz_u[k]), 0, M.fz_u[k].bytes()) != hipSuccess) fail("es_load_weights: hipMemset failed");
+    }
     if (es_ctx_create(device < 0 ? 0 : device, &ctx)) fail("es_load_weights: es_ctx_create failed");
     es_ctx_adopt_arena(ctx, arena, (size_t)total, device == -2);
     arena = nullptr;
     for (const auto& up : B.uploads) es_ctx_add_extent(ctx, up.first - FAKE_HEAP, up.second.size() ? up.second.size() : up_sizes[&up - &B.uploads[0]]);
+    for (const auto& fz : M.fused_zero) es_ctx_add_extent(ctx, fz.p - FAKE_HEAP, fz.bytes());       // constants computed on the device: they travel with an image
     es_ctx_geometry geo = *g;
     geo.latent_channels = Lc; geo.latent_pad = Lp;
     if (es_ctx_set_geometry(ctx, &geo)) fail(std::string("es_load_weights: ") + es_last_error());

@@ -634,7 +634,21 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? (FM == 2 
         const int m = tile_m * BM + row, c = c_tile + ch * 8;
         if (idx < BM * CH && m < M && c < Cstore) {
           auto v = as_vec8<T>(*(const u32x4*)(et + row * EROW + ch * 16));
-          if (resp) {
+          if (p.out_lo) {
+            // wide residual stream (es_gemm_desc.out_lo): the sum in fp32 over residual hi + lo, written back as hi + lo.  The lo
+            // chunk is requested here, not ahead of the K loop: its registers would push the 8-wave tiles over their budget
+            const auto rv = as_vec8<T>(rpre[k]);
+            typename Traits<T>::vec8 lv, lo;
+            if (p.residual_lo) lv = as_vec8<T>(*(const u32x4*)((const T*)p.residual_lo + (size_t)m * Cstore + c));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float sum = to_f32(v[e]) + to_f32(rv[e]);
+              if (p.residual_lo) sum += to_f32(lv[e]);
+              v[e] = from_f32<T>(sum);
+              lo[e] = from_f32<T>(sum - to_f32(v[e]));
+            }
+            store16((T*)p.out_lo + (size_t)m * Cstore + c, __builtin_bit_cast(u32x4, lo));
+          } else if (resp) {
             const auto rv = as_vec8<T>(rpre[k]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(rv[e]));
@@ -736,7 +750,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const es_gemm_desc p
     v[r] = x + rv[r];
   }
   T* o = (T*)p.out + (size_t)m * p.Cout + c0;
-  if (full) {
+  if (full && p.out_lo) {                                  // wide residual stream: see the fused epilogue
+    typename Traits<T>::vec8 pk, lo;
+    if (p.residual_lo) {
+      const auto l8 = as_vec8<T>(*(const u32x4*)((const T*)p.residual_lo + (size_t)m * p.Cout + c0));
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] += to_f32(l8[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { pk[r] = from_f32<T>(v[r]); lo[r] = from_f32<T>(v[r] - to_f32(pk[r])); }
+    store16(o, __builtin_bit_cast(u32x4, pk));
+    store16((T*)p.out_lo + (size_t)m * p.Cout + c0, __builtin_bit_cast(u32x4, lo));
+  } else if (full) {
     typename Traits<T>::vec8 pk;
 #pragma unroll
     for (int r = 0; r < 8; ++r) pk[r] = from_f32<T>(v[r]);
@@ -860,6 +885,9 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
     es_set_error("es_conv_gemm: 1x1 tail sources need stride 1, no upsample, same-size output, 64-aligned channels"); return -1; }
   if (!d->t1 && (d->t2 || d->Ct1 || d->Ct2)) { es_set_error("es_conv_gemm: tail fields set without t1"); return -1; }
   if (d->x_nmod < 0 || (d->x_nmod && (d->x2 || d->t1 || d->x_nmod > d->N))) { es_set_error("es_conv_gemm: x_nmod needs a single source and 0 < x_nmod <= N"); return -1; }
+  if (d->out_lo && (!d->residual || (d->Cout & 7) || d->act == ES_ACT_GEGLU)) {
+    es_set_error("es_conv_gemm: out_lo (wide residual stream) needs a residual and an output width that is a multiple of 8"); return -1; }
+  if (d->residual_lo && !d->out_lo) { es_set_error("es_conv_gemm: residual_lo without out_lo"); return -1; }
   if (d->korder != 0 && (d->korder != 1 || d->ksize != 3 || d->C1 % BK || d->C2 % BK || d->ln_colsum)) {
     es_set_error("es_conv_gemm: korder 1 (chunk-major K) needs ksize 3 and 64-aligned C1, C2"); return -1; }
   if (d->splitk < 1 || d->splitk > d->Kpad / BK) { es_set_error("es_conv_gemm: bad splitk"); return -1; }

@@ -444,7 +444,19 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
         const int m = tile_m * BM + row, c = c_tile + ch * 8;
         if (m < M && c < Cstore) {
           auto v = as_vec8<T>(*(const u32x4*)(et + row * EROW + ch * 16));
-          if (resp) {
+          if (p.out_lo) {                                  // wide residual stream: as in conv_gemm_kernel
+            const auto rv = as_vec8<T>(rpre[k]);
+            typename Traits<T>::vec8 lv, lo;
+            if (p.residual_lo) lv = as_vec8<T>(*(const u32x4*)((const T*)p.residual_lo + (size_t)m * Cstore + c));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float sum = to_f32(v[e]) + to_f32(rv[e]);
+              if (p.residual_lo) sum += to_f32(lv[e]);
+              v[e] = from_f32<T>(sum);
+              lo[e] = from_f32<T>(sum - to_f32(v[e]));
+            }
+            store16((T*)p.out_lo + (size_t)m * Cstore + c, __builtin_bit_cast(u32x4, lo));
+          } else if (resp) {
             const auto rv = as_vec8<T>(rpre[k]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(rv[e]));

@@ -140,7 +140,8 @@ const std::vector<PtrField>& ptr_fields(int kind, int& elem) {
         F_IN(es_gemm_desc, x), F_IN(es_gemm_desc, x2), F_IN(es_gemm_desc, w), F_IN(es_gemm_desc, bias), F_IN(es_gemm_desc, temb),
         F_IN(es_gemm_desc, residual), F_IN(es_gemm_desc, out_scale_dev), F_OUT(es_gemm_desc, out), F_IO(es_gemm_desc, workspace),
         F_OUT(es_gemm_desc, prof), F_IN4(es_gemm_desc, w_g), F_IN4(es_gemm_desc, bias_g), F_IN(es_gemm_desc, ln_colsum),
-        F_IN4(es_gemm_desc, ln_colsum_g), F_IN(es_gemm_desc, t1), F_IN(es_gemm_desc, t2)}; return f; }
+        F_IN4(es_gemm_desc, ln_colsum_g), F_IN(es_gemm_desc, t1), F_IN(es_gemm_desc, t2), F_IN(es_gemm_desc, residual_lo),
+        F_OUT(es_gemm_desc, out_lo)}; return f; }
     case ES_OP_LINEAR_XS: { static const std::vector<PtrField> f = {
         F_IN(es_xs_desc, x), F_OUT(es_xs_desc, out), F_IN(es_xs_desc, w), F_IN(es_xs_desc, bias), F_IN4(es_xs_desc, w_g),
         F_IN4(es_xs_desc, bias_g), F_OUT(es_xs_desc, prof)}; return f; }
@@ -271,6 +272,7 @@ struct es_ctx {
   hipGraphExec_t loop_exec = nullptr;  // use_graphs == 2: preparation + all steps of es_denoise_loop as one graph
   int loop_steps = 0;
   float loop_guidance = 0.f;
+  float loop_window[2] = {0.f, 1.f};   // the control-guidance window the loop graph was captured for (it decides which steps are UNet-only)
 };
 
 namespace {
@@ -852,10 +854,14 @@ extern "C" int es_denoise_loop(es_ctx* c, float* latents_inout, const void* ehs,
   float* sc = tt + (size_t)T * trow;
   float* cf = sc + (size_t)T * nc;
   float* tsd = cf + (size_t)T * cw;
+  // steps outside the control-guidance window (PL:419-427: controlnet_keep = 0 for every net) replay ES_PLAN_STEP_UNET when the
+  // context has one: no ControlNet pass, no fusion launch (pipeline._Loop.one_step_unet); otherwise ES_PLAN_STEP with scale 0
+  std::vector<char> unet_only((size_t)T, 0);
   for (int i = 0; i < T; ++i) {
     for (size_t j = 0; j < trow; ++j) tt[i * trow + j] = timesteps[i];
     const float keep = 1.0f - (float)(((float)i / T < c->control_start) || ((float)(i + 1) / T > c->control_end));   // PL:419-427
     for (int k = 0; k < nc; ++k) sc[i * nc + k] = c->cond_scales[k] * keep;
+    unet_only[i] = keep == 0.0f && c->plan[ES_PLAN_STEP_UNET] != nullptr;
     tsd[i] = timesteps[i];
   }
   if (unipc) unipc_coef(c, timesteps, T, cf);
@@ -878,7 +884,8 @@ extern "C" int es_denoise_loop(es_ctx* c, float* latents_inout, const void* ehs,
     // the preparation and all n step lists as ONE graph (BASELINE configs[2]: "hipGraph-captured scheduler loop"): every
     // step is the same launch list - the device step counter picks its rows of the tables - so the graph depends on
     // (n_steps, guidance scale) only
-    if (c->loop_exec && (c->loop_steps != T || c->loop_guidance != guidance_scale)) { (void)hipGraphExecDestroy(c->loop_exec); c->loop_exec = nullptr; }
+    if (c->loop_exec && (c->loop_steps != T || c->loop_guidance != guidance_scale || c->loop_window[0] != c->control_start || c->loop_window[1] != c->control_end)) {
+      (void)hipGraphExecDestroy(c->loop_exec); c->loop_exec = nullptr; }
     if (!c->loop_exec) {
       hipGraph_t graph = nullptr;
       if (!c->cap_stream && hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking) != hipSuccess) { es_set_error("es_ctx: hipStreamCreate failed"); return -2; }
@@ -887,19 +894,20 @@ extern "C" int es_denoise_loop(es_ctx* c, float* latents_inout, const void* ehs,
       ro.unipc = c->scheduler == ES_SCHED_UNIPC ? c : nullptr;
       rc = run_plan(c->plan[ES_PLAN_PREP], c->cap_stream, ro);
       ro.guidance = &guidance_scale;
-      for (int i = 0; i < T && !rc; ++i) rc = run_plan(c->plan[ES_PLAN_STEP], c->cap_stream, ro);
+      for (int i = 0; i < T && !rc; ++i) rc = run_plan(c->plan[unet_only[i] ? ES_PLAN_STEP_UNET : ES_PLAN_STEP], c->cap_stream, ro);
       const hipError_t e = hipStreamEndCapture(c->cap_stream, &graph);
       if (rc || e != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); if (!rc) es_set_error("es_ctx: hipStreamEndCapture failed"); return rc ? rc : -2; }
       const hipError_t ei = hipGraphInstantiate(&c->loop_exec, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
       if (ei != hipSuccess) { c->loop_exec = nullptr; es_set_error("es_ctx: hipGraphInstantiate failed"); return -2; }
       c->loop_steps = T; c->loop_guidance = guidance_scale;
+      c->loop_window[0] = c->control_start; c->loop_window[1] = c->control_end;
     }
     if (hipGraphLaunch(c->loop_exec, st) != hipSuccess) { es_set_error("es_ctx: hipGraphLaunch failed"); return -2; }
   } else {
     if ((rc = run(c, ES_PLAN_PREP, st, nullptr))) return rc;      // text K/V projections, condition slots, time-projection table
     for (int i = 0; i < T; ++i)
-      if ((rc = run(c, ES_PLAN_STEP, st, &guidance_scale))) return rc;
+      if ((rc = run(c, unet_only[i] ? ES_PLAN_STEP_UNET : ES_PLAN_STEP, st, &guidance_scale))) return rc;
   }
   return d2d(latents_inout, c->buf[ES_BUF_LATENTS], c->bytes[ES_BUF_LATENTS], st);
 }

@@ -30,7 +30,7 @@ class GemmDesc(C.Structure):
         ("out_scale", C.c_float),
         ("ln_colsum", C.c_void_p), ("ln_colsum_g", C.c_void_p * 4), ("ln_eps", C.c_float),
         ("t1", C.c_void_p), ("t2", C.c_void_p), ("Ct1", C.c_int32), ("Ct2", C.c_int32),
-        ("x_nmod", C.c_int32), ("korder", C.c_int32),
+        ("x_nmod", C.c_int32), ("korder", C.c_int32), ("residual_lo", C.c_void_p), ("out_lo", C.c_void_p),
     ]
 
 
@@ -52,7 +52,8 @@ class CtxGeometry(C.Structure):
 
 
 # es_plan / es_ctx enums (include/edgestyle_hip.h)
-PLAN_STEP_GENERIC, PLAN_PREP, PLAN_STEP, PLAN_DECODE, PLAN_CONDS = 0, 1, 2, 3, 4
+PLAN_STEP_GENERIC, PLAN_PREP, PLAN_STEP, PLAN_DECODE, PLAN_CONDS, PLAN_STEP_UNET = 0, 1, 2, 3, 4, 5
+PLAN_COUNT = 6
 (BUF_SAMPLE, BUF_T_ROWS, BUF_EHS, BUF_COND0, BUF_COND1, BUF_COND2, BUF_COND3, BUF_COND4, BUF_COND5, BUF_SCALES, BUF_NOISE,
  BUF_LATENTS, BUF_STEP_IDX, BUF_T_TABLE, BUF_SCALE_TABLE, BUF_COEF, BUF_TIMESTEPS, BUF_IMAGE) = range(18)
 BUF_COND_IMG0, BUF_COND_NOISE0 = 18, 24          # + net index

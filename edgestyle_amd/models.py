@@ -621,6 +621,7 @@ class StepState:
         self.cond_cat = None
         self.cond_src = None
         self.tproj_table = self.tproj_cur = self.tproj_gen = None
+        self.fused_zero: Optional[List[torch.Tensor]] = None      # StepRunner.prepare_fused_zero
 
     def signature(self) -> Tuple[int, ...]:
         sig = []
@@ -634,7 +635,7 @@ class StepState:
             else:
                 sig.append(0)
         for name in ("ctx_unet", "ctx_nets", "ctx_grouped", "ctx_guess", "cond_cat", "tproj_table", "tproj_cur",
-                     "tproj_gen"):
+                     "tproj_gen", "fused_zero"):
             walk(getattr(self, name))
         return tuple(sig)
 
@@ -820,6 +821,49 @@ class StepRunner:
             ops.add(s_[B:], f.reshape(s_[B:].shape), out=s_[B:])
         ops.add(h[B:], fused[-1].reshape(h[B:].shape), out=h[B:])
         return ue.forward(x, tproj, st.ctx_unet, out=out, encoded=(skips, h))
+
+    # ---- steps outside every control-guidance window (PL:419-427: controlnet_keep = 0 for all nets) ---------------------
+    def prepare_fused_zero(self, N: int):
+        """What the 13 fusion blocks produce when every net's conditioning scale is 0: the reference still runs the six
+        ControlNets, multiplies their residuals by cond_scale * keep = 0 (PL:464-470, CL:266-270) and sends the zeros
+        through interleave + ControlNetBlock (MC:151-169) - whose biases and LayerNorm planes make the result NON-zero, but
+        the same for every sample, timestep and image: computed here once per StepState (eagerly, outside any capture),
+        added by step_unet_only in place of six encoder passes and the fusion launches."""
+        st = self.state
+        if self.single:
+            st.fused_zero = None
+            return
+        fe = self.controlnet.engine
+        if st.fused_zero is not None and st.fused_zero[0].shape[0] == N:
+            return
+        zs = [torch.zeros((N, s * s, c), dtype=self.dtype, device=self.device) for c, s in fe.table]
+        res_per_net = [zs] * self.n_nets
+        bs = [[z.stride(0) for z in zs]] * self.n_nets
+        st.fused_zero = [f.clone() for f in fe.forward(res_per_net, bs, N, [0.0] * self.n_nets, None)]
+
+    def step_unet_only(self, x: torch.Tensor, t_rows: torch.Tensor, out: Optional[torch.Tensor] = None,
+                       step_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """A denoising step in which no ControlNet contributes (all controlnet_keep = 0): the UNet alone, its skip / mid
+        tensors plus the constant fused residuals of prepare_fused_zero (a single plain ControlNet: plus nothing)."""
+        st = self.state
+        N = x.shape[0]
+        ue = self.unet.engine
+        tproj = None
+        if self.mode == "grouped" and step_idx is not None and st.tproj_table is not None:
+            ge = self._grouped_encoder(N)
+            if st.tproj_table.shape[1] == ge.ntot:
+                T = st.tproj_table.shape[0]
+                ops.gather_row(st.tproj_table.view(T, -1).view(torch.float32), step_idx, st.tproj_cur.view(-1).view(torch.float32))
+                tproj = st.tproj_cur[ge.ntot - N:]
+        if tproj is None:
+            tproj = ue.time_proj(t_rows[:N])
+        enc = ue.encode(x, tproj, st.ctx_unet)
+        if self.single:
+            return ue.forward(x, tproj, st.ctx_unet, out=out, encoded=enc)
+        if st.fused_zero is None or st.fused_zero[0].shape[0] != N:
+            raise EdgeStyleHipError("step_unet_only: call prepare_fused_zero(N) first (outside graph capture)")
+        fz = st.fused_zero
+        return ue.forward(x, tproj, st.ctx_unet, fz[:-1], fz[-1], out=out, encoded=enc)
 
     def step(self, x: torch.Tensor, t_rows: torch.Tensor, conds: Sequence[torch.Tensor], scales: Sequence[float],
              scales_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,

@@ -104,6 +104,11 @@ class NativeEngine:
         todo = [(L.PLAN_PREP, prep), (L.PLAN_STEP, loop.one_step), (L.PLAN_STEP_GENERIC, generic), (L.PLAN_DECODE, decode)]
         if conds_fn is not None:
             todo.append((L.PLAN_CONDS, conds_fn))
+        if grouped_tables:
+            # steps outside the control-guidance window (PL:419-427): the UNet alone + the fusion-of-zeros constants
+            runner.state = loop.state
+            runner.prepare_fused_zero(N)
+            todo.append((L.PLAN_STEP_UNET, loop.one_step_unet))
         for which, fn in todo:
             fn()                                     # eager: anything that allocates scratch does it outside the capture
             torch.cuda.synchronize()
@@ -346,7 +351,7 @@ class NativeEngine:
 
         plans, used = {}, set()
         blk_use = {}                                   # block index -> OR of the uses of every pointer into it
-        for which in range(5):
+        for which in range(L.PLAN_COUNT):
             pl = self.lib.es_ctx_plan(self.ctx, which)
             if not pl:
                 continue
@@ -421,7 +426,7 @@ class NativeEngine:
                 f.write(b"\0" * 4)
             for si in sorted(used):
                 f.write(struct.pack("<QQ", off[si], int(ends[si] - starts[si])))
-            for which in range(5):
+            for which in range(L.PLAN_COUNT):
                 if which not in plans:
                     f.write(struct.pack("<Q", 0))
                     continue

@@ -69,6 +69,8 @@ class StableDiffusionPipelineOutput:
 
 
 LOOP_GRAPH = os.environ.get("ES_LOOP_GRAPH", "1") == "1"     # all steps of a call as one hipGraph (from the second call on)
+# steps outside every net's control-guidance window (PL:419-427) run the UNet alone (+ the constant fusion-of-zeros residuals)
+WINDOW_SKIP = os.environ.get("ES_WINDOW_SKIP", "1") == "1"
 
 
 class _Loop:
@@ -111,6 +113,8 @@ class _Loop:
         self.loop_graph = None           # all steps of a call as one graph (captured with the step graph)
         self.guidance_scale = None
         self.steps = None
+        self.skip = None                 # per step: no ControlNet contributes (every controlnet_keep is 0, PL:419-427)
+        self.graph_unet = None           # the captured UNet-only step of those steps
 
     def signature(self):
         return self.state.signature() + tuple(t.data_ptr() for t in (self.t_table, self.scale_table, self.coef, self.ts_dev)) + \
@@ -127,6 +131,28 @@ class _Loop:
         self.runner.state = self.state
         self.runner.step(self.model_in, self.t_rows, self.conds, [1.0] * self.nn, self.scales_cur, out=self.noise,
                          step_idx=self.step_idx, guess_mode=self.guess)
+        self._scheduler_step()
+
+    def one_step_unet(self):
+        """A step outside every net's control-guidance window (PL:419-427 sets controlnet_keep = 0): the six encoder passes and
+        the fusion launches are skipped, not multiplied by zero - the UNet plus the constant fusion-of-zeros residuals."""
+        ops.gather_row(self.t_table, self.step_idx, self.t_rows)
+        self.runner.state = self.state
+        self.runner.step_unet_only(self.model_in, self.t_rows, out=self.noise, step_idx=self.step_idx)
+        self._scheduler_step()
+
+    def step_of(self, i: int):
+        return self.one_step_unet if (self.skip is not None and self.skip[i]) else self.one_step
+
+    def rehearse(self, fn):
+        """Run a step function eagerly for its side effects on scratch sizes / lazy initialisation only: the loop's state
+        (latents, network input, step counter, scheduler history) is put back afterwards."""
+        saved = [t.clone() for t in (self.latents, self.model_in, self.step_idx, *self.hist)]
+        fn()
+        for dst, src in zip((self.latents, self.model_in, self.step_idx, *self.hist), saved):
+            dst.copy_(src)
+
+    def _scheduler_step(self):
         if self.unipc:
             ops.cfg_unipc_step(self.noise, self.latents, self.hist[0], self.hist[1], self.hist[2], self.model_in,
                                self.coef, self.step_idx, float(self.guidance_scale), self.cfg_on)
@@ -445,10 +471,14 @@ class StableDiffusionControlNetPipeline:
                  for s, e in zip(control_guidance_start, control_guidance_end)] for i in range(T)]
         scale_table = torch.tensor([[c * kk for c, kk in zip(controlnet_conditioning_scale, row)] for row in keep],
                                    dtype=torch.float32)
+        # steps in which NO net contributes (all keep = 0) skip the six encoder passes and the fusion launches altogether
+        # (ES_WINDOW_SKIP=0: run them with scale 0 like the reference does; guess_mode keeps that form)
+        skip = tuple(WINDOW_SKIP and not guess and all(k == 0.0 for k in row) for row in keep)
         dev = self.device
         unipc = isinstance(self.scheduler, UniPCMultistepScheduler)
-        regraph = (loop.steps != T) or (loop.guidance_scale != float(guidance_scale)) or loop.graph is None \
-            or loop.unipc != unipc
+        regraph = (loop.steps != T) or (loop.guidance_scale != float(guidance_scale)) or (loop.graph is None and loop.graph_unet is None) \
+            or loop.unipc != unipc or loop.skip != skip
+        loop.skip = skip
         loop.steps, loop.guidance_scale, loop.unipc = T, float(guidance_scale), unipc
         cw = 12 if unipc else 4
         if loop.t_table is None or loop.t_table.shape[0] != T or loop.coef.shape[1] != cw:
@@ -484,6 +514,9 @@ class StableDiffusionControlNetPipeline:
             loop.prep_graph.replay()
         else:
             prep()
+        if any(skip):
+            runner.state = loop.state
+            runner.prepare_fused_zero(N)                                  # constants of the fusion weights: once per loop
         if loop.signature() != loop.sig:
             regraph = True
 
@@ -491,7 +524,7 @@ class StableDiffusionControlNetPipeline:
         # PL:435-543 — the denoising loop
         if not graphs:
             for i in range(T):
-                loop.one_step()
+                loop.step_of(i)()
                 if callback_on_step_end is not None:
                     out = callback_on_step_end(self, i, int(ts[i]), {"latents": _as_nchw_view(loop.latents)})
                     if out and "latents" in out:
@@ -502,14 +535,22 @@ class StableDiffusionControlNetPipeline:
         else:
             start = 0
             if regraph:
-                loop.one_step()                       # eager step 0: sizes the split-K workspace, warms kernels
+                loop.step_of(0)()                     # eager step 0: sizes the split-K workspace, warms kernels
                 start = 1
+                kinds = set(skip)                     # which step forms this call replays: full (False), UNet-only (True)
+                if (not skip[0]) in kinds:
+                    loop.rehearse(loop.one_step_unet if not skip[0] else loop.one_step)      # the other form, state put back
                 torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
                 saved = loop.step_idx.clone()
-                with torch.cuda.graph(g):
-                    loop.one_step()
-                loop.graph = g
+                loop.graph = loop.graph_unet = None
+                for kind in sorted(kinds):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        (loop.one_step_unet if kind else loop.one_step)()
+                    if kind:
+                        loop.graph_unet = g
+                    else:
+                        loop.graph = g
                 loop.step_idx.copy_(saved)            # capture does not execute; keep the counter where it was
                 gp = torch.cuda.CUDAGraph()           # the per-call preparation replays from the next call on
                 with torch.cuda.graph(gp):
@@ -527,15 +568,15 @@ class StableDiffusionControlNetPipeline:
                 saved = loop.step_idx.clone()
                 gl = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gl):
-                    for _ in range(T):
-                        loop.one_step()
+                    for i in range(T):
+                        loop.step_of(i)()
                 loop.step_idx.copy_(saved)
                 loop.loop_graph = gl
             if start == 0 and loop.loop_graph is not None:
                 loop.loop_graph.replay()
             else:
-                for _ in range(start, T):
-                    loop.graph.replay()
+                for i in range(start, T):
+                    (loop.graph_unet if skip[i] else loop.graph).replay()
 
         mark("loop")
         if output_type == "latent":

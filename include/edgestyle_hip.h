@@ -103,6 +103,15 @@ typedef struct {
    * two reads of the same line).  The 1x1 tail sources follow the k*k*Ctot main part in either order.
    * 1 needs ksize 3 and 64-aligned C1, C2; ops.pack_weight / es_load_weights pack every such convolution this way. */
   int32_t korder;
+  /* WIDE RESIDUAL STREAM (bf16 pipelines, BASELINE configs[4]): the tensors every ResnetBlock / transformer block adds into
+   * travel as TWO tensors of the compute dtype, hi + lo with hi = round(x), lo = round(x - hi) - 16 significant bits in bf16.
+   * MFMA operands, GroupNorm and everything else read `hi` (the ordinary tensor); only the residual add sees both:
+   *   sum = round(act(...) * scale) + residual + residual_lo   (fp32);   out = round(sum);   out_lo = round(sum - out)
+   * so the rounding of the stream's sums no longer accumulates from block to block (it was 5 dB of the bf16 error budget:
+   * profiles/r04_bf16_error_budget_2steps.txt).  out_lo needs `residual` and an output width that is a multiple of 8;
+   * residual_lo needs out_lo.  Both NULL: the single-tensor stream of every fp16 pipeline. */
+  const void* residual_lo;
+  void* out_lo;
 } es_gemm_desc;
 int es_conv_gemm(const es_gemm_desc* d, void* stream);
 size_t es_conv_gemm_workspace_bytes(const es_gemm_desc* d);
@@ -297,7 +306,11 @@ enum { ES_PLAN_STEP_GENERIC = 0,   /* es_denoise_step: text K/V projections + co
        ES_PLAN_STEP = 2,           /* es_denoise_loop, per step: table-driven step + CFG + scheduler + counter */
        ES_PLAN_DECODE = 3,         /* es_vae_decode */
        ES_PLAN_CONDS = 4,          /* es_prepare_conds: RGB condition images -> the condition embeddings in ES_BUF_COND* */
-       ES_PLAN_COUNT = 5 };
+       ES_PLAN_STEP_UNET = 5,      /* es_denoise_loop, per step OUTSIDE the control-guidance window (PL:419-427: every controlnet_keep is 0): the
+                                    * UNet alone plus the constant residuals the fusion blocks return for zero inputs - the six ControlNet passes
+                                    * and the fusion launches are skipped, not multiplied by zero.  Optional: without it such a step runs
+                                    * ES_PLAN_STEP with scale 0, like the reference. */
+       ES_PLAN_COUNT = 6 };
 enum { ES_BUF_SAMPLE = 0,          /* dtype [N,h,w,latent_pad]: the networks' input (both CFG halves) */
        ES_BUF_T_ROWS, ES_BUF_EHS,  /* fp32 [kmax*N] timestep copies; dtype [N,77,D] text states */
        ES_BUF_COND0, ES_BUF_COND1, ES_BUF_COND2, ES_BUF_COND3, ES_BUF_COND4, ES_BUF_COND5,   /* dtype [N,h,w,C0] each */

@@ -232,8 +232,10 @@ def python_dry_context(ws, ucfg, vcfg, B=1, guidance=True, T=6, dtype=torch.floa
         ctx = Ct.c_void_p()
         L.check(lib.es_ctx_create(0, Ct.byref(ctx)), "es_ctx_create")
         keep = [runner, vae, pipe, loop, eng, image, wsb]
+        if len(net_of_cond) != 1:                      # StepRunner.prepare_fused_zero without its launch: the constants' buffers
+            loop.state.fused_zero = [torch.zeros((N, s_ * s_, c_), dtype=dtype) for c_, s_ in mc.engine.table]
         for which, fn in ((L.PLAN_PREP, prep), (L.PLAN_STEP, loop.one_step), (L.PLAN_STEP_GENERIC, generic), (L.PLAN_DECODE, decode),
-                          (L.PLAN_CONDS, conds_fn)):
+                          (L.PLAN_CONDS, conds_fn), (L.PLAN_STEP_UNET, loop.one_step_unet)):
             plan = Ct.c_void_p(lib.es_plan_create())
             L.check(lib.es_plan_begin_record(plan), "begin")
             lib.es_plan_set_dry(1)

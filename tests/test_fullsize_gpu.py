@@ -21,6 +21,15 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+# configs[4] floors: 1 dB under what the GPU box measures (profiles/r0*_fullsize_parity.jsonl; VERDICT r3 weak 2: the round-3 floors
+# sat 3-8 dB under the measurements).  Round 3 / 4 measured 38.0-38.5 dB (2 steps, vs the fp32 oracle), 36.1-36.7 dB (batch 4 vs
+# batch 1) and, for the 12-step fixture, the value recorded by test_config4_batch4_768_bf16_12_steps_vs_golden.
+CONFIG4_PSNR_FLOOR_2 = 37.0
+CONFIG4_PSNR_FLOOR_B4_VS_B1 = 35.0
+CONFIG4_PSNR_FLOOR_12 = 42.0        # measured 43.03 dB (12 DDIM steps; latents 2.0e-2 relative, flat from step 1 on)
+CONFIG4_STEP_REL_CEIL = 1.5e-2      # one step's noise_pred relative to the tensor's max: measured 1.08e-2
+
+
 def record(name, **vals):
     """Measured errors go to gpurun_out/ (scratch) so DESIGN.md can quote what the GPU box saw."""
     import json
@@ -215,7 +224,7 @@ def test_full_width_step_768_bf16_config4(full96):
     record("full_step_768_bf16", noise_max_abs=float((out - ref).abs().max()), noise_rel=rel,
            noise_ref_max=float(ref.abs().max()))
     assert out.shape == (N, 4, s, s) and torch.isfinite(out).all()
-    assert rel <= 6e-2, rel
+    assert rel <= CONFIG4_STEP_REL_CEIL, rel
 
 
 def test_full_size_pipeline_768_bf16_config4_vs_oracle(full96):
@@ -238,7 +247,7 @@ def test_full_size_pipeline_768_bf16_config4_vs_oracle(full96):
                          [c.repeat(2, 1, 1, 1) for c in pc], num_inference_steps=2, guidance_scale=7.5)
     p_ = H.psnr(img, ref)
     record("full_pipeline2_768_bf16", psnr_vs_live_oracle=p_)
-    assert p_ >= 30.0, p_
+    assert p_ >= CONFIG4_PSNR_FLOOR_2, p_
 
 
 def test_full_width_chain_modes_agree(full):
@@ -506,5 +515,70 @@ def test_config4_batch4_768_bf16_vs_oracle(full96):
                  num_inference_steps=2, output_type="pt").images.float().cpu() for b in range(B)]
     pb = [H.psnr(img[b:b + 1], solo[b]) for b in range(B)]
     record("config4_batch4_768_bf16", psnr_vs_oracle=[round(p, 2) for p in ps], psnr_batch4_vs_batch1=[round(p, 2) for p in pb])
-    assert min(ps) >= 35.0, ps
-    assert min(pb) >= 35.0, pb
+    assert min(ps) >= CONFIG4_PSNR_FLOOR_2, ps
+    assert min(pb) >= CONFIG4_PSNR_FLOOR_B4_VS_B1, pb
+
+
+def test_config4_batch4_768_bf16_12_steps_vs_golden(full96):
+    """BASELINE configs[4] over MORE than two steps: 768x768, bf16, batch 4, CFG 7.5, 12 DDIM steps, graph
+    replayed - request 0 against the committed fp32 oracle fixture (tests/golden/make_golden_768.py: latents after steps 1, 2,
+    4, 8, 12 and the decoded image), so that the growth of the bf16 error along the loop is on record.  The asserted floors sit
+    1 dB / 20 % under what the GPU box measured (profiles/r04_fullsize_parity.jsonl); north_star's 40 dB is stated for fp16."""
+    pipe = full96["pipe"]
+    ucfg = full96["ucfg"]
+    gold = load_file(os.path.join(GOLD, "full96_pipeline12.safetensors"))
+    g = torch.Generator().manual_seed(51)
+    s, c0, B = 96, ucfg.block_out_channels[0], 4
+    lat = torch.randn(B, 4, s, s, generator=g)
+    pe = (torch.randn(B, 77, ucfg.cross_attention_dim, generator=g) * 0.5).bfloat16().float()
+    ne = (torch.randn(B, 77, ucfg.cross_attention_dim, generator=g) * 0.5).bfloat16().float()
+    pc = [(torch.randn(1, c0, s, s, generator=g) * 0.3).bfloat16().float() for _ in range(6)]
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=pc, latents=lat, guidance_scale=7.5, num_inference_steps=12)
+    seen = {}
+
+    def grab(_pipe, i, t, kwargs):
+        if i + 1 in (1, 2, 4, 8, 12):
+            seen[i + 1] = kwargs["latents"][:1].float().cpu().clone()
+        return {}
+    lat_eager = pipe(output_type="latent", callback_on_step_end=grab, **kw).images.float().cpu()
+    img = pipe(output_type="pt", **kw).images.float().cpu()
+    assert img.shape == (B, 3, 768, 768) and torch.isfinite(img).all()
+    growth = {k: H.rel_err(v, gold[f"latents_step{k}"]) for k, v in seen.items()}
+    p12 = H.psnr(img[:1], gold["image"].float())
+    e12 = H.rel_err(lat_eager[:1], gold["latents_out"])
+    record("config4_batch4_768_bf16_12_steps", psnr_vs_golden=p12, latents_rel=e12,
+           latents_rel_by_step={str(k): round(v, 6) for k, v in growth.items()})
+    assert p12 >= CONFIG4_PSNR_FLOOR_12, p12
+    assert e12 <= 6e-2, e12
+
+
+def test_control_guidance_window_at_full_size_vs_oracle_and_its_step_time(full):
+    """VERDICT r3 item 7a at SD1.5 width: control_guidance_end = 0.5 over 4 DDIM steps (steps 3 and 4 run the UNet alone + the
+    fusion-of-zeros constants) against the oracle pipeline, which runs the six nets with scale 0 like the reference (PL:419-427,
+    464-470); and what the windowed half costs: per-image time of a 50-step call with the window closed at 0.5 against the same
+    call with it open (recorded; the saving is the six encoder passes of 25 steps)."""
+    import time
+    from oracle import sd15_oracle as O
+    pipe, ws, ucfg, vcfg = full["pipe"], full["ws"], full["ucfg"], full["vcfg"]
+    lat, pe, ne, pc = H.full_pipeline_inputs(seed=57)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=pc, latents=lat, guidance_scale=7.5)
+    img = pipe(num_inference_steps=4, control_guidance_end=0.5, output_type="pt", **kw).images.float().cpu()
+    assert pipe._last_loop.skip == (False, False, True, True)
+    with torch.no_grad():
+        ref = O.pipeline(ws["unet"], ucfg, ws["fusion"], H.oracle_nets(ws, ucfg), ws["vae"], vcfg, lat, pe, ne,
+                         [c.repeat(2, 1, 1, 1) for c in pc], num_inference_steps=4, guidance_scale=7.5, control_guidance_end=0.5)
+    p_ = H.psnr(img, ref)
+    times = {}
+    for name, end in (("open", 1.0), ("closed_at_half", 0.5)):
+        for _ in range(3):                                   # step graphs, whole-loop graph, one warm replay
+            pipe(num_inference_steps=50, control_guidance_end=end, output_type="pt", **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            pipe(num_inference_steps=50, control_guidance_end=end, output_type="pt", **kw)
+        torch.cuda.synchronize()
+        times[name] = (time.perf_counter() - t0) / 3 * 1e3
+    record("control_guidance_window_full_size", psnr_vs_live_oracle=p_, ms_per_image_window_open=times["open"],
+           ms_per_image_window_closed_at_half=times["closed_at_half"])
+    assert p_ >= 40.0, p_
+    assert times["closed_at_half"] < 0.85 * times["open"], times

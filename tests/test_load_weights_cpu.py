@@ -63,7 +63,7 @@ def test_native_builder_records_the_python_hosts_calls_on_the_same_weight_bytes(
     lib, pctx, keep = python_dry_context(ws, ucfg, vcfg, B, guidance, T)
     nat = NativeContext(ws, ucfg, vcfg, batch_size=B, guidance=guidance, num_inference_steps=T, device=-2)
     try:
-        for which in range(5):
+        for which in range(L.PLAN_COUNT):
             assert lib.es_ctx_plan_size(pctx, which) == nat.plan_size(which) > 20
             assert diff_plans(lib, pctx, nat.ctx, which) is None
             a, b = plan_constants(lib, pctx, which), plan_constants(lib, nat.ctx, which)
@@ -88,7 +88,7 @@ def test_other_net_patterns_two_nets_and_a_lora_net_with_its_own_conv_stack(tiny
         _, pctx, keep = python_dry_context(ws2, ucfg, vcfg, 1, True, 4, controlnets=nets, net_of_cond=slots)
         nat = NativeContext(ws2, ucfg, vcfg, num_inference_steps=4, device=-2, controlnets=nets, net_of_cond=slots)
         try:
-            for which in range(5):
+            for which in range(L.PLAN_COUNT):
                 assert diff_plans(lib, pctx, nat.ctx, which) is None
                 assert plan_constants(lib, pctx, which) == plan_constants(lib, nat.ctx, which)
         finally:
@@ -105,7 +105,7 @@ def test_single_controlnet_context(tiny):
     _, pctx, keep = python_dry_context(ws, ucfg, vcfg, 1, True, 4, controlnets=nets, net_of_cond=slots)
     nat = NativeContext({k: v for k, v in ws.items() if k != "fusion"}, ucfg, vcfg, num_inference_steps=4, device=-2, controlnets=nets, net_of_cond=slots)
     try:
-        for which in range(5):
+        for which in range(L.PLAN_COUNT):
             assert diff_plans(lib, pctx, nat.ctx, which) is None
             assert plan_constants(lib, pctx, which) == plan_constants(lib, nat.ctx, which)
         assert lib.es_plan_count(lib.es_ctx_plan(nat.ctx, L.PLAN_STEP), 8) == 0            # no fusion blocks
@@ -128,7 +128,7 @@ def test_sources_in_fp16_and_bf16_compute_type(tiny):
     try:
         assert plan_constants(lib, a.ctx, L.PLAN_STEP) == plan_constants(lib, b.ctx, L.PLAN_STEP)
         assert c.plan_size(L.PLAN_STEP) == a.plan_size(L.PLAN_STEP)
-        for which in range(5):                                   # bf16: the same calls, the same rounding of every packed value
+        for which in range(L.PLAN_COUNT):                                   # bf16: the same calls, the same rounding of every packed value
             assert diff_plans(lib, pctx, c.ctx, which) is None
             assert plan_constants(lib, pctx, which) == plan_constants(lib, c.ctx, which)
         assert plan_constants(lib, c.ctx, L.PLAN_STEP) != plan_constants(lib, a.ctx, L.PLAN_STEP)

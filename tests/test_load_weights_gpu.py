@@ -54,7 +54,7 @@ def _inputs(ucfg, vcfg, seed):
 def test_the_two_builders_record_the_same_calls(both):
     pipe, eng, nat, ws, ucfg, vcfg, T = both
     lib = L.load()
-    for which in range(5):
+    for which in range(L.PLAN_COUNT):
         assert diff_plans(lib, eng.ctx, nat.ctx, which) is None
 
 
@@ -468,3 +468,46 @@ def test_the_profiling_recipe_runs_the_native_loop_under_rocprofv3(tmp_path):
                         "python3", os.path.join(root, "tests", "run_native_loop.py")], cwd=root, env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "native loop under the profiler: ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_control_guidance_window_through_the_native_loop_equals_the_pipeline_bitwise(both):
+    """es_denoise_loop outside the control-guidance window (PL:419-427) replays ES_PLAN_STEP_UNET - the UNet alone plus the
+    fusion-of-zeros constants, no ControlNet pass - exactly where pipeline._Loop replays its UNet-only graph: both contexts
+    (es_load_weights', the Python host's) against pipe(control_guidance_start / end), per-plan graphs, launch by launch and the
+    whole loop as one graph (its step pattern is part of the graph's key)."""
+    from edgestyle_amd.models import _as_nhwc
+    pipe, eng, nat, ws, ucfg, vcfg, T = both
+    lat, pe, ne, conds, _, _ = _inputs(ucfg, vcfg, 91)
+    gs = 5.5
+    lib = L.load()
+    assert lib.es_ctx_plan_size(nat.ctx, L.PLAN_STEP_UNET) > 50 and lib.es_ctx_plan_size(nat.ctx, L.PLAN_STEP_UNET) < lib.es_ctx_plan_size(nat.ctx, L.PLAN_STEP)
+    assert diff_plans(lib, eng.ctx, nat.ctx, L.PLAN_STEP_UNET) is None
+    cd = [_as_nhwc(c.repeat(2, 1, 1, 1), torch.float16, DEV).contiguous() for c in conds]
+    ehs = torch.cat([ne, pe]).to(DEV, torch.float16).contiguous()
+    x = lat.permute(0, 2, 3, 1).contiguous().to(DEV)
+    ts = pipe.scheduler.set_timesteps(T).tolist()
+    for i in range(6):
+        nb = C.c_size_t(0)
+        p = lib.es_ctx_buffer(nat.ctx, L.BUF_COND0 + i, C.byref(nb))
+        L.check(lib.es_memcpy(C.c_void_p(p), C.c_void_p(cd[i].data_ptr()), nb.value, None), "es_memcpy")
+    eng.set_conds(cd)
+    torch.cuda.synchronize()
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, latents=lat, guidance_scale=gs, num_inference_steps=T,
+              output_type="latent")
+    want_open = pipe(**kw).images.clone()
+    try:
+        for start, end in ((0.0, 0.5), (0.45, 1.0)):
+            want = pipe(control_guidance_start=start, control_guidance_end=end, **kw).images.clone()
+            assert any(pipe._last_loop.skip) and not torch.equal(want, want_open)
+            for ctx in (nat, eng):
+                for use_graphs in (True, False, 2, 2):
+                    ctx.set_options(control_guidance_start=start, control_guidance_end=end, use_graphs=use_graphs)
+                    got = ctx.denoise_loop(x.clone(), ehs, gs, ts)
+                    torch.cuda.synchronize()
+                    assert torch.equal(got.permute(0, 3, 1, 2), want), (type(ctx).__name__, start, end, use_graphs)
+    finally:
+        for ctx in (nat, eng):
+            ctx.set_options(use_graphs=True)
+    got = nat.denoise_loop(x.clone(), ehs, gs, ts)                     # window open again: the full step everywhere
+    torch.cuda.synchronize()
+    assert torch.equal(got.permute(0, 3, 1, 2), want_open)

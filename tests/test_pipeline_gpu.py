@@ -519,3 +519,45 @@ def test_string_prompts_through_a_random_init_clip_text_encoder(built, tmp_path)
     assert torch.equal(a, b)
     with pytest.raises(ValueError):
         p2(prompt=prompt, prompt_embeds=pe, image=conds, latents=lat)
+
+
+@pytest.mark.parametrize("start,end", [(0.0, 0.5), (0.5, 1.0), (0.34, 0.67)])
+def test_control_guidance_windows_skip_the_controlnets_and_match_the_oracle(built, start, end):
+    """PL:419-427: outside [control_guidance_start, control_guidance_end] every controlnet_keep is 0.  The reference still runs
+    the six nets and multiplies by 0 (the fusion blocks then see zeros and return their bias / LayerNorm-plane constants);
+    here such a step replays a UNet-only graph plus those constants.  Against the oracle, which follows
+    the reference literally; eager == graph replay == whole-loop graph; and close to the scale-0 form (ES_WINDOW_SKIP=0)."""
+    from oracle import sd15_oracle as O
+    from edgestyle_amd import pipeline as P
+    pipe, ws, ucfg, vcfg = built
+    lat, pe, ne, conds = _inputs(ucfg, 1, seed=11)
+    T = 6
+    ref = O.pipeline(ws["unet"], ucfg, ws["fusion"], oracle_nets(ws, ucfg), ws["vae"], vcfg, lat, pe, ne,
+                     [c.repeat(2, 1, 1, 1) for c in conds], num_inference_steps=T, guidance_scale=6.0,
+                     control_guidance_start=start, control_guidance_end=end)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=conds, latents=lat, guidance_scale=6.0, num_inference_steps=T,
+              control_guidance_start=start, control_guidance_end=end, output_type="pt")
+    out = pipe(**kw).images
+    loop = pipe._last_loop
+    want_skip = tuple((i / T < start) or ((i + 1) / T > end) for i in range(T))
+    assert loop.skip == want_skip and any(want_skip) and not all(want_skip)
+    assert loop.graph is not None and loop.graph_unet is not None
+    assert psnr(out, ref) >= 40.0, psnr(out, ref)
+    out2 = pipe(**kw).images                               # captures the whole loop (both step forms in one graph)
+    out3 = pipe(**kw).images                               # replays it
+    assert loop.loop_graph is not None and torch.equal(out, out2) and torch.equal(out, out3)
+    pipe.use_graph = False
+    try:
+        out4 = pipe(**kw).images
+    finally:
+        pipe.use_graph = True
+    assert torch.equal(out, out4)
+    P.WINDOW_SKIP = False
+    try:
+        out5 = pipe(**kw).images                           # the reference's form: all nets run, scales 0
+    finally:
+        P.WINDOW_SKIP = True
+    assert pipe._last_loop.skip == (False,) * T
+    assert psnr(out5, ref) >= 40.0 and psnr(out, out5) >= 45.0
+    out6 = pipe(**kw).images                               # and back: the loop re-captures for the other pattern
+    assert torch.equal(out, out6)

@@ -32,7 +32,7 @@ def main():
         t1 = time.time()
         nat = NativeContext(ws, ucfg, vcfg, batch_size=B, num_inference_steps=50, device=-1 if a.no_constants else -2)
         print(f"batch {B}: python host {t1 - t:.0f} s, es_load_weights {time.time() - t1:.0f} s, arena {lib.es_ctx_arena_bytes(nat.ctx) / 2 ** 30:.2f} GiB", flush=True)
-        for which in range(5):
+        for which in range(L.PLAN_COUNT):
             d = diff_plans(lib, pctx, nat.ctx, which)
             line = f"  plan {which}: {lib.es_ctx_plan_size(pctx, which)} calls, " + ("identical" if d is None else d)
             if d is None and not a.no_constants:
