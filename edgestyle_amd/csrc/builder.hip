@@ -231,6 +231,9 @@ struct T {
   long long ld = 0;
   int es = 2;
   std::shared_ptr<Blk> b;
+  // wide residual stream (ops.WIDE_STREAM): the low part of a stream tensor (same shape, same views) rides on the tensor
+  unsigned long long lo = 0;
+  std::shared_ptr<Blk> lo_b;
   explicit operator bool() const { return p != 0; }
   long long hw() const { return (long long)h * w; }
   long long numel() const { return (long long)n * h * w * c; }
@@ -240,6 +243,7 @@ struct T {
   T batch(int a, int cnt = -1) const {
     T t = *this;
     t.p += (unsigned long long)a * (unsigned long long)bstride() * es;
+    if (t.lo) t.lo += (unsigned long long)a * (unsigned long long)bstride() * es;
     t.n = cnt < 0 ? n - a : cnt;
     if (a < 0 || t.n < 0 || a + t.n > n) fail("builder: batch slice out of range");
     return t;
@@ -248,6 +252,7 @@ struct T {
     T t = *this;
     if (c0 < 0 || c0 + cn > c) fail("builder: channel slice out of range");
     t.p += (unsigned long long)c0 * es;
+    t.lo = 0; t.lo_b.reset();                            // (a channel slice of a stream tensor is an operand, never a residual)
     t.c = cn;
     return t;
   }
@@ -282,6 +287,7 @@ struct CA {                       // keyword arguments of ops.conv_gemm
   std::vector<int> group_n;
   std::vector<T> tails;
   int x_rep = 1;
+  bool wide = false;              // this launch adds into the residual stream (ops.conv_gemm(wide=True))
 };
 
 // ---- the launch planner of edgestyle_amd/ops.py (plan_gemm, xs_eligible): identical decisions are what makes a natively built
@@ -382,6 +388,11 @@ struct Builder {
     T out = empty(a.n, a.h, a.w, a.c);
     ok(es_add(a.ptr(), b.ptr(), out.ptr(), a.numel(), dt, nullptr), "es_add");
     return out;
+  }
+  // ops.wide_stream: "auto" (default) = bf16 pipelines only
+  bool wide_stream() const {
+    static const std::string mode = [] { const char* e = getenv("ES_WIDE_STREAM"); return std::string(e ? e : "auto"); }();
+    return mode == "1" || (mode == "auto" && dt == ES_BF16);
   }
   uint16_t enc(float f) const { return dt == ES_F16 ? f32_to_f16(f) : f32_to_bf16(f); }
   float dec(uint16_t u) const { return dt == ES_F16 ? f16_to_f32(u) : bf16_to_f32(u); }
@@ -621,6 +632,13 @@ struct Builder {
     d.xcd_m_fastest = (!grouped && splitk == 1 && M <= 2048 && pw->w_numel() > src_numel) ? 1 : 0;
     d.x_nmod = a.x_rep > 1 ? nsrc : 0;
     d.korder = pw->korder;
+    if (a.wide && a.residual && wide_stream() && cstore % 8 == 0 && !pw->geglu) {
+      // the sum over (residual hi + lo) in fp32, stored as hi + lo (es_gemm_desc.out_lo)
+      if (a.residual.lo) d.residual_lo = (const void*)a.residual.lo;
+      T lo = empty(N, Hout, Wout, cstore);
+      d.out_lo = lo.ptr();
+      out.lo = lo.p; out.lo_b = lo.b;
+    }
     if (k == 1 && M <= 65536 && C1 % BK == 0 && C2 % BK == 0 && bn != 64 && bn != 320 && !(stages == 4 && bn != 128) && stages != 3) d.waves = 8;
     if (splitk > 1) d.workspace = (float*)workspace((unsigned long long)splitk * M * pw->rows_padded * 4);
     if (pw->ln_colsum) {
@@ -658,7 +676,7 @@ struct Builder {
     const PW* p0 = pl[0];
     const long long M = x.numel() / x.c;
     const int cstore = p0->geglu ? p0->cout / 2 : p0->cout, rep = a.x_rep;
-    if (a.residual) a.residual = a.residual.view((int)(M * rep), 1, 1, cstore);
+    if (a.residual) a.residual = a.residual.view((int)(M * rep), 1, 1, cstore);      // (views keep the low part)
     T keep = a.out;
     if (a.out) a.out = a.out.view((int)(M * rep), 1, 1, cstore);
     T y = conv_gemm(x.view((int)M, 1, 1, x.c), pl, a);
@@ -762,7 +780,7 @@ struct Resnet {
     }
     T xs = x;
     if (shortc) { CA s; s.x2 = x2; xs = B.conv_gemm(x, shortc, s); }
-    CA r; r.residual = xs;
+    CA r; r.residual = xs; r.wide = true;
     return B.conv_gemm(h, conv2, r);
   }
 };
@@ -1055,7 +1073,7 @@ struct Model {
     for (auto r : rs) if (r->conv2s) fail("builder: grouped resnets must fold conv_shortcut all alike");
     T xs = x;
     if (r0->shortc) { CA s; s.group_n = counts; xs = B.conv_gemm(x, sh, s); }
-    CA r; r.residual = xs; r.group_n = counts;
+    CA r; r.residual = xs; r.group_n = counts; r.wide = true;
     return B.conv_gemm(hh, c2, r);
   }
   T g_transformer(const std::vector<const Transformer*>& ts, const T& x, const T& kv) {
@@ -1071,14 +1089,14 @@ struct Model {
     CA gr; gr.group_n = rows;
     T q = B.linear(tok, qkv, gr);
     T a = B.attention(q.chan(0, C), q.chan(C, C), q.chan(2 * C, C), t0->heads);
-    CA r1 = gr; r1.residual = tok;
+    CA r1 = gr; r1.residual = tok; r1.wide = true;
     tok = B.linear(a, o1, r1);
     T qq = B.linear(tok, q2, gr);
     a = B.attention(qq, kv.chan(0, C), kv.chan(C, C), t0->heads);
-    CA r2 = gr; r2.residual = tok;
+    CA r2 = gr; r2.residual = tok; r2.wide = true;
     tok = B.linear(a, o2, r2);
     T f = B.linear(tok, ff1, gr);
-    CA fo; fo.x2 = tok.view(Nn, H, Wd, C); fo.residual = x; fo.group_n = counts;
+    CA fo; fo.x2 = tok.view(Nn, H, Wd, C); fo.residual = x; fo.group_n = counts; fo.wide = true;
     return B.conv_gemm(f.view(Nn, H, Wd, 4 * C), ffo, fo);
   }
   // h: [ntot,H,W,C0] -> (skips, mid) over the whole batch (GroupedEncoder.run)
@@ -1112,14 +1130,14 @@ struct Model {
     T tok = B.conv_gemm(hh, t.proj_in).view(Nn, H * Wd, 1, C);
     T q = B.linear(tok, t.qkv_ln);
     T a = B.attention(q.chan(0, C), q.chan(C, C), q.chan(2 * C, C), t.heads);
-    CA r1; r1.residual = tok;
+    CA r1; r1.residual = tok; r1.wide = true;
     tok = B.linear(a, t.o1, r1);
     T qq = B.linear(tok, t.q2_ln);
     a = B.attention(qq, kv.chan(0, C), kv.chan(C, C), t.heads);
-    CA r2; r2.residual = tok;
+    CA r2; r2.residual = tok; r2.wide = true;
     tok = B.linear(a, t.o2, r2);
     T f = B.linear(tok, t.ff1_ln);
-    CA fo; fo.x2 = tok.view(Nn, H, Wd, C); fo.residual = x;
+    CA fo; fo.x2 = tok.view(Nn, H, Wd, C); fo.residual = x; fo.wide = true;
     return B.conv_gemm(f.view(Nn, H, Wd, 4 * C), t.ffo, fo);
   }
 
@@ -1167,8 +1185,8 @@ struct Model {
     T h0 = B.empty(ntot, x.h, x.w, c0);
     {
       PWs ci; for (auto e : encs) ci.push_back(e->conv_in);
-      CA a; a.residual = cond_cat; a.group_n = counts; a.out = h0; a.x_rep = ntot / N;
-      B.conv_gemm(x, ci, a);                               // sample = conv_in(sample) + cond for every net, and the UNet's conv_in (CL:197-203)
+      CA a; a.residual = cond_cat; a.group_n = counts; a.out = h0; a.x_rep = ntot / N; a.wide = true;
+      h0 = B.conv_gemm(x, ci, a);                          // (the same buffer; with a wide stream it now carries its low part)                               // sample = conv_in(sample) + cond for every net, and the UNet's conv_in (CL:197-203)
     }
     T tproj;
     if (table_driven) {

@@ -124,7 +124,7 @@ class Resnet:
         if self.conv2s is not None and (x2 is None or (x.shape[3] % 64 == 0 and x2.shape[3] % 64 == 0)):
             return ops.conv_gemm(h, self.conv2s, tail=(x, x2))
         xs = ops.conv_gemm(x, self.short, x2=x2) if self.short is not None else x
-        return ops.conv_gemm(h, self.conv2, residual=xs)
+        return ops.conv_gemm(h, self.conv2, residual=xs, wide=True)       # x + h: a sum of the residual stream (ops.WIDE_STREAM)
 
 
 class Transformer:
@@ -177,15 +177,15 @@ class Transformer:
         fold = self.ln_fold
         qkv = ops.linear(tok, self.qkv_ln) if fold else ops.linear(ops.layer_norm(tok, *self.ln1), self.qkv)
         a = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], self.heads)
-        tok = ops.linear(a, self.o1, residual=tok)
+        tok = ops.linear(a, self.o1, residual=tok, wide=True)             # the three sums of the token stream and the block's own
         q = ops.linear(tok, self.q2_ln) if fold else ops.linear(ops.layer_norm(tok, *self.ln2), self.q2)
         a = ops.attention(q, kv[:, :, :C], kv[:, :, C:], self.heads)
-        tok = ops.linear(a, self.o2, residual=tok)
+        tok = ops.linear(a, self.o2, residual=tok, wide=True)
         f = ops.linear(tok, self.ff1_ln) if (fold and self.ff1_ln is not None) else ops.linear(ops.layer_norm(tok, *self.ln3), self.ff1)
         if self.ffo is not None:
-            return ops.conv_gemm(f.reshape(N, H, W, 4 * C), self.ffo, x2=tok.reshape(N, H, W, C), residual=x)
-        tok = ops.linear(f, self.ff2, residual=tok)
-        return ops.conv_gemm(tok.reshape(N, H, W, C), self.proj_out, residual=x)
+            return ops.conv_gemm(f.reshape(N, H, W, 4 * C), self.ffo, x2=tok.reshape(N, H, W, C), residual=x, wide=True)
+        tok = ops.linear(f, self.ff2, residual=tok, wide=True)
+        return ops.conv_gemm(tok.reshape(N, H, W, C), self.proj_out, residual=x, wide=True)
 
 
 class Encoder:
@@ -524,7 +524,7 @@ class GroupedEncoder:
         if all(r.conv2s is not None for r in rs):
             return ops.conv_gemm(h, [r.conv2s for r in rs], tail=(x,), group_n=c)
         xs = ops.conv_gemm(x, [r.short for r in rs], group_n=c) if r0.short is not None else x
-        return ops.conv_gemm(h, [r.conv2 for r in rs], residual=xs, group_n=c)
+        return ops.conv_gemm(h, [r.conv2 for r in rs], residual=xs, group_n=c, wide=True)
 
     def _transformer(self, ts, x, kv):
         c = self.counts
@@ -542,15 +542,15 @@ class GroupedEncoder:
             return ops.linear(n, [getattr(t, plain) for t in ts], group_n=rows)
         qkv = ln_linear("ln1", "qkv", "qkv_ln")
         a = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], t0.heads)
-        tok = ops.linear(a, [t.o1 for t in ts], residual=tok, group_n=rows)
+        tok = ops.linear(a, [t.o1 for t in ts], residual=tok, group_n=rows, wide=True)
         q = ln_linear("ln2", "q2", "q2_ln")
         a = ops.attention(q, kv[:, :, :C], kv[:, :, C:], t0.heads)
-        tok = ops.linear(a, [t.o2 for t in ts], residual=tok, group_n=rows)
+        tok = ops.linear(a, [t.o2 for t in ts], residual=tok, group_n=rows, wide=True)
         f = ln_linear("ln3", "ff1", "ff1_ln" if all(t.ln_fold and t.ff1_ln is not None for t in ts) else None)
         if all(t.ffo is not None for t in ts):
-            return ops.conv_gemm(f.reshape(N, H, W, 4 * C), [t.ffo for t in ts], x2=tok.reshape(N, H, W, C), residual=x, group_n=c)
-        tok = ops.linear(f, [t.ff2 for t in ts], residual=tok, group_n=rows)
-        return ops.conv_gemm(tok.reshape(N, H, W, C), [t.proj_out for t in ts], residual=x, group_n=c)
+            return ops.conv_gemm(f.reshape(N, H, W, 4 * C), [t.ffo for t in ts], x2=tok.reshape(N, H, W, C), residual=x, group_n=c, wide=True)
+        tok = ops.linear(f, [t.ff2 for t in ts], residual=tok, group_n=rows, wide=True)
+        return ops.conv_gemm(tok.reshape(N, H, W, C), [t.proj_out for t in ts], residual=x, group_n=c, wide=True)
 
     def run(self, h, tproj, ctx: List[torch.Tensor]):
         """h: [ntot,H,W,C0] (each group's conv_in(sample)+cond already applied) -> (skips, mid) over the whole batch."""

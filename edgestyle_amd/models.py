@@ -919,12 +919,12 @@ class StepRunner:
         if st.cond_cat is not None and st.cond_cat.shape == h0.shape and [c.data_ptr() for c in conds] == st.cond_src:
             # sample = conv_in(sample) + cond (CL:197-203) for every net, and the UNet's conv_in, in one grouped launch:
             # every slot reads the same sample tensor (x_rep), the conditions are batch-concatenated in slot order
-            ops.conv_gemm(x, [e.conv_in for e in encs], residual=st.cond_cat, group_n=counts, out=h0, x_rep=ge.ntot // N)
+            ops.conv_gemm(x, [e.conv_in for e in encs], residual=st.cond_cat, group_n=counts, out=h0, x_rep=ge.ntot // N, wide=True)
         else:
             a = 0
             for net, pos in self.groups:                  # sample = conv_in(sample) + cond   (CL:197-203)
                 for p in pos:
-                    ops.conv_gemm(x, net.engine.conv_in, residual=conds[p], out=h0[a:a + N])
+                    ops.conv_gemm(x, net.engine.conv_in, residual=conds[p], out=h0[a:a + N])    # (no low part: h0 is filled slice by slice)
                     a += N
             ops.conv_gemm(x, ue.conv_in, out=h0[a:a + N])
         if step_idx is not None and st.tproj_table is not None and st.tproj_table.shape[1] == ge.ntot:

@@ -455,13 +455,32 @@ def linear_xs(x: torch.Tensor, pw, M: int, out: torch.Tensor, group_rows=None) -
     return out
 
 
+# Wide residual stream (es_gemm_desc.residual_lo / out_lo): the tensors every block adds into travel as hi + lo, the low part riding
+# on the tensor object as `._lo`.  "auto" (default): bf16 pipelines only - bf16 keeps 8 significant bits, and the rounding of the
+# stream's sums, accumulating from block to block, was 5 dB of configs[4]'s error (profiles/r04_bf16_error_budget_2steps.txt);
+# fp16 pipelines keep the single-tensor stream (11 bits; nothing measurable to gain, bandwidth to lose).  ES_WIDE_STREAM=0 | 1 forces.
+WIDE_STREAM = _os.environ.get("ES_WIDE_STREAM", "auto")
+
+
+def wide_stream(dtype) -> bool:
+    return WIDE_STREAM == "1" or (WIDE_STREAM == "auto" and dtype == torch.bfloat16)
+
+
+def carry_lo(dst: torch.Tensor, src: torch.Tensor, shape=None) -> torch.Tensor:
+    """a view / reshape `dst` of the stream tensor `src` keeps its low part (viewed alike)"""
+    lo = getattr(src, "_lo", None)
+    if lo is not None:
+        dst._lo = lo.reshape(dst.shape if shape is None else shape)
+    return dst
+
+
 def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Optional[int] = None,
               upsample: bool = False, x2: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None,
               residual: Optional[torch.Tensor] = None, act: int = L.ACT_NONE, out_scale: float = 1.0,
               out_scale_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
               out_hw=None, splitk: Optional[int] = None, stages: int = 0,
               group_n: Optional[Sequence[int]] = None, tail: Optional[Sequence[torch.Tensor]] = None,
-              x_rep: int = 1):
+              x_rep: int = 1, wide: bool = False):
     """x: [N,H,W,C1] (+ x2 [N,H,W,C2]); returns [N,Hout,Wout,Cout] (Cout/2 for GEGLU).
 
     x_rep > 1: the launch covers x_rep * N samples, sample n reading x[n % N] (es_gemm_desc.x_nmod): one sample tensor
@@ -533,6 +552,16 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     d.act, d.splitk, d.bn, d.dtype, d.out_scale = act_i, splitk, bn, _dt(x), out_scale
     d.stages = stages or FORCE_STAGES
     d.korder = pw.korder
+    if wide and residual is not None and wide_stream(x.dtype) and cstore % 8 == 0 and not pw.geglu:
+        # this launch adds into the residual stream: the sum over (residual hi + lo) in fp32, stored as hi + lo
+        lo_in = getattr(residual, "_lo", None)
+        if lo_in is not None:
+            if lo_in.numel() != residual.numel() or not lo_in.is_contiguous():
+                raise L.EdgeStyleHipError("conv_gemm: the residual's low part does not match it")
+            d.residual_lo = lo_in.data_ptr()
+        out_lo = torch.empty_like(out)
+        d.out_lo = out_lo.data_ptr()
+        out._lo = out_lo
     # XCD chunk order: keep the larger operand's tiles together on one XCD (see conv_gemm_kernel)
     d.xcd_m_fastest = (1 if (pws is None and splitk == 1 and M <= 2048 and pw.w.numel() > x.numel() * x_rep + (x2.numel() if x2 is not None else 0)) else 0) \
         if XCD_ORDER < 0 else XCD_ORDER
@@ -612,11 +641,11 @@ def linear(x: torch.Tensor, pw: PackedWeight, **kw) -> torch.Tensor:
     p0 = pw[0] if isinstance(pw, (list, tuple)) else pw
     cstore = p0.cout // 2 if p0.geglu else p0.cout
     y = conv_gemm(x.reshape(M, 1, 1, shp[-1]), pw,
-                  residual=None if res is None else res.reshape(M * rep, 1, 1, cstore),
+                  residual=None if res is None else carry_lo(res.reshape(M * rep, 1, 1, cstore), res),
                   out=None if out is None else out.reshape(M * rep, 1, 1, cstore), **kw)
     if rep > 1:
-        return y.reshape(shp[0] * rep, *shp[1:-1], cstore)
-    return y.reshape(*shp[:-1], cstore)
+        return carry_lo(y.reshape(shp[0] * rep, *shp[1:-1], cstore), y)
+    return carry_lo(y.reshape(*shp[:-1], cstore), y)
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: Optional[float] = None,

@@ -903,3 +903,50 @@ def test_conv_gemm_chunk_major_k_order(N, H, C1, C2, Cout, stride, up, Ct, split
     for ko in (0, 1):
         assert rel_err(outs[ko].permute(0, 3, 1, 2), ref) < 3e-3, ko
     assert rel_err(outs[1], outs[0]) < 1e-3
+
+
+@pytest.mark.parametrize("N,H,C,Cout,k,bn,splitk", [
+    (2, 16, 128, 128, 3, 128, None),      # ResnetBlock conv2 + x
+    (2, 16, 320, 320, 1, 160, None),      # to_out + tokens (8-wave tile when the planner picks it)
+    (8, 32, 128, 320, 3, 320, None),      # the 256 x 320 tile
+    (1, 8, 256, 64, 3, 64, None),         # the 64 x 64 tile
+    (1, 8, 640, 128, 3, 128, 5),          # split-K: the reduce kernel adds and splits
+])
+def test_conv_gemm_wide_residual_stream(N, H, C, Cout, k, bn, splitk):
+    """es_gemm_desc.residual_lo / out_lo (ops.conv_gemm(wide=True) on a bf16 pipeline): the residual add sees hi + lo of the
+    stream, sums in fp32 and writes hi + lo back - out + out_lo equals round(conv) + (residual + residual_lo) to bf16's SECOND
+    8 bits (2^-15 of the value), where the single-tensor stream is good for 2^-8; and out alone is that sum rounded once."""
+    from edgestyle_amd import ops
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(N + C + Cout + k)
+    x = q16(torch.randn(N, C, H, H, generator=g), dt)
+    w = q16(torch.randn(Cout, C, k, k, generator=g) / math.sqrt(C * k * k), dt)
+    b = torch.randn(Cout, generator=g) * 0.1
+    res_wide = torch.randn(N, Cout, H, H, generator=g) * 3.0                     # a stream value with 16 significant bits
+    res_hi = q16(res_wide, dt)
+    res_lo = q16(res_wide - res_hi, dt)
+    branch = q16(F.conv2d(x, w, b, padding=k // 2), dt)                          # the epilogue rounds the branch first
+    want = branch + res_hi + res_lo
+    pw = ops.pack_weight(w, b, dt, DEV)
+    r = nhwc(res_hi, dt)
+    r._lo = nhwc(res_lo, dt)
+    prev = ops.FORCE_BN
+    try:
+        ops.FORCE_BN = bn
+        y = ops.conv_gemm(nhwc(x, dt), pw, residual=r, wide=True, splitk=splitk)
+        y1 = ops.conv_gemm(nhwc(x, dt), pw, residual=r, splitk=splitk)           # single-tensor stream: hi only
+    finally:
+        ops.FORCE_BN = prev
+    torch.cuda.synchronize()
+    assert hasattr(y, "_lo") and not hasattr(y1, "_lo")
+    hi, lo = y.float().cpu().permute(0, 3, 1, 2), y._lo.float().cpu().permute(0, 3, 1, 2)
+    scale = float(want.abs().max())
+    # the branch itself carries the GEMM's fp32-accumulation-order noise (~1e-3 of ITS scale, rounded to bf16 either way):
+    # compare against the kernel's own branch, recovered from the single-tensor result within bf16 resolution
+    assert float((hi + lo - want).abs().max()) <= 2.5e-2 * float(branch.abs().max()) + 2 ** -14 * scale
+    assert torch.equal(hi, q16(hi + lo, dt))                                     # hi is the sum rounded ONCE
+    assert float(lo.abs().max()) <= 2 ** -8 * scale
+    # and the wide sum is closer to the exact one than the single-tensor sum by construction
+    e_wide = float((hi + lo - want).abs().mean())
+    e_one = float((y1.float().cpu().permute(0, 3, 1, 2) - want).abs().mean())
+    assert e_wide < 0.5 * e_one, (e_wide, e_one)
