@@ -922,9 +922,13 @@ class StepRunner:
             ops.conv_gemm(x, [e.conv_in for e in encs], residual=st.cond_cat, group_n=counts, out=h0, x_rep=ge.ntot // N, wide=True)
         else:
             a = 0
+            wide = ops.wide_stream(x.dtype)
+            if wide:                                      # the sums' low parts, slice by slice like h0 (the UNet's slot has none: zero)
+                h0._lo = torch.zeros_like(h0)
             for net, pos in self.groups:                  # sample = conv_in(sample) + cond   (CL:197-203)
                 for p in pos:
-                    ops.conv_gemm(x, net.engine.conv_in, residual=conds[p], out=h0[a:a + N])    # (no low part: h0 is filled slice by slice)
+                    ops.conv_gemm(x, net.engine.conv_in, residual=conds[p], out=h0[a:a + N], wide=True,
+                                  out_lo=h0._lo[a:a + N] if wide else None)
                     a += N
             ops.conv_gemm(x, ue.conv_in, out=h0[a:a + N])
         if step_idx is not None and st.tproj_table is not None and st.tproj_table.shape[1] == ge.ntot:

@@ -480,7 +480,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
               out_scale_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
               out_hw=None, splitk: Optional[int] = None, stages: int = 0,
               group_n: Optional[Sequence[int]] = None, tail: Optional[Sequence[torch.Tensor]] = None,
-              x_rep: int = 1, wide: bool = False):
+              x_rep: int = 1, wide: bool = False, out_lo: Optional[torch.Tensor] = None):
     """x: [N,H,W,C1] (+ x2 [N,H,W,C2]); returns [N,Hout,Wout,Cout] (Cout/2 for GEGLU).
 
     x_rep > 1: the launch covers x_rep * N samples, sample n reading x[n % N] (es_gemm_desc.x_nmod): one sample tensor
@@ -559,7 +559,10 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
             if lo_in.numel() != residual.numel() or not lo_in.is_contiguous():
                 raise L.EdgeStyleHipError("conv_gemm: the residual's low part does not match it")
             d.residual_lo = lo_in.data_ptr()
-        out_lo = torch.empty_like(out)
+        if out_lo is None:
+            out_lo = torch.empty_like(out)
+        elif out_lo.shape != out.shape or out_lo.dtype != out.dtype or not out_lo.is_contiguous():
+            raise L.EdgeStyleHipError("conv_gemm: out_lo must match out")
         d.out_lo = out_lo.data_ptr()
         out._lo = out_lo
     # XCD chunk order: keep the larger operand's tiles together on one XCD (see conv_gemm_kernel)
