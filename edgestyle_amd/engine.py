@@ -351,9 +351,9 @@ class ControlNet(Encoder):
             h = ops.conv_gemm(h, pw, stride=2 if i % 2 == 1 else 1, act=L.ACT_SILU)
         return ops.conv_gemm(h, self.cond[-1])
 
-    def embed_latent(self, z):
+    def embed_latent(self, z, out=None):
         """VAEControlNetConditioningEmbedding tail: conv_vae_out IS conv_in (CL:36,41,595-598). z: [N,h,w,in_pad]"""
-        return ops.conv_gemm(z, self.conv_in)
+        return ops.conv_gemm(z, self.conv_in, out=out)
 
     def forward(self, x, tproj, ctx, conds: Sequence[torch.Tensor], out_scale: float = 1.0,
                 out_scale_dev=None, level_scales: Optional[Sequence[float]] = None):

@@ -770,6 +770,21 @@ class StepRunner:
                 ops.memcpy(st.cond_cat[a:a + N], conds[p])
                 a += N                                   # the UNet's slot stays zero
 
+    def refresh_cond(self, p: int, cond: torch.Tensor):
+        """One net's embedded condition changed (per-step re-sampling, pipeline._Loop.resample_conds): its slot of the
+        batch-concatenated tensor the grouped conv_in launch reads follows."""
+        st = self.state
+        if st.cond_cat is None:
+            return
+        N = cond.shape[0]
+        a = 0
+        for _, pos in self.groups:
+            for q in pos:
+                if q == p:
+                    ops.memcpy(st.cond_cat[a:a + N], cond)
+                    return
+                a += N
+
     def clear_time_table(self):
         self.state.tproj_table = self.state.tproj_cur = None
 

@@ -113,6 +113,7 @@ class _Loop:
         self.loop_graph = None           # all steps of a call as one graph (captured with the step graph)
         self.guidance_scale = None
         self.steps = None
+        self.resample = {}               # net index -> dict(net, mom, table, cur): VAE conditions re-sampled at every step
         self.skip = None                 # per step: no ControlNet contributes (every controlnet_keep is 0, PL:419-427)
         self.graph_unet = None           # the captured UNet-only step of those steps
 
@@ -124,8 +125,21 @@ class _Loop:
         """self.latents (fp32 NHWC) -> the networks' input: both CFG halves, compute dtype, channel-padded (PL:443-447)."""
         ops.latents_to_input(self.latents, self.model_in, self.cfg_on)
 
+    def resample_conds(self):
+        """The stock pipeline's per-step condition embedding (CL:199-203 -> CL:38-42) for the VAE-conditioned nets, from the
+        cached encoder moments: row `step` of the net's noise table -> (mean + std * noise) * scaling_factor -> conv_in."""
+        for i, r in self.resample.items():
+            ops.gather_row(r["table"], self.step_idx, r["cur"].view(-1))
+            vae = r["net"]._vae
+            z = ops.vae_sample(r["mom"], r["cur"], vae.cfg.latent_channels, r["net"].engine.in_pad, vae.cfg.scaling_factor)
+            r["net"].engine.embed_latent(z, out=self.conds[i])
+            self.runner.refresh_cond(i, self.conds[i])
+
     def one_step(self):
         """Everything between PL:435 and PL:522 for the step selected by the device counter."""
+        if self.resample:
+            self.runner.state = self.state
+            self.resample_conds()
         ops.gather_row(self.t_table, self.step_idx, self.t_rows)
         ops.gather_row(self.scale_table, self.step_idx, self.scales_cur)
         self.runner.state = self.state
@@ -164,6 +178,14 @@ class _Loop:
 
 class StableDiffusionControlNetPipeline:
     """Keeps the constructor / from_pretrained / __call__ surface TT:263-275 and TT:326-359 use."""
+
+    # The STOCK pipeline hands the raw condition images to the ControlNets at every step: CachedControlNetModel.forward embeds
+    # them each time (CL:199-203) and a VAE-conditioned net draws a FRESH latent_dist.sample() per step (CL:38-42) - what the
+    # reference's test script actually runs (TT:263-272).  The encoder passes are deterministic, so this class caches their
+    # moments and redoes only `(mean + std * noise_t) * sf -> conv_in` per step (a [N,4,h,w] sample and a 4 -> C0 convolution
+    # per net instead of the reference's three VAE encodes per step).  EdgeStyleStableDiffusionControlNetPipeline embeds once
+    # (PL:629-664) and keeps False.  `resample_cond_each_step=` of __call__ overrides either way.
+    resample_cond_each_step = True
 
     def __init__(self, vae: AutoencoderKL, text_encoder=None, tokenizer=None, unet: UNet2DConditionModel = None,
                  controlnet: Union[EdgeStyleMultiControlNetModel, ControlNetModel] = None, scheduler=None,
@@ -311,6 +333,7 @@ class StableDiffusionControlNetPipeline:
                     for i, (img, net) in enumerate(zip(images, nets))]
         rep = 2 if do_cfg else 1
         N = batch_size * rep
+        self._cond_moments = {}                      # net index -> encoder moments [N,h,w,2L] of its image (per-step re-sampling)
         imgs = [img.to(torch.float32).repeat_interleave(batch_size, dim=0) if img.shape[0] == 1 else img.to(torch.float32)
                 for img in images]
         out = [None] * len(nets)
@@ -328,6 +351,8 @@ class StableDiffusionControlNetPipeline:
                 vae = net._vae
                 hh, ww = imgs[i].shape[2] // vae.cfg.scale, imgs[i].shape[3] // vae.cfg.scale
                 nz = None if cond_noise is None else cond_noise[i]
+                if nz is not None and nz.dim() == 5:
+                    nz = nz[0]                               # a per-step table: the embedding made here is step 0's
                 if nz is None:
                     nz = torch.randn((N, vae.cfg.latent_channels, hh, ww), generator=generator, dtype=torch.float32)
                 noise[i] = nz
@@ -342,6 +367,7 @@ class StableDiffusionControlNetPipeline:
                     net = nets[i]
                     mom = dist.moments[k * batch_size:(k + 1) * batch_size]
                     mom = torch.cat([mom] * rep) if rep > 1 else mom
+                    self._cond_moments[i] = mom.contiguous()
                     z = ops.vae_sample(mom.contiguous(), noise[i].to(self.device), vae.cfg.latent_channels,
                                        net.engine.in_pad, vae.cfg.scaling_factor)
                     out[i] = net.engine.embed_latent(z)
@@ -384,7 +410,7 @@ class StableDiffusionControlNetPipeline:
                  guess_mode: bool = False, control_guidance_start: Union[float, List[float]] = 0.0,
                  control_guidance_end: Union[float, List[float]] = 1.0,
                  callback_on_step_end: Optional[Callable] = None, cond_noise: Optional[Sequence] = None,
-                 ip_adapter_image=None, cross_attention_kwargs=None, clip_skip: Optional[int] = None,
+                 resample_cond_each_step: Optional[bool] = None, ip_adapter_image=None, cross_attention_kwargs=None, clip_skip: Optional[int] = None,
                  callback_on_step_end_tensor_inputs: Sequence[str] = ("latents",), **kwargs):
         # the reference's signature (PL:92-120) in full; what this path does not implement is refused, never ignored
         if kwargs:
@@ -443,6 +469,32 @@ class StableDiffusionControlNetPipeline:
         mark("start")
         # PL:352-377 — condition images, embedded ONCE
         guess = bool(guess_mode)
+        # per-step re-sampling of the VAE conditions (the stock pipeline's semantics, class attribute above): which nets, and
+        # their noise tables [T, N, L, h, w] - the caller's (cond_noise[i] 5-D) or drawn per step in net order from `generator`.
+        # A 4-D cond_noise[i] pins ONE sample: that net keeps the embed-once form.
+        want_rs = self.resample_cond_each_step if resample_cond_each_step is None else bool(resample_cond_each_step)
+        rs_tables = {}
+        if want_rs and not guess and isinstance(image, (list, tuple)):
+            from .models import ControlLoRAModel
+            Nn = B * (2 if do_cfg else 1)
+            gen_h = _host_generator(generator)
+            cand = [i for i, (img, net) in enumerate(zip(image, self._nets))
+                    if isinstance(net, ControlLoRAModel) and net.config.uses_vae and torch.is_tensor(img) and img.dim() == 4
+                    and img.shape[1] == 3 and (cond_noise is None or cond_noise[i] is None or cond_noise[i].dim() == 5)]
+            if cand and all(torch.is_tensor(img) and img.dim() == 4 and img.shape[1] == 3 for img in image):
+                sc = self.vae.cfg.scale
+                shapes = {i: (Nn, self._nets[i]._vae.cfg.latent_channels, image[i].shape[2] // sc, image[i].shape[3] // sc) for i in cand}
+                given = {i: cond_noise[i] for i in cand if cond_noise is not None and cond_noise[i] is not None}
+                for i, tb in given.items():
+                    if tuple(tb.shape) != (num_inference_steps,) + shapes[i]:
+                        raise ValueError(f"cond_noise[{i}]: a per-step table must be [num_inference_steps, N, L, h, w] = "
+                                         f"{(num_inference_steps,) + shapes[i]}, got {tuple(tb.shape)}")
+                drawn = {i: [] for i in cand if i not in given}
+                for _ in range(num_inference_steps if drawn else 0):          # the reference's draw order: step by step, net by net
+                    for i in drawn:
+                        drawn[i].append(torch.randn(shapes[i], generator=gen_h, dtype=torch.float32))
+                rs_tables = {i: (given[i].float() if i in given else torch.stack(drawn[i])) for i in cand}
+                cond_noise = [rs_tables.get(i, None if cond_noise is None else cond_noise[i]) for i in range(len(image))]
         conds = self.prepare_images(image, B, do_cfg and not guess, cond_noise, generator,
                                     num_images_per_prompt)                                      # PL:352-377, 657-658
         h, w = conds[0].shape[1:3]
@@ -466,6 +518,16 @@ class StableDiffusionControlNetPipeline:
             loop = self._loops[key] = _Loop(self, B, do_cfg, h, w, guess)
         self._last_loop = loop
         N, k = loop.N, self._runner.kmax
+        rs_key = tuple(sorted(rs_tables))
+        rs_changed = tuple(sorted(loop.resample)) != rs_key or any(loop.resample[i]["table"].shape[0] != T for i in rs_key)
+        if rs_changed:
+            loop.resample = {i: dict(net=self._nets[i], mom=torch.empty_like(self._cond_moments[i]),
+                                     table=torch.empty((T, rs_tables[i][0].numel()), dtype=torch.float32, device=self.device),
+                                     cur=torch.empty(tuple(rs_tables[i].shape[1:]), dtype=torch.float32, device=self.device))
+                             for i in rs_key}
+        for i in rs_key:
+            loop.resample[i]["mom"].copy_(self._cond_moments[i])
+            loop.resample[i]["table"].copy_(rs_tables[i].reshape(T, -1))
         # PL:419-427 controlnet_keep folded into a per-step scale table
         keep = [[1.0 - float(i / T < s or (i + 1) / T > e)
                  for s, e in zip(control_guidance_start, control_guidance_end)] for i in range(T)]
@@ -477,7 +539,7 @@ class StableDiffusionControlNetPipeline:
         dev = self.device
         unipc = isinstance(self.scheduler, UniPCMultistepScheduler)
         regraph = (loop.steps != T) or (loop.guidance_scale != float(guidance_scale)) or (loop.graph is None and loop.graph_unet is None) \
-            or loop.unipc != unipc or loop.skip != skip
+            or loop.unipc != unipc or loop.skip != skip or rs_changed
         loop.skip = skip
         loop.steps, loop.guidance_scale, loop.unipc = T, float(guidance_scale), unipc
         cw = 12 if unipc else 4
@@ -673,6 +735,7 @@ class StableDiffusionControlNetPipeline:
 
 
 class EdgeStyleStableDiffusionControlNetPipeline(StableDiffusionControlNetPipeline):
-    """model/edgestyle_pipeline.py:57-664 — same call surface; the cached-condition semantics it adds over the stock
-    pipeline are what both classes implement here."""
-    pass
+    """model/edgestyle_pipeline.py:57-664 — same call surface; the condition images are embedded ONCE per call (prepare_image,
+    PL:629-664, with CachedControlNetModel's shortcut CL:199-203), where the stock pipeline re-samples the VAE conditions at
+    every step (StableDiffusionControlNetPipeline.resample_cond_each_step)."""
+    resample_cond_each_step = False

@@ -315,6 +315,14 @@ def vae_encode_sample(sd: SD, cfg, x, noise):
     return mean + torch.exp(0.5 * logvar) * noise
 
 
+def vae_cond_from_moments(sd_cn: SD, vae_cfg, moments, noise):
+    """VAEControlNetConditioningEmbedding.forward (CL:38-42) from cached encoder moments: the encode is deterministic, only
+    latent_dist.sample() changes from call to call - which is what the STOCK pipeline does every denoising step (see pipeline)."""
+    mean, logvar = moments.chunk(2, dim=1)
+    z = mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * noise
+    return conv(sd_cn, "conv_in", z * vae_cfg.scaling_factor)
+
+
 def vae_decode(sd: SD, cfg, z):
     g, eps = cfg.norm_num_groups, cfg.norm_eps
     h = conv(sd, "post_quant_conv", z, padding=0)
@@ -391,10 +399,15 @@ def denoise_step(unet_sd, unet_cfg, fusion_sd, nets, sample, t, ehs, conds, scal
 
 def pipeline(unet_sd, unet_cfg, fusion_sd, nets, vae_sd, vae_cfg, latents, prompt_embeds, negative_prompt_embeds,
              conds, num_inference_steps=50, guidance_scale=7.5, scales=None, control_guidance_start=0.0,
-             control_guidance_end=1.0, decode=True, on_step=None, guess_mode=False):
+             control_guidance_end=1.0, decode=True, on_step=None, guess_mode=False, cond_resample=None):
     """EdgeStyleStableDiffusionControlNetPipeline.__call__ (PL:91-582) for pre-embedded `conds`
     (6 x [B,C0,h,w]; duplicated for CFG here exactly like PL:657-658 does before embedding... the caller passes
-    already-embedded tensors of batch 2B when CFG is on and guess_mode is off, B otherwise)."""
+    already-embedded tensors of batch 2B when CFG is on and guess_mode is off, B otherwise).
+
+    cond_resample: {net index: (encoder moments [N,2L,h,w], noise table [T,N,L,h,w])} - the STOCK
+    StableDiffusionControlNetPipeline the reference's test script drives (TT:263-272) hands the raw condition IMAGE to the
+    ControlNets at every step, so CachedControlNetModel.forward embeds it every step (CL:199-203) and a VAE-conditioned net
+    draws a fresh latent_dist.sample() each time (CL:38-42): condition k of step i is conv_in((mean + std * noise[i]) * sf)."""
     n_nets = len(nets)
     scales = list(scales) if scales is not None else [1.0] * n_nets
     cfg_on = guidance_scale > 1.0                              # do_classifier_free_guidance
@@ -409,6 +422,10 @@ def pipeline(unet_sd, unet_cfg, fusion_sd, nets, vae_sd, vae_cfg, latents, promp
         keep = [1.0 - float(i / T < s or (i + 1) / T > e) for s, e in zip(starts, ends)]   # PL:419-427
         x = torch.cat([latents] * 2) if cfg_on else latents     # PL:443-447
         cond_scale = [c * k for c, k in zip(scales, keep)]      # PL:464-470
+        if cond_resample:
+            conds = list(conds)
+            for k, (mom, table) in cond_resample.items():       # CL:199-203 + CL:38-42 at every step
+                conds[k] = vae_cond_from_moments(nets[k][0], vae_cfg, mom, table[i])
         eps = denoise_step(unet_sd, unet_cfg, fusion_sd, nets, x, t, ehs, conds, cond_scale, guess_mode, cfg_on)
         if cfg_on:
             e_u, e_t = eps.chunk(2)

@@ -10,8 +10,10 @@ only the oracle's outputs are stored:
 
   full96_pipeline12.safetensors   request 0 of the batch-4 call: fp32 oracle, 12 DDIM steps, CFG 7.5: latents after steps
                                   1, 2, 4, 8, 12 and the decoded 768x768 image (fp16)
+  full96_pipeline50.safetensors   the same request over configs[4]'s own 50 DDIM steps (ES_STEPS=50): latents after steps 1, 5,
+                                  10, 25, 50 and the image
 
-    ES_THREADS=4 python tests/golden/make_golden_768.py          (~1 h on 4 cores, ~20 GB of RAM)
+    ES_THREADS=4 [ES_STEPS=50] python tests/golden/make_golden_768.py     (12 steps: ~15 min on 4 cores; 50 steps: ~1 h; ~20 GB of RAM)
 """
 import dataclasses
 import os
@@ -28,8 +30,8 @@ from oracle import sd15_oracle as O                       # noqa: E402
 from tests import helpers as H                            # noqa: E402
 from edgestyle_amd import weights as W                    # noqa: E402
 
-STEPS = 12
-KEEP = (1, 2, 4, 8, 12)
+STEPS = int(os.environ.get("ES_STEPS", "12"))            # 12 (committed first) or 50 (BASELINE configs[4]'s own step count)
+KEEP = (1, 2, 4, 8, 12) if STEPS == 12 else (1, 5, 10, 25, 50)
 
 
 def inputs_768(seed=51, B=4):
@@ -72,8 +74,8 @@ def main():
                              decode=False, on_step=on_step)
         img = (O.vae_decode(ws["vae"], vcfg, lat_out / vcfg.scaling_factor) / 2 + 0.5).clamp(0, 1)
     keep.update({"latents_out": lat_out.contiguous(), "image": img.half().contiguous()})
-    save_file(keep, os.path.join(HERE, "full96_pipeline12.safetensors"))
-    print(f"full96_pipeline12 {time.time() - t0:.0f}s", flush=True)
+    save_file(keep, os.path.join(HERE, f"full96_pipeline{STEPS}.safetensors"))
+    print(f"full96_pipeline{STEPS} {time.time() - t0:.0f}s", flush=True)
 
 
 if __name__ == "__main__":

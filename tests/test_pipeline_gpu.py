@@ -561,3 +561,61 @@ def test_control_guidance_windows_skip_the_controlnets_and_match_the_oracle(buil
     assert psnr(out5, ref) >= 40.0 and psnr(out, out5) >= 45.0
     out6 = pipe(**kw).images                               # and back: the loop re-captures for the other pattern
     assert torch.equal(out, out6)
+
+
+def test_stock_pipeline_resamples_the_vae_conditions_every_step(built):
+    """VERDICT r3 missing 2: what the reference's test script really runs (TT:263-272) is the STOCK
+    StableDiffusionControlNetPipeline - the raw condition images reach CachedControlNetModel.forward at every step, which embeds
+    them every time (CL:199-203), and a VAE-conditioned net draws a fresh latent_dist.sample() per step (CL:38-42).  Here the
+    encoder moments are cached and only sample + conv_in run per step, from a per-step noise table (device table, row picked by
+    the step counter inside the captured step).  Against the oracle doing CL:38-42 at every step; eager == graphs; the
+    EdgeStyle class (embed once) differs, and equals the stock class with resample_cond_each_step=False."""
+    from oracle import sd15_oracle as O
+    from edgestyle_amd.pipeline import EdgeStyleStableDiffusionControlNetPipeline
+    pipe, ws, ucfg, vcfg = built
+    assert pipe.resample_cond_each_step is True and EdgeStyleStableDiffusionControlNetPipeline.resample_cond_each_step is False
+    g = torch.Generator().manual_seed(23)
+    s, T = ucfg.sample_size, 5
+    res = s * 8
+    lat, pe, ne, _ = _inputs(ucfg, 1, seed=9)
+    imgs = [(torch.rand(1, 3, res, res, generator=g) * (2 if i % 2 == 0 else 1) - (1 if i % 2 == 0 else 0)).half().float()
+            for i in range(6)]
+    tables = [torch.randn(T, 2, 4, s, s, generator=g) if i % 2 == 0 else None for i in range(6)]
+    nets = oracle_nets(ws, ucfg)
+    oconds, rs = [], {}
+    for i in range(6):
+        im2 = torch.cat([imgs[i]] * 2)
+        if i % 2 == 0:
+            mom = O.vae_encode_moments(ws["vae"], vcfg, im2)
+            rs[i] = (mom, tables[i])
+            oconds.append(O.vae_cond_from_moments(nets[i][0], vcfg, mom, tables[i][0]))
+            assert torch.allclose(oconds[-1], O.vae_cond_embedding(nets[i][0], ws["vae"], vcfg, im2, tables[i][0]), atol=1e-5)
+        else:
+            oconds.append(O.cond_embedding(ws["openpose"], ucfg, im2))
+    ref = O.pipeline(ws["unet"], ucfg, ws["fusion"], nets, ws["vae"], vcfg, lat, pe, ne, oconds, num_inference_steps=T,
+                     guidance_scale=5.0, cond_resample=rs)
+    ref_once = O.pipeline(ws["unet"], ucfg, ws["fusion"], nets, ws["vae"], vcfg, lat, pe, ne, oconds, num_inference_steps=T,
+                          guidance_scale=5.0)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=imgs, latents=lat, guidance_scale=5.0, num_inference_steps=T,
+              cond_noise=tables, output_type="pt")
+    out = pipe(**kw).images
+    assert sorted(pipe._last_loop.resample) == [0, 2, 4]
+    assert psnr(out, ref) >= 40.0, psnr(out, ref)
+    assert psnr(out, ref_once) < psnr(out, ref) - 3.0                     # it is NOT the embed-once result
+    out2, out3 = pipe(**kw).images, pipe(**kw).images                      # whole-loop graph captured, then replayed
+    assert pipe._last_loop.loop_graph is not None and torch.equal(out, out2) and torch.equal(out, out3)
+    pipe.use_graph = False
+    try:
+        assert torch.equal(out, pipe(**kw).images)
+    finally:
+        pipe.use_graph = True
+    once = pipe(resample_cond_each_step=False, **kw).images               # the EdgeStyle class's semantics: row 0, embedded once
+    assert not pipe._last_loop.resample and psnr(once, ref_once) >= 40.0
+    es = EdgeStyleStableDiffusionControlNetPipeline(vae=pipe.vae, unet=pipe.unet, controlnet=pipe.controlnet).to(DEV)
+    assert torch.equal(es(**kw).images, once)
+    # tables drawn from the generator: deterministic per seed, different from the embed-once call of the same seed
+    kw2 = {k: v for k, v in kw.items() if k != "cond_noise"}
+    a = pipe(generator=torch.Generator().manual_seed(3), **kw2).images
+    b = pipe(generator=torch.Generator().manual_seed(3), **kw2).images
+    c = pipe(generator=torch.Generator().manual_seed(3), resample_cond_each_step=False, **kw2).images
+    assert torch.equal(a, b) and not torch.equal(a, c)
