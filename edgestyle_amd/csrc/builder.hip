@@ -234,6 +234,10 @@ struct T {
   // wide residual stream (ops.WIDE_STREAM): the low part of a stream tensor (same shape, same views) rides on the tensor
   unsigned long long lo = 0;
   std::shared_ptr<Blk> lo_b;
+  // GroupNorm statistics handed over by the producing GEMM (ops.GN_HANDOVER): fp32 [n][2 * hw/64][gnp_groups][2] of the WHOLE tensor
+  unsigned long long gnp = 0;
+  std::shared_ptr<Blk> gnp_b;
+  int gnp_groups = 0;
   explicit operator bool() const { return p != 0; }
   long long hw() const { return (long long)h * w; }
   long long numel() const { return (long long)n * h * w * c; }
@@ -244,6 +248,7 @@ struct T {
     T t = *this;
     t.p += (unsigned long long)a * (unsigned long long)bstride() * es;
     if (t.lo) t.lo += (unsigned long long)a * (unsigned long long)bstride() * es;
+    t.gnp = 0; t.gnp_b.reset(); t.gnp_groups = 0;         // (a batch slice is read as an addend / operand, never normalised as it stands)
     t.n = cnt < 0 ? n - a : cnt;
     if (a < 0 || t.n < 0 || a + t.n > n) fail("builder: batch slice out of range");
     return t;
@@ -253,6 +258,7 @@ struct T {
     if (c0 < 0 || c0 + cn > c) fail("builder: channel slice out of range");
     t.p += (unsigned long long)c0 * es;
     t.lo = 0; t.lo_b.reset();                            // (a channel slice of a stream tensor is an operand, never a residual)
+    t.gnp = 0; t.gnp_b.reset(); t.gnp_groups = 0;
     t.c = cn;
     return t;
   }
@@ -288,6 +294,7 @@ struct CA {                       // keyword arguments of ops.conv_gemm
   std::vector<T> tails;
   int x_rep = 1;
   bool wide = false;              // this launch adds into the residual stream (ops.conv_gemm(wide=True))
+  int gn_groups = 0;              // > 0: the output is read by a GroupNorm over that many groups - hand the statistics over
 };
 
 // ---- the launch planner of edgestyle_amd/ops.py (plan_gemm, xs_eligible): identical decisions are what makes a natively built
@@ -389,6 +396,7 @@ struct Builder {
     ok(es_add(a.ptr(), b.ptr(), out.ptr(), a.numel(), dt, nullptr), "es_add");
     return out;
   }
+  static bool gn_handover() { static const bool on = [] { const char* e = getenv("ES_GN_HANDOVER"); return !(e && e[0] == '0'); }(); return on; }   // ops.GN_HANDOVER
   // ops.wide_stream: "auto" (default) = bf16 pipelines only
   bool wide_stream() const {
     static const std::string mode = [] { const char* e = getenv("ES_WIDE_STREAM"); return std::string(e ? e : "auto"); }();
@@ -632,6 +640,12 @@ struct Builder {
     d.xcd_m_fastest = (!grouped && splitk == 1 && M <= 2048 && pw->w_numel() > src_numel) ? 1 : 0;
     d.x_nmod = a.x_rep > 1 ? nsrc : 0;
     d.korder = pw->korder;
+    if (a.gn_groups > 0 && gn_handover() && cstore % 8 == 0 && hw % 64 == 0 && !pw->geglu && !pw->ln_colsum && pw->cout % a.gn_groups == 0 &&
+        pw->cout / a.gn_groups <= (bn == 320 ? 160 : bn)) {
+      T part = empty(N, (int)(2 * (hw / 64)), 1, a.gn_groups * 2, 4);
+      d.gn_part = (float*)part.ptr(); d.gn_groups = a.gn_groups;
+      out.gnp = part.p; out.gnp_b = part.b; out.gnp_groups = a.gn_groups;
+    }
     if (a.wide && a.residual && wide_stream() && cstore % 8 == 0 && !pw->geglu) {
       // the sum over (residual hi + lo) in fp32, stored as hi + lo (es_gemm_desc.out_lo)
       if (a.residual.lo) d.residual_lo = (const void*)a.residual.lo;
@@ -719,6 +733,9 @@ struct Builder {
       for (size_t g = 0; g < nl.size(); ++g) { acc += group_n[g]; d.n_end[g] = acc; d.gamma_g[g] = (const float*)nl[g].g; d.beta_g[g] = (const float*)nl[g].b; }
     } else { d.gamma = (const float*)nl[0].g; d.beta = (const float*)nl[0].b; }
     d.N = N; d.HW = (int)x.hw(); d.C1 = C1; d.C2 = C2; d.groups = groups; d.eps = eps; d.silu = silu; d.dtype = dt;
+    if (x.gnp && !x2 && gn_handover() && x.gnp_groups == groups && x.hw() % 64 == 0) {      // the producer's statistics: one streaming pass
+      d.partials = (float*)x.gnp; d.ext_chunks = (int)(2 * (x.hw() / 64));
+    }
     ok(es_group_norm(&d, nullptr), "es_group_norm");
     return out;
   }
@@ -771,16 +788,17 @@ struct Resnet {
     T h = B.group_norm(x, n1, groups, eps, true, x2);
     CA a;
     if (temb_off >= 0) { a.temb = tproj.chan(temb_off, tproj.c - temb_off); a.temb_stride = tproj.ld; }
+    a.gn_groups = groups;
     h = B.conv_gemm(h, conv1, a);
     h = B.group_norm(h, n2, groups, eps, true);
     if (conv2s) {
       if (x2 && (x.c % 64 || x2.c % 64)) fail("builder: skip concat with channels that are not multiples of 64");
-      CA t; t.tails.push_back(x); if (x2) t.tails.push_back(x2);
+      CA t; t.tails.push_back(x); if (x2) t.tails.push_back(x2); t.gn_groups = groups;
       return B.conv_gemm(h, conv2s, t);
     }
     T xs = x;
     if (shortc) { CA s; s.x2 = x2; xs = B.conv_gemm(x, shortc, s); }
-    CA r; r.residual = xs; r.wide = true;
+    CA r; r.residual = xs; r.wide = true; r.gn_groups = groups;
     return B.conv_gemm(h, conv2, r);
   }
 };
@@ -1066,14 +1084,14 @@ struct Model {
     T hh = B.group_norm(x, norms(rs, 1), r0->groups, r0->eps, true, T(), counts);
     PWs c1, c2, c2s, sh; bool all_s = true;
     for (auto r : rs) { c1.push_back(r->conv1); c2.push_back(r->conv2); c2s.push_back(r->conv2s); sh.push_back(r->shortc); if (!r->conv2s) all_s = false; }
-    CA a; a.temb = tproj.chan(r0->temb_off, tproj.c - r0->temb_off); a.temb_stride = tproj.ld; a.group_n = counts;
+    CA a; a.temb = tproj.chan(r0->temb_off, tproj.c - r0->temb_off); a.temb_stride = tproj.ld; a.group_n = counts; a.gn_groups = r0->groups;
     hh = B.conv_gemm(hh, c1, a);
     hh = B.group_norm(hh, norms(rs, 2), r0->groups, r0->eps, true, T(), counts);
-    if (all_s) { CA t; t.tails.push_back(x); t.group_n = counts; return B.conv_gemm(hh, c2s, t); }
+    if (all_s) { CA t; t.tails.push_back(x); t.group_n = counts; t.gn_groups = r0->groups; return B.conv_gemm(hh, c2s, t); }
     for (auto r : rs) if (r->conv2s) fail("builder: grouped resnets must fold conv_shortcut all alike");
     T xs = x;
     if (r0->shortc) { CA s; s.group_n = counts; xs = B.conv_gemm(x, sh, s); }
-    CA r; r.residual = xs; r.group_n = counts; r.wide = true;
+    CA r; r.residual = xs; r.group_n = counts; r.wide = true; r.gn_groups = r0->groups;
     return B.conv_gemm(hh, c2, r);
   }
   T g_transformer(const std::vector<const Transformer*>& ts, const T& x, const T& kv) {
@@ -1096,7 +1114,7 @@ struct Model {
     CA r2 = gr; r2.residual = tok; r2.wide = true;
     tok = B.linear(a, o2, r2);
     T f = B.linear(tok, ff1, gr);
-    CA fo; fo.x2 = tok.view(Nn, H, Wd, C); fo.residual = x; fo.group_n = counts; fo.wide = true;
+    CA fo; fo.x2 = tok.view(Nn, H, Wd, C); fo.residual = x; fo.group_n = counts; fo.wide = true; fo.gn_groups = t0->groups;
     return B.conv_gemm(f.view(Nn, H, Wd, 4 * C), ffo, fo);
   }
   // h: [ntot,H,W,C0] -> (skips, mid) over the whole batch (GroupedEncoder.run)
@@ -1114,7 +1132,7 @@ struct Model {
       }
       if (e0->downsample[i]) {
         PWs ds; for (auto e : encs) ds.push_back(e->downsample[i]);
-        CA a; a.stride = 2; a.group_n = counts;
+        CA a; a.stride = 2; a.group_n = counts; a.gn_groups = ucfg.groups;
         hh = B.conv_gemm(hh, ds, a);
         skips.push_back(hh);
       }
@@ -1137,7 +1155,7 @@ struct Model {
     CA r2; r2.residual = tok; r2.wide = true;
     tok = B.linear(a, t.o2, r2);
     T f = B.linear(tok, t.ff1_ln);
-    CA fo; fo.x2 = tok.view(Nn, H, Wd, C); fo.residual = x; fo.wide = true;
+    CA fo; fo.x2 = tok.view(Nn, H, Wd, C); fo.residual = x; fo.wide = true; fo.gn_groups = t.groups;
     return B.conv_gemm(f.view(Nn, H, Wd, 4 * C), t.ffo, fo);
   }
 
@@ -1185,7 +1203,7 @@ struct Model {
     T h0 = B.empty(ntot, x.h, x.w, c0);
     {
       PWs ci; for (auto e : encs) ci.push_back(e->conv_in);
-      CA a; a.residual = cond_cat; a.group_n = counts; a.out = h0; a.x_rep = ntot / N; a.wide = true;
+      CA a; a.residual = cond_cat; a.group_n = counts; a.out = h0; a.x_rep = ntot / N; a.wide = true; a.gn_groups = ucfg.groups;
       h0 = B.conv_gemm(x, ci, a);                          // (the same buffer; with a wide stream it now carries its low part)                               // sample = conv_in(sample) + cond for every net, and the UNet's conv_in (CL:197-203)
     }
     T tproj;
@@ -1270,7 +1288,8 @@ struct Model {
     B.gather_row(t_table, T_, step_idx, t_rows, kmax * N);
     B.gather_row(tproj_table, T_, step_idx, tproj_cur, (int)((long long)ntot * width * 2 / 4));
     T tp = tproj_cur.batch(ncn);
-    T hh = B.conv_gemm(model_in, unet.conv_in, CA());
+    CA ci_; ci_.gn_groups = ucfg.groups;
+    T hh = B.conv_gemm(model_in, unet.conv_in, ci_);
     std::vector<T> skips;
     skips.push_back(hh);
     int ci = 0;
@@ -1280,7 +1299,7 @@ struct Model {
         if (unet.down[i][j].second >= 0) { hh = transformer(unet.tr[unet.down[i][j].second], hh, ctx_unet[ci]); ++ci; }
         skips.push_back(hh);
       }
-      if (unet.downsample[i]) { CA a; a.stride = 2; hh = B.conv_gemm(hh, unet.downsample[i], a); skips.push_back(hh); }
+      if (unet.downsample[i]) { CA a; a.stride = 2; a.gn_groups = ucfg.groups; hh = B.conv_gemm(hh, unet.downsample[i], a); skips.push_back(hh); }
     }
     hh = unet.mid0.run(B, hh, tp);
     hh = transformer(unet.tr[unet.mid_attn], hh, ctx_unet[ci]);

@@ -161,4 +161,61 @@ ES_DEVICE void store8(void* ptr, u32x2 v) {
 #endif
 }
 
+// GroupNorm statistics from a GEMM epilogue (es_gemm_desc.gn_part).  `tile` is an LDS image [rows][erow bytes] of the FINAL stored
+// values (dtype T) of `rows` consecutive output pixels starting at global pixel m0 and `cols` output channels starting at c0;
+// every 64-pixel block and every GroupNorm group that overlaps the tile's channels gets its (sum, sum of squares) written to
+//   part[((n * 2 * (HW/64) + 2 * block + slot) * groups + g) * 2 + {0, 1}]
+// slot 0 = the tile the group starts in, slot 1 = the next one (zero where the group ends in its first tile).  ONE summation
+// order for every caller - 8 sub-blocks of 8 pixels sequentially, the 8 sub-sums sequentially, the group's channels in order - so
+// the statistics do not depend on tile shape, wave count or split-K (grouped and per-net launches stay bitwise equal).
+// `scratch`: LDS floats, (rows / 8 + rows / 64) * cols * 2 of them.  All NT threads call it; it ends behind a barrier-free write.
+template <typename T, int NT>
+ES_DEVICE void gn_emit_partials(const char* tile, const int erow, const int rows, const int cols, float* scratch, float* part,
+                                const int m0, const int M, const int c0, const int Cout, const int HW, const int groups, const int tid) {
+  const int oct = cols >> 3;
+  float* sub = scratch;                                  // [rows/8][cols][2]
+  float* chn = scratch + (rows >> 3) * cols * 2;         // [rows/64][cols][2]
+  for (int it = tid; it < (rows >> 3) * oct; it += NT) {
+    const int sb = it / oct, o = it - sb * oct;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const auto v = as_vec8<T>(*(const u32x4*)(tile + (sb * 8 + r) * erow + o * 16));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float f = to_f32(v[e]); s[e] += f; q[e] = __builtin_fmaf(f, f, q[e]); }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sub[(sb * cols + o * 8 + e) * 2] = s[e]; sub[(sb * cols + o * 8 + e) * 2 + 1] = q[e]; }
+  }
+  __syncthreads();
+  for (int it = tid; it < (rows >> 6) * cols; it += NT) {
+    const int rb = it / cols, c = it - rb * cols;
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s += sub[((rb * 8 + j) * cols + c) * 2]; q += sub[((rb * 8 + j) * cols + c) * 2 + 1]; }
+    chn[it * 2] = s; chn[it * 2 + 1] = q;
+  }
+  __syncthreads();
+  const int cpg = Cout / groups;
+  const int g0 = c0 / cpg;                               // first group that overlaps the tile
+  int c1 = c0 + cols; if (c1 > Cout) c1 = Cout;
+  const int ng = c1 > c0 ? (c1 - 1) / cpg - g0 + 1 : 0;
+  const int nch = HW >> 6;
+  for (int it = tid; it < (rows >> 6) * ng; it += NT) {
+    const int rb = it / ng, g = g0 + (it - rb * ng);
+    const int m = m0 + rb * 64;
+    if (m >= M) continue;
+    const int a = g * cpg > c0 ? g * cpg : c0, b = (g + 1) * cpg < c1 ? (g + 1) * cpg : c1;
+    float s = 0.f, q = 0.f;
+    for (int c = a; c < b; ++c) { s += chn[(rb * cols + c - c0) * 2]; q += chn[(rb * cols + c - c0) * 2 + 1]; }
+    const int n = m / HW, blk = (m - n * HW) >> 6;
+    const int slot = g * cpg < c0 ? 1 : 0;
+    float* o = part + (((size_t)n * 2 * nch + 2 * blk + slot) * groups + g) * 2;
+    o[0] = s; o[1] = q;
+    if (!slot && (g + 1) * cpg <= c1) { o[groups * 2] = 0.f; o[groups * 2 + 1] = 0.f; }      // the group ends here: its second entry is zero
+  }
+}
+
 #define ES_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : -2)

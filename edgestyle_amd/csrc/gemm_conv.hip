@@ -107,6 +107,8 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? (FM == 2 
   constexpr int XT = BM * RB;        // bytes per stage
   constexpr int WT = BN * RB;
   static_assert((size_t)BM * (BN * 2 + 16) <= (size_t)STAGES * (BM + BN) * RB, "the epilogue tile must fit the stage ring");
+  static_assert(LN || (size_t)BM * (BN * 2 + 16) + (size_t)(BM / 8 + BM / 64) * BN * 8 <= (size_t)STAGES * (BM + BN) * RB,
+                "the GroupNorm-statistics scratch (gn_emit_partials) must fit behind the epilogue tile");
   constexpr int BNP = BN;            // couts staged by the epilogue
   constexpr int EROW = BNP * 2 + 16; // epilogue tile row stride (bytes), padded against bank conflicts
   constexpr int NI = XI + WI;        // LDS-DMA instructions per wave per K-step
@@ -654,7 +656,12 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? (FM == 2 
             for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(rv[e]));
           }
           store16(outp + (size_t)m * Cstore + c, __builtin_bit_cast(u32x4, v));
+          if (p.gn_part) *(u32x4*)(et + row * EROW + ch * 16) = __builtin_bit_cast(u32x4, v);   // the FINAL value back into the tile
         }
+      }
+      if (p.gn_part) {                                     // GroupNorm statistics of this tile for the consumer (es_gemm_desc.gn_part)
+        __syncthreads();
+        gn_emit_partials<T, NT>(et, EROW, BM, BNo, (float*)(et + BM * EROW), p.gn_part, tile_m * BM, M, c_tile, Cstore, HWout, p.gn_groups, tid);
       }
     } else {
       // narrow outputs (conv_out: 4 or 3 channels): scalar tail path
@@ -771,6 +778,101 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const es_gemm_desc p
   }
 }
 
+// The same reduction for outputs whose GroupNorm statistics are handed over (es_gemm_desc.gn_part): one workgroup owns 64 pixels x
+// CB channels (CB = a divisor of rows_padded that holds whole GroupNorm groups like an N tile does), so that the final values pass
+// through an LDS tile and gn_emit_partials sums them in the order the fused epilogues use.  Same arithmetic per element as
+// splitk_reduce_kernel (the two produce identical outputs).
+template <typename T, int CB>
+__global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const es_gemm_desc p, const int M) {
+  constexpr int OCT = CB / 8, ITEMS = 64 * OCT / 256, EROW = CB * 2 + 16;
+  __shared__ __attribute__((aligned(16))) char smem[64 * EROW + (8 + 1) * CB * 8];
+  const int tid = threadIdx.x;
+  const int nct = p.rows_padded / CB;
+  const int mb = blockIdx.x / nct, ct = blockIdx.x - mb * nct;
+  const int HW = p.Hout * p.Wout;
+  float scale = p.out_scale;
+  if (p.out_scale_dev) scale *= *p.out_scale_dev;
+  const size_t zstride = (size_t)M * p.rows_padded;
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = tid + it * 256;
+    const int row = idx / OCT, o = idx - row * OCT;
+    const int m = mb * 64 + row, c0 = ct * CB + o * 8;
+    u32x4 res = {0u, 0u, 0u, 0u};
+    if (c0 < p.Cout) {                                     // (Cout % 8 == 0: whole octets)
+      const int n = m / HW;
+      const float* bsel = p.bias;
+      if (p.ngroups > 1) {
+        const int tm = m >> 7;
+        bsel = p.bias_g[(tm >= p.mt_end[0]) + (tm >= p.mt_end[1]) + (tm >= p.mt_end[2])];
+      }
+      float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, tv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (bsel) {
+        const f32x4 b0 = *(const f32x4*)(bsel + c0), b1 = *(const f32x4*)(bsel + c0 + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { bv[r] = b0[r]; bv[4 + r] = b1[r]; }
+      }
+      if (p.temb) {
+        const T* tp = (const T*)p.temb + (size_t)n * p.temb_stride + c0;
+        if ((p.temb_stride & 7) == 0 && (((size_t)p.temb) & 15) == 0) {
+          const auto t8 = as_vec8<T>(*(const u32x4*)tp);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) tv[r] = to_f32(t8[r]);
+        } else {
+          for (int r = 0; r < 8; ++r) tv[r] = to_f32(tp[r]);
+        }
+      }
+      if (p.residual) {
+        const auto r8 = as_vec8<T>(*(const u32x4*)((const T*)p.residual + (size_t)m * p.Cout + c0));
+#pragma unroll
+        for (int r = 0; r < 8; ++r) rv[r] = to_f32(r8[r]);
+      }
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+      const float* w = p.workspace + (size_t)m * p.rows_padded + c0;
+      int z = 0;
+      for (; z + 4 <= p.splitk; z += 4) {
+        f32x4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = *(const f32x4*)(w + (z + u) * zstride); b[u] = *(const f32x4*)(w + (z + u) * zstride + 4); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s0 += a[u]; s1 += b[u]; }
+      }
+      for (; z < p.splitk; ++z) {
+        s0 += *(const f32x4*)(w + z * zstride);
+        s1 += *(const f32x4*)(w + z * zstride + 4);
+      }
+      float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        float x = v[r] + bv[r] + tv[r];
+        if (p.act == ES_ACT_SILU) x = silu_f(x);
+        x = to_f32(from_f32<T>(x * scale));
+        v[r] = x + rv[r];
+      }
+      typename Traits<T>::vec8 pk, lo;
+      if (p.out_lo) {
+        if (p.residual_lo) {
+          const auto l8 = as_vec8<T>(*(const u32x4*)((const T*)p.residual_lo + (size_t)m * p.Cout + c0));
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] += to_f32(l8[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { pk[r] = from_f32<T>(v[r]); lo[r] = from_f32<T>(v[r] - to_f32(pk[r])); }
+        store16((T*)p.out_lo + (size_t)m * p.Cout + c0, __builtin_bit_cast(u32x4, lo));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pk[r] = from_f32<T>(v[r]);
+      }
+      res = __builtin_bit_cast(u32x4, pk);
+      store16((T*)p.out + (size_t)m * p.Cout + c0, res);
+    }
+    *(u32x4*)(smem + row * EROW + o * 16) = res;
+  }
+  __syncthreads();
+  gn_emit_partials<T, 256>(smem, EROW, 64, CB, (float*)(smem + 64 * EROW), p.gn_part, mb * 64, M, ct * CB, p.Cout, HW, p.gn_groups, tid);
+}
+
 template <typename T>
 int launch(const es_gemm_desc& d, hipStream_t st) {
   const int M = d.N * d.Hout * d.Wout;
@@ -837,7 +939,14 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
 #undef ES_LAUNCH_F
 #undef ES_LAUNCH_K
 #undef ES_LAUNCH_LN
-  if (d.splitk > 1) {
+  if (d.splitk > 1 && d.gn_part) {
+    // statistics hand-over: 64 pixels x CB channels per workgroup, CB like the N tile the statistics' two-entry scheme assumes
+    const int cb = d.bn == 320 ? 160 : d.bn;
+    dim3 grid((unsigned)((M / 64) * (d.rows_padded / cb)));
+    if (cb == 160) hipLaunchKernelGGL((splitk_reduce_gn_kernel<T, 160>), grid, dim3(256), 0, st, d, M);
+    else if (cb == 128) hipLaunchKernelGGL((splitk_reduce_gn_kernel<T, 128>), grid, dim3(256), 0, st, d, M);
+    else hipLaunchKernelGGL((splitk_reduce_gn_kernel<T, 64>), grid, dim3(256), 0, st, d, M);
+  } else if (d.splitk > 1) {
     const long long total = (long long)M * (d.rows_padded / 8);
     hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, M);
   }
@@ -888,6 +997,12 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
   if (d->out_lo && (!d->residual || (d->Cout & 7) || d->act == ES_ACT_GEGLU)) {
     es_set_error("es_conv_gemm: out_lo (wide residual stream) needs a residual and an output width that is a multiple of 8"); return -1; }
   if (d->residual_lo && !d->out_lo) { es_set_error("es_conv_gemm: residual_lo without out_lo"); return -1; }
+  if (d->gn_part) {
+    const int hw = d->Hout * d->Wout;
+    if (d->gn_groups < 1 || d->Cout % d->gn_groups || (d->Cout & 7) || hw % 64 || d->act == ES_ACT_GEGLU || d->ln_colsum ||
+        d->Cout / d->gn_groups > (d->bn == 320 ? 160 : d->bn)) {
+      es_set_error("es_conv_gemm: gn_part needs H*W % 64 == 0, Cout % 8 == 0 and whole GroupNorm groups no wider than the N tile"); return -1; }
+  }
   if (d->korder != 0 && (d->korder != 1 || d->ksize != 3 || d->C1 % BK || d->C2 % BK || d->ln_colsum)) {
     es_set_error("es_conv_gemm: korder 1 (chunk-major K) needs ksize 3 and 64-aligned C1, C2"); return -1; }
   if (d->splitk < 1 || d->splitk > d->Kpad / BK) { es_set_error("es_conv_gemm: bad splitk"); return -1; }

@@ -462,7 +462,12 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
             for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(rv[e]));
           }
           store16(outp + (size_t)m * Cstore + c, __builtin_bit_cast(u32x4, v));
+          if (p.gn_part) *(u32x4*)(et + row * EROW + ch * 16) = __builtin_bit_cast(u32x4, v);   // the FINAL value back into the tile
         }
+      }
+      if (p.gn_part) {                                     // GroupNorm statistics for the consumer (es_gemm_desc.gn_part)
+        __syncthreads();
+        gn_emit_partials<T, 512>(et, EROW, BM, 160, (float*)(et + BM * EROW), p.gn_part, tile_m * BM, M, c_tile, Cstore, HWout, p.gn_groups, tid);
       }
     } else {
       for (int idx = tid; idx < BM * 160; idx += 512) {

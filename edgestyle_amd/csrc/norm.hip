@@ -416,7 +416,7 @@ int launch_gn(const es_gn_desc& d, hipStream_t st) {
   const int C = d.C1 + d.C2;
   int cpt = 0;
   static const bool slab_on = !(getenv("ES_GN_SLAB") && getenv("ES_GN_SLAB")[0] == '0');   // tuning switch
-  const int gpb = slab_on ? gn_slab_gpb(d, cpt) : 0;
+  const int gpb = (slab_on && d.ext_chunks <= 0) ? gn_slab_gpb(d, cpt) : 0;
   if (gpb) {
     const int W = gpb * (C / d.groups);
     const size_t lds = (size_t)(2 * (256 / (W / 8)) * W + 2 * gpb) * sizeof(float);
@@ -428,11 +428,13 @@ int launch_gn(const es_gn_desc& d, hipStream_t st) {
   }
   int ppb = d.HW / GN_MAX_CHUNK;
   if (ppb < 16) ppb = 16;
-  const int nchunk = (d.HW + ppb - 1) / ppb;
+  // ext_chunks > 0: the producing GEMM launch already wrote the per-(sample, group) partial sums (es_gemm_desc.gn_part): the
+  // apply pass below reduces them in its prologue exactly as it reduces gn_stats_kernel's - no statistics launch, one read of x
+  const int nchunk = d.ext_chunks > 0 ? d.ext_chunks : (d.HW + ppb - 1) / ppb;
   const int CH8 = C / 8;
   const int PS = CH8 <= 256 ? 256 / CH8 : 1;
   const size_t lds_stats = (size_t)2 * PS * C * sizeof(float);
-  hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(nchunk, d.N), dim3(256), lds_stats, st, d);
+  if (d.ext_chunks <= 0) hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(nchunk, d.N), dim3(256), lds_stats, st, d);
   const long long total = (long long)d.HW * (C / 8);
   // workgroups per sample: every workgroup first reduces the partials and builds the scale / shift tables (~2 us), so a thread
   // should stream more than one round of loads behind that prologue - 16 items where that still leaves >= 1024 workgroups for the
@@ -501,6 +503,8 @@ extern "C" int es_group_norm(const es_gn_desc* d, void* stream) {
   if (C > 8192) { es_set_error("es_group_norm: C too large for the LDS tables"); return -1; }
   if (d->N < 1 || d->HW < 1) { es_set_error("es_group_norm: empty problem"); return -1; }
   if ((long long)d->HW * (C / 8) >= (1ll << 30)) { es_set_error("es_group_norm: sample too large for 32-bit chunk indices"); return -1; }
+  if (d->ext_chunks < 0 || (d->ext_chunks > 0 && (d->x2 || d->C2 || d->HW % 64 || d->ext_chunks != 2 * (d->HW / 64)))) {
+    es_set_error("es_group_norm: ext_chunks (statistics from the producer) needs one source, H*W % 64 == 0 and 2 * H*W / 64 entries"); return -1; }
   ES_PLAN_RECORD(ES_OP_GROUP_NORM, d, sizeof(*d));
   hipStream_t st = (hipStream_t)stream;
   es_gn_desc dd = *d;                                  // unused group-table entries must compare false (see es_conv_gemm)

@@ -119,12 +119,14 @@ class Resnet:
         h = ops.group_norm(x, self.n1[0], self.n1[1], self.groups, self.eps, True, x2=x2)
         temb = None if self.temb_off is None else tproj[:, self.temb_off:]
         # a split-K conv1 leaves its partial slabs for norm2 to sum (one-launch GroupNorm geometries only)
-        h = ops.conv_gemm(h, self.conv1, temb=temb)
+        # (gn_groups: the launch's epilogue hands the GroupNorm statistics of its output over to the GroupNorm that reads it -
+        #  norm2 here, the next block's norm1 / Transformer2DModel.norm for the block's output; ops.GN_HANDOVER)
+        h = ops.conv_gemm(h, self.conv1, temb=temb, gn_groups=self.groups)
         h = ops.group_norm(h, self.n2[0], self.n2[1], self.groups, self.eps, True)
         if self.conv2s is not None and (x2 is None or (x.shape[3] % 64 == 0 and x2.shape[3] % 64 == 0)):
-            return ops.conv_gemm(h, self.conv2s, tail=(x, x2))
+            return ops.conv_gemm(h, self.conv2s, tail=(x, x2), gn_groups=self.groups)
         xs = ops.conv_gemm(x, self.short, x2=x2) if self.short is not None else x
-        return ops.conv_gemm(h, self.conv2, residual=xs, wide=True)       # x + h: a sum of the residual stream (ops.WIDE_STREAM)
+        return ops.conv_gemm(h, self.conv2, residual=xs, wide=True, gn_groups=self.groups)   # x + h: a sum of the residual stream (ops.WIDE_STREAM)
 
 
 class Transformer:
@@ -183,9 +185,9 @@ class Transformer:
         tok = ops.linear(a, self.o2, residual=tok, wide=True)
         f = ops.linear(tok, self.ff1_ln) if (fold and self.ff1_ln is not None) else ops.linear(ops.layer_norm(tok, *self.ln3), self.ff1)
         if self.ffo is not None:
-            return ops.conv_gemm(f.reshape(N, H, W, 4 * C), self.ffo, x2=tok.reshape(N, H, W, C), residual=x, wide=True)
+            return ops.conv_gemm(f.reshape(N, H, W, 4 * C), self.ffo, x2=tok.reshape(N, H, W, C), residual=x, wide=True, gn_groups=self.groups)
         tok = ops.linear(f, self.ff2, residual=tok, wide=True)
-        return ops.conv_gemm(tok.reshape(N, H, W, C), self.proj_out, residual=x, wide=True)
+        return ops.conv_gemm(tok.reshape(N, H, W, C), self.proj_out, residual=x, wide=True, gn_groups=self.groups)
 
 
 class Encoder:
@@ -260,7 +262,7 @@ class Encoder:
                     h = a(h, ctx[ci]); ci += 1
                 skips.append(h)
             if self.downsample[i] is not None:
-                h = ops.conv_gemm(h, self.downsample[i], stride=2)
+                h = ops.conv_gemm(h, self.downsample[i], stride=2, gn_groups=self.cfg.norm_num_groups)
                 skips.append(h)
         h = self.mid0(h, tproj)
         h = self.mid_attn(h, ctx[ci])
@@ -295,7 +297,7 @@ class UNet(Encoder):
     def encode(self, x, tproj, ctx):
         """conv_in + down blocks + mid block: independent of the ControlNet residuals, so it can run concurrently
         with the ControlNet passes on another stream."""
-        h = ops.conv_gemm(x, self.conv_in)
+        h = ops.conv_gemm(x, self.conv_in, gn_groups=self.cfg.norm_num_groups)
         return self.run(h, tproj, ctx)
 
     def forward(self, x, tproj, ctx, down_res: Optional[Sequence] = None, mid_res=None, out=None, encoded=None,
@@ -519,12 +521,12 @@ class GroupedEncoder:
         c = self.counts
         r0 = rs[0]
         h = ops.group_norm(x, [r.n1[0] for r in rs], [r.n1[1] for r in rs], r0.groups, r0.eps, True, group_n=c)
-        h = ops.conv_gemm(h, [r.conv1 for r in rs], temb=tproj[:, r0.temb_off:], group_n=c)
+        h = ops.conv_gemm(h, [r.conv1 for r in rs], temb=tproj[:, r0.temb_off:], group_n=c, gn_groups=r0.groups)
         h = ops.group_norm(h, [r.n2[0] for r in rs], [r.n2[1] for r in rs], r0.groups, r0.eps, True, group_n=c)
         if all(r.conv2s is not None for r in rs):
-            return ops.conv_gemm(h, [r.conv2s for r in rs], tail=(x,), group_n=c)
+            return ops.conv_gemm(h, [r.conv2s for r in rs], tail=(x,), group_n=c, gn_groups=r0.groups)
         xs = ops.conv_gemm(x, [r.short for r in rs], group_n=c) if r0.short is not None else x
-        return ops.conv_gemm(h, [r.conv2 for r in rs], residual=xs, group_n=c, wide=True)
+        return ops.conv_gemm(h, [r.conv2 for r in rs], residual=xs, group_n=c, wide=True, gn_groups=r0.groups)
 
     def _transformer(self, ts, x, kv):
         c = self.counts
@@ -548,9 +550,10 @@ class GroupedEncoder:
         tok = ops.linear(a, [t.o2 for t in ts], residual=tok, group_n=rows, wide=True)
         f = ln_linear("ln3", "ff1", "ff1_ln" if all(t.ln_fold and t.ff1_ln is not None for t in ts) else None)
         if all(t.ffo is not None for t in ts):
-            return ops.conv_gemm(f.reshape(N, H, W, 4 * C), [t.ffo for t in ts], x2=tok.reshape(N, H, W, C), residual=x, group_n=c, wide=True)
+            return ops.conv_gemm(f.reshape(N, H, W, 4 * C), [t.ffo for t in ts], x2=tok.reshape(N, H, W, C), residual=x, group_n=c, wide=True,
+                                 gn_groups=t0.groups)
         tok = ops.linear(f, [t.ff2 for t in ts], residual=tok, group_n=rows, wide=True)
-        return ops.conv_gemm(tok.reshape(N, H, W, C), [t.proj_out for t in ts], residual=x, group_n=c, wide=True)
+        return ops.conv_gemm(tok.reshape(N, H, W, C), [t.proj_out for t in ts], residual=x, group_n=c, wide=True, gn_groups=t0.groups)
 
     def run(self, h, tproj, ctx: List[torch.Tensor]):
         """h: [ntot,H,W,C0] (each group's conv_in(sample)+cond already applied) -> (skips, mid) over the whole batch."""
@@ -564,7 +567,7 @@ class GroupedEncoder:
                     h = self._transformer([e.down[i][j][1] for e in self.encs], h, ctx[ci]); ci += 1
                 skips.append(h)
             if e0.downsample[i] is not None:
-                h = ops.conv_gemm(h, [e.downsample[i] for e in self.encs], stride=2, group_n=self.counts)
+                h = ops.conv_gemm(h, [e.downsample[i] for e in self.encs], stride=2, group_n=self.counts, gn_groups=e0.cfg.norm_num_groups)
                 skips.append(h)
         h = self._resnet([e.mid0 for e in self.encs], h, tproj)
         h = self._transformer([e.mid_attn for e in self.encs], h, ctx[ci])

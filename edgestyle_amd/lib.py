@@ -31,6 +31,7 @@ class GemmDesc(C.Structure):
         ("ln_colsum", C.c_void_p), ("ln_colsum_g", C.c_void_p * 4), ("ln_eps", C.c_float),
         ("t1", C.c_void_p), ("t2", C.c_void_p), ("Ct1", C.c_int32), ("Ct2", C.c_int32),
         ("x_nmod", C.c_int32), ("korder", C.c_int32), ("residual_lo", C.c_void_p), ("out_lo", C.c_void_p),
+        ("gn_part", C.c_void_p), ("gn_groups", C.c_int32),
     ]
 
 
@@ -79,6 +80,7 @@ class GnDesc(C.Structure):
         ("N", C.c_int32), ("HW", C.c_int32), ("C1", C.c_int32), ("C2", C.c_int32), ("groups", C.c_int32),
         ("eps", C.c_float), ("silu", C.c_int32), ("dtype", C.c_int32),
         ("ngroups", C.c_int32), ("n_end", C.c_int32 * 4), ("gamma_g", C.c_void_p * 4), ("beta_g", C.c_void_p * 4),
+        ("ext_chunks", C.c_int32),
     ]
 
 

@@ -934,18 +934,26 @@ class StepRunner:
         if st.cond_cat is not None and st.cond_cat.shape == h0.shape and [c.data_ptr() for c in conds] == st.cond_src:
             # sample = conv_in(sample) + cond (CL:197-203) for every net, and the UNet's conv_in, in one grouped launch:
             # every slot reads the same sample tensor (x_rep), the conditions are batch-concatenated in slot order
-            ops.conv_gemm(x, [e.conv_in for e in encs], residual=st.cond_cat, group_n=counts, out=h0, x_rep=ge.ntot // N, wide=True)
+            ops.conv_gemm(x, [e.conv_in for e in encs], residual=st.cond_cat, group_n=counts, out=h0, x_rep=ge.ntot // N, wide=True,
+                          gn_groups=ue.cfg.norm_num_groups)
         else:
             a = 0
             wide = ops.wide_stream(x.dtype)
             if wide:                                      # the sums' low parts, slice by slice like h0 (the UNet's slot has none: zero)
                 h0._lo = torch.zeros_like(h0)
+            G = ue.cfg.norm_num_groups                    # ... and the GroupNorm statistics of the slices, into one table (ops.GN_HANDOVER)
+            hw = x.shape[1] * x.shape[2]
+            gnp = torch.empty((ge.ntot, 2 * (hw // 64), G, 2), dtype=torch.float32, device=x.device) \
+                if (ops.GN_HANDOVER and hw % 64 == 0 and c0 % 8 == 0 and c0 % G == 0) else None
+            gkw = lambda a_: dict(gn_groups=G, gn_part=gnp[a_:a_ + N]) if gnp is not None else {}
             for net, pos in self.groups:                  # sample = conv_in(sample) + cond   (CL:197-203)
                 for p in pos:
                     ops.conv_gemm(x, net.engine.conv_in, residual=conds[p], out=h0[a:a + N], wide=True,
-                                  out_lo=h0._lo[a:a + N] if wide else None)
+                                  out_lo=h0._lo[a:a + N] if wide else None, **gkw(a))
                     a += N
-            ops.conv_gemm(x, ue.conv_in, out=h0[a:a + N])
+            ops.conv_gemm(x, ue.conv_in, out=h0[a:a + N], **gkw(a))
+            if gnp is not None:
+                h0._gnp = (gnp, G)
         if step_idx is not None and st.tproj_table is not None and st.tproj_table.shape[1] == ge.ntot:
             # one gather instead of 4 x (sinusoid + 3 linears) per step; fp16/bf16 rows moved as fp32 words
             T = st.tproj_table.shape[0]

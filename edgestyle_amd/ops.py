@@ -462,6 +462,12 @@ def linear_xs(x: torch.Tensor, pw, M: int, out: torch.Tensor, group_rows=None) -
 WIDE_STREAM = _os.environ.get("ES_WIDE_STREAM", "auto")
 
 
+# GroupNorm statistics handed over by the producing GEMM (es_gemm_desc.gn_part -> es_gn_desc.ext_chunks): the convolution whose
+# output a GroupNorm normalises writes the per-(sample, 64-pixel block, group) sums from its epilogue; the GroupNorm is then one
+# streaming pass (no statistics launch, no second read).  The table rides on the output tensor as `._gnp`.  ES_GN_HANDOVER=0: off.
+GN_HANDOVER = _os.environ.get("ES_GN_HANDOVER", "1") == "1"
+
+
 def wide_stream(dtype) -> bool:
     return WIDE_STREAM == "1" or (WIDE_STREAM == "auto" and dtype == torch.bfloat16)
 
@@ -480,7 +486,8 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
               out_scale_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
               out_hw=None, splitk: Optional[int] = None, stages: int = 0,
               group_n: Optional[Sequence[int]] = None, tail: Optional[Sequence[torch.Tensor]] = None,
-              x_rep: int = 1, wide: bool = False, out_lo: Optional[torch.Tensor] = None):
+              x_rep: int = 1, wide: bool = False, out_lo: Optional[torch.Tensor] = None, gn_groups: int = 0,
+              gn_part: Optional[torch.Tensor] = None):
     """x: [N,H,W,C1] (+ x2 [N,H,W,C2]); returns [N,Hout,Wout,Cout] (Cout/2 for GEGLU).
 
     x_rep > 1: the launch covers x_rep * N samples, sample n reading x[n % N] (es_gemm_desc.x_nmod): one sample tensor
@@ -552,6 +559,15 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     d.act, d.splitk, d.bn, d.dtype, d.out_scale = act_i, splitk, bn, _dt(x), out_scale
     d.stages = stages or FORCE_STAGES
     d.korder = pw.korder
+    if (gn_groups > 0 and GN_HANDOVER and cstore % 8 == 0 and (Hout * Wout) % 64 == 0 and not pw.geglu and pw.ln_colsum is None
+            and pw.cout % gn_groups == 0 and pw.cout // gn_groups <= (160 if bn == 320 else bn)):
+        # the consumer of `out` is a GroupNorm over gn_groups groups: hand its statistics over from this launch's epilogue
+        shape = (N, 2 * (Hout * Wout // 64), gn_groups, 2)
+        part = gn_part if gn_part is not None else torch.empty(shape, dtype=torch.float32, device=x.device)
+        if tuple(part.shape) != shape or part.dtype != torch.float32 or not part.is_contiguous():
+            raise L.EdgeStyleHipError(f"conv_gemm: gn_part must be a contiguous fp32 {shape}")
+        d.gn_part, d.gn_groups = part.data_ptr(), gn_groups
+        out._gnp = (part, gn_groups)
     if wide and residual is not None and wide_stream(x.dtype) and cstore % 8 == 0 and not pw.geglu:
         # this launch adds into the residual stream: the sum over (residual hi + lo) in fp32, stored as hi + lo
         lo_in = getattr(residual, "_lo", None)
@@ -705,6 +721,10 @@ def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu: bool
         if isinstance(gamma, (list, tuple)):
             gamma, beta = gamma[0], beta[0]
         d.gamma, d.beta, d.partials = gamma.data_ptr(), beta.data_ptr(), part.data_ptr()
+    gnp = getattr(x, "_gnp", None)
+    if gnp is not None and x2 is None and GN_HANDOVER and gnp[1] == groups and (H * W) % 64 == 0 \
+            and tuple(gnp[0].shape) == (N, 2 * (H * W // 64), groups, 2):
+        d.partials, d.ext_chunks = gnp[0].data_ptr(), 2 * (H * W // 64)      # the producer's statistics: one streaming pass
     d.N, d.HW, d.C1, d.C2, d.groups = N, H * W, C1, C2, groups
     d.eps, d.silu, d.dtype = eps, 1 if silu else 0, _dt(x)
     L.check(L.load().es_group_norm(C.byref(d), _stream()), "es_group_norm")

@@ -112,6 +112,15 @@ typedef struct {
    * residual_lo needs out_lo.  Both NULL: the single-tensor stream of every fp16 pipeline. */
   const void* residual_lo;
   void* out_lo;
+  /* GroupNorm statistics handed over by the producer: the epilogue (fused or split-K reduce) also writes, for every 64-pixel block
+   * of its output and every GroupNorm group, the block's sum and sum of squares - fp32 [N][2 * HW/64][gn_groups][2]: entry
+   * 2 * block + 0 holds the part of a group inside the N tile the group STARTS in, entry 2 * block + 1 the part inside the next
+   * N tile (zero when the group ends in its first tile) - summed in ONE fixed order whatever tile, wave count or split-K the launch
+   * uses (64 pixels as 8 sequential sub-blocks of 8, then the group's channels in order).  es_group_norm with
+   * es_gn_desc.ext_chunks = 2 * HW/64 then normalises in a single pass: no statistics launch, no second read.  Needs the
+   * output's H*W % 64 == 0, Cout % 8 == 0 and Cout / gn_groups <= the N tile.  NULL: no statistics. */
+  float* gn_part;
+  int32_t gn_groups;
 } es_gemm_desc;
 int es_conv_gemm(const es_gemm_desc* d, void* stream);
 size_t es_conv_gemm_workspace_bytes(const es_gemm_desc* d);
@@ -171,6 +180,9 @@ typedef struct {
   int32_t n_end[4];
   const float* gamma_g[4];
   const float* beta_g[4];
+  /* > 0: `partials` already HOLDS the statistics of x as ext_chunks partial sums per (sample, group) - written by the producing
+   * es_conv_gemm launch (es_gemm_desc.gn_part, ext_chunks = 2 * HW/64): no statistics pass, one read of x.  One source only. */
+  int32_t ext_chunks;
 } es_gn_desc;
 int es_group_norm(const es_gn_desc* d, void* stream);
 size_t es_group_norm_partials_bytes(int N, int groups);

@@ -951,3 +951,80 @@ def test_conv_gemm_wide_residual_stream(N, H, C, Cout, k, bn, splitk):
     e_wide = float((hi + lo - want).abs().mean())
     e_one = float((y1.float().cpu().permute(0, 3, 1, 2) - want).abs().mean())
     assert e_wide < 0.5 * e_one, (e_wide, e_one)
+
+
+@pytest.mark.parametrize("N,H,C,Cout,k,bn,splitk", [
+    (2, 16, 128, 320, 3, 160, None),      # 10-channel groups inside one 160-wide tile
+    (2, 16, 128, 640, 3, 128, None),      # 20-channel groups straddle the 128-wide tiles: the two-entry scheme
+    (8, 32, 128, 320, 3, 320, None),      # the 256 x 320 tile (two epilogue passes of 160)
+    (1, 8, 256, 1280, 3, 64, None),       # 40-channel groups over 64-wide tiles
+    (1, 8, 640, 1280, 3, 128, 5),         # split-K: the statistics come from the reduce kernel
+    (3, 8, 64, 64, 1, 64, None),          # tiny width: 2-channel groups
+])
+def test_group_norm_statistics_handed_over_by_the_producer(N, H, C, Cout, k, bn, splitk):
+    """es_gemm_desc.gn_part -> es_gn_desc.ext_chunks: the convolution's epilogue writes the per-(sample,
+    64-pixel block, group) sums of its output; the GroupNorm that reads it is one streaming pass.  Same normalised tensor as the
+    stand-alone GroupNorm of the same convolution output (statistics summed in another order: fp32 rounding apart), both against
+    torch; the convolution's own output is bit-identical with and without the hand-over."""
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(N + C + Cout + k + bn)
+    x = q16(torch.randn(N, C, H, H, generator=g))
+    w = q16(torch.randn(Cout, C, k, k, generator=g) / math.sqrt(C * k * k))
+    b = torch.randn(Cout, generator=g) * 0.5
+    gam, bet = (1 + 0.1 * torch.randn(Cout, generator=g)).to(DEV), (0.1 * torch.randn(Cout, generator=g)).to(DEV)
+    pw = ops.pack_weight(w, b, torch.float16, DEV)
+    prev = ops.FORCE_BN
+    try:
+        ops.FORCE_BN = bn
+        y0 = ops.conv_gemm(nhwc(x), pw, splitk=splitk)
+        y1 = ops.conv_gemm(nhwc(x), pw, splitk=splitk, gn_groups=32)
+    finally:
+        ops.FORCE_BN = prev
+    assert torch.equal(y0, y1) and hasattr(y1, "_gnp") and not hasattr(y0, "_gnp")
+    n0 = ops.group_norm(y0, gam, bet, 32, 1e-5, True)          # stand-alone statistics
+    n1 = ops.group_norm(y1, gam, bet, 32, 1e-5, True)          # the producer's
+    torch.cuda.synchronize()
+    part = y1._gnp[0].double().cpu()                            # [N, 2 * HW/64, 32, 2]
+    yc = y1.double().cpu().reshape(N, H * H, 32, Cout // 32)
+    assert torch.allclose(part[..., 0].sum(1), yc.sum((1, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(part[..., 1].sum(1), (yc * yc).sum((1, 3)), rtol=1e-4, atol=1e-2)
+    ref = F.silu(F.group_norm(y1.float().permute(0, 3, 1, 2), 32, gam, bet, 1e-5))
+    assert rel_err(n1.permute(0, 3, 1, 2), ref) < 3e-3 and rel_err(n0.permute(0, 3, 1, 2), ref) < 3e-3
+    assert rel_err(n1, n0) < 2e-3
+
+
+def test_group_norm_hand_over_does_not_depend_on_the_tile_or_the_grouping():
+    """The statistics a producer hands over are summed in ONE order whatever tile, split-K or grouping the launch uses: the
+    same convolution through the 64-, 128-, 160-wide and 256 x 320 tiles and through a split-K launch gives bit-identical partial
+    tables (their outputs are bit-identical for splitk 1 already), and a grouped launch equals its per-net launches."""
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(5)
+    N, H, C, Cout = 8, 32, 128, 640
+    x = nhwc(q16(torch.randn(N, C, H, H, generator=g)))
+    pws = [ops.pack_weight(q16(torch.randn(Cout, C, 3, 3, generator=g) / math.sqrt(9 * C)), torch.randn(Cout, generator=g) * 0.3,
+                           torch.float16, DEV) for _ in range(2)]
+    prev = ops.FORCE_BN
+    tabs, outs = {}, {}
+    try:
+        for bn in (64, 128, 320):
+            ops.FORCE_BN = bn
+            y = ops.conv_gemm(x, pws[0], splitk=1, gn_groups=32)
+            tabs[bn], outs[bn] = y._gnp[0].clone(), y.clone()
+        ops.FORCE_BN = 128
+        grp = ops.conv_gemm(x, pws, group_n=[4, 4], splitk=1, gn_groups=32)
+        sep = [ops.conv_gemm(x[i * 4:(i + 1) * 4].contiguous(), pws[i], splitk=1, gn_groups=32) for i in range(2)]
+    finally:
+        ops.FORCE_BN = prev
+    torch.cuda.synchronize()
+    assert torch.equal(outs[64], outs[128]) and torch.equal(outs[128], outs[320])
+    # per (sample, block, group) the two entries may be split differently between N tiles: their SUM is what the consumer adds up,
+    # and it is made of the same per-channel sums - compare that sum
+    for bn in (128, 320):
+        a = tabs[64].view(N, -1, 2, 32, 2)
+        b = tabs[bn].view(N, -1, 2, 32, 2)
+        assert torch.allclose(a.sum(2), b.sum(2), rtol=2e-6, atol=1e-4)
+    assert torch.equal(grp, torch.cat(sep)) and torch.equal(grp._gnp[0], torch.cat([s._gnp[0] for s in sep]))
+    gam, bet = torch.ones(Cout, device=DEV), torch.zeros(Cout, device=DEV)
+    n_grp = ops.group_norm(grp, [gam, gam], [bet, bet], 32, 1e-5, True, group_n=[4, 4])
+    n_sep = torch.cat([ops.group_norm(s, gam, bet, 32, 1e-5, True) for s in sep])
+    assert torch.equal(n_grp, n_sep)
