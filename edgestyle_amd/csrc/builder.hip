@@ -396,7 +396,12 @@ struct Builder {
     ok(es_add(a.ptr(), b.ptr(), out.ptr(), a.numel(), dt, nullptr), "es_add");
     return out;
   }
-  static bool gn_handover() { static const bool on = [] { const char* e = getenv("ES_GN_HANDOVER"); return !(e && e[0] == '0'); }(); return on; }   // ops.GN_HANDOVER
+  // ops.gn_handover: a rule of the shape alone - where the stand-alone GroupNorm is the two-launch form
+  static bool gn_handover(long long hw, int c, int groups) {
+    static const std::string mode = [] { const char* e = getenv("ES_GN_HANDOVER"); return std::string(e ? e : "1"); }();
+    if ((mode != "1" && mode != "all") || c % 8 || hw % 64 || c % groups || c / groups > 64) return false;
+    return mode == "all" || !es_group_norm_is_slab((int)hw, c, groups);
+  }
   // ops.wide_stream: "auto" (default) = bf16 pipelines only
   bool wide_stream() const {
     static const std::string mode = [] { const char* e = getenv("ES_WIDE_STREAM"); return std::string(e ? e : "auto"); }();
@@ -640,8 +645,7 @@ struct Builder {
     d.xcd_m_fastest = (!grouped && splitk == 1 && M <= 2048 && pw->w_numel() > src_numel) ? 1 : 0;
     d.x_nmod = a.x_rep > 1 ? nsrc : 0;
     d.korder = pw->korder;
-    if (a.gn_groups > 0 && gn_handover() && cstore % 8 == 0 && hw % 64 == 0 && !pw->geglu && !pw->ln_colsum && pw->cout % a.gn_groups == 0 &&
-        pw->cout / a.gn_groups <= (bn == 320 ? 160 : bn)) {
+    if (a.gn_groups > 0 && gn_handover(hw, cstore, a.gn_groups) && !pw->geglu && !pw->ln_colsum && pw->cout / a.gn_groups <= (bn == 320 ? 160 : bn)) {
       T part = empty(N, (int)(2 * (hw / 64)), 1, a.gn_groups * 2, 4);
       d.gn_part = (float*)part.ptr(); d.gn_groups = a.gn_groups;
       out.gnp = part.p; out.gnp_b = part.b; out.gnp_groups = a.gn_groups;
@@ -733,7 +737,7 @@ struct Builder {
       for (size_t g = 0; g < nl.size(); ++g) { acc += group_n[g]; d.n_end[g] = acc; d.gamma_g[g] = (const float*)nl[g].g; d.beta_g[g] = (const float*)nl[g].b; }
     } else { d.gamma = (const float*)nl[0].g; d.beta = (const float*)nl[0].b; }
     d.N = N; d.HW = (int)x.hw(); d.C1 = C1; d.C2 = C2; d.groups = groups; d.eps = eps; d.silu = silu; d.dtype = dt;
-    if (x.gnp && !x2 && gn_handover() && x.gnp_groups == groups && x.hw() % 64 == 0) {      // the producer's statistics: one streaming pass
+    if (x.gnp && !x2 && gn_handover(x.hw(), C1, groups) && x.gnp_groups == groups) {      // the producer's statistics: one streaming pass
       d.partials = (float*)x.gnp; d.ext_chunks = (int)(2 * (x.hw() / 64));
     }
     ok(es_group_norm(&d, nullptr), "es_group_norm");

@@ -783,8 +783,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const es_gemm_desc p
 // through an LDS tile and gn_emit_partials sums them in the order the fused epilogues use.  Same arithmetic per element as
 // splitk_reduce_kernel (the two produce identical outputs).
 template <typename T, int CB>
-__global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const es_gemm_desc p, const int M) {
-  constexpr int OCT = CB / 8, ITEMS = 64 * OCT / 256, EROW = CB * 2 + 16;
+__global__ __launch_bounds__(64 * (CB / 8)) void splitk_reduce_gn_kernel(const es_gemm_desc p, const int M) {
+  // one (pixel, 8 channels) item per thread, like splitk_reduce_kernel: every thread's slab loads are in flight at once (a first
+  // version with 256 threads and 4-5 items per thread took 14 us where the plain reduce takes 8: its round trips ran one after another)
+  constexpr int OCT = CB / 8, NTH = 64 * OCT, ITEMS = 1, EROW = CB * 2 + 16;
   __shared__ __attribute__((aligned(16))) char smem[64 * EROW + (8 + 1) * CB * 8];
   const int tid = threadIdx.x;
   const int nct = p.rows_padded / CB;
@@ -795,7 +797,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const es_gemm_des
   const size_t zstride = (size_t)M * p.rows_padded;
 #pragma unroll
   for (int it = 0; it < ITEMS; ++it) {
-    const int idx = tid + it * 256;
+    const int idx = tid + it * NTH;
     const int row = idx / OCT, o = idx - row * OCT;
     const int m = mb * 64 + row, c0 = ct * CB + o * 8;
     u32x4 res = {0u, 0u, 0u, 0u};
@@ -870,7 +872,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const es_gemm_des
     *(u32x4*)(smem + row * EROW + o * 16) = res;
   }
   __syncthreads();
-  gn_emit_partials<T, 256>(smem, EROW, 64, CB, (float*)(smem + 64 * EROW), p.gn_part, mb * 64, M, ct * CB, p.Cout, HW, p.gn_groups, tid);
+  gn_emit_partials<T, NTH>(smem, EROW, 64, CB, (float*)(smem + 64 * EROW), p.gn_part, mb * 64, M, ct * CB, p.Cout, HW, p.gn_groups, tid);
 }
 
 template <typename T>
@@ -941,11 +943,12 @@ int launch(const es_gemm_desc& d, hipStream_t st) {
 #undef ES_LAUNCH_LN
   if (d.splitk > 1 && d.gn_part) {
     // statistics hand-over: 64 pixels x CB channels per workgroup, CB like the N tile the statistics' two-entry scheme assumes
-    const int cb = d.bn == 320 ? 160 : d.bn;
+    // (CB channels per workgroup: 64 x CB / 8 <= 1024 threads, and CB must hold a GroupNorm group: es_conv_gemm checks cpg <= 64 here)
+    const int cb = (d.bn == 320 || d.bn == 160) ? 80 : (d.bn == 128 ? 128 : 64);
     dim3 grid((unsigned)((M / 64) * (d.rows_padded / cb)));
-    if (cb == 160) hipLaunchKernelGGL((splitk_reduce_gn_kernel<T, 160>), grid, dim3(256), 0, st, d, M);
-    else if (cb == 128) hipLaunchKernelGGL((splitk_reduce_gn_kernel<T, 128>), grid, dim3(256), 0, st, d, M);
-    else hipLaunchKernelGGL((splitk_reduce_gn_kernel<T, 64>), grid, dim3(256), 0, st, d, M);
+    if (cb == 80) hipLaunchKernelGGL((splitk_reduce_gn_kernel<T, 80>), grid, dim3(64 * 10), 0, st, d, M);
+    else if (cb == 128) hipLaunchKernelGGL((splitk_reduce_gn_kernel<T, 128>), grid, dim3(64 * 16), 0, st, d, M);
+    else hipLaunchKernelGGL((splitk_reduce_gn_kernel<T, 64>), grid, dim3(64 * 8), 0, st, d, M);
   } else if (d.splitk > 1) {
     const long long total = (long long)M * (d.rows_padded / 8);
     hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, M);
@@ -1000,7 +1003,7 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
   if (d->gn_part) {
     const int hw = d->Hout * d->Wout;
     if (d->gn_groups < 1 || d->Cout % d->gn_groups || (d->Cout & 7) || hw % 64 || d->act == ES_ACT_GEGLU || d->ln_colsum ||
-        d->Cout / d->gn_groups > (d->bn == 320 ? 160 : d->bn)) {
+        d->Cout / d->gn_groups > (d->bn == 320 ? 160 : d->bn) || (d->splitk > 1 && d->Cout / d->gn_groups > 64)) {
       es_set_error("es_conv_gemm: gn_part needs H*W % 64 == 0, Cout % 8 == 0 and whole GroupNorm groups no wider than the N tile"); return -1; }
   }
   if (d->korder != 0 && (d->korder != 1 || d->ksize != 3 || d->C1 % BK || d->C2 % BK || d->ln_colsum)) {

@@ -944,7 +944,7 @@ class StepRunner:
             G = ue.cfg.norm_num_groups                    # ... and the GroupNorm statistics of the slices, into one table (ops.GN_HANDOVER)
             hw = x.shape[1] * x.shape[2]
             gnp = torch.empty((ge.ntot, 2 * (hw // 64), G, 2), dtype=torch.float32, device=x.device) \
-                if (ops.GN_HANDOVER and hw % 64 == 0 and c0 % 8 == 0 and c0 % G == 0) else None
+                if ops.gn_handover(hw, c0, G) else None
             gkw = lambda a_: dict(gn_groups=G, gn_part=gnp[a_:a_ + N]) if gnp is not None else {}
             for net, pos in self.groups:                  # sample = conv_in(sample) + cond   (CL:197-203)
                 for p in pos:

@@ -465,7 +465,21 @@ WIDE_STREAM = _os.environ.get("ES_WIDE_STREAM", "auto")
 # GroupNorm statistics handed over by the producing GEMM (es_gemm_desc.gn_part -> es_gn_desc.ext_chunks): the convolution whose
 # output a GroupNorm normalises writes the per-(sample, 64-pixel block, group) sums from its epilogue; the GroupNorm is then one
 # streaming pass (no statistics launch, no second read).  The table rides on the output tensor as `._gnp`.  ES_GN_HANDOVER=0: off.
-GN_HANDOVER = _os.environ.get("ES_GN_HANDOVER", "1") == "1"
+GN_HANDOVER = _os.environ.get("ES_GN_HANDOVER", "1") in ("1", "all")
+
+
+def gn_handover(hw: int, c: int, groups: int) -> bool:
+    """Does a GEMM whose [.., hw, c] output feeds a GroupNorm over `groups` groups hand the statistics over?  A rule of the SHAPE
+    alone (grouped and per-net launches of a layer must agree): where the stand-alone GroupNorm is the two-launch form - slabs too
+    large for a workgroup's registers, the 64 x 64 level - the hand-over removes its statistics launch and second read; the
+    one-launch slab form of the deeper levels already reads its input once, and there the hand-over measured a net loss
+    (profiles/r04_gn_handover.txt)."""
+    if not GN_HANDOVER or c % 8 or hw % 64 or c % groups or c // groups > 64:
+        return False
+    return GN_HANDOVER_ALL or not L.load().es_group_norm_is_slab(hw, c, groups)
+
+
+GN_HANDOVER_ALL = _os.environ.get("ES_GN_HANDOVER", "1") == "all"     # tool switch: also where the consumer is the slab form
 
 
 def wide_stream(dtype) -> bool:
@@ -559,8 +573,8 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     d.act, d.splitk, d.bn, d.dtype, d.out_scale = act_i, splitk, bn, _dt(x), out_scale
     d.stages = stages or FORCE_STAGES
     d.korder = pw.korder
-    if (gn_groups > 0 and GN_HANDOVER and cstore % 8 == 0 and (Hout * Wout) % 64 == 0 and not pw.geglu and pw.ln_colsum is None
-            and pw.cout % gn_groups == 0 and pw.cout // gn_groups <= (160 if bn == 320 else bn)):
+    if (gn_groups > 0 and gn_handover(Hout * Wout, cstore, gn_groups) and not pw.geglu and pw.ln_colsum is None
+            and pw.cout // gn_groups <= (160 if bn == 320 else bn)):
         # the consumer of `out` is a GroupNorm over gn_groups groups: hand its statistics over from this launch's epilogue
         shape = (N, 2 * (Hout * Wout // 64), gn_groups, 2)
         part = gn_part if gn_part is not None else torch.empty(shape, dtype=torch.float32, device=x.device)
@@ -722,7 +736,7 @@ def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu: bool
             gamma, beta = gamma[0], beta[0]
         d.gamma, d.beta, d.partials = gamma.data_ptr(), beta.data_ptr(), part.data_ptr()
     gnp = getattr(x, "_gnp", None)
-    if gnp is not None and x2 is None and GN_HANDOVER and gnp[1] == groups and (H * W) % 64 == 0 \
+    if gnp is not None and x2 is None and gn_handover(H * W, C1, groups) and gnp[1] == groups \
             and tuple(gnp[0].shape) == (N, 2 * (H * W // 64), groups, 2):
         d.partials, d.ext_chunks = gnp[0].data_ptr(), 2 * (H * W // 64)      # the producer's statistics: one streaming pass
     d.N, d.HW, d.C1, d.C2, d.groups = N, H * W, C1, C2, groups

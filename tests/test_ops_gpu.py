@@ -960,6 +960,8 @@ def test_conv_gemm_wide_residual_stream(N, H, C, Cout, k, bn, splitk):
     (1, 8, 256, 1280, 3, 64, None),       # 40-channel groups over 64-wide tiles
     (1, 8, 640, 1280, 3, 128, 5),         # split-K: the statistics come from the reduce kernel
     (3, 8, 64, 64, 1, 64, None),          # tiny width: 2-channel groups
+    (2, 64, 64, 320, 3, 160, None),       # the 64 x 64 level (the shape the shipped policy hands over)
+    (2, 64, 128, 320, 3, 160, 3),         # ... from a split-K launch (the UNet decoder at batch 1)
 ])
 def test_group_norm_statistics_handed_over_by_the_producer(N, H, C, Cout, k, bn, splitk):
     """es_gemm_desc.gn_part -> es_gn_desc.ext_chunks: the convolution's epilogue writes the per-(sample,
@@ -973,16 +975,16 @@ def test_group_norm_statistics_handed_over_by_the_producer(N, H, C, Cout, k, bn,
     b = torch.randn(Cout, generator=g) * 0.5
     gam, bet = (1 + 0.1 * torch.randn(Cout, generator=g)).to(DEV), (0.1 * torch.randn(Cout, generator=g)).to(DEV)
     pw = ops.pack_weight(w, b, torch.float16, DEV)
-    prev = ops.FORCE_BN
+    prev = ops.FORCE_BN, ops.GN_HANDOVER_ALL
     try:
-        ops.FORCE_BN = bn
+        ops.FORCE_BN, ops.GN_HANDOVER_ALL = bn, True           # every shape (the shipped policy hands over at the 64 x 64 level only)
         y0 = ops.conv_gemm(nhwc(x), pw, splitk=splitk)
         y1 = ops.conv_gemm(nhwc(x), pw, splitk=splitk, gn_groups=32)
+        assert torch.equal(y0, y1) and hasattr(y1, "_gnp") and not hasattr(y0, "_gnp")
+        n0 = ops.group_norm(y0, gam, bet, 32, 1e-5, True)      # stand-alone statistics
+        n1 = ops.group_norm(y1, gam, bet, 32, 1e-5, True)      # the producer's
     finally:
-        ops.FORCE_BN = prev
-    assert torch.equal(y0, y1) and hasattr(y1, "_gnp") and not hasattr(y0, "_gnp")
-    n0 = ops.group_norm(y0, gam, bet, 32, 1e-5, True)          # stand-alone statistics
-    n1 = ops.group_norm(y1, gam, bet, 32, 1e-5, True)          # the producer's
+        ops.FORCE_BN, ops.GN_HANDOVER_ALL = prev
     torch.cuda.synchronize()
     part = y1._gnp[0].double().cpu()                            # [N, 2 * HW/64, 32, 2]
     yc = y1.double().cpu().reshape(N, H * H, 32, Cout // 32)
@@ -1003,9 +1005,10 @@ def test_group_norm_hand_over_does_not_depend_on_the_tile_or_the_grouping():
     x = nhwc(q16(torch.randn(N, C, H, H, generator=g)))
     pws = [ops.pack_weight(q16(torch.randn(Cout, C, 3, 3, generator=g) / math.sqrt(9 * C)), torch.randn(Cout, generator=g) * 0.3,
                            torch.float16, DEV) for _ in range(2)]
-    prev = ops.FORCE_BN
+    prev = ops.FORCE_BN, ops.GN_HANDOVER_ALL
     tabs, outs = {}, {}
     try:
+        ops.GN_HANDOVER_ALL = True
         for bn in (64, 128, 320):
             ops.FORCE_BN = bn
             y = ops.conv_gemm(x, pws[0], splitk=1, gn_groups=32)
@@ -1013,8 +1016,11 @@ def test_group_norm_hand_over_does_not_depend_on_the_tile_or_the_grouping():
         ops.FORCE_BN = 128
         grp = ops.conv_gemm(x, pws, group_n=[4, 4], splitk=1, gn_groups=32)
         sep = [ops.conv_gemm(x[i * 4:(i + 1) * 4].contiguous(), pws[i], splitk=1, gn_groups=32) for i in range(2)]
+        gam, bet = torch.ones(Cout, device=DEV), torch.zeros(Cout, device=DEV)
+        n_grp = ops.group_norm(grp, [gam, gam], [bet, bet], 32, 1e-5, True, group_n=[4, 4])
+        n_sep = torch.cat([ops.group_norm(s, gam, bet, 32, 1e-5, True) for s in sep])
     finally:
-        ops.FORCE_BN = prev
+        ops.FORCE_BN, ops.GN_HANDOVER_ALL = prev
     torch.cuda.synchronize()
     assert torch.equal(outs[64], outs[128]) and torch.equal(outs[128], outs[320])
     # per (sample, block, group) the two entries may be split differently between N tiles: their SUM is what the consumer adds up,
@@ -1024,7 +1030,4 @@ def test_group_norm_hand_over_does_not_depend_on_the_tile_or_the_grouping():
         b = tabs[bn].view(N, -1, 2, 32, 2)
         assert torch.allclose(a.sum(2), b.sum(2), rtol=2e-6, atol=1e-4)
     assert torch.equal(grp, torch.cat(sep)) and torch.equal(grp._gnp[0], torch.cat([s._gnp[0] for s in sep]))
-    gam, bet = torch.ones(Cout, device=DEV), torch.zeros(Cout, device=DEV)
-    n_grp = ops.group_norm(grp, [gam, gam], [bet, bet], 32, 1e-5, True, group_n=[4, 4])
-    n_sep = torch.cat([ops.group_norm(s, gam, bet, 32, 1e-5, True) for s in sep])
     assert torch.equal(n_grp, n_sep)
