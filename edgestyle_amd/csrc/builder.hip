@@ -398,7 +398,7 @@ struct Builder {
   }
   // ops.gn_handover: a rule of the shape alone - where the stand-alone GroupNorm is the two-launch form
   static bool gn_handover(long long hw, int c, int groups) {
-    static const std::string mode = [] { const char* e = getenv("ES_GN_HANDOVER"); return std::string(e ? e : "1"); }();
+    static const std::string mode = [] { const char* e = getenv("ES_GN_HANDOVER"); return std::string(e ? e : "0"); }();      // off by default: measured a net loss (ops.py)
     if ((mode != "1" && mode != "all") || c % 8 || hw % 64 || c % groups || c / groups > 64) return false;
     return mode == "all" || !es_group_norm_is_slab((int)hw, c, groups);
   }

@@ -464,8 +464,12 @@ WIDE_STREAM = _os.environ.get("ES_WIDE_STREAM", "auto")
 
 # GroupNorm statistics handed over by the producing GEMM (es_gemm_desc.gn_part -> es_gn_desc.ext_chunks): the convolution whose
 # output a GroupNorm normalises writes the per-(sample, 64-pixel block, group) sums from its epilogue; the GroupNorm is then one
-# streaming pass (no statistics launch, no second read).  The table rides on the output tensor as `._gnp`.  ES_GN_HANDOVER=0: off.
-GN_HANDOVER = _os.environ.get("ES_GN_HANDOVER", "1") in ("1", "all")
+# streaming pass (no statistics launch, no second read).  The table rides on the output tensor as `._gnp`.
+# OFF by default (ES_GN_HANDOVER=1: at the 64 x 64 level, where the stand-alone GroupNorm is the two-launch form; "all": everywhere):
+# built and measured in round 4, it LOSES - the epilogues' extra LDS passes and barriers cost more than the statistics launch they
+# replace (batch 1: 476 vs 466 ms per image at the 64 x 64 level only, 482 everywhere; batch 8: 2623 vs 2553 ms;
+# profiles/r04_gn_handover.txt) - the deeper levels' one-launch slab GroupNorm already reads its input once.
+GN_HANDOVER = _os.environ.get("ES_GN_HANDOVER", "0") in ("1", "all")
 
 
 def gn_handover(hw: int, c: int, groups: int) -> bool:
@@ -479,7 +483,7 @@ def gn_handover(hw: int, c: int, groups: int) -> bool:
     return GN_HANDOVER_ALL or not L.load().es_group_norm_is_slab(hw, c, groups)
 
 
-GN_HANDOVER_ALL = _os.environ.get("ES_GN_HANDOVER", "1") == "all"     # tool switch: also where the consumer is the slab form
+GN_HANDOVER_ALL = _os.environ.get("ES_GN_HANDOVER", "0") == "all"     # tool switch: also where the consumer is the slab form
 
 
 def wide_stream(dtype) -> bool:

@@ -975,16 +975,16 @@ def test_group_norm_statistics_handed_over_by_the_producer(N, H, C, Cout, k, bn,
     b = torch.randn(Cout, generator=g) * 0.5
     gam, bet = (1 + 0.1 * torch.randn(Cout, generator=g)).to(DEV), (0.1 * torch.randn(Cout, generator=g)).to(DEV)
     pw = ops.pack_weight(w, b, torch.float16, DEV)
-    prev = ops.FORCE_BN, ops.GN_HANDOVER_ALL
+    prev = ops.FORCE_BN, ops.GN_HANDOVER_ALL, ops.GN_HANDOVER
     try:
-        ops.FORCE_BN, ops.GN_HANDOVER_ALL = bn, True           # every shape (the shipped policy hands over at the 64 x 64 level only)
+        ops.FORCE_BN, ops.GN_HANDOVER_ALL, ops.GN_HANDOVER = bn, True, True      # opt-in feature (ES_GN_HANDOVER), every shape
         y0 = ops.conv_gemm(nhwc(x), pw, splitk=splitk)
         y1 = ops.conv_gemm(nhwc(x), pw, splitk=splitk, gn_groups=32)
         assert torch.equal(y0, y1) and hasattr(y1, "_gnp") and not hasattr(y0, "_gnp")
         n0 = ops.group_norm(y0, gam, bet, 32, 1e-5, True)      # stand-alone statistics
         n1 = ops.group_norm(y1, gam, bet, 32, 1e-5, True)      # the producer's
     finally:
-        ops.FORCE_BN, ops.GN_HANDOVER_ALL = prev
+        ops.FORCE_BN, ops.GN_HANDOVER_ALL, ops.GN_HANDOVER = prev
     torch.cuda.synchronize()
     part = y1._gnp[0].double().cpu()                            # [N, 2 * HW/64, 32, 2]
     yc = y1.double().cpu().reshape(N, H * H, 32, Cout // 32)
@@ -1005,10 +1005,10 @@ def test_group_norm_hand_over_does_not_depend_on_the_tile_or_the_grouping():
     x = nhwc(q16(torch.randn(N, C, H, H, generator=g)))
     pws = [ops.pack_weight(q16(torch.randn(Cout, C, 3, 3, generator=g) / math.sqrt(9 * C)), torch.randn(Cout, generator=g) * 0.3,
                            torch.float16, DEV) for _ in range(2)]
-    prev = ops.FORCE_BN, ops.GN_HANDOVER_ALL
+    prev = ops.FORCE_BN, ops.GN_HANDOVER_ALL, ops.GN_HANDOVER
     tabs, outs = {}, {}
     try:
-        ops.GN_HANDOVER_ALL = True
+        ops.GN_HANDOVER_ALL = ops.GN_HANDOVER = True
         for bn in (64, 128, 320):
             ops.FORCE_BN = bn
             y = ops.conv_gemm(x, pws[0], splitk=1, gn_groups=32)
@@ -1020,7 +1020,7 @@ def test_group_norm_hand_over_does_not_depend_on_the_tile_or_the_grouping():
         n_grp = ops.group_norm(grp, [gam, gam], [bet, bet], 32, 1e-5, True, group_n=[4, 4])
         n_sep = torch.cat([ops.group_norm(s, gam, bet, 32, 1e-5, True) for s in sep])
     finally:
-        ops.FORCE_BN, ops.GN_HANDOVER_ALL = prev
+        ops.FORCE_BN, ops.GN_HANDOVER_ALL, ops.GN_HANDOVER = prev
     torch.cuda.synchronize()
     assert torch.equal(outs[64], outs[128]) and torch.equal(outs[128], outs[320])
     # per (sample, block, group) the two entries may be split differently between N tiles: their SUM is what the consumer adds up,
