@@ -276,7 +276,8 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? (FM == 2 
   unsigned voff[XI];
 #pragma unroll
   for (int i = 0; i < XI; ++i) voff[i] = OOB;
-  int cur_tap = -1, cur_second = -1;
+  const void* xbase = p.x;                                // (aligned launches) the current segment's source, its size, the scalar channel offset
+  int xrec = 0, soff_x = 0, seg_left = 0;
   // (a free function, not a second lambda: with a closure nested inside issue_tile's closure hipcc stopped scalarising
   //  the captures once the tail sources were added, and kept them - and the by-value descriptor - in scratch memory)
   const int ks_tail = (KK * Ctot) / BKT;               // first K-step of the tail sources (aligned launches only)
@@ -295,7 +296,16 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? (FM == 2 
     if constexpr ((ES_ABLATE & 16) != 0) {
       // ablation: no activation DMAs
     } else if constexpr (ALIGNED) {
-      const bool tail = ks >= ks_tail;                    // wave-uniform, like everything below (== tap >= KK)
+      // Tap-major order: inside a (tap, source) segment the next K-step reads the same rows 64 channels further on - ONE scalar add.
+      // Round 3 re-derived the tap, the source (four-way select chains over base pointers and sizes) and the channel bookkeeping at
+      // every K-step: ~75 scalar instructions per wave and K-step ahead of the MFMAs.  Now only at segment boundaries (every
+      // C / 64 K-steps); measured on the 256 x 320 tile, which shares the scheme: +2.5 ... +7.5 % (profiles/r04_gemm_segments.txt).
+      bool fast = false;
+      if constexpr (!KO) fast = seg_left > 0;
+      if (fast) {
+        soff_x += 128; --seg_left;
+      } else {
+      const bool tail = KO ? ks >= ks_tail : tap >= KK;         // wave-uniform, like everything below
       int q0 = pC1, q1 = pC2, q2 = pCt1, q3 = pCt2;
       asm("" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3));
       const int c1 = tail ? q2 : q0;
@@ -313,28 +323,44 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? (FM == 2 
           if (pk_up) pix = pix0[i] + ((int)(((tmask[i] >> 10) & 1) + ky) >> 1) * pk_wsrc + ((int)(((tmask[i] >> 11) & 1) + kx) >> 1);
           voff[i] = (tmask[i] & tb) ? __umul24((unsigned)pix, cs2) + (unsigned)(kc * 16) : 0xFFFFFF00u;
         }
-      } else if (tap != cur_tap || second != cur_second) {
+      } else {
         row_offsets(tap, cs, kc * 8);
-        cur_tap = tap; cur_second = second;
       }
 #if ES_ABLATE & 64
 #pragma unroll
       for (int i = 0; i < XI; ++i) voff[i] = OOB;
 #endif
-      // one load path; the descriptor is rebuilt from wave-uniform selects of (base, bytes) - a four-way branch over four
-      // ready-made descriptors made hipcc keep the by-value kernel descriptor in scratch memory (3.4x slower kernels)
+      // the source of this segment: wave-uniform selects of (base, bytes) - a four-way branch over four ready-made descriptors made
+      // hipcc keep the by-value kernel descriptor in scratch memory (3.4x slower kernels)
       // (the empty asm makes the eight candidates opaque values: hipcc otherwise rewrites "select of loads from the
       //  closure" into "load from a selected closure ADDRESS", which pins the closure and every variable it captures in
       //  scratch memory - 300-800 bytes per lane and 3.4x slower kernels)
       const void *b0 = px, *b1 = px2, *b2 = pt1, *b3 = pt2;
       int n0 = nX1, n1 = nX2, n2 = nT1, n3 = nT2;
       asm("" : "+s"(b0), "+s"(b1), "+s"(b2), "+s"(b3), "+s"(n0), "+s"(n1), "+s"(n2), "+s"(n3));
-      const void* const base = tail ? (second ? b3 : b2) : (second ? b1 : b0);
-      const int nrec = tail ? (second ? n3 : n2) : (second ? n1 : n0);
-      const auto rS = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, nrec, 0x00020000);
+      xbase = tail ? (second ? b3 : b2) : (second ? b1 : b0);
+      xrec = tail ? (second ? n3 : n2) : (second ? n1 : n0);
+      soff_x = cc * 2;
+      if constexpr (KO) {
+        if (tap < KK) {
+          if (++tap == KK) { cpos += BKT; if (cpos >= Ctot) cpos = 0; else tap = 0; }     // next chunk, or on to the tail
+        } else {
+          cpos += BKT;
+        }
+      } else {
+        // the whole segment at once: (tap, cpos) move to the first K-step of the NEXT segment
+        const int seg_end = second ? (tail ? q2 + q3 : Ctot) : c1;
+        seg_left = __builtin_amdgcn_readfirstlane(((seg_end - cpos) >> 6) - 1);
+        cpos = seg_end;
+        if (tap < KK && cpos >= Ctot) { cpos = 0; ++tap; }
+        cpos = __builtin_amdgcn_readfirstlane(cpos);
+        tap = __builtin_amdgcn_readfirstlane(tap);
+      }
+      }
+      const auto rS = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, (short)0, xrec, 0x00020000);
 #pragma unroll
       for (int i = 0; i < XI; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, (lptr_t)(xs + (wave * XI + i) * 1024), 16, (int)voff[i], cc * 2, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, (lptr_t)(xs + (wave * XI + i) * 1024), 16, (int)voff[i], soff_x, 0, 0);
     } else {
       // small-Cin layers (conv_in, cond embedding): tap and channel differ per lane, single source
       if (ks * BKT + kc * 8 < Ktrue) {
@@ -347,13 +373,7 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? (FM == 2 
       for (int i = 0; i < XI; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rX1, (lptr_t)(xs + (wave * XI + i) * 1024), 16, (int)voff[i], 0, 0, 0);
     }
-    if constexpr (KO) {
-      if (tap < KK) {
-        if (++tap == KK) { cpos += BKT; if (cpos >= Ctot) cpos = 0; else tap = 0; }     // next chunk, or on to the tail
-      } else {
-        cpos += BKT;
-      }
-    } else {
+    if constexpr (!ALIGNED) {
       cpos += BKT;
       if (tap < KK) { while (cpos >= Ctot) { cpos -= Ctot; ++tap; } }      // (the tail is the last tap: cpos just runs on)
     }

@@ -199,7 +199,6 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
   unsigned voff[XI];
 #pragma unroll
   for (int i = 0; i < XI; ++i) voff[i] = OOB;
-  int cur_tap = -1, cur_second = -1;
   const int ks_tail = (KK * Ctot) / 64;
   const int pk_ksize = p.ksize, pk_pad = p.pad, pk_up = p.upsample, pk_wsrc = p.Wsrc;
 
@@ -216,8 +215,19 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
   const void* xbase = px;
   int xrec = 0, soff_x = 0;
   bool x_skip = false;                                  // ES8P_ABL & 32 only
+  // (tap-major order) K-tiles of the current (tap, source) segment that are still to be prepared: inside a segment the next tile is
+  // the same rows 64 channels further on - ONE scalar add; everything else (tap -> row offsets, which of the four sources, its
+  // descriptor) changes only between segments.  Round 3 re-derived all of it every K-tile: ~75 scalar instructions (select chains
+  // over the four sources, the tap / channel bookkeeping) in the segment of phase 1 that runs beside the partner wave's 20 MFMAs -
+  // longer than those MFMAs, so it paced the slot (the chunk-major experiment of round 4, which ADDS ~25 instructions there, lost 7 %).
+  int seg_left = 0;
   auto select_x = [&](int ks) __attribute__((always_inline)) {
-    const bool tail = ks >= ks_tail;
+    bool fast = false;
+    if constexpr (!KO) fast = seg_left > 0;
+    if (fast) {
+      soff_x += 128; --seg_left;
+    } else {
+    const bool tail = KO ? ks >= ks_tail : tap >= KK;
     if constexpr (KO && (ES8P_ABL & 32) != 0) x_skip = !tail && tap != 0;
     int q0 = pC1, q1 = pC2, q2 = pCt1, q3 = pCt2;
     asm("" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3));
@@ -236,9 +246,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
         if (pk_up) pix = pix0[i] + ((int)(((tmask[i] >> 10) & 1) + ky) >> 1) * pk_wsrc + ((int)(((tmask[i] >> 11) & 1) + kx) >> 1);
         voff[i] = (tmask[i] & tb) ? __umul24((unsigned)pix, cs2) + (unsigned)(kc * 16) : OOB;
       }
-    } else if (tap != cur_tap || second != cur_second) {
+    } else {
       row_offsets4(voff, iy0, ix0, nb, tap, cs, kc * 8, pk_ksize, KK, pk_pad, Hin, Win, pk_up, pk_wsrc);
-      cur_tap = tap; cur_second = second;
     }
     const void *b0 = px, *b1 = px2, *b2 = pt1, *b3 = pt2;
     int n0 = nX1, n1 = nX2, n2 = nT1, n3 = nT2;
@@ -254,8 +263,14 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
         cpos += 64;
       }
     } else {
-      cpos += 64;
-      if (tap < KK) { while (cpos >= Ctot) { cpos -= Ctot; ++tap; } }
+      // the whole segment at once: (tap, cpos) move to the first tile of the NEXT segment
+      const int seg_end = second ? (tail ? q2 + q3 : Ctot) : c1;
+      seg_left = __builtin_amdgcn_readfirstlane(((seg_end - cpos) >> 6) - 1);
+      cpos = seg_end;
+      if (tap < KK && cpos >= Ctot) { cpos = 0; ++tap; }
+      cpos = __builtin_amdgcn_readfirstlane(cpos);
+      tap = __builtin_amdgcn_readfirstlane(tap);
+    }
     }
   };
   auto issue_x = [&](int boff, int h) __attribute__((always_inline)) {
