@@ -519,37 +519,41 @@ def test_config4_batch4_768_bf16_vs_oracle(full96):
     assert min(pb) >= CONFIG4_PSNR_FLOOR_B4_VS_B1, pb
 
 
-def test_config4_batch4_768_bf16_12_steps_vs_golden(full96):
-    """BASELINE configs[4] over MORE than two steps: 768x768, bf16, batch 4, CFG 7.5, 12 DDIM steps, graph
-    replayed - request 0 against the committed fp32 oracle fixture (tests/golden/make_golden_768.py: latents after steps 1, 2,
-    4, 8, 12 and the decoded image), so that the growth of the bf16 error along the loop is on record.  The asserted floors sit
-    1 dB / 20 % under what the GPU box measured (profiles/r04_fullsize_parity.jsonl); north_star's 40 dB is stated for fp16."""
+@pytest.mark.parametrize("steps", [12, 50])
+def test_config4_batch4_768_bf16_many_steps_vs_golden(full96, steps):
+    """BASELINE configs[4] over MORE than two steps: 768x768, bf16, batch 4, CFG 7.5, graph replayed -
+    request 0 against the committed fp32 oracle fixtures (tests/golden/make_golden_768.py): 12 DDIM steps (latents after steps 1,
+    2, 4, 8, 12) and configs[4]'s OWN 50 steps (latents after 1, 5, 10, 25, 50), each with the decoded image - so the growth of the
+    bf16 error along the loop is on record.  north_star's gate is PSNR >= 40 dB on the decoded image: asserted here at both step
+    counts (measured 43.9 dB at 12 steps with the wide residual stream, 43.0 without; the 2-step tests above sit at 39 dB because
+    the first steps carry the largest error and DDIM contracts it afterwards)."""
     pipe = full96["pipe"]
     ucfg = full96["ucfg"]
-    gold = load_file(os.path.join(GOLD, "full96_pipeline12.safetensors"))
+    gold = load_file(os.path.join(GOLD, f"full96_pipeline{steps}.safetensors"))
+    marks = (1, 2, 4, 8, 12) if steps == 12 else (1, 5, 10, 25, 50)
     g = torch.Generator().manual_seed(51)
     s, c0, B = 96, ucfg.block_out_channels[0], 4
     lat = torch.randn(B, 4, s, s, generator=g)
     pe = (torch.randn(B, 77, ucfg.cross_attention_dim, generator=g) * 0.5).bfloat16().float()
     ne = (torch.randn(B, 77, ucfg.cross_attention_dim, generator=g) * 0.5).bfloat16().float()
     pc = [(torch.randn(1, c0, s, s, generator=g) * 0.3).bfloat16().float() for _ in range(6)]
-    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=pc, latents=lat, guidance_scale=7.5, num_inference_steps=12)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, image=pc, latents=lat, guidance_scale=7.5, num_inference_steps=steps)
     seen = {}
 
     def grab(_pipe, i, t, kwargs):
-        if i + 1 in (1, 2, 4, 8, 12):
+        if i + 1 in marks:
             seen[i + 1] = kwargs["latents"][:1].float().cpu().clone()
         return {}
     lat_eager = pipe(output_type="latent", callback_on_step_end=grab, **kw).images.float().cpu()
     img = pipe(output_type="pt", **kw).images.float().cpu()
     assert img.shape == (B, 3, 768, 768) and torch.isfinite(img).all()
     growth = {k: H.rel_err(v, gold[f"latents_step{k}"]) for k, v in seen.items()}
-    p12 = H.psnr(img[:1], gold["image"].float())
-    e12 = H.rel_err(lat_eager[:1], gold["latents_out"])
-    record("config4_batch4_768_bf16_12_steps", psnr_vs_golden=p12, latents_rel=e12,
+    p_ = H.psnr(img[:1], gold["image"].float())
+    e_ = H.rel_err(lat_eager[:1], gold["latents_out"])
+    record(f"config4_batch4_768_bf16_{steps}_steps", psnr_vs_golden=p_, latents_rel=e_,
            latents_rel_by_step={str(k): round(v, 6) for k, v in growth.items()})
-    assert p12 >= CONFIG4_PSNR_FLOOR_12, p12
-    assert e12 <= 6e-2, e12
+    assert p_ >= (CONFIG4_PSNR_FLOOR_12 if steps == 12 else 40.0), p_
+    assert e_ <= 6e-2, e_
 
 
 def test_control_guidance_window_at_full_size_vs_oracle_and_its_step_time(full):
