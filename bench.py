@@ -133,7 +133,7 @@ def cpu_model() -> str:
     return "unknown"
 
 
-def gemm_roofline(pipe, traffic_profile="r03_gemm_pmc_traffic_b1.json", replay_iters=20):
+def gemm_roofline(pipe, traffic_profile="r04_gemm_pmc_traffic_b1.json", replay_iters=20):
     """Price the implicit-GEMM kernel against the dense fp16 MFMA peak with ALGORITHMIC flops (2*M*Cout*k*k*Cin) over
     the es_conv_gemm launches of one captured denoising step (the unit replayed 50x per image = 96 % of the image's
     FLOPs).  Two clocks, both reported:
@@ -463,7 +463,7 @@ def main(argv=None):
             line["throughput_mode"] = {"workload": "BASELINE configs[2]: same path, batch=8 per step", "value": round(8 / t8, 4),
                                        "unit": "images/s", "ms_per_step": round(t8 * 1e3, 1), "steps": n8, "warmup": 2}
             if not args.no_roofline:
-                r8 = gemm_roofline(pipe, traffic_profile="r03_gemm_pmc_traffic_b8.json", replay_iters=5)
+                r8 = gemm_roofline(pipe, traffic_profile="r04_gemm_pmc_traffic_b8.json", replay_iters=5)
                 line["throughput_mode"]["roofline"] = {k: r8[k] for k in (
                     "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "mfma_util_pmc", "launches_per_step",
                     "avg_launch_us", "gemm_time_per_step_ms", "conv3x3_only", "stamped", "how") if k in r8}

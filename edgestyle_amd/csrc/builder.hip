@@ -12,8 +12,9 @@
 //
 // Scope: the reference's configurations - the fused six-slot multi-ControlNet model (TT:252-258) or ONE ControlNet whose 13
 // residuals go to the UNet without fusion blocks (PL:338-351, BASELINE configs[0]) - with 64-aligned channel widths, grouped
-// lockstep execution, DDIM or UniPC (es_ctx_set_scheduler).  What the Python builder offers beyond that (guess_mode, latent
-// sizes whose groups do not tile) is refused here with an error, never approximated.
+// lockstep execution or guess_mode's per-group chains (es_ctx_geometry.guess_mode), DDIM or UniPC (es_ctx_set_scheduler).  What
+// the Python builder offers beyond that (latent sizes whose groups do not tile, outside guess_mode) is refused here with an error,
+// never approximated.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -390,6 +391,10 @@ struct Builder {
     return a;
   }
   unsigned long long workspace(unsigned long long bytes) { ws_bytes = std::max(ws_bytes, bytes); return FAKE_WS; }
+  void add_into(const T& a, const T& b, const T& out) {     // ops.add(a, b, out=out)
+    if (!a.contig() || !b.contig() || !out.contig() || a.numel() != b.numel() || a.numel() != out.numel()) fail("builder: add of non-contiguous or differently sized tensors");
+    ok(es_add(a.ptr(), b.ptr(), out.ptr(), a.numel(), dt, nullptr), "es_add");
+  }
   T add(const T& a, const T& b) {                          // ops.add
     if (!a.contig() || !b.contig() || a.numel() != b.numel()) fail("builder: add of non-contiguous or differently sized tensors");
     T out = empty(a.n, a.h, a.w, a.c);
@@ -1080,6 +1085,10 @@ struct Model {
   // StepRunner.prepare_fused_zero: what the fusion blocks return for zero residuals (biases and LayerNorm planes only) - constants,
   // filled by ONE real es_fusion_blocks launch at the end of es_load_weights; `fz_zero` / `fz_u` are that launch's zero inputs and scratch
   std::vector<T> fused_zero, fz_zero, fz_u;
+  // guess_mode (es_ctx_geometry.guess_mode; StepRunner._step_guess): per-group K/V projections of the ControlNets' text states
+  bool guess = false;
+  int Bc = 2;                                              // samples the ControlNets run on: the conditional half under CFG
+  std::vector<std::vector<T>> ctx_guess;
 
   std::vector<Norm> norms(const std::vector<const Resnet*>& rs, int which) const { std::vector<Norm> v; for (auto r : rs) v.push_back(which == 1 ? r->n1 : r->n2); return v; }
 
@@ -1200,6 +1209,39 @@ struct Model {
     }
     return tproj_gen;
   }
+  // EdgeStyleMultiControlNetModel's engine.forward (MC:151-169): rpn[net][level] = that net's residual (first sample; the batch
+  // stride is the tensor's), Nf samples per net, optional addends (the UNet's own skip / mid tensors: outputs are then the sums)
+  std::vector<T> fuse(const std::vector<std::vector<T>>& rpn, int Nf, const std::vector<T>* addends) {
+    const size_t nl = rpn[0].size();
+    std::vector<es_fusion_desc> fd(nl);
+    std::vector<T> us, outs;
+    for (size_t k = 0; k < nl; ++k) {
+      const FusionParams& fp = fusion[k];
+      const int HW = fp.s * fp.s, Cc = fp.c;
+      auto key = std::make_pair(Nf, (int)k);
+      auto it = B.fusion_scratch.find(key);
+      if (it == B.fusion_scratch.end()) it = B.fusion_scratch.emplace(key, B.persistent(es_fusion_scratch_bytes(Nf))).first;
+      T u = B.empty(Nf, HW, 1, Cc), out = B.empty(Nf, HW, 1, Cc);
+      es_fusion_desc& d = fd[k];
+      memset(&d, 0, sizeof(d));
+      for (int i = 0; i < 6; ++i) { d.res[i] = rpn[i][k].ptr(); d.res_bs[i] = rpn[i][k].bstride(); d.res_scale[i] = 1.f; }
+      d.res_scale_dev = (const float*)scales_cur.ptr();
+      d.w1 = (const float*)fp.w1; d.b1 = (const float*)fp.b1; d.g1 = (const void*)fp.g1; d.be1 = (const void*)fp.be1;
+      d.w2 = (const float*)fp.w2; d.b2 = (const float*)fp.b2; d.g2 = (const void*)fp.g2; d.be2 = (const void*)fp.be2;
+      d.w3 = (const float*)fp.w3; d.b3 = (const float*)fp.b3;
+      d.scratch = (float*)it->second; d.u = u.ptr(); d.out = out.ptr();
+      d.N = Nf; d.HW = HW; d.C = Cc; d.eps = 1e-5f; d.dtype = B.dt;
+      if (addends) {
+        const T& ad = (*addends)[k];
+        if (ad.numel() != (long long)Nf * HW * Cc || !ad.contig()) fail("builder: fusion addend of another size");
+        d.addend = ad.ptr();
+      }
+      us.push_back(u);
+      outs.push_back(out.view(Nf, fp.s, fp.s, Cc));
+    }
+    Builder::ok(es_fusion_blocks(fd.data(), (int)fd.size(), nullptr), "es_fusion_blocks");
+    return outs;
+  }
   // StepRunner._step_grouped + UNet.forward(presummed)
   void step(bool table_driven) {
     const T& x = model_in;
@@ -1240,30 +1282,9 @@ struct Model {
     }
     std::vector<int> first(nn, 0);
     { int a = 0; for (const auto& g : groups) for (int p : g.second) { first[p] = a; a += N; } }
-    std::vector<es_fusion_desc> fd(srcs.size());
-    std::vector<T> us;
-    for (size_t k = 0; k < srcs.size(); ++k) {
-      const FusionParams& fp = fusion[k];
-      const int HW = fp.s * fp.s, Cc = fp.c;
-      auto key = std::make_pair(N, (int)k);
-      auto it = B.fusion_scratch.find(key);
-      if (it == B.fusion_scratch.end()) it = B.fusion_scratch.emplace(key, B.persistent(es_fusion_scratch_bytes(N))).first;
-      T u = B.empty(N, HW, 1, Cc), out = B.empty(N, HW, 1, Cc);
-      es_fusion_desc& d = fd[k];
-      memset(&d, 0, sizeof(d));
-      for (int i = 0; i < 6; ++i) { d.res[i] = res[k].batch(first[i]).ptr(); d.res_bs[i] = res[k].bstride(); d.res_scale[i] = 1.f; }
-      d.res_scale_dev = (const float*)scales_cur.ptr();
-      d.w1 = (const float*)fp.w1; d.b1 = (const float*)fp.b1; d.g1 = (const void*)fp.g1; d.be1 = (const void*)fp.be1;
-      d.w2 = (const float*)fp.w2; d.b2 = (const float*)fp.b2; d.g2 = (const void*)fp.g2; d.be2 = (const void*)fp.be2;
-      d.w3 = (const float*)fp.w3; d.b3 = (const float*)fp.b3;
-      d.scratch = (float*)it->second; d.u = u.ptr(); d.out = out.ptr();
-      d.N = N; d.HW = HW; d.C = Cc; d.eps = 1e-5f; d.dtype = B.dt;
-      if (enc[k].numel() != (long long)N * HW * Cc || !enc[k].contig()) fail("builder: fusion addend of another size");
-      d.addend = enc[k].ptr();
-      us.push_back(u);
-      fused.push_back(out.view(N, fp.s, fp.s, Cc));
-    }
-    Builder::ok(es_fusion_blocks(fd.data(), (int)fd.size(), nullptr), "es_fusion_blocks");
+    std::vector<std::vector<T>> rpn(nn);
+    for (int i = 0; i < nn; ++i) for (size_t k = 0; k < srcs.size(); ++k) rpn[i].push_back(res[k].batch(first[i]));
+    fused = fuse(rpn, N, &enc);
     }
     srcs.clear(); skips.clear(); enc.clear(); mid = T();
     unet_decoder(fused, tproj.batch(ncn));                  // skip + residual already summed: PL:500-510
@@ -1286,6 +1307,79 @@ struct Model {
     CA o; o.out = noise;
     B.conv_gemm(hh, unet.conv_out, o);
   }
+  // Encoder.run of ONE encoder (engine.Encoder.run): h -> (skips, mid)
+  void enc_run(const Encoder& e, T hh, const T& tp, const std::vector<T>& ctx, std::vector<T>& skips, T& mid) {
+    skips.push_back(hh);
+    int ci = 0;
+    for (size_t i = 0; i < e.down.size(); ++i) {
+      for (size_t j = 0; j < e.down[i].size(); ++j) {
+        hh = e.down[i][j].first.run(B, hh, tp);
+        if (e.down[i][j].second >= 0) { hh = transformer(e.tr[e.down[i][j].second], hh, ctx[ci]); ++ci; }
+        skips.push_back(hh);
+      }
+      if (e.downsample[i]) { CA a; a.stride = 2; a.gn_groups = ucfg.groups; hh = B.conv_gemm(hh, e.downsample[i], a); skips.push_back(hh); }
+    }
+    hh = e.mid0.run(B, hh, tp);
+    hh = transformer(e.tr[e.mid_attn], hh, ctx[ci]);
+    mid = e.mid1.run(B, hh, tp);
+  }
+  // ---- guess_mode (StepRunner.set_context(guess_mode=True) / _step_guess; CL:256-264, PL:453-459, 487-497) -------------------------
+  void set_context_guess() {
+    for (size_t ti = 0; ti < unet.tr.size(); ++ti) unet.tr[ti].context(B, ehs, ctx_unet[ti], 1);
+    const T ehs_c = ehs.batch(N - Bc);                      // the ControlNets see the last Bc rows: the conditional half under CFG
+    size_t gi = 0;
+    for (const auto& g : groups) {
+      const ControlNet& net = *nets[g.first];
+      for (int ti = 0; ti < net.n_enc_tr; ++ti) net.tr[ti].context(B, ehs_c, ctx_guess[gi][ti], (int)g.second.size());
+      ++gi;
+    }
+  }
+  // torch.logspace(-1, 0, n) of dtype float (ATen's CPU kernel fills the second half from the end), as models._guess_level_scales hands it over
+  static std::vector<float> guess_level_scales(int n) {
+    std::vector<float> ls((size_t)n);
+    const double step = (0.0 - (-1.0)) / (double)(n - 1);  // (the exponent and the power in double, the result rounded to float)
+    for (int i = 0; i < n; ++i) ls[i] = (float)(i < n / 2 ? pow(10.0, -1.0 + step * (double)i) : pow(10.0, 0.0 - step * (double)(n - i - 1)));
+    return ls;
+  }
+  void step_guess() {
+    const T& x = model_in;
+    const int Bh = N - Bc;                                  // first row of the ControlNet batch inside x (0 without CFG)
+    const T xc = x.batch(Bh);
+    const std::vector<float> ls = guess_level_scales((int)table.size());
+    std::vector<std::vector<T>> rpn(nn);
+    size_t gi = 0;
+    for (const auto& g : groups) {
+      const ControlNet& cn = *nets[g.first];
+      const int k = (int)g.second.size();
+      T tp = cn.time_proj(B, t_rows, k * Bc);
+      // ControlNet.forward: sample = conv_in(sample) + cond per net (CL:197-203), one batched pass, the zero-convs scaled per level
+      const int c0 = cn.conv_in->cout;
+      T h0 = B.empty(k * Bc, x.h, x.w, c0);
+      for (int i = 0; i < k; ++i) { CA a; a.residual = conds[g.second[i]]; a.out = h0.batch(i * Bc, Bc); B.conv_gemm(xc, cn.conv_in, a); }
+      std::vector<T> skips; T mid;
+      enc_run(cn, h0, tp, ctx_guess[gi], skips, mid);
+      std::vector<T> res;
+      // (one plain ControlNet: its conditioning scale rides on the same epilogue, StepRunner._cn_scale)
+      for (size_t lvl = 0; lvl <= skips.size(); ++lvl) {
+        CA a; a.out_scale = ls[lvl];
+        if (nn == 1) a.out_scale_dev = scales_cur.chan(0, 1);
+        res.push_back(lvl < skips.size() ? B.conv_gemm(skips[lvl], cn.zero[lvl], a) : B.conv_gemm(mid, cn.zero_mid, a));
+      }
+      for (int j = 0; j < k; ++j) for (const auto& r : res) rpn[g.second[j]].push_back(r.batch(j * Bc));
+      ++gi;
+    }
+    std::vector<T> fused = nn == 1 ? rpn[0] : fuse(rpn, Bc, nullptr);
+    T tpu = unet.time_proj(B, t_rows, N);
+    CA ci_; ci_.gn_groups = ucfg.groups;
+    T hh = B.conv_gemm(x, unet.conv_in, ci_);
+    std::vector<T> skips;
+    enc_run(unet, hh, tpu, ctx_unet, skips, hh);
+    // torch.cat([zeros, d]) + skip == add into the conditional half (PL:487-497), in place
+    for (size_t k2 = 0; k2 < skips.size(); ++k2) { T v = skips[k2].batch(Bh); B.add_into(v, fused[k2].view(v.n, v.h, v.w, v.c), v); }
+    { T v = hh.batch(Bh); B.add_into(v, fused.back().view(v.n, v.h, v.w, v.c), v); }
+    skips.push_back(hh);
+    unet_decoder(skips, tpu);
+  }
   // pipeline._Loop.one_step_unet / StepRunner.step_unet_only: a step outside every control-guidance window (PL:419-427) - the UNet
   // alone, its skip / mid tensors plus the constant fusion-of-zeros residuals (a single ControlNet: plus nothing)
   void one_step_unet() {
@@ -1295,19 +1389,7 @@ struct Model {
     CA ci_; ci_.gn_groups = ucfg.groups;
     T hh = B.conv_gemm(model_in, unet.conv_in, ci_);
     std::vector<T> skips;
-    skips.push_back(hh);
-    int ci = 0;
-    for (size_t i = 0; i < unet.down.size(); ++i) {
-      for (size_t j = 0; j < unet.down[i].size(); ++j) {
-        hh = unet.down[i][j].first.run(B, hh, tp);
-        if (unet.down[i][j].second >= 0) { hh = transformer(unet.tr[unet.down[i][j].second], hh, ctx_unet[ci]); ++ci; }
-        skips.push_back(hh);
-      }
-      if (unet.downsample[i]) { CA a; a.stride = 2; a.gn_groups = ucfg.groups; hh = B.conv_gemm(hh, unet.downsample[i], a); skips.push_back(hh); }
-    }
-    hh = unet.mid0.run(B, hh, tp);
-    hh = transformer(unet.tr[unet.mid_attn], hh, ctx_unet[ci]);
-    hh = unet.mid1.run(B, hh, tp);
+    enc_run(unet, hh, tp, ctx_unet, skips, hh);
     if (nn != 1) {
       if (fused_zero.size() != skips.size() + 1) fail("builder: fusion-of-zeros constants do not match the residual levels");
       for (size_t k = 0; k < skips.size(); ++k) skips[k] = B.add(skips[k], fused_zero[k].view(skips[k].n, skips[k].h, skips[k].w, skips[k].c));
@@ -1322,7 +1404,7 @@ struct Model {
   void one_step() {                                         // pipeline._Loop.one_step: PL:435-522 for the step the device counter selects
     B.gather_row(t_table, T_, step_idx, t_rows, kmax * N);
     B.gather_row(scale_table, T_, step_idx, scales_cur, nn);
-    step(true);
+    if (guess) step_guess(); else step(true);
     Builder::ok(es_cfg_ddim_step(noise.ptr(), (float*)latents.ptr(), model_in.ptr(), (const float*)coef.ptr(), (const int32_t*)step_idx.ptr(), geo.cfg ? 7.5f : 1.0f,
                                  B_, h * w, ucfg.in_ch, model_in.c, geo.cfg, T_, B.dt, nullptr), "es_cfg_ddim_step");
     Builder::ok(es_incr((int32_t*)step_idx.ptr(), nullptr), "es_incr");
@@ -1335,7 +1417,7 @@ struct Model {
   struct CondGroup { bool vae; int net; std::vector<int> idx; T gb; };
   std::vector<CondGroup> cgroups;
   void embed_conds() {
-    const int rep = geo.cfg ? 2 : 1;
+    const int rep = Bc / B_, N = Bc;                        // (guess_mode under CFG: the ControlNets only see the conditional half)
     for (const auto& g : cgroups) {
       T x8 = B.empty(g.gb.n, g.gb.h, g.gb.w, 8);
       Builder::ok(es_nchw_f32_to_nhwc((const float*)g.gb.ptr(), x8.ptr(), g.gb.n, 3, (int)g.gb.hw(), 8, B.dt, nullptr), "es_nchw_f32_to_nhwc");
@@ -1436,8 +1518,10 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
     M.geo = *g;
     B.dt = g->dtype;
     M.B_ = g->B; M.N = g->cfg ? 2 * g->B : g->B; M.T_ = g->n_steps; M.h = g->h; M.w = g->w; M.nn = g->n_conds;
-    const int N = M.N, TS = M.T_, h = g->h, w = g->w, Bn = g->B, NN = g->n_conds;
-    {   // the groups of the lockstep pass: nets that share weights run as one batched chain; every group must tile
+    M.guess = g->guess_mode != 0;
+    M.Bc = M.guess ? g->B : M.N;
+    const int N = M.N, TS = M.T_, h = g->h, w = g->w, Bn = g->B, NN = g->n_conds, Nc = M.Bc;
+    if (!M.guess) {   // the groups of the lockstep pass: nets that share weights run as one batched chain; every group must tile
       int cnt[6] = {};
       for (int p = 0; p < NN; ++p) {
         const int ni = wts->net_of_cond[p];
@@ -1502,7 +1586,7 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
     M.latents = B.persistent_t(Bn, h, w, Lc, 4);
     M.model_in = B.persistent_t(N, h, w, Lp);
     M.noise = B.persistent_t(N, h, w, u.out_ch);
-    for (int i = 0; i < NN; ++i) M.conds.push_back(B.persistent_t(N, h, w, c0));
+    for (int i = 0; i < NN; ++i) M.conds.push_back(B.persistent_t(Nc, h, w, c0));
     M.ehs = B.persistent_t(N, mc->text_tokens > 0 ? mc->text_tokens : 77, 1, u.cross);
     M.step_idx = B.persistent_t(1, 1, 1, 1, 4);
     M.t_rows = B.persistent_t(1, 1, 1, M.kmax * N, 4);
@@ -1525,12 +1609,17 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
       }
       for (int ti = 0; ti < n_enc; ++ti) M.ctx_unet.push_back(M.ctx_grouped[ti].batch(a, N));
       for (size_t ti = n_enc; ti < M.unet.tr.size(); ++ti) M.ctx_unet.push_back(B.persistent_t(N, T77, 1, M.unet.tr[ti].kv2->cout));
+      if (M.guess)                                                 // StepRunner.set_context(guess_mode=True): each group's own K/V rows
+        for (const auto& gp : M.groups) {
+          M.ctx_guess.emplace_back();
+          for (int ti = 0; ti < n_enc; ++ti) M.ctx_guess.back().push_back(B.persistent_t((int)gp.second.size() * Nc, T77, 1, M.nets[gp.first]->tr[ti].kv2->cout));
+        }
     }
     M.cond_cat = B.persistent_t(M.ntot, h, w, c0);                 // the UNet's slot stays zero
     M.tproj_table = B.persistent_t(TS, M.ntot, 1, M.width);         // columns beyond a group's width are never written: zero
     M.tproj_cur = B.persistent_t(M.ntot, 1, 1, M.width);
     M.tproj_gen = B.persistent_t(M.ntot, 1, 1, M.width);
-    if (NN != 1)                                                   // StepRunner.prepare_fused_zero (constants, filled below)
+    if (NN != 1 && !M.guess)                                       // StepRunner.prepare_fused_zero (constants, filled below)
       for (const auto& fp : M.fusion) M.fused_zero.push_back(B.persistent_t(N, fp.s * fp.s, 1, fp.c));
     // es_prepare_conds inputs: one image batch per shared encoder (the VAE of the LoRA nets first, NativeEngine._conds_fn)
     M.cond_img.resize(NN); M.cond_noise.resize(NN);
@@ -1551,22 +1640,30 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
         for (size_t k = 0; k < cg.idx.size(); ++k) {
           T im = cg.gb.batch((int)k * Bn, Bn);
           M.cond_img[cg.idx[k]] = im;
-          if (cg.vae) M.cond_noise[cg.idx[k]] = B.persistent_t(N, h, w, v.latent, 4);   // NCHW fp32 [N,L,h,w]
+          if (cg.vae) M.cond_noise[cg.idx[k]] = B.persistent_t(Nc, h, w, v.latent, 4);  // NCHW fp32 [N,L,h,w]
         }
         M.cgroups.push_back(cg);
       }
     }
     // ---- the five launch lists
     for (int i = 0; i < ES_PLAN_COUNT; ++i) plans[i] = es_plan_create();
-    { Recording r(plans[ES_PLAN_PREP]); M.set_context(); M.set_conds(); M.set_time_table(); }
-    { Recording r(plans[ES_PLAN_STEP]); M.one_step(); }
-    { Recording r(plans[ES_PLAN_STEP_GENERIC]); M.set_context(); M.set_conds(); M.step(false); }
+    if (M.guess) {
+      // guess_mode: no lockstep tables - the ControlNets run on another batch than the UNet (NativeEngine with guess_mode=True).
+      // ES_PLAN_STEP_UNET stays empty: steps outside the control-guidance window run ES_PLAN_STEP with all scales 0
+      { Recording r(plans[ES_PLAN_PREP]); M.set_context_guess(); }
+      { Recording r(plans[ES_PLAN_STEP]); M.one_step(); }
+      { Recording r(plans[ES_PLAN_STEP_GENERIC]); M.set_context_guess(); M.step_guess(); }
+    } else {
+      { Recording r(plans[ES_PLAN_PREP]); M.set_context(); M.set_conds(); M.set_time_table(); }
+      { Recording r(plans[ES_PLAN_STEP]); M.one_step(); }
+      { Recording r(plans[ES_PLAN_STEP_GENERIC]); M.set_context(); M.set_conds(); M.step(false); }
+      { Recording r(plans[ES_PLAN_STEP_UNET]); M.one_step_unet(); }
+    }
     { Recording r(plans[ES_PLAN_DECODE]); M.decode(); }
     { Recording r(plans[ES_PLAN_CONDS]); M.embed_conds(); }
-    { Recording r(plans[ES_PLAN_STEP_UNET]); M.one_step_unet(); }
     // zero inputs and scratch of the ONE real launch that fills the fusion-of-zeros constants once the arena exists (the arena is
     // zero-filled and nothing has run in it by then: any block of the activation heap reads as zeros)
-    if (NN != 1)
+    if (NN != 1 && !M.guess)
       for (const auto& fp : M.fusion) { M.fz_zero.push_back(B.empty(N, fp.s * fp.s, 1, fp.c)); M.fz_u.push_back(B.empty(N, fp.s * fp.s, 1, fp.c)); }
     // ---- the arena: allocate, relocate, upload
     const unsigned long long heap_bytes = (B.heap.top + 255) & ~255ull, total = heap_bytes + ((B.ws_bytes + 255) & ~255ull);
@@ -1599,7 +1696,7 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
       }
     if (device == -2)
       for (auto& up : B.uploads) memcpy((void*)(mp.heap_base + (up.first - FAKE_HEAP)), up.second.data(), up.second.size());
-    if (device >= 0 && NN != 1) {
+    if (device >= 0 && NN != 1 && !M.guess) {
       // the constants ES_PLAN_STEP_UNET adds: ControlNetBlock(interleave(zeros)) of every level (MC:151-169 with all scales 0)
       std::vector<es_fusion_desc> fd(M.fusion.size());
       for (size_t k = 0; k < fd.size(); ++k) {
@@ -1629,7 +1726,11 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
     es_ctx_geometry geo = *g;
     geo.latent_channels = Lc; geo.latent_pad = Lp;
     if (es_ctx_set_geometry(ctx, &geo)) fail(std::string("es_load_weights: ") + es_last_error());
-    for (int i = 0; i < ES_PLAN_COUNT; ++i) { if (es_ctx_set_plan(ctx, i, plans[i])) fail(std::string("es_load_weights: ") + es_last_error()); plans[i] = nullptr; }
+    for (int i = 0; i < ES_PLAN_COUNT; ++i) {
+      if (M.guess && i == ES_PLAN_STEP_UNET) continue;       // (not recorded in guess_mode: destroyed with the other leftovers below)
+      if (es_ctx_set_plan(ctx, i, plans[i])) fail(std::string("es_load_weights: ") + es_last_error());
+      plans[i] = nullptr;
+    }
     auto bind = [&](int slot, const T& t) { if (es_ctx_bind(ctx, slot, real(t), t.bytes())) fail(std::string("es_load_weights: ") + es_last_error()); };
     bind(ES_BUF_SAMPLE, M.model_in); bind(ES_BUF_T_ROWS, M.t_rows); bind(ES_BUF_EHS, M.ehs); bind(ES_BUF_SCALES, M.scales_cur);
     bind(ES_BUF_NOISE, M.noise); bind(ES_BUF_LATENTS, M.latents); bind(ES_BUF_STEP_IDX, M.step_idx); bind(ES_BUF_T_TABLE, M.t_table);
@@ -1640,6 +1741,7 @@ extern "C" int es_load_weights(const es_weights* wts, const es_model_config* mc,
       bind(ES_BUF_COND_IMG0 + i, M.cond_img[i]);
       if (M.cond_noise[i]) bind(ES_BUF_COND_NOISE0 + i, M.cond_noise[i]);
     }
+    for (auto*& p : plans) if (p) { es_plan_destroy(p); p = nullptr; }
     *out = ctx;
     return 0;
   } catch (const std::exception& e) {

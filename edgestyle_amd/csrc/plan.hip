@@ -861,7 +861,7 @@ extern "C" int es_denoise_loop(es_ctx* c, float* latents_inout, const void* ehs,
     for (size_t j = 0; j < trow; ++j) tt[i * trow + j] = timesteps[i];
     const float keep = 1.0f - (float)(((float)i / T < c->control_start) || ((float)(i + 1) / T > c->control_end));   // PL:419-427
     for (int k = 0; k < nc; ++k) sc[i * nc + k] = c->cond_scales[k] * keep;
-    unet_only[i] = keep == 0.0f && c->plan[ES_PLAN_STEP_UNET] != nullptr;
+    unet_only[i] = keep == 0.0f && c->plan[ES_PLAN_STEP_UNET] != nullptr && es_plan_size(c->plan[ES_PLAN_STEP_UNET]) > 0;
     tsd[i] = timesteps[i];
   }
   if (unipc) unipc_coef(c, timesteps, T, cf);

@@ -49,7 +49,7 @@ class XsDesc(C.Structure):
 class CtxGeometry(C.Structure):
     _fields_ = [("B", C.c_int32), ("cfg", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
                 ("latent_channels", C.c_int32), ("latent_pad", C.c_int32), ("n_conds", C.c_int32),
-                ("n_steps", C.c_int32), ("dtype", C.c_int32)]
+                ("n_steps", C.c_int32), ("dtype", C.c_int32), ("guess_mode", C.c_int32)]
 
 
 # es_plan / es_ctx enums (include/edgestyle_hip.h)

@@ -31,8 +31,9 @@ def _p(t: Optional[torch.Tensor]):
 class NativeEngine:
     def __init__(self, pipe, batch_size: int = 1, guidance: bool = True, num_inference_steps: int = 50,
                  height: Optional[int] = None, width: Optional[int] = None, use_graphs: bool = True,
-                 embed_conditions: bool = True):
-        """embed_conditions: also record ES_PLAN_CONDS (es_prepare_conds: RGB condition images -> embeddings), when every
+                 embed_conditions: bool = True, guess_mode: bool = False):
+        """guess_mode: the recorded step is guess_mode's (CL:256-264, PL:453-459, 487-497).
+        embed_conditions: also record ES_PLAN_CONDS (es_prepare_conds: RGB condition images -> embeddings), when every
         net's conditioning path is one this builder knows (VAE-conditioned ControlLoRA nets, conv-stack ControlNets)."""
         if not isinstance(pipe.scheduler, DDIMScheduler):
             raise EdgeStyleHipError("the native loop implements the DDIM update (the BASELINE metric's scheduler)")
@@ -52,9 +53,10 @@ class NativeEngine:
         conds = [torch.randn(1, c0, h, w, generator=g) * 0.3 for _ in range(nn)]
         kw = dict(prompt_embeds=pe, negative_prompt_embeds=pe if guidance else None, image=conds if nn > 1 else conds[0],
                   latents=torch.randn(B, ucfg.in_channels, h, w, generator=g), guidance_scale=7.5 if guidance else 1.0,
-                  num_inference_steps=T)
+                  num_inference_steps=T, guess_mode=bool(guess_mode))
         pipe(output_type="pt", **kw)
-        loop = self.loop = pipe._loops[(B, guidance, h, w, False)]
+        guess = self.guess = bool(guess_mode)
+        loop = self.loop = pipe._loops[(B, guidance, h, w, guess)]
         runner = self.runner = pipe._runner
         N = loop.N
         # the coefficient table the recorded scheduler call reads: room for UniPC's 12 columns (es_ctx_set_scheduler), the DDIM
@@ -66,21 +68,23 @@ class NativeEngine:
         self.dtype = pipe.dtype
         self.ts_dev = torch.zeros((T,), dtype=torch.float32, device=dev)
         self.ts_dev.copy_(pipe.scheduler.set_timesteps(T).float())
-        grouped_tables = runner.mode == "grouped"
+        grouped_tables = runner.mode == "grouped" and not guess
+        n_cn = loop.conds[0].shape[0]
 
         def prep():
             runner.state = loop.state
-            runner.set_context(loop.ehs)
+            runner.set_context(loop.ehs, guess, n_cn)
             if grouped_tables:
                 runner.set_conds(loop.conds)
                 runner.set_time_table(self.ts_dev, N)
 
         def generic():
             runner.state = loop.state
-            runner.set_context(loop.ehs)
+            runner.set_context(loop.ehs, guess, n_cn)
             if grouped_tables:
                 runner.set_conds(loop.conds)
-            runner.step(loop.model_in, loop.t_rows, loop.conds, [1.0] * nn, loop.scales_cur, out=loop.noise, step_idx=None)
+            runner.step(loop.model_in, loop.t_rows, loop.conds, [1.0] * nn, loop.scales_cur, out=loop.noise, step_idx=None,
+                        guess_mode=guess)
 
         out = {}
 
@@ -90,14 +94,15 @@ class NativeEngine:
 
         # -- es_prepare_conds: static inputs + the embedding walk of pipeline.prepare_images as C-ABI launches only --------
         self.cond_img, self.cond_noise = [None] * nn, [None] * nn
-        conds_fn = self._conds_fn(pipe, loop, B, guidance, h, w) if embed_conditions else None
+        conds_fn = self._conds_fn(pipe, loop, B, guidance and not guess, h, w) if embed_conditions else None
 
         self._keep = []
         ctx = C.c_void_p()
         L.check(self.lib.es_ctx_create(dev.index or 0, C.byref(ctx)), "es_ctx_create")
         self.ctx = ctx
         geo = L.CtxGeometry(B=B, cfg=int(guidance), h=h, w=w, latent_channels=ucfg.in_channels,
-                            latent_pad=pipe.unet.engine.in_pad, n_conds=nn, n_steps=T, dtype=L.ES_F16 if self.dtype == torch.float16 else L.ES_BF16)
+                            latent_pad=pipe.unet.engine.in_pad, n_conds=nn, n_steps=T, dtype=L.ES_F16 if self.dtype == torch.float16 else L.ES_BF16,
+                            guess_mode=int(guess))
         L.check(self.lib.es_ctx_set_geometry(ctx, C.byref(geo)), "es_ctx_set_geometry")
         self._geo = geo
         self.plan_sizes = {}
@@ -147,7 +152,7 @@ class NativeEngine:
         # pipeline's cache - a later pipe(...) with the same (B, cfg, h, w) builds its own loop and may replace ITS tables
         # (another num_inference_steps re-allocates tproj_table) without freeing anything a plan still reads - and every
         # tensor the plans can reference is pinned here for the life of the context.
-        pipe._loops.pop((B, guidance, h, w, False), None)
+        pipe._loops.pop((B, guidance, h, w, guess), None)
         if getattr(pipe, "_last_loop", None) is loop:
             pipe._last_loop = None
         from .models import StepState
@@ -532,7 +537,7 @@ class NativeContext:
     def __init__(self, ws, ucfg, vcfg, batch_size: int = 1, guidance: bool = True, num_inference_steps: int = 50,
                  height: Optional[int] = None, width: Optional[int] = None, dtype=torch.float16, device: int = 0,
                  controlnets=(("lora0", L.NET_CONTROL_LORA_VAE), ("openpose", L.NET_CONTROLNET), ("lora1", L.NET_CONTROL_LORA_VAE)),
-                 net_of_cond=(0, 1, 2, 1, 2, 1)):
+                 net_of_cond=(0, 1, 2, 1, 2, 1), guess_mode: bool = False):
         self.lib = L.load()
         self.ucfg, self.vcfg = ucfg, vcfg
         h = (height // vcfg.scale) if height else ucfg.sample_size
@@ -557,7 +562,7 @@ class NativeContext:
             wts.net_of_cond[i] = n
         geo = L.CtxGeometry(B=batch_size, cfg=int(guidance), h=h, w=w, latent_channels=ucfg.in_channels,
                             latent_pad=(ucfg.in_channels + 7) // 8 * 8, n_conds=nn, n_steps=num_inference_steps,
-                            dtype=L.ES_F16 if dtype == torch.float16 else L.ES_BF16)
+                            dtype=L.ES_F16 if dtype == torch.float16 else L.ES_BF16, guess_mode=int(bool(guess_mode)))
         mc = model_config(ucfg, vcfg)
         ctx = C.c_void_p()
         L.check(self.lib.es_load_weights(C.byref(wts), C.byref(mc), C.byref(geo), device, C.byref(ctx)), "es_load_weights")

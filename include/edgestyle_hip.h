@@ -347,6 +347,9 @@ typedef struct {
   int32_t n_conds;                 /* 6 (the fused multi-ControlNet) or 1 (a single ControlNet) */
   int32_t n_steps;                 /* the ES_PLAN_PREP time table is built for this many steps */
   int32_t dtype;
+  int32_t guess_mode;              /* 1: the recorded step is guess_mode's (CL:256-264, PL:453-459, 487-497): per-net chains with log-spaced
+                                    * level scales; under CFG the ControlNets see the conditional half only - the condition slots then hold
+                                    * B samples - and the fused residuals are added to that half */
 } es_ctx_geometry;
 int es_ctx_create(int device, es_ctx** out);
 void es_ctx_destroy(es_ctx* c);                         /* destroys its plans too */

@@ -163,9 +163,9 @@ def psnr(a, b, peak=1.0):
 # native.py) can run on host tensors.  Used to hold es_load_weights' plans against the Python host's, call by call.
 # ----------------------------------------------------------------------------------------------------------------
 def python_dry_context(ws, ucfg, vcfg, B=1, guidance=True, T=6, dtype=torch.float16,
-                       controlnets=(("lora0", 1), ("openpose", 0), ("lora1", 1)), net_of_cond=(0, 1, 2, 1, 2, 1), rank=4):
-    """-> (lib, es_ctx) holding the five plans the Python host records for this configuration (addresses are host
-    addresses of scratch tensors: only good for plan_records)."""
+                       controlnets=(("lora0", 1), ("openpose", 0), ("lora1", 1)), net_of_cond=(0, 1, 2, 1, 2, 1), rank=4, guess=False):
+    """-> (lib, es_ctx) holding the plans the Python host records for this configuration (addresses are host
+    addresses of scratch tensors: only good for plan_records).  guess: NativeEngine(guess_mode=True)'s recording."""
     import ctypes as Ct
     from types import SimpleNamespace
     from edgestyle_amd import lib as L, ops, models as M, native as Nat
@@ -206,25 +206,29 @@ def python_dry_context(ws, ucfg, vcfg, B=1, guidance=True, T=6, dtype=torch.floa
         pipe = EdgeStyleStableDiffusionControlNetPipeline(vae=vae, unet=runner.unet, controlnet=runner.controlnet)
         pipe._runner = runner
         h = w = ucfg.sample_size
-        loop = _Loop(pipe, B, guidance, h, w)
+        loop = _Loop(pipe, B, guidance, h, w, guess)
         N, k, nn = loop.N, runner.kmax, len(net_of_cond)
         loop.t_table = torch.zeros((T, k * N)); loop.scale_table = torch.zeros((T, nn)); loop.coef = torch.zeros((T, 4))
         loop.ts_dev = torch.zeros((T,)); loop.guidance_scale, loop.steps = (7.5 if guidance else 1.0), T
         eng = SimpleNamespace(cond_img=[None] * nn, cond_noise=[None] * nn, dtype=dtype)
-        conds_fn = Nat.NativeEngine._conds_fn(eng, pipe, loop, B, guidance, h, w)
+        conds_fn = Nat.NativeEngine._conds_fn(eng, pipe, loop, B, guidance and not guess, h, w)
+        n_cn = loop.conds[0].shape[0]
         image = {}
 
         def prep():
             runner.state = loop.state
-            runner.set_context(loop.ehs)
-            runner.set_conds(loop.conds)
-            runner.set_time_table(loop.ts_dev, N)
+            runner.set_context(loop.ehs, guess, n_cn)
+            if not guess:
+                runner.set_conds(loop.conds)
+                runner.set_time_table(loop.ts_dev, N)
 
         def generic():
             runner.state = loop.state
-            runner.set_context(loop.ehs)
-            runner.set_conds(loop.conds)
-            runner.step(loop.model_in, loop.t_rows, loop.conds, [1.0] * nn, loop.scales_cur, out=loop.noise, step_idx=None)
+            runner.set_context(loop.ehs, guess, n_cn)
+            if not guess:
+                runner.set_conds(loop.conds)
+            runner.step(loop.model_in, loop.t_rows, loop.conds, [1.0] * nn, loop.scales_cur, out=loop.noise, step_idx=None,
+                        guess_mode=guess)
 
         def decode():
             dec = vae.decode_nhwc(loop.model_in[:B], unscaled_latents=True)
@@ -232,10 +236,12 @@ def python_dry_context(ws, ucfg, vcfg, B=1, guidance=True, T=6, dtype=torch.floa
         ctx = Ct.c_void_p()
         L.check(lib.es_ctx_create(0, Ct.byref(ctx)), "es_ctx_create")
         keep = [runner, vae, pipe, loop, eng, image, wsb]
-        if len(net_of_cond) != 1:                      # StepRunner.prepare_fused_zero without its launch: the constants' buffers
+        if len(net_of_cond) != 1 and not guess:        # StepRunner.prepare_fused_zero without its launch: the constants' buffers
             loop.state.fused_zero = [torch.zeros((N, s_ * s_, c_), dtype=dtype) for c_, s_ in mc.engine.table]
         for which, fn in ((L.PLAN_PREP, prep), (L.PLAN_STEP, loop.one_step), (L.PLAN_STEP_GENERIC, generic), (L.PLAN_DECODE, decode),
                           (L.PLAN_CONDS, conds_fn), (L.PLAN_STEP_UNET, loop.one_step_unet)):
+            if guess and which == L.PLAN_STEP_UNET:    # (not recorded in guess_mode: native.NativeEngine)
+                continue
             plan = Ct.c_void_p(lib.es_plan_create())
             L.check(lib.es_plan_begin_record(plan), "begin")
             lib.es_plan_set_dry(1)

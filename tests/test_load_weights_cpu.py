@@ -248,3 +248,29 @@ def test_dry_recording_validates_but_does_not_launch():
         assert lib.es_plan_set_dry(0) == 1
         lib.es_plan_end_record(plan)
         lib.es_plan_destroy(plan)
+
+
+@pytest.mark.parametrize("B,guidance,nets,slots", [(1, True, None, None), (2, False, None, None), (1, True, (("openpose", 0),), (0,))])
+def test_guess_mode_context(tiny, B, guidance, nets, slots):
+    """es_ctx_geometry.guess_mode (CL:256-264; PL:453-459, 487-497): the ControlNets as per-group chains on the conditional half
+    only, zero-convs scaled 0.1..1 log-spaced, the fused residuals added into the conditional half of the UNet's skips in place -
+    the calls NativeEngine(guess_mode=True) records, argument for argument (the level scales included: float bits)."""
+    ucfg, vcfg, ws = tiny
+    lib = L.load()
+    kw = {} if nets is None else dict(controlnets=nets, net_of_cond=slots)
+    _, pctx, keep = python_dry_context(ws, ucfg, vcfg, B, guidance, 4, guess=True, **kw)
+    wsn = ws if nets is None else {k: v for k, v in ws.items() if k != "fusion"}
+    nat = NativeContext(wsn, ucfg, vcfg, batch_size=B, guidance=guidance, num_inference_steps=4, device=-2, guess_mode=True, **kw)
+    try:
+        for which in range(L.PLAN_COUNT):
+            if which == L.PLAN_STEP_UNET:
+                assert nat.plan_size(which) == -1                              # steps outside the window replay ES_PLAN_STEP with scales 0
+                continue
+            assert lib.es_ctx_plan_size(pctx, which) == nat.plan_size(which) > 5
+            assert diff_plans(lib, pctx, nat.ctx, which) is None
+            assert plan_constants(lib, pctx, which) == plan_constants(lib, nat.ctx, which)
+        n_adds = lib.es_plan_count(lib.es_ctx_plan(nat.ctx, L.PLAN_STEP), 14)          # ES_OP_ADD: 12 skips + the mid tensor
+        assert n_adds == 13
+    finally:
+        nat.close()
+        lib.es_ctx_destroy(pctx)

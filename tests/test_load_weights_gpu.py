@@ -511,3 +511,54 @@ def test_control_guidance_window_through_the_native_loop_equals_the_pipeline_bit
     got = nat.denoise_loop(x.clone(), ehs, gs, ts)                     # window open again: the full step everywhere
     torch.cuda.synchronize()
     assert torch.equal(got.permute(0, 3, 1, 2), want_open)
+
+
+@pytest.mark.parametrize("guidance", [True, False])
+def test_guess_mode_context_equals_the_pipeline_bitwise(both, guidance):
+    """es_ctx_geometry.guess_mode = 1 (CL:256-264; PL:453-459, 487-497): under CFG the ControlNets run on the conditional half
+    only - their condition slots hold B rows - the 13 levels are scaled 0.1..1 log-spaced and the fused residuals go into the
+    conditional half of the UNet's skips.  es_load_weights' context against NativeEngine(guess_mode=True) call by call, and both
+    against pipe(guess_mode=True) bit for bit: per-plan graphs, launch by launch, one graph for the loop; RGB condition images
+    through es_prepare_conds; a control-guidance window (no UNet-only plan in guess_mode: ES_PLAN_STEP with all scales 0)."""
+    from edgestyle_amd.native import NativeEngine, NativeContext
+    pipe, _, _, ws, ucfg, vcfg, T = both
+    lat, pe, ne, conds, imgs, noise = _inputs(ucfg, vcfg, 71)
+    gs = 5.0 if guidance else 1.0
+    lib = L.load()
+    eng = NativeEngine(pipe, batch_size=1, guidance=guidance, num_inference_steps=T, guess_mode=True)
+    nat = NativeContext(ws, ucfg, vcfg, batch_size=1, guidance=guidance, num_inference_steps=T, device=0, guess_mode=True)
+    nat.set_alphas_cumprod(pipe.scheduler.alphas_cumprod)
+    try:
+        for which in range(L.PLAN_COUNT):
+            if which == L.PLAN_STEP_UNET:
+                assert lib.es_ctx_plan_size(nat.ctx, which) == -1 and lib.es_ctx_plan_size(eng.ctx, which) == -1
+                continue
+            assert diff_plans(lib, eng.ctx, nat.ctx, which) is None
+        noise1 = [None if z is None else z[:1].contiguous() for z in noise]      # one CFG half only: the ControlNets' batch is B
+        kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne if guidance else None, image=imgs, latents=lat, guidance_scale=gs,
+                  num_inference_steps=T, cond_noise=noise1, guess_mode=True)
+        want_lat = pipe(output_type="latent", **kw).images.clone()
+        want_img = pipe(output_type="pt", **kw).images.clone()
+        plain = pipe(output_type="latent", **dict(kw, guess_mode=False, cond_noise=noise if guidance else noise1)).images
+        assert not torch.equal(plain, want_lat)
+        want_win = pipe(output_type="latent", control_guidance_end=0.5, **kw).images.clone()
+        assert not torch.equal(want_win, want_lat)
+        ehs = (torch.cat([ne, pe]) if guidance else pe).to(DEV, torch.float16).contiguous()
+        x = lat.permute(0, 2, 3, 1).contiguous().to(DEV)
+        ts = pipe.scheduler.set_timesteps(T).tolist()
+        for ctx in (nat, eng):
+            for use_graphs in (True, False, 2):
+                ctx.set_options(use_graphs=use_graphs)
+                ctx.prepare_conds([im.to(DEV) for im in imgs], [None if z is None else z.to(DEV) for z in noise1])
+                got = ctx.denoise_loop(x.clone(), ehs, gs, ts)
+                img = ctx.vae_decode(got)
+                torch.cuda.synchronize()
+                assert torch.equal(got.permute(0, 3, 1, 2), want_lat), (type(ctx).__name__, use_graphs, float((got.permute(0, 3, 1, 2) - want_lat).abs().max()))
+                assert torch.equal(img, want_img)
+            ctx.set_options(control_guidance_end=0.5, use_graphs=True)
+            got = ctx.denoise_loop(x.clone(), ehs, gs, ts)
+            torch.cuda.synchronize()
+            assert torch.equal(got.permute(0, 3, 1, 2), want_win), type(ctx).__name__
+    finally:
+        nat.close()
+        eng.close()

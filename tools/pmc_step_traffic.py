@@ -10,6 +10,7 @@ WRITE_SIZE x 1024; the counters sit at the L2 -> fabric boundary (bytes served b
 launches.json (bench.py ES_DUMP_GEMM=1) supplies the algorithmic bytes of the same launch list."""
 import csv
 import json
+import os
 import re
 import sys
 
@@ -59,7 +60,7 @@ def main(fetch_csv, write_csv, launches_json, out_json):
     rd = 2 * 1024 * (F["conv_gemm_kernel"]["KiB_per_step"] + F["linear_xs_kernel"]["KiB_per_step"])
     wr = 1024 * (W["conv_gemm_kernel"]["KiB_per_step"] + W["linear_xs_kernel"]["KiB_per_step"])
     out = {
-        "round": 3,
+        "round": int(os.environ.get("ES_ROUND", "4")),
         "workload": "the GEMM launches (conv_gemm_kernel + linear_xs_kernel) of one batch-1 denoising step of the REAL "
                     "pipeline (bench.py --no-graph: same launch list as the captured step, eager so that counters can be "
                     f"collected per dispatch), steps averaged: {nf} (FETCH pass) / {nw} (WRITE pass)",
