@@ -39,6 +39,7 @@
 #endif
 
 int es_conv_gemm8p_launch(const es_gemm_desc& d, hipStream_t st);   // gemm_conv8p.hip: the 256 x 320 phase-interleaved tile
+bool es_conv_gemm8p_takes(const es_gemm_desc& d);                    // ... and whether its epilogue has the form this launch needs
 
 namespace {
 
@@ -896,7 +897,11 @@ __global__ __launch_bounds__(64 * (CB / 8)) void splitk_reduce_gn_kernel(const e
 }
 
 template <typename T>
-int launch(const es_gemm_desc& d, hipStream_t st) {
+int launch(const es_gemm_desc& d0, hipStream_t st) {
+  es_gemm_desc d = d0;
+  // the 256 x 320 tile keeps the common epilogue forms only (gemm_conv8p.hip); an activation, time-embedding rows that differ inside a
+  // 128-pixel half or meet a residual, or a Cout that is no multiple of 8 run on the 128 x 160 tile: the same results
+  if (d.bn == 320 && !es_conv_gemm8p_takes(d)) { d.bn = 160; d.stages = 2; }
   const int M = d.N * d.Hout * d.Wout;
   const int nk = d.Kpad / BK;
   const int Ctot = d.C1 + d.C2;

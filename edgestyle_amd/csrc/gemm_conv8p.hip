@@ -42,9 +42,14 @@
 // Tool-only builds (tools/ab8p.sh): ES8P_ABL removes one ingredient (results are wrong by construction).  ABL bits: 1 = every DMA out of range (issued, zero-filled, no memory traffic),
 // 2 = no MFMAs, 4 = no barrier stagger, 8 = activation DMAs out of range only, 16 = weight DMAs out of range only, 32 = chunk-major order with the
 // activation tile staged on tap 0 of every 64-channel chunk ONLY (taps 1-8 multiply whatever the buffer holds: the DMA count and L2->LDS bytes of an
-// LDS-resident halo patch, on non-zero data - what that design could gain at most).  The product library is built with ES8P_ABL == 0.
+// LDS-resident halo patch, on non-zero data - what that design could gain at most), 64 = no residual loads in the epilogue, 128 = no output stores.  The product library is built with ES8P_ABL == 0.
 #ifndef ES8P_ABL
 #define ES8P_ABL 0
+#endif
+// Tool-only diagnostic build (tools/epi8p_stamps.py): ES8P_STAMPS=1 writes s_memtime stamps of wave 0 of the first and the last workgroup
+// (entry | prologue issued | first K-tile landed | K loop done | pass-0 tile written | pass-0 stored | pass-1 tile written | end) into prof[256 ...]
+#ifndef ES8P_STAMPS
+#define ES8P_STAMPS 0
 #endif
 
 
@@ -57,7 +62,7 @@ constexpr int XT = BM * RB, WT = BN * RB, BUF = XT + WT;      // 32 KB + 40 KB p
 constexpr int FN = 5, FM = 8;                                 // cout / pixel fragments per wave
 constexpr int XI = 4, WI = 5;                                 // DMA pieces per wave per K-tile
 constexpr unsigned OOB = 0xFFFFFF00u;
-constexpr int EROW = 160 * 2 + 16;                            // epilogue tile row stride (bytes): 160 couts per pass
+constexpr int EROW = BN * 2 + 16;                             // epilogue tile row stride (bytes): 320 couts, 128 pixel rows per pass
 
 ES_DEVICE void row_offsets4(unsigned (&voff)[XI], const int (&iy0)[XI], const int (&ix0)[XI], const int (&nb)[XI],
                             const int tp, const int cs, const int chan, const int ksize, const int KK, const int pad,
@@ -95,7 +100,15 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
     if (p.xcd_m_fastest) { const int t = fast_div(w, tm, inv_tm); tile_m = w - t * tm; z = fast_div(t, tn, inv_tn); tile_n = t - z * tn; }
     else                 { const int t = fast_div(w, tn, inv_tn); tile_n = w - t * tn; z = fast_div(t, tm, inv_tm); tile_m = t - z * tm; }
   }
+#if ES8P_STAMPS
+  const int sblk = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 1 : (blockIdx.x == gridDim.x / 2 ? 2 : -1));
+  auto stamp = [&](int k) __attribute__((always_inline)) {
+    if (p.prof && sblk >= 0 && tid == 0) p.prof[256 + sblk * 8 + k] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
+#else
   if (p.prof && tid == 0) atomicMin(p.prof, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 
   int ks0 = 0, ks1 = nk;
   if (p.splitk > 1) {
@@ -304,8 +317,14 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
   const int xo0 = ((0 + fq) ^ (frow & 7)) << 4, xo1 = ((4 + fq) ^ (frow & 7)) << 4;
   const int xrow = (grp8 * 128 + frow) * RB;
   const int wrow = XT + (wn * 80 + frow) * RB;
+#if ES8P_STAMPS
+  stamp(1);
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+#if ES8P_STAMPS
+  stamp(2);
+#endif
   if (!(ES8P_ABL & 4) && grp8 == 1) __builtin_amdgcn_s_barrier();            // group 1 runs one barrier behind group 0
 
   typename Traits<T>::vec8 xa[4], wa[FN];
@@ -371,6 +390,9 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
     boff = nboff;
   }
   if (!(ES8P_ABL & 4) && grp8 == 0) __builtin_amdgcn_s_barrier();            // balance the stagger: every wave is past its last LDS read
+#if ES8P_STAMPS
+  stamp(3);
+#endif
 
   const int prow = grp8 * 128 + frow;                     // + j * 16 : pixel row inside the tile
   const int pcol = wn * 80 + fq * 4;                      // + i * 16 : cout column inside the tile
@@ -390,119 +412,170 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
     return;
   }
 
-  // ---------------- epilogue: two passes of 160 couts through an LDS tile [pixel][cout] ----------------
+  {
+  // ---------------- epilogue: two passes of 128 pixels (one wave group's half each) through an LDS tile [pixel][320 couts] ----------------
+  // Round 3 ran the passes over cout halves with every run-time option (time embedding, activation, scale, the kinds of residual) tested
+  // per VALUE inside fully unrolled loops: 15 k instructions, 111 k cycles per workgroup against 150 k for the whole K loop of a level-0
+  // convolution (tools/epi8p_stamps.py).  Now the options are decided once per pass and the common forms are straight-line code:
+  //   write phase (the four waves that own the pixel half, one per SIMD): (acc + bias) + temb, [SiLU], * scale -> LDS, the time-embedding
+  //     row fetched once per wave when all 128 pixels belong to one sample (H*W % 128 == 0);
+  //   store phase (all eight waves): 16-byte chunks of whole 640-byte rows, [+ residual | + residual pair -> value pair], coalesced stores.
+  // Same arithmetic in the same order as conv_gemm_kernel: bit-identical outputs.
   const int Cstore = p.Cout;
   float scale = p.out_scale;
   if (p.out_scale_dev) scale *= *p.out_scale_dev;
+  // lane coordinates re-derived from the thread index (opaque to the compiler: nothing of the epilogue is kept in registers across the K loop)
+  int tid_e = threadIdx.x;
+  asm volatile("" : "+v"(tid_e));
+  const int tid = tid_e, frow = tid_e & 15, fq = (tid_e >> 4) & 3;
+  const int pcol = wn * 80 + fq * 4;
   char* et = smem;
   T* outp = (T*)p.out;
   const T* resp = (const T*)p.residual;
-  const bool vec_store = (Cstore & 7) == 0;
-  constexpr int CH = 20;                                   // 16-byte chunks per tile row and pass
-  constexpr int RPF = BM * CH / 512;                       // chunks per thread and pass
+  constexpr int CH = 40;                                   // 16-byte chunks per tile row
+  constexpr int RPF = 128 * CH / 512;                      // chunks per thread and pass
+  const int cbase = tile_n * BN;
+  const bool tuni = p.temb != nullptr;                     // (es_conv_gemm8p_takes: then H*W % 128 == 0 - one sample per pixel half - and no residual)
+  // WMODE: 0 = bias only, 1 = bias + one time-embedding row per wave        SMODE: 0 = no residual, 1 = residual, 2 = value pair out, 3 = value pair in and out
+  // (an activation, per-pixel time-embedding rows, Cout % 8 != 0: es_conv_gemm runs those on the 128 x 160 tile, es_conv_gemm8p_takes)
+  auto passes = [&](auto wmode_c, auto smode_c) __attribute__((always_inline)) {
+    constexpr int WMODE = decltype(wmode_c)::value, SMODE = decltype(smode_c)::value;
+    constexpr bool RES = SMODE != 0;
+    constexpr int PF = !RES ? 0 : (SMODE >= 2 ? RPF / 2 : RPF);   // residual chunks prefetched (value pairs: half of them, registers)
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int c_tile = tile_n * BN + pass * 160;
-    u32x4 rpre[RPF];
-    if (resp && vec_store) {                               // residual rows requested before the LDS transposition
+    for (int pass = 0; pass < 2; ++pass) {
+      const int m_tile = tile_m * BM + pass * 128;
+      u32x4 rpre[RES ? PF : 1];
+      // the residual chunks this thread will add: requested by the group that does NOT write this pass while it waits for the tile, by the
+      // writing group after its accumulators are in LDS (never live beside them: 160 + 40 registers would not fit)
+      auto load_res = [&]() __attribute__((always_inline)) {
+        if constexpr (RES) {
 #pragma unroll
-      for (int k = 0; k < RPF; ++k) {
-        const int idx = tid + k * 512;
-        const int row = (idx * 3277) >> 16, ch = idx - row * CH;       // idx / 20 for idx < 5120
-        const int m = tile_m * BM + row, c = c_tile + ch * 8;
-        rpre[k] = u32x4{0u, 0u, 0u, 0u};
-        if (m < M && c < Cstore) rpre[k] = *(const u32x4*)(resp + (size_t)m * Cstore + c);
-      }
-    }
-    if (pass) __syncthreads();                             // previous pass's tile no longer read
-    if ((wn >> 1) == pass) {
-      f32x4 bias[FN];
+          for (int k = 0; k < PF; ++k) {
+            const int idx = tid + k * 512;
+            const int row = ((idx >> 3) * 13108) >> 16, ch = idx - row * CH;   // idx / 40 for idx < 5120
+            const int m = m_tile + row, c = cbase + ch * 8;
+            rpre[k] = u32x4{0u, 0u, 0u, 0u};
+            if (!(ES8P_ABL & 64) && resp && m < M && c < Cstore) rpre[k] = *(const u32x4*)(resp + (size_t)m * Cstore + c);
+          }
+        }
+      };
+      if (pass) __syncthreads();                           // previous pass's tile no longer read
+      if (grp8 == pass) {
+        char* wbase = et + frow * EROW + (wn * 80 + fq * 4) * 2;
+        f32x4 bias[FN];
 #pragma unroll
-      for (int i = 0; i < FN; ++i)
-        bias[i] = bsel ? *(const f32x4*)(bsel + tile_n * BN + pcol + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < FN; ++i)
+          bias[i] = bsel ? *(const f32x4*)(bsel + cbase + pcol + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+          f32x4 tvv[WMODE == 1 ? FN : 1];
+          if constexpr (WMODE == 1) {
+            const int m0 = m_tile < M ? m_tile : M - 1;
+            const int n = m0 / HWout;                      // (wave-uniform: the whole pixel half lies in sample n)
+            const T* trow = (const T*)p.temb + (size_t)n * p.temb_stride;
 #pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        const int m = tile_m * BM + prow + j * 16;
-        const int mc = m < M ? m : M - 1;
-        const int n = small_m ? fast_div(mc, HWout, inv_hw) : mc / HWout;
+            for (int i = 0; i < FN; ++i) {
+              const int c = cbase + pcol + i * 16;
+              tvv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+              if (c + 3 < p.Cout) {
+                const auto t4 = *(const typename Traits<T>::vec4*)(trow + c);
 #pragma unroll
-        for (int i = 0; i < FN; ++i) {
-          const int c = tile_n * BN + pcol + i * 16;
-          float tv[4] = {0.f, 0.f, 0.f, 0.f};
-          if (p.temb && c < p.Cout) {
-            const T* tp = (const T*)p.temb + (size_t)n * p.temb_stride + c;
-            if (c + 3 < p.Cout) {
-              const auto t4 = *(const typename Traits<T>::vec4*)tp;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) tv[r] = to_f32(t4[r]);
-            } else {
-              for (int r = 0; r < 4 && c + r < p.Cout; ++r) tv[r] = to_f32(tp[r]);
+                for (int r = 0; r < 4; ++r) tvv[i][r] = to_f32(t4[r]);
+              } else {
+                for (int r = 0; r < 4 && c + r < p.Cout; ++r) tvv[i][r] = to_f32(trow[c + r]);
+              }
             }
           }
-          typename Traits<T>::vec4 pk;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float x = acc[i][j][r] + bias[i][r] + tv[r];
-            if (p.act == ES_ACT_SILU) x = silu_f(x);
-            pk[r] = from_f32<T>(x * scale);
-          }
-          *(typename Traits<T>::vec4*)(et + (prow + j * 16) * EROW + ((wn & 1) * 80 + fq * 4 + i * 16) * 2) = pk;
-        }
-      }
-    }
-    __syncthreads();
-    if (vec_store) {
+          for (int j = 0; j < FM; ++j) {
 #pragma unroll
-      for (int k = 0; k < RPF; ++k) {
-        const int idx = tid + k * 512;
-        const int row = (idx * 3277) >> 16, ch = idx - row * CH;
-        const int m = tile_m * BM + row, c = c_tile + ch * 8;
-        if (m < M && c < Cstore) {
-          auto v = as_vec8<T>(*(const u32x4*)(et + row * EROW + ch * 16));
-          if (p.out_lo) {                                  // wide residual stream: as in conv_gemm_kernel
-            const auto rv = as_vec8<T>(rpre[k]);
-            typename Traits<T>::vec8 lv, lo;
-            if (p.residual_lo) lv = as_vec8<T>(*(const u32x4*)((const T*)p.residual_lo + (size_t)m * Cstore + c));
+            for (int i = 0; i < FN; ++i) {
+              typename Traits<T>::vec4 pk;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              float sum = to_f32(v[e]) + to_f32(rv[e]);
-              if (p.residual_lo) sum += to_f32(lv[e]);
-              v[e] = from_f32<T>(sum);
-              lo[e] = from_f32<T>(sum - to_f32(v[e]));
+              for (int r = 0; r < 4; ++r) {
+                float x = acc[i][j][r] + bias[i][r];
+                if constexpr (WMODE == 1) x += tvv[i][r]; else x += 0.f;      // (+ 0: as the general form rounds a -0)
+                pk[r] = from_f32<T>(x * scale);
+              }
+              *(typename Traits<T>::vec4*)(wbase + j * 16 * EROW + i * 32) = pk;
             }
-            store16((T*)p.out_lo + (size_t)m * Cstore + c, __builtin_bit_cast(u32x4, lo));
-          } else if (resp) {
-            const auto rv = as_vec8<T>(rpre[k]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(rv[e]));
           }
-          store16(outp + (size_t)m * Cstore + c, __builtin_bit_cast(u32x4, v));
-          if (p.gn_part) *(u32x4*)(et + row * EROW + ch * 16) = __builtin_bit_cast(u32x4, v);   // the FINAL value back into the tile
+        }
+        load_res();
+      } else {
+        load_res();
+      }
+      __syncthreads();
+#if ES8P_STAMPS
+      stamp(4 + pass * 2);
+#endif
+      {
+#pragma unroll
+        for (int k = 0; k < RPF; ++k) {
+          const int idx = tid + k * 512;
+          const int row = ((idx >> 3) * 13108) >> 16, ch = idx - row * CH;
+          const int m = m_tile + row, c = cbase + ch * 8;
+          if (m < M && c < Cstore) {
+            auto v = as_vec8<T>(*(const u32x4*)(et + row * EROW + ch * 16));
+            const size_t o = (size_t)m * Cstore + c;
+            constexpr bool wide = SMODE >= 2, wide_in = SMODE == 3;
+            if constexpr (wide) {                                    // wide residual stream: as in conv_gemm_kernel
+              const auto rv = as_vec8<T>(k < PF ? rpre[k < PF ? k : 0] : *(const u32x4*)(resp + o));
+              typename Traits<T>::vec8 lv, lo;
+              if constexpr (wide_in) lv = as_vec8<T>(*(const u32x4*)((const T*)p.residual_lo + o));
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                float sum = to_f32(v[e]) + to_f32(rv[e]);
+                if constexpr (wide_in) sum += to_f32(lv[e]);
+                v[e] = from_f32<T>(sum);
+                lo[e] = from_f32<T>(sum - to_f32(v[e]));
+              }
+              store16((T*)p.out_lo + o, __builtin_bit_cast(u32x4, lo));
+            } else if constexpr (SMODE == 1) {
+              const auto rv = as_vec8<T>(rpre[k < PF ? k : 0]);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(rv[e]));
+            }
+            if (!(ES8P_ABL & 128)) store16(outp + o, __builtin_bit_cast(u32x4, v));
+            else asm volatile("" ::"v"(v));
+            if (p.gn_part) *(u32x4*)(et + row * EROW + ch * 16) = __builtin_bit_cast(u32x4, v);   // the FINAL value back into the tile
+          }
+          if constexpr (SMODE >= 2) __builtin_amdgcn_sched_barrier(0);   // (value pairs: chunk by chunk, or the tile reads of all ten are hoisted and spill)
+        }
+        if (p.gn_part) {                                   // GroupNorm statistics for the consumer (es_gemm_desc.gn_part)
+          __syncthreads();
+          gn_emit_partials<T, 512>(et, EROW, 128, BN, (float*)(et + 128 * EROW), p.gn_part, m_tile, M, cbase, Cstore, HWout, p.gn_groups, tid);
         }
       }
-      if (p.gn_part) {                                     // GroupNorm statistics for the consumer (es_gemm_desc.gn_part)
-        __syncthreads();
-        gn_emit_partials<T, 512>(et, EROW, BM, 160, (float*)(et + BM * EROW), p.gn_part, tile_m * BM, M, c_tile, Cstore, HWout, p.gn_groups, tid);
-      }
-    } else {
-      for (int idx = tid; idx < BM * 160; idx += 512) {
-        const int row = idx / 160, cc = idx - row * 160;
-        const int m = tile_m * BM + row, c = c_tile + cc;
-        if (m < M && c < Cstore) {
-          float x = to_f32(*(const T*)(et + row * EROW + cc * 2));
-          if (resp) x += to_f32(resp[(size_t)m * Cstore + c]);
-          outp[(size_t)m * Cstore + c] = from_f32<T>(x);
-        }
-      }
+#if ES8P_STAMPS
+      stamp(5 + pass * 2);
+#endif
     }
+  };
+  using std::integral_constant;
+  if (tuni) passes(integral_constant<int, 1>{}, integral_constant<int, 0>{});
+  else if (p.out_lo) { if (p.residual_lo) passes(integral_constant<int, 0>{}, integral_constant<int, 3>{}); else passes(integral_constant<int, 0>{}, integral_constant<int, 2>{}); }
+  else if (resp) passes(integral_constant<int, 0>{}, integral_constant<int, 1>{});
+  else passes(integral_constant<int, 0>{}, integral_constant<int, 0>{});
   }
+#if !ES8P_STAMPS
   if (p.prof && tid == 0) atomicMax(p.prof + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 }  // namespace
 
+// the epilogue forms this tile implements (split-K launches write raw partials: every form)
+bool es_conv_gemm8p_takes(const es_gemm_desc& d) {
+  if (d.splitk > 1) return true;
+  if (d.act != ES_ACT_NONE || (d.Cout & 7)) return false;
+  if (d.temb && (((d.Hout * d.Wout) & 127) || d.residual)) return false;
+  return true;
+}
+
 // called by es_conv_gemm (gemm_conv.hip) after validation, for d.bn == 320
 int es_conv_gemm8p_launch(const es_gemm_desc& d, hipStream_t st) {
+  if (!es_conv_gemm8p_takes(d)) return -2;
   const int M = d.N * d.Hout * d.Wout;
   const int nk = d.Kpad / 64;
   const int tn = d.rows_padded / BN;

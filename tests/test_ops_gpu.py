@@ -699,6 +699,26 @@ def test_conv_gemm_big_tile_equals_small_tile():
                                                 act=lib.ACT_SILU, splitk=splitk))
         assert torch.equal(big, small), splitk
         assert rel_err(big.permute(0, 3, 1, 2), ref) < 3e-3
+    # The epilogue forms the 256 x 320 tile implements itself (round 4; the combination above - an activation, or a time embedding
+    # beside a residual - is handed to the 128 x 160 tile by es_conv_gemm): bias only / + residual on a ragged M, and the time
+    # embedding as one row per 128-pixel half (H*W % 128 == 0: ragged last tile of half a tile), out_scale on top
+    for kw, want in ((dict(), F.conv2d(torch.cat([x1, x2], 1), w, b, padding=1)),
+                     (dict(residual=nhwc(res)), F.conv2d(torch.cat([x1, x2], 1), w, b, padding=1) + res),
+                     (dict(residual=nhwc(res), out_scale=0.37), F.conv2d(torch.cat([x1, x2], 1), w, b, padding=1) * 0.37 + res)):
+        big, small = both(lambda: ops.conv_gemm(nhwc(x1), pw, x2=nhwc(x2), splitk=1, **kw))
+        assert torch.equal(big, small), list(kw)
+        assert rel_err(big.permute(0, 3, 1, 2), want) < 3e-3, list(kw)
+    xt = q16(torch.randn(N, C1, 8, 16, generator=g))                            # 3 x 128 pixels: M = 384 = one tile and a half
+    wt_ = q16(torch.randn(Cout, C1, 3, 3, generator=g) / math.sqrt(9 * C1))
+    pwt_ = ops.pack_weight(wt_, b, torch.float16, DEV)
+    big, small = both(lambda: ops.conv_gemm(nhwc(xt), pwt_, temb=tdev, splitk=1))
+    assert torch.equal(big, small)
+    assert rel_err(big.permute(0, 3, 1, 2), F.conv2d(xt, wt_, b, padding=1) + temb[:, :, None, None]) < 3e-3
+    # the two-word residual stream on the big tile: first word pair out of a one-word residual (bf16)
+    xb, rb = nhwc(x1, torch.bfloat16), nhwc(res, torch.bfloat16)
+    pwb = ops.pack_weight(q16(w[:, :C1], torch.bfloat16), b, torch.bfloat16, DEV)
+    big, small = both(lambda: ops.conv_gemm(xb, pwb, residual=rb, wide=True, splitk=1))
+    assert torch.equal(big, small) and torch.equal(big._lo, small._lo) and float(big._lo.float().abs().max()) > 0
     # stride 2 and 1x1, Cout = 320 (a single N tile)
     w2 = q16(torch.randn(320, C1, 3, 3, generator=g) / math.sqrt(9 * C1))
     pw2 = ops.pack_weight(w2, None, torch.float16, DEV)
