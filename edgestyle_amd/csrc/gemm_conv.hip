@@ -587,7 +587,47 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? (FM == 2 
       }
       __syncthreads();
     }
-    {
+    // The common forms as straight-line code (round 4: the options used to be tested per VALUE inside the unrolled loops - ~35 instructions
+    // per value; tools/epi8p_stamps.py measured the same code at 40 % of a level-0 convolution's time on the 256 x 320 tile): no
+    // activation, and the time embedding - if any - as ONE row per workgroup (all BM pixels of the tile in one sample: H*W % BM == 0).
+    // Same arithmetic in the same order as the general form below: (acc + bias) + temb, * scale.
+    const bool tuni = !LN && p.temb && (HWout % BM) == 0;  // (LayerNorm-folded launches are linear layers: no time embedding, no registers for one)
+    if (!geglu && p.act == ES_ACT_NONE && (!p.temb || tuni)) {
+      f32x4 tvv[LN ? 1 : FN];
+#pragma unroll
+      for (int i = 0; i < (LN ? 1 : FN); ++i) tvv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (tuni) {
+        const int m0 = tile_m * BM < M ? tile_m * BM : M - 1;
+        const T* trow = (const T*)p.temb + (size_t)(m0 / HWout) * p.temb_stride;
+#pragma unroll
+        for (int i = 0; i < (LN ? 0 : FN); ++i) {
+          const int c = tile_n * BN + pcol + i * 16;
+          if (c + 3 < p.Cout) {
+            const auto t4 = *(const typename Traits<T>::vec4*)(trow + c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tvv[i][r] = to_f32(t4[r]);
+          } else {
+            for (int r = 0; r < 4 && c + r < p.Cout; ++r) tvv[i][r] = to_f32(trow[c + r]);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        float ln_mean = 0.f, ln_rstd = 1.f;
+        if constexpr (LN) { ln_mean = rowstat[(prow + j * 16) * 2]; ln_rstd = rowstat[(prow + j * 16) * 2 + 1]; }
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+          typename Traits<T>::vec4 pk;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float a = acc[i][j][r];
+            if constexpr (LN) a = ln_rstd * (a - ln_mean * lncs[i][r]);
+            pk[r] = from_f32<T>((a + bias[i][r] + tvv[LN ? 0 : i][r]) * scale);
+          }
+          *(typename Traits<T>::vec4*)(et + (prow + j * 16) * EROW + (pcol + i * 16) * 2) = pk;
+        }
+      }
+    } else {
 #pragma unroll
       for (int j = 0; j < FM; ++j) {
         const int m = tile_m * BM + prow + j * 16;
@@ -650,36 +690,44 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? (FM == 2 
     if (vec_store) {
       const int CH = BNo / 8;
       const float inv_ch = __builtin_amdgcn_rcpf((float)CH);
+      // one form per kind of residual (0 none, 1 plain, 2 value pair out, 3 value pair in and out), chosen once
+      auto store_rows = [&](auto mode_c) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(mode_c)::value;
 #pragma unroll
-      for (int k = 0; k < RPF; ++k) {
-        const int idx = tid + k * NT;
-        const int row = fast_div(idx, CH, inv_ch), ch = idx - row * CH;
-        const int m = tile_m * BM + row, c = c_tile + ch * 8;
-        if (idx < BM * CH && m < M && c < Cstore) {
-          auto v = as_vec8<T>(*(const u32x4*)(et + row * EROW + ch * 16));
-          if (p.out_lo) {
-            // wide residual stream (es_gemm_desc.out_lo): the sum in fp32 over residual hi + lo, written back as hi + lo.  The lo
-            // chunk is requested here, not ahead of the K loop: its registers would push the 8-wave tiles over their budget
-            const auto rv = as_vec8<T>(rpre[k]);
-            typename Traits<T>::vec8 lv, lo;
-            if (p.residual_lo) lv = as_vec8<T>(*(const u32x4*)((const T*)p.residual_lo + (size_t)m * Cstore + c));
+        for (int k = 0; k < RPF; ++k) {
+          const int idx = tid + k * NT;
+          const int row = fast_div(idx, CH, inv_ch), ch = idx - row * CH;
+          const int m = tile_m * BM + row, c = c_tile + ch * 8;
+          if (idx < BM * CH && m < M && c < Cstore) {
+            auto v = as_vec8<T>(*(const u32x4*)(et + row * EROW + ch * 16));
+            const size_t o = (size_t)m * Cstore + c;
+            if constexpr (MODE >= 2) {
+              // wide residual stream (es_gemm_desc.out_lo): the sum in fp32 over residual hi + lo, written back as hi + lo.  The lo
+              // chunk is requested here, not ahead of the K loop: its registers would push the 8-wave tiles over their budget
+              const auto rv = as_vec8<T>(rpre[k]);
+              typename Traits<T>::vec8 lv, lo;
+              if constexpr (MODE == 3) lv = as_vec8<T>(*(const u32x4*)((const T*)p.residual_lo + o));
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              float sum = to_f32(v[e]) + to_f32(rv[e]);
-              if (p.residual_lo) sum += to_f32(lv[e]);
-              v[e] = from_f32<T>(sum);
-              lo[e] = from_f32<T>(sum - to_f32(v[e]));
+              for (int e = 0; e < 8; ++e) {
+                float sum = to_f32(v[e]) + to_f32(rv[e]);
+                if constexpr (MODE == 3) sum += to_f32(lv[e]);
+                v[e] = from_f32<T>(sum);
+                lo[e] = from_f32<T>(sum - to_f32(v[e]));
+              }
+              store16((T*)p.out_lo + o, __builtin_bit_cast(u32x4, lo));
+            } else if constexpr (MODE == 1) {
+              const auto rv = as_vec8<T>(rpre[k]);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(rv[e]));
             }
-            store16((T*)p.out_lo + (size_t)m * Cstore + c, __builtin_bit_cast(u32x4, lo));
-          } else if (resp) {
-            const auto rv = as_vec8<T>(rpre[k]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(rv[e]));
+            store16(outp + o, __builtin_bit_cast(u32x4, v));
+            if (p.gn_part) *(u32x4*)(et + row * EROW + ch * 16) = __builtin_bit_cast(u32x4, v);   // the FINAL value back into the tile
           }
-          store16(outp + (size_t)m * Cstore + c, __builtin_bit_cast(u32x4, v));
-          if (p.gn_part) *(u32x4*)(et + row * EROW + ch * 16) = __builtin_bit_cast(u32x4, v);   // the FINAL value back into the tile
         }
-      }
+      };
+      if (p.out_lo) { if (p.residual_lo) store_rows(std::integral_constant<int, 3>{}); else store_rows(std::integral_constant<int, 2>{}); }
+      else if (resp) store_rows(std::integral_constant<int, 1>{});
+      else store_rows(std::integral_constant<int, 0>{});
       if (p.gn_part) {                                     // GroupNorm statistics of this tile for the consumer (es_gemm_desc.gn_part)
         __syncthreads();
         gn_emit_partials<T, NT>(et, EROW, BM, BNo, (float*)(et + BM * EROW), p.gn_part, tile_m * BM, M, c_tile, Cstore, HWout, p.gn_groups, tid);
