@@ -57,13 +57,17 @@ namespace {
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-constexpr int BM = 256, BN = 320, RB = 128;
-constexpr int XT = BM * RB, WT = BN * RB, BUF = XT + WT;      // 32 KB + 40 KB per K-tile
-constexpr int FN = 5, FM = 8;                                 // cout / pixel fragments per wave
-constexpr int XI = 4, WI = 5;                                 // DMA pieces per wave per K-tile
+// Pixel rows per workgroup: 256 (the tile this file was written for) or 128 (round 4: the same loop on half the pixels, for launches
+// with too few 256-pixel tiles to fill the chip - the 32 x 32 and 16 x 16 levels of a batch-1 step; es_gemm_desc.bm).  Per wave group
+// GP = BM / 2 pixels, per phase a quarter of the tile: 4 | 2 pixel fragments x 5 cout fragments = 20 | 10 MFMAs.
+constexpr int BN = 320, RB = 128;
+constexpr int WT = BN * RB;                                   // 40 KB of weights per K-tile
+constexpr int FN = 5;                                         // cout fragments per wave
+constexpr int WI = 5;                                         // weight DMA pieces per wave per K-tile
 constexpr unsigned OOB = 0xFFFFFF00u;
 constexpr int EROW = BN * 2 + 16;                             // epilogue tile row stride (bytes): 320 couts, 128 pixel rows per pass
 
+template <int XI>
 ES_DEVICE void row_offsets4(unsigned (&voff)[XI], const int (&iy0)[XI], const int (&ix0)[XI], const int (&nb)[XI],
                             const int tp, const int cs, const int chan, const int ksize, const int KK, const int pad,
                             const int Hin, const int Win, const int upsample, const int Wsrc) {
@@ -79,10 +83,14 @@ ES_DEVICE void row_offsets4(unsigned (&voff)[XI], const int (&iy0)[XI], const in
   }
 }
 
-template <typename T, bool KO /* chunk-major K order, es_gemm_desc.korder == 1 */>
+template <typename T, bool KO /* chunk-major K order, es_gemm_desc.korder == 1 */, int BM /* 256 | 128 pixel rows */>
 __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc p, const int M, const int nk,
                                                              const void* const tail1, const void* const tail2,
                                                              const int tailC1, const int tailC2) {
+  constexpr int XT = BM * RB, BUF = XT + WT;            // 32 | 16 KB of pixels + 40 KB of weights per K-tile
+  constexpr int GP = BM / 2;                            // pixel rows per wave group
+  constexpr int FM = GP / 16, FMH = FM / 2;             // pixel fragments per wave, per phase
+  constexpr int XI = BM / 64, XQ = XI / 2;              // pixel DMA pieces per wave per K-tile, per pixel quarter
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -129,11 +137,11 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
   const int HWout = p.Hout * p.Wout;
   const bool small_m = M < (1 << 24);
   const float inv_hw = __builtin_amdgcn_rcpf((float)HWout), inv_w = __builtin_amdgcn_rcpf((float)p.Wout);
-  // X pieces of this wave: i = 2 * h + e -> tile rows 128 * grp8 + 64 * h + 16 * wn + 8 * e + lrow (its own pixel half)
+  // X pieces of this wave: i = XQ * h + e -> tile rows GP * grp8 + GP/2 * h + 8 * (XQ * wn + e) + lrow (its own pixel half)
   int iy0[XI], ix0[XI], nb[XI];
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
-    const int m = tile_m * BM + grp8 * 128 + (i >> 1) * 64 + wn * 16 + (i & 1) * 8 + lrow;
+    const int m = tile_m * BM + grp8 * GP + (i / XQ) * (GP / 2) + (wn * XQ + (i % XQ)) * 8 + lrow;
     iy0[i] = -(1 << 20); ix0[i] = -(1 << 20); nb[i] = 0;
     if (m < M) {
       int n, oy, ox;
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
         voff[i] = (tmask[i] & tb) ? __umul24((unsigned)pix, cs2) + (unsigned)(kc * 16) : OOB;
       }
     } else {
-      row_offsets4(voff, iy0, ix0, nb, tap, cs, kc * 8, pk_ksize, KK, pk_pad, Hin, Win, pk_up, pk_wsrc);
+      row_offsets4<XI>(voff, iy0, ix0, nb, tap, cs, kc * 8, pk_ksize, KK, pk_pad, Hin, Win, pk_up, pk_wsrc);
     }
     const void *b0 = px, *b1 = px2, *b2 = pt1, *b3 = pt2;
     int n0 = nX1, n1 = nX2, n2 = nT1, n3 = nT2;
@@ -291,9 +299,9 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
     const auto rS = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, (short)0, xrec, 0x00020000);
 #pragma unroll
     for (int i = 0; i < XI; ++i)
-      if ((i >> 1) == h)
+      if (i / XQ == h)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            rS, (lptr_t)(smem + boff + (grp8 * 16 + (i >> 1) * 8 + wn * 2 + (i & 1)) * 1024), 16,
+            rS, (lptr_t)(smem + boff + (grp8 * (GP / 8) + (i / XQ) * (GP / 16) + wn * XQ + (i % XQ)) * 1024), 16,
             (ES8P_ABL & (1 | 8)) ? (int)OOB : (int)voff[i], soff_x, 0, 0);
   };
 
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
   // per-lane fragment read offsets inside a K-tile buffer: row r of a sub-tile sits at r * 128, its 16-byte chunk c at
   // slot c ^ (r & 7); every fragment row of this lane has r & 7 == frow & 7
   const int xo0 = ((0 + fq) ^ (frow & 7)) << 4, xo1 = ((4 + fq) ^ (frow & 7)) << 4;
-  const int xrow = (grp8 * 128 + frow) * RB;
+  const int xrow = (grp8 * GP + frow) * RB;
   const int wrow = XT + (wn * 80 + frow) * RB;
 #if ES8P_STAMPS
   stamp(1);
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
 #endif
   if (!(ES8P_ABL & 4) && grp8 == 1) __builtin_amdgcn_s_barrier();            // group 1 runs one barrier behind group 0
 
-  typename Traits<T>::vec8 xa[4], wa[FN];
+  typename Traits<T>::vec8 xa[FMH], wa[FN];
   int boff = 0;
   for (int t = 0; t < nkt; ++t) {
     const bool nxt = t + 1 < nkt;                         // wave-uniform
@@ -341,19 +349,19 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
     __builtin_amdgcn_sched_barrier(0);                                                \
     __builtin_amdgcn_s_setprio(1);                                                    \
     if constexpr ((ES8P_ABL & 2) != 0) {                                              \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(xa[j]));    \
+      _Pragma("unroll") for (int j = 0; j < FMH; ++j) asm volatile("" ::"v"(xa[j]));  \
       _Pragma("unroll") for (int i = 0; i < FN; ++i) asm volatile("" ::"v"(wa[i]));   \
     } else {                                                                          \
     _Pragma("unroll") for (int i = 0; i < FN; ++i)                                    \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                   \
-        acc[i][(H) * 4 + j] = mfma16(wa[i], xa[j], acc[i][(H) * 4 + j]);              \
+      _Pragma("unroll") for (int j = 0; j < FMH; ++j)                                 \
+        acc[i][(H) * FMH + j] = mfma16(wa[i], xa[j], acc[i][(H) * FMH + j]);          \
     }                                                                                 \
     __builtin_amdgcn_s_setprio(0);                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                \
     __builtin_amdgcn_s_barrier();
     // ---- phase 0: (h 0, kk 0) ----
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xa[j] = ES_RD(xrow + xo0 + (0 * 64 + j * 16) * RB);
+    for (int j = 0; j < FMH; ++j) xa[j] = ES_RD(xrow + xo0 + (0 * (GP / 2) + j * 16) * RB);
 #pragma unroll
     for (int i = 0; i < FN; ++i) wa[i] = ES_RD(wrow + xo0 + i * 16 * RB);
     if (nxt) {
@@ -365,24 +373,24 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
     ES_MFMA(0)
     // ---- phase 1: (h 1, kk 0) ----
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xa[j] = ES_RD(xrow + xo0 + (1 * 64 + j * 16) * RB);
+    for (int j = 0; j < FMH; ++j) xa[j] = ES_RD(xrow + xo0 + (1 * (GP / 2) + j * 16) * RB);
     if (nxt) { issue_w(ksn, nboff, 2, WI); select_x(ksn); }
     ES_MFMA(1)
     // ---- phase 2: (h 0, kk 1) ----
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xa[j] = ES_RD(xrow + xo1 + (0 * 64 + j * 16) * RB);
+    for (int j = 0; j < FMH; ++j) xa[j] = ES_RD(xrow + xo1 + (0 * (GP / 2) + j * 16) * RB);
 #pragma unroll
     for (int i = 0; i < FN; ++i) wa[i] = ES_RD(wrow + xo1 + i * 16 * RB);
     if (nxt) issue_x(nboff, 0);
     ES_MFMA(0)
     // ---- phase 3: (h 1, kk 1) ----
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xa[j] = ES_RD(xrow + xo1 + (1 * 64 + j * 16) * RB);
+    for (int j = 0; j < FMH; ++j) xa[j] = ES_RD(xrow + xo1 + (1 * (GP / 2) + j * 16) * RB);
     if (nxt) {
       issue_x(nboff, 1);
       if (KO && (ES8P_ABL & 32) != 0 && x_skip) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else
-      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");    // weights + first pixel quarter of the next tile have landed
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XQ) : "memory");   // weights + first pixel quarter of the next tile have landed
     }
     ES_MFMA(1)
 #undef ES_MFMA
@@ -394,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
   stamp(3);
 #endif
 
-  const int prow = grp8 * 128 + frow;                     // + j * 16 : pixel row inside the tile
+  const int prow = grp8 * GP + frow;                      // + j * 16 : pixel row inside the tile
   const int pcol = wn * 80 + fq * 4;                      // + i * 16 : cout column inside the tile
   // ---------------- split-K: raw fp32 partials ----------------
   if (p.splitk > 1) {
@@ -433,9 +441,9 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
   T* outp = (T*)p.out;
   const T* resp = (const T*)p.residual;
   constexpr int CH = 40;                                   // 16-byte chunks per tile row
-  constexpr int RPF = 128 * CH / 512;                      // chunks per thread and pass
+  constexpr int RPF = GP * CH / 512;                       // chunks per thread and pass
   const int cbase = tile_n * BN;
-  const bool tuni = p.temb != nullptr;                     // (es_conv_gemm8p_takes: then H*W % 128 == 0 - one sample per pixel half - and no residual)
+  const bool tuni = p.temb != nullptr;                     // (es_conv_gemm8p_takes: then H*W % GP == 0 - one sample per pixel half - and no residual)
   // WMODE: 0 = bias only, 1 = bias + one time-embedding row per wave        SMODE: 0 = no residual, 1 = residual, 2 = value pair out, 3 = value pair in and out
   // (an activation, per-pixel time-embedding rows, Cout % 8 != 0: es_conv_gemm runs those on the 128 x 160 tile, es_conv_gemm8p_takes)
   auto passes = [&](auto wmode_c, auto smode_c) __attribute__((always_inline)) {
@@ -444,7 +452,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
     constexpr int PF = !RES ? 0 : (SMODE >= 2 ? RPF / 2 : RPF);   // residual chunks prefetched (value pairs: half of them, registers)
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-      const int m_tile = tile_m * BM + pass * 128;
+      const int m_tile = tile_m * BM + pass * GP;
       u32x4 rpre[RES ? PF : 1];
       // the residual chunks this thread will add: requested by the group that does NOT write this pass while it waits for the tile, by the
       // writing group after its accumulators are in LDS (never live beside them: 160 + 40 registers would not fit)
@@ -544,7 +552,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
         }
         if (p.gn_part) {                                   // GroupNorm statistics for the consumer (es_gemm_desc.gn_part)
           __syncthreads();
-          gn_emit_partials<T, 512>(et, EROW, 128, BN, (float*)(et + 128 * EROW), p.gn_part, m_tile, M, cbase, Cstore, HWout, p.gn_groups, tid);
+          gn_emit_partials<T, 512>(et, EROW, GP, BN, (float*)(et + GP * EROW), p.gn_part, m_tile, M, cbase, Cstore, HWout, p.gn_groups, tid);
         }
       }
 #if ES8P_STAMPS
@@ -569,7 +577,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
 bool es_conv_gemm8p_takes(const es_gemm_desc& d) {
   if (d.splitk > 1) return true;
   if (d.act != ES_ACT_NONE || (d.Cout & 7)) return false;
-  if (d.temb && (((d.Hout * d.Wout) & 127) || d.residual)) return false;
+  if (d.temb && (((d.Hout * d.Wout) % (d.bm == 128 ? 64 : 128)) || d.residual)) return false;
   return true;
 }
 
@@ -579,19 +587,26 @@ int es_conv_gemm8p_launch(const es_gemm_desc& d, hipStream_t st) {
   const int M = d.N * d.Hout * d.Wout;
   const int nk = d.Kpad / 64;
   const int tn = d.rows_padded / BN;
-  dim3 grid(((M + BM - 1) / BM) * tn * d.splitk);
-  constexpr size_t lds = 2 * (size_t)BUF;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_gemm8p_kernel<f16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)conv_gemm8p_kernel<bf16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)conv_gemm8p_kernel<f16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)conv_gemm8p_kernel<bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-#define ES8P_LAUNCH(TT, KOV) hipLaunchKernelGGL((conv_gemm8p_kernel<TT, KOV>), grid, dim3(512), lds, st, d, M, nk, d.t1, d.t2, d.Ct1, d.Ct2)
-  if (d.dtype == ES_F16) { if (d.korder) ES8P_LAUNCH(f16, true); else ES8P_LAUNCH(f16, false); }
-  else                   { if (d.korder) ES8P_LAUNCH(bf16, true); else ES8P_LAUNCH(bf16, false); }
+  const int bm = d.bm == 128 ? 128 : 256;
+  dim3 grid(((M + bm - 1) / bm) * tn * d.splitk);
+#define ES8P_LAUNCH(TT, KOV, BMV)                                                                                        \
+  do {                                                                                                                    \
+    auto kfn = conv_gemm8p_kernel<TT, KOV, BMV>;                                                                          \
+    constexpr size_t lds = 2 * ((size_t)BMV * RB + WT);                                                                   \
+    static bool attr_set = false;                                                                                         \
+    if (!attr_set) {                                                                                                      \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+      attr_set = true;                                                                                                    \
+    }                                                                                                                     \
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, st, d, M, nk, d.t1, d.t2, d.Ct1, d.Ct2);                                \
+  } while (0)
+#define ES8P_LAUNCH_T(TT)                                                                                                \
+  do {                                                                                                                    \
+    if (bm == 128) { if (d.korder) ES8P_LAUNCH(TT, true, 128); else ES8P_LAUNCH(TT, false, 128); }                        \
+    else           { if (d.korder) ES8P_LAUNCH(TT, true, 256); else ES8P_LAUNCH(TT, false, 256); }                        \
+  } while (0)
+  if (d.dtype == ES_F16) ES8P_LAUNCH_T(f16); else ES8P_LAUNCH_T(bf16);
+#undef ES8P_LAUNCH_T
 #undef ES8P_LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
