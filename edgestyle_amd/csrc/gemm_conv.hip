@@ -1048,14 +1048,13 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
     for (int g = 0; g < d->ngroups; ++g)
       if (!d->w_g[g] || d->mt_end[g] <= (g ? d->mt_end[g - 1] : 0)) { es_set_error("es_conv_gemm: bad group table"); return -1; }
     if (d->mt_end[d->ngroups - 1] != tm || (d->N * d->Hout * d->Wout) % 128) { es_set_error("es_conv_gemm: groups must tile M in whole 128-pixel tiles"); return -1; }
-    if (d->bn == 320 && d->bm != 128)
+    if (d->bn == 320)
       for (int g = 0; g < d->ngroups; ++g)
         if (d->mt_end[g] & 1) { es_set_error("es_conv_gemm: 256-pixel tiles need groups of whole 256-pixel tiles"); return -1; }
   }
   if (d->bn != 64 && d->bn != 128 && d->bn != 160 && d->bn != 320) { es_set_error("es_conv_gemm: bn must be 64, 128, 160 or 320"); return -1; }
   if (d->bn == 64 && (d->C1 % BK || d->C2 % BK || d->stages == 3 || d->waves == 8 || d->act == ES_ACT_GEGLU)) {
     es_set_error("es_conv_gemm: bn=64 is the 64x64 tile: 64-aligned channels, 2 or 4 stages, no GEGLU"); return -1; }
-  if (d->bm != 0 && d->bm != 128 && d->bm != 256) { es_set_error("es_conv_gemm: bm must be 0, 128 or 256"); return -1; }
   if (d->bn == 320 && (d->C1 % BK || d->C2 % BK || (d->stages != 0 && d->stages != 2) || d->act == ES_ACT_GEGLU || d->waves == 8)) {
     es_set_error("es_conv_gemm: bn=320 is the 256-pixel phase-interleaved tile: 64-aligned channels, 2 stages, no GEGLU"); return -1; }
   if (d->rows_padded % d->bn || d->rows_padded < d->Cout) { es_set_error("es_conv_gemm: bad rows_padded"); return -1; }

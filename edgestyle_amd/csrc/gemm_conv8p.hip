@@ -57,9 +57,9 @@ namespace {
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// Pixel rows per workgroup: 256 (the tile this file was written for) or 128 (round 4: the same loop on half the pixels, for launches
-// with too few 256-pixel tiles to fill the chip - the 32 x 32 and 16 x 16 levels of a batch-1 step; es_gemm_desc.bm).  Per wave group
-// GP = BM / 2 pixels, per phase a quarter of the tile: 4 | 2 pixel fragments x 5 cout fragments = 20 | 10 MFMAs.
+// Pixel rows per workgroup are a template parameter of the kernel; only BM = 256 is instantiated.  Round 4 measured the same loop on a
+// 128 x 320 tile (10 MFMAs per phase, for launches with fewer 256-pixel tiles than CUs): never ahead of the 128 x 160 tile with its two
+// workgroups per CU (profiles/r04_bm128_ablation.txt: 844 against 1025 TFLOP/s on the level-1 grouped convolution of a batch-1 step).
 constexpr int BN = 320, RB = 128;
 constexpr int WT = BN * RB;                                   // 40 KB of weights per K-tile
 constexpr int FN = 5;                                         // cout fragments per wave
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
 bool es_conv_gemm8p_takes(const es_gemm_desc& d) {
   if (d.splitk > 1) return true;
   if (d.act != ES_ACT_NONE || (d.Cout & 7)) return false;
-  if (d.temb && (((d.Hout * d.Wout) % (d.bm == 128 ? 64 : 128)) || d.residual)) return false;
+  if (d.temb && (((d.Hout * d.Wout) & 127) || d.residual)) return false;
   return true;
 }
 
@@ -587,7 +587,7 @@ int es_conv_gemm8p_launch(const es_gemm_desc& d, hipStream_t st) {
   const int M = d.N * d.Hout * d.Wout;
   const int nk = d.Kpad / 64;
   const int tn = d.rows_padded / BN;
-  const int bm = d.bm == 128 ? 128 : 256;
+  constexpr int bm = 256;
   dim3 grid(((M + bm - 1) / bm) * tn * d.splitk);
 #define ES8P_LAUNCH(TT, KOV, BMV)                                                                                        \
   do {                                                                                                                    \
@@ -602,8 +602,7 @@ int es_conv_gemm8p_launch(const es_gemm_desc& d, hipStream_t st) {
   } while (0)
 #define ES8P_LAUNCH_T(TT)                                                                                                \
   do {                                                                                                                    \
-    if (bm == 128) { if (d.korder) ES8P_LAUNCH(TT, true, 128); else ES8P_LAUNCH(TT, false, 128); }                        \
-    else           { if (d.korder) ES8P_LAUNCH(TT, true, 256); else ES8P_LAUNCH(TT, false, 256); }                        \
+    if (d.korder) ES8P_LAUNCH(TT, true, 256); else ES8P_LAUNCH(TT, false, 256);                                           \
   } while (0)
   if (d.dtype == ES_F16) ES8P_LAUNCH_T(f16); else ES8P_LAUNCH_T(bf16);
 #undef ES8P_LAUNCH_T

@@ -36,7 +36,6 @@ class lane:
 XCD_ORDER = -1      # tuning knob: -1 auto, 0 tile_n fastest, 1 tile_m fastest
 DEEP_RING = _os.environ.get("ES_DEEP_RING", "1") == "1"     # 4-stage LDS ring for launches of <= 1 workgroup per CU
 FORCE_BN = 0        # tuning knob: 0 = per-launch choice between the legal N tiles
-FORCE_BM = 0        # tuning knob: pixel rows of the bn = 320 tile (128: the half-height form; 0 = the planner's choice)
 FORCE_STAGES = 0    # tuning knob (tools/gemm_bench.py): 0 = kernel picks the LDS ring depth
 FORCE_WAVES = 0     # tuning knob: 0 = planner picks 4 or 8 waves per 128-pixel workgroup
 EIGHT_WAVES = _os.environ.get("ES_EIGHT_WAVES", "1") == "1"
@@ -578,7 +577,6 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     d.act, d.splitk, d.bn, d.dtype, d.out_scale = act_i, splitk, bn, _dt(x), out_scale
     d.stages = stages or FORCE_STAGES
     d.korder = pw.korder
-    d.bm = FORCE_BM if bn == 320 else 0
     if (gn_groups > 0 and gn_handover(Hout * Wout, cstore, gn_groups) and not pw.geglu and pw.ln_colsum is None
             and pw.cout // gn_groups <= (160 if bn == 320 else bn)):
         # the consumer of `out` is a GroupNorm over gn_groups groups: hand its statistics over from this launch's epilogue
@@ -628,7 +626,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
             d.t2, d.Ct2 = tails[1].data_ptr(), tails[1].shape[3]
     if pws is not None:
         hw = Hout * Wout
-        gran = 256 if (bn == 320 and int(d.bm) != 128) else BM
+        gran = 256 if bn == 320 else BM
         if len(pws) > 4 or len(group_n) != len(pws) or sum(group_n) != N or any((n * hw) % gran for n in group_n):
             raise L.EdgeStyleHipError(f"grouped conv_gemm: groups must cover N in whole {gran}-pixel tiles (<= 4 groups)")
         d.ngroups = len(pws)

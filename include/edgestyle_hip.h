@@ -121,10 +121,6 @@ typedef struct {
    * output's H*W % 64 == 0, Cout % 8 == 0 and Cout / gn_groups <= the N tile.  NULL: no statistics. */
   float* gn_part;
   int32_t gn_groups;
-  /* pixel rows per workgroup of the bn = 320 tile: 0 | 256 = the 256 x 320 tile, 128 = the same phase-interleaved loop on 128 x 320
-   * (launches with fewer 256-pixel tiles than CUs; grouped launches then need whole 128-pixel tiles per group only).  Ignored for
-   * the other values of bn. */
-  int32_t bm;
 } es_gemm_desc;
 int es_conv_gemm(const es_gemm_desc* d, void* stream);
 size_t es_conv_gemm_workspace_bytes(const es_gemm_desc* d);

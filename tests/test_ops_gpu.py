@@ -669,20 +669,19 @@ def test_grouped_launches_equal_separate_launches():
         ops.conv_gemm(x, pws, group_n=[3, 5, 4, 2])      # 3 samples x 64 px is not a whole number of 128-px tiles
 
 
-@pytest.mark.parametrize("bm", [0, 128])
-def test_conv_gemm_big_tile_equals_small_tile(bm):
-    """bn=320 (256-pixel x 320-cout tile, 8 waves, streamed W fragments, two-pass epilogue; bm = 128: the same loop on 128 x 320,
-    es_gemm_desc.bm) must reproduce the 128-pixel tile bit for bit (same K order per accumulator) and match F.conv2d: concat + temb +
-    residual + SiLU, ragged M, split-K, grouped weights, 1x1, stride 2."""
+def test_conv_gemm_big_tile_equals_small_tile():
+    """bn=320 (256-pixel x 320-cout tile, 8 waves, streamed W fragments, two-pass epilogue) must reproduce the
+    128-pixel tile bit for bit (same K order per accumulator) and match F.conv2d: concat + temb + residual + SiLU,
+    ragged M, split-K, grouped weights, 1x1, stride 2."""
     from edgestyle_amd import ops, lib
     g = torch.Generator().manual_seed(21)
 
     def both(fn):
-        ops.FORCE_BN, ops.FORCE_BM = 320, bm
+        ops.FORCE_BN = 320
         try:
             big = fn()
         finally:
-            ops.FORCE_BN, ops.FORCE_BM = 0, 0
+            ops.FORCE_BN = 0
         return big, fn()
 
     N, C1, C2, Cout, H = 3, 128, 64, 640, 12            # M = 432: one full + one ragged 256-pixel tile, 2 N tiles
@@ -748,17 +747,12 @@ def test_conv_gemm_big_tile_equals_small_tile(bm):
         big, small = both(lambda: ops.conv_gemm(nhwc(x1), pwt, tail=(nhwc(t1), nhwc(t2)), splitk=splitk))
         assert torch.equal(big, small), splitk
         assert rel_err(big.permute(0, 3, 1, 2), reft) < 3e-3, splitk
-    xs_ = xg[:, :8, :8].contiguous()                      # 64-pixel samples: groups of 128 / 256 / 128 pixels
-    if bm == 128:                                         # ... whole 128-pixel tiles: legal for the half-height form
-        big, small = both(lambda: ops.conv_gemm(xs_, pws, group_n=counts, splitk=1))
-        assert torch.equal(big, small)
-    else:
-        with pytest.raises(Exception):                    # 128-pixel group boundaries cannot use 256-pixel tiles
-            ops.FORCE_BN = 320
-            try:
-                ops.conv_gemm(xs_, pws, group_n=counts)
-            finally:
-                ops.FORCE_BN = 0
+    with pytest.raises(Exception):                        # 128-pixel group boundaries cannot use 256-pixel tiles
+        ops.FORCE_BN = 320
+        try:
+            ops.conv_gemm(xg[:, :8, :8].contiguous(), pws, group_n=counts)   # 64-pixel samples: groups of 128/256/128 px
+        finally:
+            ops.FORCE_BN = 0
 
 
 @pytest.mark.parametrize("N,H,C,Cout,Ct1,Ct2,splitk", [
