@@ -302,8 +302,8 @@ struct CA {                       // keyword arguments of ops.conv_gemm
 // context bit-identical to a Python-built one; tests/test_host_cpu.py sweeps both over the shapes of the model ---------------
 #pragma clang fp contract(off)
 constexpr double PLAN_T160 = 1.25, PLAN_ALONE = 0.9, PLAN_TFIX = 2.0, PLAN_RED_FIX = 12.0, PLAN_SLAB_BYTES_PER_UNIT = 4.0e6;
-constexpr double PLAN_T320 = 2.3, PLAN_T320_FIX = 4.0;
-constexpr int PLAN_BIG_MIN_M = 16384, PLAN_BIG_MIN_NK = 16;
+constexpr double PLAN_T320 = 2.3, PLAN_T320_FIX = 3.0;
+constexpr int PLAN_BIG_MIN_M = 2048, PLAN_BIG_MIN_NK = 16;
 constexpr double PLAN_T64_ALONE = 0.5, PLAN_T64 = 0.16, PLAN_T64_LONG = 1.5;
 constexpr int PLAN_SMALL_MAX_M = 16384, PLAN_MIN_SLICE = 12, PLAN_NK_NOSPLIT = 10, PLAN_RESIDENT = 512;
 
@@ -332,7 +332,9 @@ bool plan_gemm(long long M, int rows_padded, int kpad, bool geglu, const int* bn
         const double ex = std::max(0.0, w - 1.0);
         tk = (PLAN_T64_ALONE + PLAN_T64 * (ex * ex)) * (nk <= 40 ? 1.0 : PLAN_T64_LONG);
       } else tk = (bn == 160 ? PLAN_T160 : 1.0) * (wgs <= PLAN_RESIDENT / 2 ? PLAN_ALONE : 1.0);
-      double t = (double)((wgs + resident - 1) / resident) * (((double)nk / (double)sk) * tk + (bn == 320 ? PLAN_T320_FIX : PLAN_TFIX));
+      // (the 256 x 320 tile costs its fractional number of rounds, no less than 0.9: ops.plan_gemm_reference)
+      const double rounds = bn == 320 ? std::max((double)wgs / 256.0, 0.9) : (double)((wgs + resident - 1) / resident);
+      double t = rounds * (((double)nk / (double)sk) * tk + (bn == 320 ? PLAN_T320_FIX : PLAN_TFIX));
       if (sk > 1) t += PLAN_RED_FIX + (double)sk * (double)M * (double)rows_padded * 8.0 / PLAN_SLAB_BYTES_PER_UNIT;
       if (!have || t < bt) { have = true; bt = t; bbn = bn; bsk = sk; bwgs = wgs; }
     }

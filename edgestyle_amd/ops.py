@@ -263,10 +263,11 @@ def _get_workspace(nbytes: int, device) -> torch.Tensor:
 #   * a 160-wide tile costs 1.25x a 128-wide one per K-step; a workgroup alone on its CU runs ~10 % faster;
 #   * split-K pays a reduce launch (~12 units) plus the fp32 slab round trip, needs >= 12 K-steps per slice and is
 #     never worth it for K <= 640.
-#   * the big tile (256 px x 320 couts, one workgroup per CU) does the work of two 160-wide workgroups in ~4 % less
-#     time (half the L2->LDS bytes); it only pays on launches of many rounds, so it is offered from 32k pixels up.
+#   * the big tile (256 px x 320 couts, one workgroup per CU) does the work of two 160-wide workgroups in ~8 % less
+#     time (half the L2->LDS bytes) and is charged FRACTIONAL rounds; since round 4 (lean epilogue) it is offered from 2048 pixels up,
+#     where it wins as a split-K launch of ~256 workgroups (the 16 x 16 decoder level at batch 8: 1.3-1.5x, tools/plan_fit_bench.py).
 PLAN_T160, PLAN_ALONE, PLAN_TFIX, PLAN_RED_FIX, PLAN_SLAB_BYTES_PER_UNIT = 1.25, 0.9, 2.0, 12.0, 4.0e6
-PLAN_T320, PLAN_BIG_MIN_M, PLAN_T320_FIX, PLAN_BIG_MIN_NK = 2.3, 16384, 4.0, 16
+PLAN_T320, PLAN_BIG_MIN_M, PLAN_T320_FIX, PLAN_BIG_MIN_NK = 2.3, 2048, 3.0, 16
 #   * the 64x64 tile (tiny launches): a K-step costs 0.5 units with the CU to itself and 0.5 + 0.16 (w - 1)^2 with w
 #     workgroups per CU (measured 0.87 at w = 2.5, 2.0 at w = 3.75); x1.5 for K > 2560, where MFMA throughput starts to
 #     matter and the small tile reads LDS twice as often per FLOP;
@@ -331,7 +332,11 @@ def plan_gemm_reference(M: int, rows_padded: int, kpad: int, geglu: bool = False
                 tk = (PLAN_T64_ALONE + PLAN_T64 * max(0.0, w - 1.0) ** 2) * (1.0 if nk <= 40 else PLAN_T64_LONG)
             else:
                 tk = (PLAN_T160 if bn == 160 else 1.0) * (PLAN_ALONE if wgs <= PLAN_RESIDENT // 2 else 1.0)
-            t = -(-wgs // resident) * ((nk / sk) * tk + (PLAN_T320_FIX if bn == 320 else PLAN_TFIX))
+            # rounds of workgroups: whole ones for the two-per-CU tiles; the 256 x 320 tile (one workgroup per CU, long tiles) is
+            # measured to cost its FRACTIONAL number of rounds - 896 tiles = 3.5 rounds run in 3.5 tile times, the CUs of a part-filled
+            # round run faster (tools/plan_fit_bench.py, round 4) - and no less than 0.9 of a round
+            rounds = max(wgs / 256.0, 0.9) if bn == 320 else float(-(-wgs // resident))
+            t = rounds * ((nk / sk) * tk + (PLAN_T320_FIX if bn == 320 else PLAN_TFIX))
             if sk > 1:
                 t += PLAN_RED_FIX + sk * M * rows_padded * 8.0 / PLAN_SLAB_BYTES_PER_UNIT
             if best is None or t < best[0]:
