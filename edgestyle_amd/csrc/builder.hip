@@ -559,7 +559,7 @@ struct Builder {
   // -- ops (edgestyle_amd/ops.py): descriptors handed to the C ABI, which validates and records them --------------------------
   static void ok(int rc, const char* what) { if (rc) fail(std::string(what) + ": " + es_last_error()); }
 
-  T linear_xs(const T& x, const PWs& pl, long long M, const T& out, const std::vector<long long>& group_rows) {
+  T linear_xs(const T& x, const PWs& pl, long long M, const T& out, const std::vector<long long>& group_rows, const T& residual = T()) {
     const PW* pw = pl[0];
     const int K = pw->kpad, ch = K == 320 ? 64 : 32;
     const int pline = 128 / (pw->geglu ? ch : 2 * ch);
@@ -579,6 +579,7 @@ struct Builder {
     d.M = (int)M; d.K = K; d.Cout = pw->cout; d.rows_padded = pw->rows_padded; d.ldo = out.c;
     d.geglu = pw->geglu; d.ln = pw->ln_colsum != 0; d.ln_eps = pw->ln_eps;
     d.nslices = nslices; d.chunks_per_slice = lps * pline; d.dtype = dt;
+    if (residual) d.residual = residual.ptr();
     if (pl.size() > 1) {
       d.ngroups = (int)pl.size();
       long long acc = 0;
@@ -613,7 +614,11 @@ struct Builder {
     T out = a.out ? a.out : empty(N, Hout, Wout, cstore);
     if (out.numel() != (long long)N * Hout * Wout * cstore || !out.contig()) fail("conv_gemm: output buffer of another size");
     const long long M = (long long)N * Hout * Wout, hw = (long long)Hout * Wout;
-    const bool plain = k == 1 && a.stride == 1 && !a.upsample && !a.x2 && !a.temb && !a.residual && a.tails.empty() && a.x_rep == 1 &&
+    // (a residual rides on es_linear_xs at K = 320, unless the launch carries the two-word residual stream: ops.conv_gemm)
+    static const bool xs_residual = [] { const char* e = getenv("ES_XS_RESIDUAL"); return !e || std::string(e) == "1"; }();
+    const bool xs_res = !a.residual || (xs_residual && pw->kpad == 320 && !pw->geglu && !pw->ln_colsum && a.residual.contig() &&
+                                        a.residual.numel() == (long long)N * Hout * Wout * cstore && !(a.wide && wide_stream()));
+    const bool plain = k == 1 && a.stride == 1 && !a.upsample && !a.x2 && !a.temb && xs_res && a.tails.empty() && a.x_rep == 1 &&
                        a.act == ES_ACT_NONE && a.out_scale == 1.f && !a.out_scale_dev;
     if (plain && xs_shape_ok(M, pw->ksize, pw->kpad, pw->cin, pw->ctail, pw->cout, pw->geglu)) {
       bool e = true;
@@ -626,7 +631,7 @@ struct Builder {
         std::vector<long long> rows;
         for (int n : a.group_n) rows.push_back(n * hw);
         T xo = out;
-        linear_xs(x, grouped ? pl : PWs{pw}, M, xo, rows);
+        linear_xs(x, grouped ? pl : PWs{pw}, M, xo, rows, a.residual);
         return out;
       }
     }

@@ -53,7 +53,7 @@ constexpr int XS_LDS = XS_STAGES * XS_STAGE + 8 * 32 * XS_OROW;
 
 template <int N> ES_DEVICE void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int KC /* K / 32 */, bool GEGLU, bool LN>
+template <typename T, int KC /* K / 32 */, bool GEGLU, bool LN, bool RES = false>
 __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
   constexpr int K = KC * 32;
   constexpr int NF = KC == 10 ? 4 : 2;          // 16-column fragments per stage
@@ -63,6 +63,7 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
   constexpr int OUTB = GEGLU ? CH : CH * 2;      // stored bytes per row per stage
   constexpr int P = 128 / OUTB;                  // stages per full 128-byte output line
   static_assert(KC == 10 || KC == 20, "K = 320 or 640");
+  static_assert(!RES || (P == 1 && !GEGLU && !LN), "residual: K = 320, a full output line per stage (the attention / proj output layers)");
   static_assert(NF * 16 * K * 2 == XS_STAGE_W, "stage geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -164,6 +165,21 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
 
   char* ostage = smem + XS_STAGES * XS_STAGE + wave * (32 * XS_OROW);
   const auto rO = __builtin_amdgcn_make_buffer_rsrc(p.out, (short)0, (int)((size_t)p.M * p.ldo * 2), 0x00020000);
+  // residual rows (es_xs_desc.residual: out = x W^T + bias + residual, the attention / proj output layers): the 16-byte chunks a lane
+  // stores are requested at the TOP of the stage that produces them - four range-checked loads, issued unconditionally like the stores so
+  // that the counted waits see the same queue in every wave - and consumed in its epilogue (the late waves': one stage later, two sets)
+  const auto rR = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? p.residual : p.out), (short)0, (int)((size_t)p.M * p.ldo * 2), 0x00020000);
+  auto load_res = [&](int ci, u32x4 (&rr)[4]) __attribute__((always_inline)) {
+    if constexpr (RES) {
+      const int line = c0 + ci;                      // P == 1: one 64-channel line per stage
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = i * 8 + (lane >> 3), col = lane & 7;
+        const unsigned off = (unsigned)(((size_t)(r0 + row) * p.ldo + line * 64 + col * 8) * 2);
+        rr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rR, (int)off, 0, 0));
+      }
+    }
+  };
 
   // The two waves that share a SIMD (w and w + 4) run the same program between the same barriers: left alone they do
   // their MFMAs together and their epilogue arithmetic together, and the matrix pipe idles through every epilogue
@@ -185,7 +201,8 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
   // top of iteration ci-2): the next stage's NDMA, plus the 4 output stores of every finished line group in between.
   // Early waves store the line of stage c at the end of iteration c, late waves at the start of iteration c + 1; the
   // first iterations (no stores yet in the window) use the conservative count.
-  auto top = [&](int ci) __attribute__((always_inline)) {
+  // (with a residual: four more loads per stage in the window, already retired by the epilogue that consumed them)
+  auto top = [&](int ci, u32x4 (&rr)[4]) __attribute__((always_inline)) {
     const int cio = ci - (late ? 1 : 0);
     if (XS_ABLATE & 8) {
     } else if (ci + 1 >= nch) {
@@ -193,13 +210,14 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
     } else if (ci < (late ? 3 : 2)) {
       wait_vm<NDMA>();
     } else if constexpr (P == 1) {
-      wait_vm<NDMA + 8>();
+      wait_vm<NDMA + 8 + (RES ? 4 : 0)>();
     } else if constexpr (P == 2) {
       wait_vm<NDMA + 4>();
     } else {
       if ((cio & 3) < 2) wait_vm<NDMA + 4>(); else wait_vm<NDMA>();
     }
     if (!(XS_ABLATE & 8)) __builtin_amdgcn_s_barrier();   // everyone's pieces of stage ci landed; everyone is done with stage ci-1
+    load_res(ci, rr);
     if (!(XS_ABLATE & 16) && ci + 2 < nch) issue(c0 + ci + 2, (ci + 2) % XS_STAGES);
   };
 
@@ -242,8 +260,15 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
   };
 
   // epilogue of stage ci: registers -> wave-private LDS tile -> (every P stages) full-line global stores
-  auto epilogue = [&](int ci, const f32x4 (&acc)[NF][2], const f32x4 (&bias)[NF]) __attribute__((always_inline)) {
+  auto epilogue = [&](int ci, const f32x4 (&acc)[NF][2], const f32x4 (&bias)[NF], const u32x4 (&rr)[4]) __attribute__((always_inline)) {
     const int sub = ci % P;                       // position of this stage inside its 128-byte output line
+    if constexpr (RES) {
+      // the residual chunks of this stage have landed?  Younger operations of this wave: an early wave has issued the DMAs of stage
+      // ci + 2 since; a late wave (it runs this one stage later) those, the stores of stage ci - 1, the next four residual loads and
+      // the DMAs of stage ci + 3.  Near the ends, where some of these were not issued, wait for everything.
+      if (!late) { if (ci + 2 < nch) wait_vm<NDMA>(); else wait_vm<0>(); }
+      else { if (ci >= 1 && ci + 3 < nch) wait_vm<NDMA + 4 + 4 + NDMA>(); else wait_vm<0>(); }
+    }
 #pragma unroll
     for (int nf = 0; nf < NF; nf += (GEGLU ? 2 : 1)) {
 #pragma unroll
@@ -268,7 +293,14 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = i * 8 + (lane >> 3), col = lane & 7;
-        const u32x4 v = *(const u32x4*)(ostage + row * XS_OROW + col * 16);
+        u32x4 v = *(const u32x4*)(ostage + row * XS_OROW + col * 16);
+        if constexpr (RES) {
+          auto a = as_vec8<T>(v);
+          const auto b = as_vec8<T>(rr[i]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] = from_f32<T>(to_f32(a[e]) + to_f32(b[e]));
+          v = __builtin_bit_cast(u32x4, a);
+        }
         // range-checked buffer store (rows >= M fall beyond num_records and are dropped by the hardware): the store
         // is issued unconditionally, so every wave's VMEM count per iteration is the same - the counted waits above
         // depend on it.  aux 16 = sc1 (write-through, like the GEMM's output stores)
@@ -280,9 +312,10 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
   };
 
   f32x4 accA[NF][2], accB[NF][2], bA[NF], bB[NF];
+  u32x4 rrA[4], rrB[4];
   if (!late) {
     for (int ci = 0; ci < nch; ++ci) {
-      top(ci);
+      top(ci, rrA);
 #if XS_STAMPS
       stamp(ci, 0);
 #endif
@@ -290,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
 #if XS_STAMPS
       stamp(ci, 1);
 #endif
-      epilogue(ci, accA, bA);
+      epilogue(ci, accA, bA, rrA);
 #if XS_STAMPS
       stamp(ci, 2);
 #endif
@@ -299,11 +332,11 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
     // unrolled by two so that the two accumulator sets keep static names
     int ci = 0;
     for (; ci + 1 < nch; ci += 2) {
-      top(ci);
+      top(ci, rrA);
 #if XS_STAMPS
       stamp(ci, 0);
 #endif
-      if (ci > 0) epilogue(ci - 1, accB, bB);
+      if (ci > 0) epilogue(ci - 1, accB, bB, rrB);
 #if XS_STAMPS
       stamp(ci, 1);
 #endif
@@ -311,11 +344,11 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
 #if XS_STAMPS
       stamp(ci, 2);
 #endif
-      top(ci + 1);
+      top(ci + 1, rrB);
 #if XS_STAMPS
       stamp(ci + 1, 0);
 #endif
-      epilogue(ci, accA, bA);
+      epilogue(ci, accA, bA, rrA);
 #if XS_STAMPS
       stamp(ci + 1, 1);
 #endif
@@ -325,12 +358,12 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
 #endif
     }
     if (ci < nch) {
-      top(ci);
-      if (ci > 0) epilogue(ci - 1, accB, bB);
+      top(ci, rrA);
+      if (ci > 0) epilogue(ci - 1, accB, bB, rrB);
       compute(ci, accA, bA);
-      epilogue(ci, accA, bA);
+      epilogue(ci, accA, bA, rrA);
     } else if (nch > 0) {
-      epilogue(nch - 1, accB, bB);
+      epilogue(nch - 1, accB, bB, rrB);
     }
   }
 #if !XS_STAMPS
@@ -338,10 +371,10 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
 #endif
 }
 
-template <typename T, int KC, bool GEGLU, bool LN>
+template <typename T, int KC, bool GEGLU, bool LN, bool RES = false>
 int launch_one(const es_xs_desc& d, hipStream_t st) {
   const int rbs = (d.M + XS_ROWS - 1) / XS_ROWS;
-  auto kfn = linear_xs_kernel<T, KC, GEGLU, LN>;
+  auto kfn = linear_xs_kernel<T, KC, GEGLU, LN, RES>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, XS_LDS);
@@ -354,6 +387,7 @@ int launch_one(const es_xs_desc& d, hipStream_t st) {
 template <typename T>
 int launch(const es_xs_desc& d, hipStream_t st) {
   const bool g = d.geglu != 0, ln = d.ln != 0;
+  if (d.residual) return launch_one<T, 10, false, false, true>(d, st);     // (K = 320, no GEGLU, no LayerNorm: checked by es_linear_xs)
   if (d.K == 320) {
     if (g) return ln ? launch_one<T, 10, true, true>(d, st) : launch_one<T, 10, true, false>(d, st);
     return ln ? launch_one<T, 10, false, true>(d, st) : launch_one<T, 10, false, false>(d, st);
@@ -383,6 +417,7 @@ extern "C" int es_linear_xs(const es_xs_desc* d, void* stream) {
       ((size_t)d->M + 256) * d->ldo * 2 >= 0xFFFFFF00ull) {
     es_set_error("es_linear_xs: operand larger than 2 GiB (32-bit buffer offsets)"); return -1; }
   if (d->ngroups > 4) { es_set_error("es_linear_xs: at most 4 groups"); return -1; }
+  if (d->residual && (d->K != 320 || d->geglu || d->ln)) { es_set_error("es_linear_xs: a residual needs K = 320, no GEGLU, no LayerNorm fold (rows of ldo elements, like out)"); return -1; }
   es_xs_desc dd = *d;
   if (d->ngroups > 1) {
     const int tm = (d->M + 127) / 128;

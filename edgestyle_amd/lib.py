@@ -43,6 +43,7 @@ class XsDesc(C.Structure):
         ("M", C.c_int32), ("K", C.c_int32), ("Cout", C.c_int32), ("rows_padded", C.c_int32),
         ("ldo", C.c_int32), ("geglu", C.c_int32), ("ln", C.c_int32), ("ln_eps", C.c_float),
         ("nslices", C.c_int32), ("chunks_per_slice", C.c_int32), ("dtype", C.c_int32),
+        ("residual", C.c_void_p),
     ]
 
 

@@ -369,6 +369,7 @@ def plan_launch(M: int, pw: "PackedWeight", bn: int):
 
 
 XS_ENABLED = _os.environ.get("ES_XS", "1") == "1"      # row-stationary short-K linear kernel (csrc/linear_xs.hip)
+XS_RESIDUAL = _os.environ.get("ES_XS_RESIDUAL", "1") == "1"   # ... also for the K = 320 output projections that add a residual
 XS_TARGET_WGS = 256
 XS_MIN_M = int(_os.environ.get("ES_XS_MIN_M", "8192"))   # 0: no size policy (tests exercise every shape)
 _zero_bias = {}
@@ -405,8 +406,9 @@ def xs_eligible(M: int, pw: "PackedWeight", pws, group_n, hw: int) -> bool:
     return bool(L.load().es_linear_xs_eligible(int(M), int(pw.ksize), int(pw.kpad), int(pw.cin), int(pw.ctail), int(pw.cout), int(pw.geglu)))
 
 
-def linear_xs(x: torch.Tensor, pw, M: int, out: torch.Tensor, group_rows=None) -> torch.Tensor:
-    """x: [M, K] contiguous; pw (or list of pw for a grouped launch with `group_rows` rows each) -> out [M, cstore]."""
+def linear_xs(x: torch.Tensor, pw, M: int, out: torch.Tensor, group_rows=None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x: [M, K] contiguous; pw (or list of pw for a grouped launch with `group_rows` rows each) -> out [M, cstore]
+    (+ residual [M, cstore] contiguous: K = 320 only)."""
     pws = None
     if isinstance(pw, (list, tuple)):
         pws = list(pw) if len(pw) > 1 else None
@@ -436,6 +438,7 @@ def linear_xs(x: torch.Tensor, pw, M: int, out: torch.Tensor, group_rows=None) -
     d.ldo = out.shape[-1]
     d.geglu, d.ln, d.ln_eps = int(pw.geglu), int(pw.ln_colsum is not None), pw.ln_eps
     d.nslices, d.chunks_per_slice, d.dtype = nslices, lps * pline, _dt(x)
+    d.residual = residual.data_ptr() if residual is not None else None
     if pws is not None:
         d.ngroups = len(pws)
         acc = 0
@@ -449,9 +452,9 @@ def linear_xs(x: torch.Tensor, pw, M: int, out: torch.Tensor, group_rows=None) -
     if PROFILE is not None:
         d.prof = PROFILE.next((2.0 * M * pw.cout * K, 1, (M, pw.cout, K, 1, 1, 0),
                                dict(N=M, H=1, W=1, C1=K, C2=0, cout=pw.cout, k=1, stride=1, pad=0, upsample=False,
-                                    geglu=pw.geglu, splitk=1, Hout=1, Wout=1, residual=False, temb=False, bn=0, stages=3,
+                                    geglu=pw.geglu, splitk=1, Hout=1, Wout=1, residual=residual is not None, temb=False, bn=0, stages=3,
                                     group_n=list(group_rows) if pws is not None else None, ctail=0, kernel="linear_xs",
-                                    algorithmic_bytes=_algorithmic_bytes(x, None, pw, pws, out, None))))
+                                    algorithmic_bytes=_algorithmic_bytes(x, None, pw, pws, out, residual))))
         dd = L.XsDesc()
         C.memmove(C.byref(dd), C.byref(d), C.sizeof(L.XsDesc))
         dd.prof = None
@@ -550,12 +553,16 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     if out is None:
         out = torch.empty((N, Hout, Wout, cstore), dtype=x.dtype, device=x.device)
     M = N * Hout * Wout
-    if (k == 1 and stride == 1 and not upsample and x2 is None and temb is None and residual is None and not tails
+    # (a residual rides on es_linear_xs at K = 320 - Attention.to_out / proj_out of the 64 x 64 level - unless this launch carries the
+    #  two-word residual stream of a bf16 pipeline, which only es_conv_gemm implements)
+    xs_res = residual is None or (XS_RESIDUAL and pw.kpad == 320 and not pw.geglu and pw.ln_colsum is None and residual.is_contiguous()
+                                  and residual.numel() == M * cstore and not (wide and wide_stream(x.dtype)))
+    if (k == 1 and stride == 1 and not upsample and x2 is None and temb is None and xs_res and not tails
             and x_rep == 1 and act == L.ACT_NONE and out_scale == 1.0 and out_scale_dev is None and splitk is None and FORCE_BN == 0
             and x.is_contiguous() and out.is_contiguous()
             and xs_eligible(M, pw, pws, group_n, Hout * Wout)):
         linear_xs(x.reshape(M, C1), pws if pws is not None else pw, M, out.reshape(M, cstore),
-                  None if pws is None else [n * Hout * Wout for n in group_n])
+                  None if pws is None else [n * Hout * Wout for n in group_n], residual=residual)
         return out
     big_ok = BIG_TILE and C1 % BK == 0 and C2 % BK == 0 and not pw.geglu and pw.ln_colsum is None and \
         (group_n is None or all((n * Hout * Wout) % 256 == 0 for n in group_n))

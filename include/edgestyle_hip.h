@@ -150,6 +150,9 @@ typedef struct {
   float ln_eps;
   int32_t nslices, chunks_per_slice;
   int32_t dtype;
+  /* optional: out = x W^T + bias + residual - rows of ldo elements, like out (Attention.to_out + residual, BasicTransformerBlock).
+   * K = 320 only, no GEGLU, no LayerNorm fold */
+  const void* residual;
 } es_xs_desc;
 int es_linear_xs(const es_xs_desc* d, void* stream);
 

@@ -875,6 +875,38 @@ def test_linear_xs_row_stationary_kernel(dtype):
     again = ops.linear(xg.to(DEV, dtype), pws, group_n=counts)
     assert rel_err(yg, torch.cat(refs)) < tol
     assert torch.equal(yg, again)                         # deterministic: same launch twice, bit for bit
+    # residual (es_xs_desc.residual; round 4): out = x W^T + bias + residual at K = 320 - Attention.to_out / proj_out of the 64 x 64
+    # level - many stages per workgroup (every counted wait of the steady state), few (the tails), N slices, ragged M, grouped
+    for M, Cout, counts in ((2048, 320, None), (700, 1280, None), (40, 320, None), (256 * 14, 320, [512, 1536, 1024, 512]), (8192, 640, None)):
+        x = q16(torch.randn(M, 320, generator=g) * 1.5, dtype)
+        res = q16(torch.randn(M, Cout, generator=g) * 2.0, dtype)
+        ws = [(torch.randn(Cout, 320, generator=g) / math.sqrt(320), torch.randn(Cout, generator=g) * 0.1) for _ in (counts or [M])]
+        pws = [ops.pack_weight(w, b, dtype, DEV) for w, b in ws]
+        rows = counts or [M]
+        ref = torch.cat([F.linear(x[sum(rows[:i]):sum(rows[:i + 1])], w, b) for i, (w, b) in enumerate(ws)]) + res
+        kw = dict(group_n=counts) if counts else {}
+        pw = pws if counts else pws[0]
+        xd, rd = x.to(DEV, dtype), res.to(DEV, dtype)
+        ops.XS_RESIDUAL = False
+        try:
+            tiled = ops.linear(xd, pw, residual=rd, **kw)
+        finally:
+            ops.XS_RESIDUAL = True
+        prof = ops.PROFILE
+        class Rec:                                          # which kernel ran: the profiler hook sees the descriptor kind
+            descs, metas = [], []
+            def next(self, meta):
+                self.metas.append(meta); return None
+        ops.PROFILE = Rec()
+        try:
+            got = ops.linear(xd, pw, residual=rd, **kw)
+            assert ops.PROFILE.metas[-1][3].get("kernel") == "linear_xs" and ops.PROFILE.metas[-1][3]["residual"]
+        finally:
+            ops.PROFILE = prof
+        again = ops.linear(xd, pw, residual=rd, **kw)
+        torch.cuda.synchronize()
+        assert rel_err(got, ref) < tol, (M, Cout, rel_err(got, ref))
+        assert rel_err(got, tiled) < tol and torch.equal(got, again)
     ops.XS_MIN_M = 8192
 
 
