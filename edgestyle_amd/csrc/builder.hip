@@ -361,7 +361,6 @@ int choose_bn(int cout) { return (cout % 160 == 0 && cout % 128 != 0) ? 160 : 12
 struct Builder {
   Heap heap;
   unsigned long long ws_bytes = 0;
-  unsigned long long sk_counters = 0;
   int dt = ES_F16;
   std::vector<std::pair<unsigned long long, std::vector<char>>> uploads;     // (fake address, bytes) of everything persistent with contents
   std::deque<PW> pws;
@@ -671,15 +670,7 @@ struct Builder {
       out.lo = lo.p; out.lo_b = lo.b;
     }
     if (k == 1 && M <= 65536 && C1 % BK == 0 && C2 % BK == 0 && bn != 64 && bn != 320 && !(stages == 4 && bn != 128) && stages != 3) d.waves = 8;
-    if (splitk > 1) {
-      d.workspace = (float*)workspace((unsigned long long)splitk * M * pw->rows_padded * 4);
-      // arrival counters of the split-K tiles (ops._get_sk_counters): a zero region of the arena, zero again after every launch
-      static const bool sk_fused = [] { const char* e = getenv("ES_SK_FUSED"); return !e || std::string(e) == "1"; }();
-      if (sk_fused) {
-        if (!sk_counters) sk_counters = persistent((size_t)ES_SPLITK_MAX_TILES * 4);
-        d.sk_counters = (int32_t*)sk_counters;
-      }
-    }
+    if (splitk > 1) d.workspace = (float*)workspace((unsigned long long)splitk * M * pw->rows_padded * 4);
     if (pw->ln_colsum) {
       for (const PW* q : pl) if (!q->ln_colsum) fail("LayerNorm-folded weights need a plain linear launch (all groups folded)");
       if (a.x2 || k != 1) fail("LayerNorm-folded weights need a plain linear launch");

@@ -153,14 +153,6 @@ ES_DEVICE void store16(void* ptr, u32x4 v) {
 #endif
 }
 
-// 16-byte global loads at DEVICE scope (`sc1`): they see what other XCDs have written through with store16 (their L2s are not
-// coherent with this one) without invalidating this XCD's whole L2, which a __threadfence() acquire would (measured: a step 1.4x
-// slower with fences in every split-K workgroup).  Issued in a batch; load16_dev_wait() retires them (the compiler does not track
-// inline-asm loads: the values must pass through the wait as operands).
-ES_DEVICE void load16_dev(f32x4& v, const void* ptr) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory"); }
-ES_DEVICE void load16_dev_wait(f32x4& a, f32x4& b, f32x4& c, f32x4& d) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory"); }
-ES_DEVICE void load16_dev_wait(f32x4& a) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a)::"memory"); }
-
 ES_DEVICE void store8(void* ptr, u32x2 v) {
 #if ES_WT_STORES
   asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");

@@ -39,8 +39,7 @@
 #endif
 
 int es_conv_gemm8p_launch(const es_gemm_desc& d, hipStream_t st);   // gemm_conv8p.hip: the 256 x 320 phase-interleaved tile
-bool es_conv_gemm8p_takes(const es_gemm_desc& d);                    // ... whether it runs this launch at all,
-bool es_conv_gemm8p_epilogue(const es_gemm_desc& d);                 // ... and whether its own epilogue has the form the launch needs
+bool es_conv_gemm8p_takes(const es_gemm_desc& d);                    // ... and whether its epilogue has the form this launch needs
 
 namespace {
 
@@ -402,7 +401,7 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? (FM == 2 
   f32x4 bias[FN];
 #pragma unroll
   for (int i = 0; i < FN; ++i)
-    bias[i] = (bsel && (p.splitk == 1 || p.sk_counters)) ? *(const f32x4*)(bsel + tile_n * BN + wn * (BN / 2) + fq * 4 + i * 16)
+    bias[i] = (bsel && p.splitk == 1) ? *(const f32x4*)(bsel + tile_n * BN + wn * (BN / 2) + fq * 4 + i * 16)
                                       : f32x4{0.f, 0.f, 0.f, 0.f};
   // LayerNorm fold: column sums of the (gamma-folded) weights for this lane's couts, and this wave's share of the row
   // statistics.  The X fragments a wave loads for its MFMAs cover its 16*FM rows x the whole K-step, and the two waves
@@ -529,60 +528,10 @@ __global__ __launch_bounds__(BM * 8 / FM, (STAGES == 2 && BM == 128) ? (FM == 2 
           store16(wsp + (size_t)m * p.rows_padded + tile_n * BN + pcol + i * 16, __builtin_bit_cast(u32x4, acc[i][j]));
       }
     }
-    if (!p.sk_counters || p.gn_part) {                   // the slabs are summed by splitk_reduce_kernel, launched behind this one
 #if !ES_STAMPS
-      if (p.prof && tid == 0) atomicMax(p.prof + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    if (p.prof && tid == 0) atomicMax(p.prof + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
-      return;
-    }
-    // Round 4: the LAST slice of a tile to finish sums the slabs itself (es_gemm_desc.sk_counters: one arrival counter per tile,
-    // zero between launches) and runs the ordinary epilogue - no reduce launch behind every split-K GEMM (50 of them in a batch-1
-    // step, ~8 us each plus the dependency bubble).  Every slice - the last one too - has written its slab; the sum runs over the
-    // slabs in slice order, as splitk_reduce_kernel's does: the same bits whichever slice happens to arrive last.
-    //   release: the slab stores are write-through at device scope (store16, sc1): once they are complete (vmcnt 0) the arrival is counted
-    //     by a device-scope atomic;  acquire: the last arrival reads the slabs with device-scope loads (load16_dev).  No __threadfence():
-    //     its release writes back and its acquire invalidates the XCD's whole L2 - with one in every split-K workgroup a batch-1 step
-    //     ran 1.4x slower (636 vs 458 ms per image).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slab stores (write-through, device scope) are complete
-    __syncthreads();                                      // every wave of this workgroup has stored and fenced; the stage ring is free
-    int* const ticket = (int*)smem;
-    if (tid == 0) {
-      int* const ctr = p.sk_counters + tile_m * (p.rows_padded / BN) + tile_n;
-      const int t = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t == p.splitk - 1) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // (the counter is this tile's alone: ready for the next launch)
-      *ticket = t;
-    }
-    __syncthreads();
-    const bool last = *ticket == p.splitk - 1;
-    if (!last) {
-#if !ES_STAMPS
-      if (p.prof && tid == 0) atomicMax(p.prof + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-#endif
-      return;
-    }
-    const size_t zstride = (size_t)M * p.rows_padded;
-#pragma unroll
-    for (int j = 0; j < FM; ++j) {
-      const int m = tile_m * BM + prow + j * 16;
-      const int mc = m < M ? m : M - 1;                   // (rows beyond M are never stored: any finite values do)
-      const float* src = p.workspace + (size_t)mc * p.rows_padded + tile_n * BN + pcol;
-#pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-        int zz = 0;
-        for (; zz + 4 <= p.splitk; zz += 4) {             // four slices' loads in flight, added in slice order
-          f32x4 a[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) load16_dev(a[u], src + (zz + u) * zstride + i * 16);
-          load16_dev_wait(a[0], a[1], a[2], a[3]);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) sum += a[u];
-        }
-        for (; zz < p.splitk; ++zz) { f32x4 a1; load16_dev(a1, src + zz * zstride + i * 16); load16_dev_wait(a1); sum += a1; }
-        acc[i][j] = sum;
-      }
-    }
-    __syncthreads();                                      // (the ticket word is part of the epilogue tile)
+    return;
   }
 
   // ---------------- epilogue phase A: registers -> LDS tile [pixel][cout] in T ----------------
@@ -1002,11 +951,6 @@ int launch(const es_gemm_desc& d0, hipStream_t st) {
   // 128-pixel half or meet a residual, or a Cout that is no multiple of 8 run on the 128 x 160 tile: the same results
   if (d.bn == 320 && !es_conv_gemm8p_takes(d)) { d.bn = 160; d.stages = 2; }
   const int M = d.N * d.Hout * d.Wout;
-  // split-K: the last slice of a tile sums the slabs itself when the host handed over arrival counters (es_gemm_desc.sk_counters) and
-  // the launch has no more tiles than counters; the GroupNorm hand-over keeps its own reduce kernel
-  if (d.splitk <= 1 || d.gn_part || (d.bn == 320 && !es_conv_gemm8p_epilogue(d)) ||
-      (long long)((M + (d.bn == 320 ? 255 : (d.bn == 64 ? 63 : 127))) / (d.bn == 320 ? 256 : (d.bn == 64 ? 64 : 128))) * (d.rows_padded / d.bn) > ES_SPLITK_MAX_TILES)
-    d.sk_counters = nullptr;
   const int nk = d.Kpad / BK;
   const int Ctot = d.C1 + d.C2;
   const bool aligned = (Ctot % BK == 0) && (d.C1 % BK == 0);
@@ -1078,7 +1022,7 @@ int launch(const es_gemm_desc& d0, hipStream_t st) {
     if (cb == 80) hipLaunchKernelGGL((splitk_reduce_gn_kernel<T, 80>), grid, dim3(64 * 10), 0, st, d, M);
     else if (cb == 128) hipLaunchKernelGGL((splitk_reduce_gn_kernel<T, 128>), grid, dim3(64 * 16), 0, st, d, M);
     else hipLaunchKernelGGL((splitk_reduce_gn_kernel<T, 64>), grid, dim3(64 * 8), 0, st, d, M);
-  } else if (d.splitk > 1 && !d.sk_counters) {
+  } else if (d.splitk > 1) {
     const long long total = (long long)M * (d.rows_padded / 8);
     hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, M);
   }

@@ -416,48 +416,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
           store16(wsp + (size_t)m * p.rows_padded + tile_n * BN + pcol + i * 16, __builtin_bit_cast(u32x4, acc[i][j]));
       }
     }
-    if (!p.sk_counters || p.gn_part) {                   // the slabs are summed by splitk_reduce_kernel, launched behind this one
-      if (p.prof && tid == 0) atomicMax(p.prof + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-      return;
-    }
-    // the last slice of a tile to finish sums the slabs in slice order and runs the epilogue below (see conv_gemm_kernel)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slab stores (write-through, device scope) are complete
-    __syncthreads();
-    int* const ticket = (int*)smem;
-    if (tid == 0) {
-      int* const ctr = p.sk_counters + tile_m * (p.rows_padded / BN) + tile_n;
-      const int t = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t == p.splitk - 1) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *ticket = t;
-    }
-    __syncthreads();
-    if (*ticket != p.splitk - 1) {
-      if (p.prof && tid == 0) atomicMax(p.prof + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-      return;
-    }
-    const size_t zstride = (size_t)M * p.rows_padded;
-#pragma unroll
-    for (int j = 0; j < FM; ++j) {
-      const int m = tile_m * BM + prow + j * 16;
-      const int mc = m < M ? m : M - 1;
-      const float* src = p.workspace + (size_t)mc * p.rows_padded + tile_n * BN + pcol;
-#pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-        int zz = 0;
-        for (; zz + 4 <= p.splitk; zz += 4) {
-          f32x4 a[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) load16_dev(a[u], src + (zz + u) * zstride + i * 16);
-          load16_dev_wait(a[0], a[1], a[2], a[3]);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) sum += a[u];
-        }
-        for (; zz < p.splitk; ++zz) { f32x4 a1; load16_dev(a1, src + zz * zstride + i * 16); load16_dev_wait(a1); sum += a1; }
-        acc[i][j] = sum;
-      }
-    }
-    __syncthreads();
+    if (p.prof && tid == 0) atomicMax(p.prof + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    return;
   }
 
   {
@@ -613,19 +573,17 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
 
 }  // namespace
 
-// the epilogue forms this tile implements ...
-bool es_conv_gemm8p_epilogue(const es_gemm_desc& d) {
+// the epilogue forms this tile implements (split-K launches write raw partials: every form)
+bool es_conv_gemm8p_takes(const es_gemm_desc& d) {
+  if (d.splitk > 1) return true;
   if (d.act != ES_ACT_NONE || (d.Cout & 7)) return false;
   if (d.temb && (((d.Hout * d.Wout) & 127) || d.residual)) return false;
   return true;
 }
-// ... and the launches it takes: a split-K launch can leave any other form to splitk_reduce_kernel (es_conv_gemm then withholds the
-// arrival counters: the slabs are not summed in here)
-bool es_conv_gemm8p_takes(const es_gemm_desc& d) { return d.splitk > 1 || es_conv_gemm8p_epilogue(d); }
 
 // called by es_conv_gemm (gemm_conv.hip) after validation, for d.bn == 320
 int es_conv_gemm8p_launch(const es_gemm_desc& d, hipStream_t st) {
-  if (!es_conv_gemm8p_takes(d) || (d.splitk > 1 && d.sk_counters && !es_conv_gemm8p_epilogue(d))) return -2;
+  if (!es_conv_gemm8p_takes(d)) return -2;
   const int M = d.N * d.Hout * d.Wout;
   const int nk = d.Kpad / 64;
   const int tn = d.rows_padded / BN;

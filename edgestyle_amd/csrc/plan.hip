@@ -141,7 +141,7 @@ const std::vector<PtrField>& ptr_fields(int kind, int& elem) {
         F_IN(es_gemm_desc, residual), F_IN(es_gemm_desc, out_scale_dev), F_OUT(es_gemm_desc, out), F_IO(es_gemm_desc, workspace),
         F_OUT(es_gemm_desc, prof), F_IN4(es_gemm_desc, w_g), F_IN4(es_gemm_desc, bias_g), F_IN(es_gemm_desc, ln_colsum),
         F_IN4(es_gemm_desc, ln_colsum_g), F_IN(es_gemm_desc, t1), F_IN(es_gemm_desc, t2), F_IN(es_gemm_desc, residual_lo),
-        F_OUT(es_gemm_desc, out_lo), F_OUT(es_gemm_desc, gn_part), F_IO(es_gemm_desc, sk_counters)}; return f; }
+        F_OUT(es_gemm_desc, out_lo), F_OUT(es_gemm_desc, gn_part)}; return f; }
     case ES_OP_LINEAR_XS: { static const std::vector<PtrField> f = {
         F_IN(es_xs_desc, x), F_OUT(es_xs_desc, out), F_IN(es_xs_desc, w), F_IN(es_xs_desc, bias), F_IN4(es_xs_desc, w_g),
         F_IN4(es_xs_desc, bias_g), F_OUT(es_xs_desc, prof), F_IN(es_xs_desc, residual)}; return f; }

@@ -31,7 +31,7 @@ class GemmDesc(C.Structure):
         ("ln_colsum", C.c_void_p), ("ln_colsum_g", C.c_void_p * 4), ("ln_eps", C.c_float),
         ("t1", C.c_void_p), ("t2", C.c_void_p), ("Ct1", C.c_int32), ("Ct2", C.c_int32),
         ("x_nmod", C.c_int32), ("korder", C.c_int32), ("residual_lo", C.c_void_p), ("out_lo", C.c_void_p),
-        ("gn_part", C.c_void_p), ("gn_groups", C.c_int32), ("sk_counters", C.c_void_p),
+        ("gn_part", C.c_void_p), ("gn_groups", C.c_int32),
     ]
 
 

@@ -242,21 +242,6 @@ _workspace = {}
 _workspace_retired = []
 
 
-_sk_counters = {}
-SK_FUSED = _os.environ.get("ES_SK_FUSED", "1") == "1"    # split-K: the last slice of a tile sums the slabs (no reduce launch)
-
-
-def _get_sk_counters(device) -> torch.Tensor:
-    """es_gemm_desc.sk_counters: ES_SPLITK_MAX_TILES arrival counters, zero between launches (the kernels reset them)."""
-    key = (str(device), LANE)
-    t = _sk_counters.get(key)
-    if t is None:
-        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
-            raise L.EdgeStyleHipError("split-K arrival counters allocated during graph capture; run one eager warm-up first")
-        t = _sk_counters[key] = torch.zeros(1024, dtype=torch.int32, device=device)
-    return t
-
-
 def _get_workspace(nbytes: int, device) -> torch.Tensor:
     device = (device, LANE)
     ws = _workspace.get(device)
@@ -641,8 +626,6 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     if splitk > 1:
         ws = _get_workspace(splitk * M * pw.rows_padded * 4, x.device)
         d.workspace = ws.data_ptr()
-        if SK_FUSED:
-            d.sk_counters = _get_sk_counters(x.device).data_ptr()
     if pw.ln_colsum is not None:
         if (pws is not None and any(q.ln_colsum is None for q in pws)) or x2 is not None or k != 1:
             raise L.EdgeStyleHipError("LayerNorm-folded weights need a plain linear launch (all groups folded)")

@@ -121,12 +121,7 @@ typedef struct {
    * output's H*W % 64 == 0, Cout % 8 == 0 and Cout / gn_groups <= the N tile.  NULL: no statistics. */
   float* gn_part;
   int32_t gn_groups;
-  /* split-K launches: ES_SPLITK_MAX_TILES arrival counters (int32), ZERO when the launch starts and zero again when it ends.  With
-   * them the last slice of every tile to finish sums the fp32 slabs itself (in slice order: the same bits as the reduce kernel) and
-   * runs the epilogue; without them (NULL) a reduce kernel is launched behind the GEMM.  One buffer serves every launch of a stream. */
-  int32_t* sk_counters;
 } es_gemm_desc;
-#define ES_SPLITK_MAX_TILES 1024
 int es_conv_gemm(const es_gemm_desc* d, void* stream);
 size_t es_conv_gemm_workspace_bytes(const es_gemm_desc* d);
 

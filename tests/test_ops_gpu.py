@@ -1083,57 +1083,3 @@ def test_group_norm_hand_over_does_not_depend_on_the_tile_or_the_grouping():
         assert torch.allclose(a.sum(2), b.sum(2), rtol=2e-6, atol=1e-4)
     assert torch.equal(grp, torch.cat(sep)) and torch.equal(grp._gnp[0], torch.cat([s._gnp[0] for s in sep]))
     assert torch.equal(n_grp, n_sep)
-
-
-@pytest.mark.parametrize("N,H,C,Cout,k,bn,splitk,extra", [
-    (2, 16, 256, 256, 3, 128, 4, "res"),        # 128 x 128 tile: 4 x 2 tiles x 4 slices, residual
-    (2, 16, 320, 320, 3, 160, 9, "temb"),       # 160-wide tile, a slice count that is no multiple of four, time embedding
-    (1, 8, 640, 128, 3, 64, 5, "silu"),         # 64 x 64 tile, an activation in the fused epilogue
-    (3, 12, 128, 640, 3, 320, 3, "res"),        # the 256 x 320 tile: ragged M, its own two-pass epilogue after the sum
-    (3, 12, 128, 640, 3, 320, 3, "silu"),       # ... a form it leaves to the reduce kernel (no counters: two launches)
-    (2, 16, 128, 100, 3, 128, 4, "narrow"),     # Cout % 8 != 0: the scalar store path behind the sum
-    (2, 32, 128, 128, 1, 128, 2, "wide"),       # bf16 two-word residual stream out of a split-K launch
-])
-def test_split_k_summed_by_the_last_slice_equals_the_reduce_kernel(N, H, C, Cout, k, bn, splitk, extra):
-    """es_gemm_desc.sk_counters (round 4): the last slice of a tile to finish sums the fp32 slabs in slice order and runs the epilogue -
-    bit for bit what splitk_reduce_kernel produces behind the same GEMM (ES_SK_FUSED=0), for every tile, and the arrival counters are
-    zero again after every launch (the same launch repeated gives the same bits)."""
-    from edgestyle_amd import ops, lib
-    dt = torch.bfloat16 if extra == "wide" else torch.float16
-    g = torch.Generator().manual_seed(N * 7 + C + Cout + splitk)
-    x = q16(torch.randn(N, C, H, H, generator=g), dt)
-    w = q16(torch.randn(Cout, C, k, k, generator=g) / math.sqrt(C * k * k), dt)
-    b = torch.randn(Cout, generator=g) * 0.1
-    pw = ops.pack_weight(w, b, dt, DEV)
-    kw = {}
-    ref = F.conv2d(x, w, b, padding=k // 2)
-    if extra in ("res", "wide"):
-        res = q16(torch.randn(N, Cout, H, H, generator=g), dt)
-        kw["residual"] = nhwc(res, dt)
-        ref = ref + res
-        if extra == "wide":
-            kw["wide"] = True
-    elif extra == "temb":
-        t = q16(torch.randn(N, Cout, generator=g))
-        kw["temb"] = t.to(DEV, dt)
-        ref = ref + t[:, :, None, None]
-    elif extra == "silu":
-        kw["act"] = lib.ACT_SILU
-        ref = F.silu(ref)
-    prev = ops.FORCE_BN, ops.SK_FUSED
-    try:
-        ops.FORCE_BN = bn
-        ops.SK_FUSED = False
-        want = ops.conv_gemm(nhwc(x, dt), pw, splitk=splitk, **kw)
-        want_lo = getattr(want, "_lo", None)
-        ops.SK_FUSED = True
-        got = [ops.conv_gemm(nhwc(x, dt), pw, splitk=splitk, **kw) for _ in range(3)]
-    finally:
-        ops.FORCE_BN, ops.SK_FUSED = prev
-    torch.cuda.synchronize()
-    assert rel_err(want.permute(0, 3, 1, 2), ref) < (3e-3 if dt == torch.float16 else 2e-2)
-    for y in got:
-        assert torch.equal(y, want)
-        if want_lo is not None:
-            assert torch.equal(y._lo, want_lo)
-    assert int(ops._get_sk_counters(torch.device(DEV, torch.cuda.current_device())).abs().sum()) == 0
