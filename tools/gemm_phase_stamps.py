@@ -32,7 +32,8 @@ def bench(fn, R=10):
     return best * 1e3
 
 
-for M, K, N, res in [(8192, 320, 320, True), (2048, 640, 640, True), (512, 1280, 1280, True), (8192, 320, 1600 // 5 * 5, False)]:
+for M, K, N, res in [(8192, 320, 320, True), (2048, 640, 640, True), (512, 1280, 1280, True), (8192, 320, 1600 // 5 * 5, False),
+                     (14336, 640, 640, True), (3584, 1280, 1280, True), (57344, 320, 320, True), (3584, 1280, 3840, False)]:
     x = torch.randn(M, K, generator=g).to(DEV, torch.float16)
     r = torch.randn(M, N, generator=g).to(DEV, torch.float16) if res else None
     pws = [ops.pack_weight(torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g) * 0.1, torch.float16, DEV) for _ in range(4)]
