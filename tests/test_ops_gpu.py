@@ -877,7 +877,10 @@ def test_linear_xs_row_stationary_kernel(dtype):
     assert torch.equal(yg, again)                         # deterministic: same launch twice, bit for bit
     # residual (es_xs_desc.residual; round 4): out = x W^T + bias + residual at K = 320 - Attention.to_out / proj_out of the 64 x 64
     # level - many stages per workgroup (every counted wait of the steady state), few (the tails), N slices, ragged M, grouped
-    for M, Cout, counts in ((2048, 320, None), (700, 1280, None), (40, 320, None), (256 * 14, 320, [512, 1536, 1024, 512]), (8192, 640, None)):
+    # (M > 32768: one slice per row block - 5 or 20 stages per workgroup, the steady state of the counted waits; below that the N range
+    #  is split and a workgroup runs one or two stages)
+    for M, Cout, counts in ((2048, 320, None), (700, 1280, None), (40, 320, None), (256 * 14, 320, [512, 1536, 1024, 512]), (8192, 640, None),
+                            (40000, 320, None), (33000, 1280, None), (256 * 160, 640, [8192, 16384, 8192, 8192])):
         x = q16(torch.randn(M, 320, generator=g) * 1.5, dtype)
         res = q16(torch.randn(M, Cout, generator=g) * 2.0, dtype)
         ws = [(torch.randn(Cout, 320, generator=g) / math.sqrt(320), torch.randn(Cout, generator=g) * 0.1) for _ in (counts or [M])]
