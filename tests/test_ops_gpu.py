@@ -1011,7 +1011,7 @@ def test_conv_gemm_wide_residual_stream(N, H, C, Cout, k, bn, splitk):
 @pytest.mark.parametrize("N,H,C,Cout,k,bn,splitk", [
     (2, 16, 128, 320, 3, 160, None),      # 10-channel groups inside one 160-wide tile
     (2, 16, 128, 640, 3, 128, None),      # 20-channel groups straddle the 128-wide tiles: the two-entry scheme
-    (8, 32, 128, 320, 3, 320, None),      # the 256 x 320 tile (two epilogue passes of 160)
+    (8, 32, 128, 320, 3, 320, None),      # the 256 x 320 tile (two epilogue passes of 128 pixels x 320 couts)
     (1, 8, 256, 1280, 3, 64, None),       # 40-channel groups over 64-wide tiles
     (1, 8, 640, 1280, 3, 128, 5),         # split-K: the statistics come from the reduce kernel
     (3, 8, 64, 64, 1, 64, None),          # tiny width: 2-channel groups
