@@ -3,6 +3,7 @@
 
   python bench.py --gpus 1 --steps K --warmup W          # one process, cuda:0
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          # no launcher: starts the N ranks itself (self_launch)
 
 One "step" = one pass of the hot path over one batch: condition embedding (3 VAE encodes + 3 openpose conv
 stacks on the CFG-duplicated batch, PL:629-664) -> 50 x [6 ControlNet passes -> 13 fusion blocks -> UNet -> CFG ->
@@ -308,6 +309,24 @@ def native_abi_leg(pipe, ws, ucfg, vcfg, B, T, dtype, dev_index, lat, pe, ne, im
         nat.close()
 
 
+def self_launch(n: int, argv) -> int:
+    """Start `n` ranks of this script (one per GPU) as CHILD processes of a parent that has not initialised the GPU, the way
+    the driver's own command does it: `python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1
+    --master-port P bench.py <argv>`.  stdout (rank 0's one JSON line) and stderr pass straight through."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    log(f"--gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd[1:9])} ...")
+    return subprocess.call(cmd, env=env)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -337,6 +356,12 @@ def main(argv=None):
     ap.add_argument("--fake-pipeline", action="store_true",
                     help="CPU rehearsal of the multi-rank control flow (gloo, no GPU, no kernels): NOT a measurement")
     args = ap.parse_args(argv)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: no launcher in front of us.  This parent never touches a GPU (no torch.cuda call,
+        # no HIP call); it starts one fresh rank per GPU through torch.distributed.run, forwards rank 0's JSON line and
+        # exits with the children's code.  Under an existing launcher (WORLD_SIZE set) the code below runs as before.
+        sys.exit(self_launch(args.gpus, sys.argv[1:] if argv is None else list(argv)))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -420,6 +445,9 @@ def main(argv=None):
             "data": "synthetic (seeded random-init SD1.5-shaped weights, random conds/latents/prompt embeds, seed 42)",
             "config": {"workload": "", "images_per_gpu": B, "ddim_steps": args.ddim_steps, "parallelism": f"dp{world} (independent images, one RCCL gather)"},
         }
+        if world > 1:
+            line["rccl_ranks"] = torch.distributed.get_world_size()
+            line["dist_backend"] = torch.distributed.get_backend()         # "nccl" is RCCL on ROCm
         cfg_idx = 4 if args.resolution != 512 else (3 if world > 1 else (1 if B == 1 else 2))
         what = f"{world}xMI355X data-parallel, {world * B} independent try-ons ({B} per GPU, per-image seeds), one RCCL gather of the decoded images; " if world > 1 else ""
         line["config"]["workload"] = ("TINY plumbing config" if args.tiny else

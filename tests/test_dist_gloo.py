@@ -72,3 +72,27 @@ def test_bench_two_rank_control_flow_rehearsal():
     reh = d["rehearsal"]
     assert len(reh["gathered_image_means"]) == 16 and reh["gathered_image_means"] == reh["expected"]
     assert len(set(reh["expected"])) == 16                 # sixteen different try-ons, ordered by global index
+
+
+def test_bench_launches_its_own_ranks_without_torchrun():
+    """`python bench.py --gpus 2` with NO launcher in front (the form the driver records for its single-GPU run): the parent
+    must start the two ranks itself - as child processes, never by touching a device or re-executing itself - forward rank 0's
+    one JSON line and exit with the children's code."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--fake-pipeline"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["dist_backend"] == "gloo"      # (rehearsal backend)
+    assert d["rehearsal"]["gathered_image_means"] == d["rehearsal"]["expected"]
+    # a failing child is the parent's failure
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--fake-pipeline",
+                          "--batch", "-1"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0
