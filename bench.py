@@ -27,6 +27,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "frac_at_sustained_clock", "sclk_mhz", "power_w", "clock_samples", "traffic",
+                 "traffic_source", "mfma_util_pmc", "launches_per_step", "avg_launch_us", "gemm_time_per_step_ms", "conv3x3_only",
+                 "families_stamped", "stamped", "how")
 
 
 def host_cores() -> int:
@@ -134,6 +137,60 @@ def cpu_model() -> str:
     return "unknown"
 
 
+class ClockSampler:
+    """sclk / package power while a region runs: a thread polls `rocm-smi --showclocks --showpower` (the probe of
+    tools/clock_probe.py, ~3 samples per second; it costs host CPU only - the timed regions replay hipGraphs).  The chip sits at
+    its package power limit under the MFMA-dense kernels (MI355X_MICROARCH.md, DVFS give-back), so a fraction of the 2.4 GHz peak
+    means little without the clock the part actually held: `summary()` gives the medians, the first sample dropped."""
+    def __init__(self, period=0.3):
+        import threading
+        self.period, self.samples, self._stop, self._th = period, [], threading.Event(), None
+
+    def _poll(self):
+        import re
+        import subprocess
+        while not self._stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+                sclk = power = None
+                for ln in out.splitlines():
+                    if "sclk" in ln:
+                        m = re.search(r"\((\d+)Mhz\)", ln)
+                        sclk = float(m.group(1)) if m and sclk is None else sclk
+                    elif "ower (W)" in ln and power is None:
+                        try:
+                            power = float(ln.rsplit(":", 1)[-1])
+                        except ValueError:
+                            pass
+                if sclk is not None or power is not None:
+                    self.samples.append((time.time(), sclk, power))
+            except Exception:           # no rocm-smi on this host: the fields stay null
+                return
+            self._stop.wait(self.period)
+
+    def start(self):
+        import threading
+        self.samples, self._stop = [], threading.Event()
+        self._th = threading.Thread(target=self._poll, daemon=True)
+        self._t0 = time.time()
+        self._th.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self._th is not None:
+            self._th.join(timeout=15)
+        return self.summary()
+
+    def summary(self):
+        import statistics
+        sm = [x for x in self.samples if x[0] >= self._t0 + 0.25] or self.samples      # (a sample taken as the region starts shows the idle clock)
+        clk = [x[1] for x in sm if x[1] is not None]
+        pw = [x[2] for x in sm if x[2] is not None]
+        return {"sclk_mhz": round(statistics.median(clk), 0) if clk else None, "power_w": round(statistics.median(pw), 0) if pw else None,
+                "samples": len(sm)}
+
+
 def gemm_roofline(pipe, traffic_profile="r04_gemm_pmc_traffic_b1.json", replay_iters=20):
     """Price the implicit-GEMM kernel against the dense fp16 MFMA peak with ALGORITHMIC flops (2*M*Cout*k*k*Cin) over
     the es_conv_gemm launches of one captured denoising step (the unit replayed 50x per image = 96 % of the image's
@@ -144,7 +201,9 @@ def gemm_roofline(pipe, traffic_profile="r04_gemm_pmc_traffic_b1.json", replay_i
       * `replay`: the same launch list run by the production kernels (no stamps), GEMM launches only, captured as one
         graph and timed by HIP events around `replay_iters` replays on the launching stream - what rocprofv3's
         per-kernel average (profiles/) must agree with."""
-    res = pipe.profile_one_step(gemm_replay_iters=replay_iters)
+    sampler = ClockSampler()
+    res = pipe.profile_one_step(gemm_replay_iters=replay_iters, around_replay=(sampler.start, sampler.stop))
+    clk = sampler.summary()
     tot_f = sum(m[0] for m, _ in res)
     tot_t = sum(t for _, t in res)
     f3 = sum(m[0] for m, _ in res if m[1] == 3)
@@ -217,6 +276,19 @@ def gemm_roofline(pipe, traffic_profile="r04_gemm_pmc_traffic_b1.json", replay_i
                            f"events around {replay_iters} replays on the launching stream"})
     else:
         out.update({k: stamped[k] for k in ("achieved", "frac", "avg_launch_us", "gemm_time_per_step_ms", "how")})
+    # the ceiling the kernels actually ran under: the clock and package power held DURING the event-timed replays (`frac` itself
+    # stays against the 2.4 GHz dense peak)
+    out["sclk_mhz"], out["power_w"], out["clock_samples"] = clk["sclk_mhz"], clk["power_w"], clk["samples"]
+    out["frac_at_sustained_clock"] = (round(out["achieved"] / (MFMA_PEAK_TFLOPS * clk["sclk_mhz"] / 2400.0), 4)
+                                      if clk["sclk_mhz"] and out.get("achieved") else None)
+    out["clock_source"] = "rocm-smi --showclocks --showpower polled while the GEMM launch list replays (medians); peak clock 2400 MHz"
+    # per family: the 3x3 convolutions against everything else (1x1 convolutions, linear layers, linear_xs), from the stamps
+    fam = {}
+    for (fl, k, _shp, _g), t in res:
+        a = fam.setdefault("k3" if k == 3 else "k1", [0, 0.0, 0.0])
+        a[0] += 1; a[1] += t; a[2] += fl
+    out["families_stamped"] = {k: {"launches": c, "ms": round(t * 1e3, 3), "tflops": round(fl / t / 1e12, 1) if t else None}
+                               for k, (c, t, fl) in sorted(fam.items())}
     return out
 
 
@@ -262,6 +334,70 @@ def cpu_baseline_and_parity(pipe, ws, ucfg, B, steps_total, tiny):
                       f"+ UNet, CFG batch {N}) = {dt:.1f} s each on {cores} threads, x{steps_total}; condition embedding "
                       "and VAE decode excluded"}
     return base, parity
+
+
+def call_phases(pipe, one):
+    """HIP-event times of the phases of ONE pipeline call (pipeline.collect_timing): condition embedding / per-call preparation /
+    the denoising loop / VAE decode + post-processing.  One extra call after the timed region (events + a device sync per call)."""
+    pipe.collect_timing = True
+    try:
+        one()
+        torch.cuda.synchronize()
+        t = dict(getattr(pipe, "timing", {}) or {})
+    finally:
+        pipe.collect_timing = False
+    return {k: round(float(v), 3) for k, v in t.items()}
+
+
+def vae_decode_accounting(pipe, B, decode_ms):
+    """Algorithmic bytes of one VAE decode (every activation read once and written once, op by op as the decode is
+    launched: convolutions with their residual / shortcut sources, GroupNorm, the mid-block attention; weights counted apart)
+    and the rate the measured decode phase moves them at, against the 8 TB/s HBM3E peak."""
+    from edgestyle_amd import ops
+    acc = {"act": 0, "w": 0, "launches": 0, "flops": 0.0}
+    real = (ops.conv_gemm, ops.group_norm, ops.attention)
+
+    def nb(t):
+        return 0 if t is None else t.numel() * t.element_size()
+
+    def conv(x, pw, **kw):
+        out = real[0](x, pw, **kw)
+        pws = list(pw) if isinstance(pw, (list, tuple)) else [pw]
+        acc["act"] += nb(x) + nb(kw.get("x2")) + nb(kw.get("residual")) + sum(nb(t) for t in (kw.get("tail") or ()) if t is not None) + nb(out)
+        acc["w"] += sum(nb(q.w) for q in pws)
+        acc["flops"] += 2.0 * out.shape[0] * out.shape[1] * out.shape[2] * pws[0].cout * pws[0].kpad
+        acc["launches"] += 1
+        return out
+
+    def gn(x, *a, **kw):
+        out = real[1](x, *a, **kw)
+        acc["act"] += nb(x) + nb(kw.get("x2")) + nb(out)
+        acc["launches"] += 1
+        return out
+
+    def attn(q, k, v, *a, **kw):
+        out = real[2](q, k, v, *a, **kw)
+        acc["act"] += nb(q) + nb(k) + nb(v) + nb(out)
+        acc["launches"] += 1
+        return out
+    s = pipe.unet.cfg.sample_size
+    z = torch.zeros(B, s, s, pipe.vae.engine.lat_pad, dtype=pipe.dtype, device=pipe.device)
+    ops.conv_gemm, ops.group_norm, ops.attention = conv, gn, attn
+    try:
+        pipe.vae.decode_nhwc(z, unscaled_latents=True)
+        torch.cuda.synchronize()
+    finally:
+        ops.conv_gemm, ops.group_norm, ops.attention = real
+    out = {"ms": round(decode_ms, 3) if decode_ms else None, "images": B, "launches": acc["launches"],
+           "algorithmic_bytes": int(acc["act"]), "weight_bytes": int(acc["w"]), "algorithmic_gflop": round(acc["flops"] / 1e9, 1),
+           "peak": 8.0, "unit": "TB/s",
+           "how": "bytes = every activation tensor of the decode read once and written once, op by op (SURVEY 8d); ms = the decode phase "
+                  "of one pipeline call (graph replay + [0,1] post-processing + the copy out of the graph's buffer), HIP events"}
+    if decode_ms:
+        out["achieved"] = round(acc["act"] / (decode_ms * 1e-3) / 1e12, 3)
+        out["frac"] = round(out["achieved"] / 8.0, 4)
+        out["tflops"] = round(acc["flops"] / (decode_ms * 1e-3) / 1e12, 1)
+    return out
 
 
 def native_abi_leg(pipe, ws, ucfg, vcfg, B, T, dtype, dev_index, lat, pe, ne, imgs, cn, want_img, iters=3, graphs=2):
@@ -347,6 +483,10 @@ def main(argv=None):
                     help="skip the extra 768x768 bf16 batch-4 (BASELINE configs[4]) measurement")
     ap.add_argument("--no-throughput-mode", action="store_true",
                     help="skip the extra batch-8 (BASELINE configs[2]) measurement reported beside the headline value")
+    ap.add_argument("--throughput-sweep", default="12",
+                    help="batch sizes measured beside configs[2] (2 timed calls each, comma-separated; empty string: none).  One call "
+                         "holds at most 13 try-ons: the lockstep encoder pass has 14 samples per try-on and its widest activation "
+                         "(tokens x 1280 at the 64 x 64 level) must stay below the 2 GiB that 32-bit buffer offsets address")
     ap.add_argument("--no-native-abi", action="store_true",
                     help="skip the extra leg that serves the same request through the C ABI alone (es_load_weights context)")
     ap.add_argument("--native-graphs", type=int, default=2, choices=(0, 1, 2),
@@ -422,11 +562,13 @@ def main(argv=None):
         sync()
         log(f"warmup {i} done")
     barrier()
+    sampler = ClockSampler().start() if (rank == 0 and not fake) else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one()
     barrier()
     dt = time.perf_counter() - t0
+    clock = sampler.stop() if sampler is not None else None
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)       # MAX over ranks
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -459,8 +601,15 @@ def main(argv=None):
             line["config"]["workload"] = "REHEARSAL (no kernels run): " + line["config"]["workload"]
             line["rehearsal"] = {"gathered_image_means": [round(float(v), 6) for v in img[:, 0, 0, 0]],
                                  "expected": [round(float(make_inputs(ucfg, vcfg, 1, device, 42, j)[0].mean()), 6) for j in range(world * B)]}
+        if clock is not None:
+            line["clock"] = dict(clock, source="rocm-smi --showclocks --showpower polled during the timed region (medians); peak clock 2400 MHz")
+        if not fake and args.steps:
+            line["phases_ms"] = dict(call_phases(pipe, one), how="HIP events at the phase boundaries of ONE extra pipeline call after "
+                                     "the timed region: condition embedding / per-call preparation / denoising loop / VAE decode + post-processing")
         if not args.no_roofline:
-            line["roofline"] = gemm_roofline(pipe)
+            # enough replays of the step's GEMM launch list for the clock sampler to see the sustained state (~1.5 s)
+            est = max(dt / max(args.steps, 1) / max(args.ddim_steps, 1) * 0.7, 1e-4)
+            line["roofline"] = gemm_roofline(pipe, replay_iters=int(min(400, max(20, 1.5 / est))))
             log("roofline leg done")
         if not args.no_cpu_baseline and world == 1:
             # before the batch-8 leg: the parity step must run the very configuration the timed region replayed
@@ -490,11 +639,10 @@ def main(argv=None):
             assert bool(torch.isfinite(img8).all())
             line["throughput_mode"] = {"workload": "BASELINE configs[2]: same path, batch=8 per step", "value": round(8 / t8, 4),
                                        "unit": "images/s", "ms_per_step": round(t8 * 1e3, 1), "steps": n8, "warmup": 2}
+            line["throughput_mode"]["phases_ms"] = call_phases(pipe, one8)
             if not args.no_roofline:
-                r8 = gemm_roofline(pipe, traffic_profile="r04_gemm_pmc_traffic_b8.json", replay_iters=5)
-                line["throughput_mode"]["roofline"] = {k: r8[k] for k in (
-                    "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "mfma_util_pmc", "launches_per_step",
-                    "avg_launch_us", "gemm_time_per_step_ms", "conv3x3_only", "stamped", "how") if k in r8}
+                r8 = gemm_roofline(pipe, traffic_profile="r04_gemm_pmc_traffic_b8.json", replay_iters=int(min(100, max(5, 1.5 / (t8 / args.ddim_steps * 0.65)))))
+                line["throughput_mode"]["roofline"] = {k: r8[k] for k in ROOFLINE_KEYS if k in r8}
             log(f"throughput mode (batch 8): {8 / t8:.3f} images/s")
             if not args.no_native_abi and not args.no_graph:
                 n8abi = native_abi_leg(pipe, ws, ucfg, vcfg, 8, args.ddim_steps, dtype, dev_index, lat8, pe8, ne8, imgs8, cn8, img8, iters=3,
@@ -503,6 +651,34 @@ def main(argv=None):
                                                                                "bitwise_equal_to_pipeline")}
                 log(f"throughput mode through the C ABI alone: {n8abi['value']:.3f} images/s")
             del lat8, pe8, ne8, imgs8, cn8, img8
+            # beside - never instead of - configs[2]: larger batches (2 timed calls each), so that the launch-granularity share of what
+            # separates batch 8 from the conv path's ceiling is on record
+            sweep = []
+            for bs in [int(v) for v in args.throughput_sweep.split(",") if v.strip()]:
+                try:
+                    latS, peS, neS, imgsS, cnS = make_inputs(ucfg, vcfg, bs, device, seed=42)
+
+                    def oneS():
+                        return pipe(prompt_embeds=peS, negative_prompt_embeds=neS, image=imgsS, latents=latS, guidance_scale=7.5,
+                                    num_inference_steps=args.ddim_steps, output_type="pt", cond_noise=cnS).images
+                    oneS(); oneS()
+                    torch.cuda.synchronize()
+                    tS = time.perf_counter()
+                    for _ in range(2):
+                        imgS = oneS()
+                    torch.cuda.synchronize()
+                    tS = (time.perf_counter() - tS) / 2
+                    assert bool(torch.isfinite(imgS).all())
+                    sweep.append({"batch": bs, "value": round(bs / tS, 4), "unit": "images/s", "ms_per_step": round(tS * 1e3, 1), "steps": 2, "warmup": 2})
+                    log(f"throughput sweep, batch {bs}: {bs / tS:.3f} images/s")
+                    for k in [k for k in pipe._loops if k[0] == bs]:
+                        del pipe._loops[k]                      # that batch size's graphs and buffers
+                    del latS, peS, neS, imgsS, cnS, imgS
+                    torch.cuda.empty_cache()
+                except Exception as e:                          # a sweep point must never cost the line
+                    sweep.append({"batch": bs, "error": repr(e)[:200]})
+            if sweep:
+                line["throughput_sweep"] = sweep
         if not args.no_stress_mode and world == 1 and not args.tiny and args.resolution == 512 and dtype == torch.float16:
             # BASELINE configs[4]: bf16, 768x768, batch 4 (outside the reference's own domain): three warmed,
             # timed pipeline calls on a second pipeline object; the 512 one is released first
@@ -530,6 +706,15 @@ def main(argv=None):
                                    "value": round(4 / t5, 4), "unit": "images/s", "ms_per_step": round(t5 * 1e3, 1),
                                    "steps": n5, "warmup": 2, "dtype": "bf16"}
             log(f"stress mode (768x768 bf16 batch 4): {4 / t5:.3f} images/s")
+            ph5 = call_phases(pipe5, one5)
+            line["stress_mode"]["phases_ms"] = ph5
+            # the HBM-bound piece of this configuration: the VAE decode at 768x768 (128 channels at 768x768 = 151 MB per tensor and image)
+            line["stress_mode"]["vae_decode"] = vae_decode_accounting(pipe5, 4, ph5.get("decode"))
+            if not args.no_roofline:
+                r5 = gemm_roofline(pipe5, traffic_profile="r05_gemm_pmc_traffic_768_b4.json",
+                                   replay_iters=int(min(60, max(5, 1.5 / (t5 / args.ddim_steps * 0.65)))))
+                line["stress_mode"]["roofline"] = {k: r5[k] for k in ROOFLINE_KEYS if k in r5}
+            log(f"stress mode accounting done: decode {line['stress_mode']['vae_decode']}")
         faulthandler.cancel_dump_traceback_later()
         print(json.dumps(line), flush=True)
     if world > 1:

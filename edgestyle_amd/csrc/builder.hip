@@ -644,6 +644,10 @@ struct Builder {
     if (small_ok) cand[nc++] = 64;
     int bn, splitk, stages;
     if (!plan_gemm(M, pw->rows_padded, pw->kpad, pw->geglu, cand, nc, pw->ln_colsum == 0, &bn, &splitk, &stages)) fail("plan_gemm: rows_padded fits no N tile");
+    if (bn == 320 && splitk == 1 && !es_conv_gemm8p_form_ok(act_i, pw->cout, a.temb ? 1 : 0, hw, a.residual ? 1 : 0)) {
+      // the 256 x 320 tile does not implement this epilogue form: plan again without it (ops.conv_gemm does the same)
+      if (!plan_gemm(M, pw->rows_padded, pw->kpad, pw->geglu, cand + 1, nc - 1, pw->ln_colsum == 0, &bn, &splitk, &stages)) fail("plan_gemm: rows_padded fits no N tile");
+    }
     es_gemm_desc d;
     memset(&d, 0, sizeof(d));
     d.x = x.ptr(); d.x2 = a.x2 ? a.x2.ptr() : nullptr; d.w = (const void*)pw->w; d.bias = (const float*)pw->bias;

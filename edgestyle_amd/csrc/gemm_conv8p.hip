@@ -574,11 +574,14 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
 }  // namespace
 
 // the epilogue forms this tile implements (split-K launches write raw partials: every form)
+extern "C" int es_conv_gemm8p_form_ok(int act, int cout, int has_temb, long long out_hw, int has_residual) {
+  if (act != ES_ACT_NONE || (cout & 7)) return 0;
+  if (has_temb && ((out_hw & 127) || has_residual)) return 0;
+  return 1;
+}
 bool es_conv_gemm8p_takes(const es_gemm_desc& d) {
   if (d.splitk > 1) return true;
-  if (d.act != ES_ACT_NONE || (d.Cout & 7)) return false;
-  if (d.temb && (((d.Hout * d.Wout) & 127) || d.residual)) return false;
-  return true;
+  return es_conv_gemm8p_form_ok(d.act, d.Cout, d.temb != nullptr, (long long)d.Hout * d.Wout, d.residual != nullptr) != 0;
 }
 
 // called by es_conv_gemm (gemm_conv.hip) after validation, for d.bn == 320

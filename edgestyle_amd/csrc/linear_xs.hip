@@ -53,7 +53,7 @@ constexpr int XS_LDS = XS_STAGES * XS_STAGE + 8 * 32 * XS_OROW;
 
 template <int N> ES_DEVICE void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int KC /* K / 32 */, bool GEGLU, bool LN, bool RES = false>
+template <typename T, int KC /* K / 32 */, bool GEGLU, bool LN, bool RES = false, bool PP = false /* two-barrier ping-pong (below) */>
 __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
   constexpr int K = KC * 32;
   constexpr int NF = KC == 10 ? 4 : 2;          // 16-column fragments per stage
@@ -195,7 +195,17 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
 #ifndef XS_PRIO
 #define XS_PRIO 1
 #endif
-  if (XS_PRIO && late) __builtin_amdgcn_s_setprio(1);
+#ifndef XS_RDMIX        // ping-pong form: fragment reads interleaved with the MFMA pairs (1) or in bursts of NF (0)
+#define XS_RDMIX 1
+#endif
+#ifndef XS_WPF          // ping-pong form: K-chunks of weight fragments read ahead of their MFMAs
+#define XS_WPF 2
+#endif
+#ifndef XS_PRIO_PP      // ping-pong form: 0 none, 1 static for the younger half, (XS_PRIO == 2: around the MFMA slot)
+#define XS_PRIO_PP 0
+#endif
+  if (XS_PRIO == 1 && late && !PP) __builtin_amdgcn_s_setprio(1);
+  if (PP && XS_PRIO_PP == 1 && late) __builtin_amdgcn_s_setprio(1);
 
   // top of iteration ci: stage ci landed?  VMEM operations of this wave younger than its DMAs of stage ci (issued at the
   // top of iteration ci-2): the next stage's NDMA, plus the 4 output stores of every finished line group in between.
@@ -224,8 +234,11 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
   // MFMAs of stage ci into acc (+ the stage's bias values, which live in the LDS stage that is recycled two barriers on)
   auto compute = [&](int ci, f32x4 (&acc)[NF][2], f32x4 (&bias)[NF]) __attribute__((always_inline)) {
     const char* sb = smem + (ci % XS_STAGES) * XS_STAGE;
-    // weight fragments are read one K-chunk (NF x 16 bytes per lane) ahead of the MFMAs that consume them
-    typename Traits<T>::vec8 wf[2][NF];
+    // weight fragments are read XS_WPF K-chunks (NF x 16 bytes per lane each) ahead of the MFMAs that consume them.  One chunk ahead covers
+    // 8 MFMAs = 128 cycles, less than an LDS round trip while four waves read and the other four stage their outputs: in the ping-pong
+    // form (one MFMA stream per SIMD, nothing to hide behind) stamps showed the MFMA slot paced by it - 80 MFMAs in 2000-2350 cycles
+    constexpr int WPF = PP ? XS_WPF : 1;
+    typename Traits<T>::vec8 wf[WPF + 1][NF];
     auto wread = [&](int kc, typename Traits<T>::vec8 (&dst)[NF]) __attribute__((always_inline)) {
       const int st = kc >> 1, h = kc & 1;
 #pragma unroll
@@ -234,7 +247,8 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
         dst[nf] = as_vec8<T>(*(const u32x4*)(sb + st * SUB + row * 128 + (((4 * h + fq) ^ (row & 7)) << 4)));
       }
     };
-    wread(0, wf[0]);
+#pragma unroll
+    for (int a = 0; a < WPF && a < KC; ++a) wread(a, wf[a]);
     // the bias enters as the C operand of each accumulator's first MFMA: no add in the epilogue
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
@@ -244,18 +258,35 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
     }
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
-      if (!(XS_ABLATE & 32) && kc + 1 < KC) wread(kc + 1, wf[(kc + 1) & 1]);
+      if constexpr (PP && XS_RDMIX) {
+        // ping-pong form: ONE fragment read ahead of every MFMA pair instead of NF reads in a burst ahead of 2 NF MFMAs - a burst
+        // of four ds_read_b128 from each of the four MFMA waves at once took 45-85 cycles to issue where an MFMA covers 16
+        // (stamps: 80 MFMAs in 1650 cycles without the reads, 1950-2350 with them, whatever the prefetch depth)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          if (!(XS_ABLATE & 32) && kc + WPF < KC) {
+            const int k2 = kc + WPF, st = k2 >> 1, h = k2 & 1, row = nf * 16 + frow;
+            wf[k2 % (WPF + 1)][nf] = as_vec8<T>(*(const u32x4*)(sb + st * SUB + row * 128 + (((4 * h + fq) ^ (row & 7)) << 4)));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acc[nf][0] = mfma16(wf[(XS_ABLATE & 32) ? 0 : (kc % (WPF + 1))][nf], xr[0][kc], acc[nf][0]);
+          acc[nf][1] = mfma16(wf[(XS_ABLATE & 32) ? 0 : (kc % (WPF + 1))][nf], xr[1][kc], acc[nf][1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+      if (!(XS_ABLATE & 32) && kc + WPF < KC) wread(kc + WPF, wf[(kc + WPF) % (WPF + 1)]);
       __builtin_amdgcn_sched_barrier(0);          // (hipcc otherwise sinks every read to just before its first MFMA)
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) {
 #if XS_ABLATE & 1
-        asm volatile("" ::"v"(wf[(XS_ABLATE & 32) ? 0 : (kc & 1)][nf]), "v"(xr[0][kc]), "v"(xr[1][kc]));
+        asm volatile("" ::"v"(wf[(XS_ABLATE & 32) ? 0 : (kc % (WPF + 1))][nf]), "v"(xr[0][kc]), "v"(xr[1][kc]));
 #else
-        acc[nf][0] = mfma16(wf[(XS_ABLATE & 32) ? 0 : (kc & 1)][nf], xr[0][kc], acc[nf][0]);
-        acc[nf][1] = mfma16(wf[(XS_ABLATE & 32) ? 0 : (kc & 1)][nf], xr[1][kc], acc[nf][1]);
+        acc[nf][0] = mfma16(wf[(XS_ABLATE & 32) ? 0 : (kc % (WPF + 1))][nf], xr[0][kc], acc[nf][0]);
+        acc[nf][1] = mfma16(wf[(XS_ABLATE & 32) ? 0 : (kc % (WPF + 1))][nf], xr[1][kc], acc[nf][1]);
 #endif
       }
       __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
 
@@ -266,7 +297,8 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
       // the residual chunks of this stage have landed?  Younger operations of this wave: an early wave has issued the DMAs of stage
       // ci + 2 since; a late wave (it runs this one stage later) those, the stores of stage ci - 1, the next four residual loads and
       // the DMAs of stage ci + 3.  Near the ends, where some of these were not issued, wait for everything.
-      if (!late) { if (ci + 2 < nch) wait_vm<NDMA>(); else wait_vm<0>(); }
+      // (ping-pong form: both groups issue the DMAs of stage ci + 2 right before this epilogue - nothing else is younger)
+      if (PP || !late) { if (ci + 2 < nch) wait_vm<NDMA>(); else wait_vm<0>(); }
       else { if (ci >= 1 && ci + 3 < nch) wait_vm<NDMA + 4 + 4 + NDMA>(); else wait_vm<0>(); }
     }
 #pragma unroll
@@ -313,6 +345,53 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
 
   f32x4 accA[NF][2], accB[NF][2], bA[NF], bB[NF];
   u32x4 rrA[4], rrB[4];
+  if constexpr (PP) {
+    // Two-barrier ping-pong (round 5).  In-kernel stamps of the one-barrier form on the plain projections (tools/xs_stamps.py, 57344 x 320
+    // -> 960): the "half a stage out of phase" of waves 4-7 is only as long as an epilogue, and a plain epilogue is short - both waves of a
+    // SIMD then run their 80 MFMAs at the same time (the early wave's MFMA phase stretched from 1300 to 3600 cycles), and the ~1500 cycles of
+    // barrier + six DMA issues + fragment-read latency + epilogue at the stage boundary see no MFMA at all (29 % of the stage).  Here the two
+    // groups alternate by construction, as in gemm_conv8p.hip: a stage is TWO slots between workgroup barriers; in a slot one group only
+    // issues MFMAs (stage t) while the other does everything else (DMAs of stage t + 2, epilogue of stage t, output stores); group 1 runs
+    // one slot behind group 0.  Ring of three stages as before; every wave issues the DMAs of stage t + 2 right after its MFMAs of stage t
+    // (the buffer's last reader, group 1's MFMAs of stage t - 1, finished two barriers earlier) and retires its pieces of stage t + 1 by a
+    // COUNTED wait before the barrier that opens group 0's MFMA slot of that stage: group 0 at the end of its own "other" slot, group 1 at
+    // the end of its MFMA slot.  One accumulator set per wave (the epilogue of a stage ends before the next MFMAs start).
+    constexpr int ST = 4;                          // output stores per finished 128-byte line
+    constexpr int RS = RES ? 4 : 0;                // residual loads per stage
+    auto line_done = [&](int t) { return t >= 0 && (t % P) == P - 1; };
+    // every wave: its pieces of stage 0 have landed (stage 1's stay in flight)
+    if (nch > 1) wait_vm<NDMA>(); else wait_vm<0>();
+    if (late) __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < nch; ++t) {
+      __builtin_amdgcn_s_barrier();                // stage t complete and visible (group 0: barrier 2t, group 1: barrier 2t + 1)
+      load_res(t, rrA);                            // (the residual chunks arrive behind the MFMAs)
+#if XS_STAMPS
+      stamp(t, 0);
+#endif
+      if (XS_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+      compute(t, accA, bA);
+      if (XS_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+#if XS_STAMPS
+      stamp(t, 1);
+#endif
+      if (late && t + 1 < nch) {
+        // group 1: its pieces of stage t + 1 (issued one slot ago, ahead of the stores of stage t - 1 and this stage's residual loads)
+        if (t + 2 >= nch && t == 0) wait_vm<RS>();
+        else if (line_done(t - 1)) wait_vm<ST + RS>(); else wait_vm<RS>();
+      }
+      if (!late || t + 1 < nch) __builtin_amdgcn_s_barrier();
+      if (!(XS_ABLATE & 16) && t + 2 < nch) issue(c0 + t + 2, (t + 2) % XS_STAGES);
+      epilogue(t, accA, bA, rrA);
+      if (!late && t + 1 < nch) {
+        // group 0: its pieces of stage t + 1 (younger: the DMAs of stage t + 2 just issued, this stage's stores)
+        if (t + 2 < nch) { if (line_done(t)) wait_vm<NDMA + ST>(); else wait_vm<NDMA>(); }
+        else { if (line_done(t)) wait_vm<ST>(); else wait_vm<0>(); }
+      }
+#if XS_STAMPS
+      stamp(t, 2);
+#endif
+    }
+  } else
   if (!late) {
     for (int ci = 0; ci < nch; ++ci) {
       top(ci, rrA);
@@ -371,10 +450,10 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
 #endif
 }
 
-template <typename T, int KC, bool GEGLU, bool LN, bool RES = false>
+template <typename T, int KC, bool GEGLU, bool LN, bool RES = false, bool PP = false>
 int launch_one(const es_xs_desc& d, hipStream_t st) {
   const int rbs = (d.M + XS_ROWS - 1) / XS_ROWS;
-  auto kfn = linear_xs_kernel<T, KC, GEGLU, LN, RES>;
+  auto kfn = linear_xs_kernel<T, KC, GEGLU, LN, RES, PP>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, XS_LDS);
@@ -384,9 +463,18 @@ int launch_one(const es_xs_desc& d, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// form of the plain (no GEGLU) launches: 1 = two-barrier ping-pong (default), 0 = the one-barrier form (ES_XS_PP=0; es_linear_xs_set_pp for
+// A/B runs inside one process).  Same arithmetic in the same order either way: bit-identical outputs.
+int xs_pp = [] { const char* e = getenv("ES_XS_PP"); return e ? atoi(e) : 1; }();
+
 template <typename T>
 int launch(const es_xs_desc& d, hipStream_t st) {
   const bool g = d.geglu != 0, ln = d.ln != 0;
+  if (xs_pp && !g) {
+    if (d.residual) return launch_one<T, 10, false, false, true, true>(d, st);
+    if (d.K == 320) return ln ? launch_one<T, 10, false, true, false, true>(d, st) : launch_one<T, 10, false, false, false, true>(d, st);
+    return ln ? launch_one<T, 20, false, true, false, true>(d, st) : launch_one<T, 20, false, false, false, true>(d, st);
+  }
   if (d.residual) return launch_one<T, 10, false, false, true>(d, st);     // (K = 320, no GEGLU, no LayerNorm: checked by es_linear_xs)
   if (d.K == 320) {
     if (g) return ln ? launch_one<T, 10, true, true>(d, st) : launch_one<T, 10, true, false>(d, st);
@@ -399,6 +487,8 @@ int launch(const es_xs_desc& d, hipStream_t st) {
 }  // namespace
 
 extern "C" void es_set_error(const char* msg);
+
+extern "C" int es_linear_xs_set_pp(int on) { const int prev = xs_pp; xs_pp = on; return prev; }
 
 extern "C" int es_linear_xs(const es_xs_desc* d, void* stream) {
   if (!d->x || !d->out || (d->ngroups <= 1 && (!d->w || !d->bias))) { es_set_error("es_linear_xs: null pointer (bias is required: pass zeros)"); return -1; }

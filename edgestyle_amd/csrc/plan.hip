@@ -8,6 +8,7 @@
 // on the caller's stream (or replayed as a hipGraph instantiated from it), outputs are copied out.  No interpreter, no
 // torch, no allocation in these calls.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -323,6 +324,27 @@ int h2d(void* dst, const void* src, size_t n, hipStream_t st) {
 bool ctx_trace() { static const bool on = [] { const char* e = getenv("ES_CTX_TRACE"); return e && e[0] == '1'; }(); return on; }
 #define ES_TRACE(...) do { if (ctx_trace()) { fprintf(stderr, "[es_ctx] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
+// A profiler that intercepts the HSA queues (rocprofv3 = rocprofiler-sdk) rewrites AQL packets; the HIP runtime's graph packet
+// capture block-copies packets it pre-built at instantiate time, and hipGraphLaunch of a context's SECOND kind of graph then
+// faults inside the runtime (host SIGSEGV, profiles/r04_rocprof_graph_fault.txt).  DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 makes the
+// runtime enqueue graph nodes one by one and is what every profiling script of tools/ exports; a caller who profiles WITHOUT it
+// must not reach the faulting path: the context then replays its plans launch by launch (same kernels, same order).
+bool graph_hazard() {
+  static const bool v = [] {
+    const char* cap = getenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE");
+    if (cap && cap[0] == '0') return false;
+    const char* tl = getenv("ROCP_TOOL_LIBRARIES");
+    const char* pre = getenv("LD_PRELOAD");
+    bool prof = (tl && *tl) || (pre && strstr(pre, "rocprof"));
+    if (!prof && dlsym(RTLD_DEFAULT, "rocprofiler_configure")) prof = true;
+    if (prof) fprintf(stderr, "[edgestyle_hip] a queue-intercepting profiler is attached and DEBUG_CLR_GRAPH_PACKET_CAPTURE is not 0: "
+                              "the context replays its plans launch by launch instead of as hipGraphs (export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 "
+                              "to profile the graph path; profiles/r04_rocprof_graph_fault.txt)\n");
+    return prof;
+  }();
+  return v;
+}
+
 int run(es_ctx* c, int which, hipStream_t st, const float* guidance) {
   es_plan* p = c->plan[which];
   if (!p) { es_set_error("es_ctx: plan not set"); return -1; }
@@ -332,7 +354,7 @@ int run(es_ctx* c, int which, hipStream_t st, const float* guidance) {
   RunOpts ro;
   ro.guidance = guidance;
   ro.unipc = c->scheduler == ES_SCHED_UNIPC ? c : nullptr;
-  if (!c->use_graphs || cs != hipStreamCaptureStatusNone) return run_plan(p, st, ro);
+  if (!c->use_graphs || cs != hipStreamCaptureStatusNone || graph_hazard()) return run_plan(p, st, ro);
   const float gs = guidance ? *guidance : 0.f;
   if (c->exec[which] && c->exec_guidance[which] != gs) { (void)hipGraphExecDestroy(c->exec[which]); c->exec[which] = nullptr; }
   if (!c->exec[which]) {
@@ -559,6 +581,8 @@ extern "C" void* es_ctx_buffer(const es_ctx* c, int slot, size_t* bytes) {      
   if (bytes) *bytes = c->bytes[slot];
   return c->buf[slot];
 }
+extern "C" int es_ctx_graph_hazard(void) { return graph_hazard() ? 1 : 0; }
+
 extern "C" int es_ctx_set_options(es_ctx* c, const float* cond_scales, float control_guidance_start, float control_guidance_end, int use_graphs) {
   if (!c) { es_set_error("es_ctx_set_options: null ctx"); return -1; }
   if (cond_scales) memcpy(c->cond_scales, cond_scales, sizeof(c->cond_scales));
@@ -880,7 +904,7 @@ extern "C" int es_denoise_loop(es_ctx* c, float* latents_inout, const void* ehs,
   if ((rc = d2d(c->buf[ES_BUF_EHS], ehs, c->bytes[ES_BUF_EHS], st))) return rc;
   if ((rc = es_latents_to_input((const float*)c->buf[ES_BUF_LATENTS], c->buf[ES_BUF_SAMPLE], g.B, g.h * g.w, g.latent_channels,
                                 g.latent_pad, g.cfg, g.dtype, stream))) return rc;
-  if (c->use_graphs == 2) {
+  if (c->use_graphs == 2 && !graph_hazard()) {
     // the preparation and all n step lists as ONE graph (BASELINE configs[2]: "hipGraph-captured scheduler loop"): every
     // step is the same launch list - the device step counter picks its rows of the tables - so the graph depends on
     // (n_steps, guidance scale) only

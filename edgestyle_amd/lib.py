@@ -144,6 +144,7 @@ SYMBOLS = {
     "es_conv_gemm": (C.c_int, [C.POINTER(GemmDesc), _P]),
     "es_conv_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
     "es_linear_xs": (C.c_int, [C.POINTER(XsDesc), _P]),
+    "es_linear_xs_set_pp": (C.c_int, [_I]),
     "es_attention": (C.c_int, [C.POINTER(AttnDesc), _P]),
     "es_group_norm": (C.c_int, [C.POINTER(GnDesc), _P]),
     "es_group_norm_partials_bytes": (C.c_size_t, [_I, _I]),
@@ -202,6 +203,8 @@ SYMBOLS = {
     "es_plan_gemm_choice": (C.c_int, [C.c_longlong, _I, _I, _I, C.POINTER(C.c_int), _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.POINTER(C.c_int)]),
     "es_linear_xs_eligible": (C.c_int, [C.c_longlong, _I, _I, _I, _I, _I, _I]),
+    "es_conv_gemm8p_form_ok": (C.c_int, [_I, _I, _I, C.c_longlong, _I]),
+    "es_ctx_graph_hazard": (C.c_int, []),
     "es_plan_set_dry": (C.c_int, [_I]),
 }
 

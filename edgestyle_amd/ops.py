@@ -570,6 +570,11 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     cand = ((320,) if big_ok else ()) + (160, 128) + ((64,) if small_ok else ())
     bn, auto_splitk, auto_stages = plan_gemm(M, pw.rows_padded, pw.kpad, pw.geglu,
                                              bns=cand if FORCE_BN == 0 else (FORCE_BN,), allow_split=pw.ln_colsum is None)
+    if bn == 320 and FORCE_BN == 0 and (auto_splitk if splitk is None else splitk) == 1 and not L.load().es_conv_gemm8p_form_ok(
+            int(act_i), int(pw.cout), int(temb is not None), int(Hout * Wout), int(residual is not None)):
+        # the 256 x 320 tile does not implement this epilogue form (an activation, time-embedding rows that differ inside a 128-pixel
+        # half or meet a residual): plan again without it, so that the tile planned, recorded and reported is the tile that runs
+        bn, auto_splitk, auto_stages = plan_gemm(M, pw.rows_padded, pw.kpad, pw.geglu, bns=cand[1:], allow_split=pw.ln_colsum is None)
     if splitk is None:
         splitk = auto_splitk
         stages = stages or auto_stages
@@ -798,7 +803,16 @@ def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) ->
     if out is None:
         out = torch.empty_like(a)
     L.check(L.load().es_add(_ptr(a), _ptr(b), _ptr(out), a.numel(), _dt(a), _stream()), "es_add")
+    _drop_riders(out)
     return out
+
+
+def _drop_riders(t: torch.Tensor):
+    """A tensor written in place no longer matches what rides on its Python object: the low word of the two-word residual stream
+    (`._lo`) and the GroupNorm statistics its producer handed over (`._gnp`) describe the OLD contents."""
+    for name in ("_lo", "_gnp"):
+        if hasattr(t, name):
+            delattr(t, name)
 
 
 def nchw_to_nhwc(x: torch.Tensor, dtype, cpad: Optional[int] = None) -> torch.Tensor:
@@ -855,6 +869,7 @@ def memcpy(dst: torch.Tensor, src: torch.Tensor):
     if not (dst.is_contiguous() and src.is_contiguous()) or dst.numel() * dst.element_size() != nb:
         raise L.EdgeStyleHipError("memcpy: contiguous tensors of equal byte size")
     L.check(L.load().es_memcpy(_ptr(dst), _ptr(src), nb, _stream()), "es_memcpy")
+    _drop_riders(dst)
 
 
 def memcpy2d(dst_ptr: int, dpitch: int, src_ptr: int, spitch: int, width: int, height: int):

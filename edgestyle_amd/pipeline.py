@@ -679,14 +679,15 @@ class StableDiffusionControlNetPipeline:
         return StableDiffusionPipelineOutput(images=img, nsfw_content_detected=None)
 
 
-    def profile_one_step(self, gemm_replay_iters: int = 0):
+    def profile_one_step(self, gemm_replay_iters: int = 0, around_replay=None):
         """Re-capture the step graph of the most recent call with in-kernel timing stamps on every es_conv_gemm
         launch, replay ONE step, and return [(meta, seconds)] (ops.Profiler).  Used by bench.py's roofline leg.
 
         gemm_replay_iters > 0 additionally times the SAME launch list as the production kernels run it (no stamp
         atomics): only the es_conv_gemm launches (with their split-K reduces), captured as one graph and replayed that
         many times between two HIP events on the launching stream; the average per replay lands in
-        `self.last_gemm_replay_ms`."""
+        `self.last_gemm_replay_ms`.  `around_replay` = (start, stop): called right before / after that event-timed
+        region (bench.py samples the sustained clock and package power there)."""
         if not self._loops:
             raise EdgeStyleHipError("run the pipeline once before profiling")
         loop = self._last_loop or list(self._loops.values())[-1]
@@ -727,7 +728,13 @@ class StableDiffusionControlNetPipeline:
                 e1.record()
                 torch.cuda.synchronize()
                 return e0.elapsed_time(e1) / gemm_replay_iters
-            self.last_gemm_replay_ms = timed(0)
+            if around_replay is not None:
+                around_replay[0]()
+            try:
+                self.last_gemm_replay_ms = timed(0)
+            finally:
+                if around_replay is not None:
+                    around_replay[1]()
             self.last_conv3_replay_ms = timed(3)     # the 3x3 convolutions alone (with their split-K reduces)
         loop.step_idx.zero_()
         del g

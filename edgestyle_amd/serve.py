@@ -2,8 +2,8 @@
 
 The reference serves one request at a time from a Gradio callback (`try_on`, app.py:151-182: six conditioning
 images + a prompt -> `pipeline(...).images[0]`, generator re-seeded to 42 per request, app.py:162).  On an MI355X one
-request leaves most of the chip idle in the UNet decoder (batch 1 = 1.95 images/s, batch 8 = 2.75 images/s on the same
-GPU), so the service here batches: requests that agree on (steps, guidance scale, control window, size) and arrive
+request leaves most of the chip idle in the UNet decoder (batch 8 delivers ~1.5x the images/s of batch 1 on the same
+GPU: the current pair is in the bench line, `value` against `throughput_mode.value`), so the service here batches: requests that agree on (steps, guidance scale, control window, size) and arrive
 within `max_wait_s` of each other run as ONE pipeline call of up to `max_batch` images, each with its own latents
 drawn from its own seed — a request's image does not depend on what it was batched with (tests/test_host_cpu.py).
 

@@ -155,6 +155,9 @@ typedef struct {
   const void* residual;
 } es_xs_desc;
 int es_linear_xs(const es_xs_desc* d, void* stream);
+/* tool / test knob: the form of the plain (no GEGLU) launches - 1 = two-barrier ping-pong between the wave groups (default; ES_XS_PP=0
+ * in the environment turns it off), 0 = the one-barrier form.  Bit-identical outputs.  Returns the previous setting. */
+int es_linear_xs_set_pp(int on);
 
 /* Fused attention softmax(Q K^T * scale) V (flash-style, online softmax, MFMA).
  * Replaces torch.nn.functional.scaled_dot_product_attention under diffusers Attention (attn1/attn2/VAE attn).
@@ -449,6 +452,16 @@ int es_load_weights(const es_weights* w, const es_model_config* cfg, const es_ct
 int es_plan_gemm_choice(long long M, int rows_padded, int kpad, int geglu, const int* bns, int n_bns, int allow_split,
                         int* bn, int* splitk, int* stages);
 int es_linear_xs_eligible(long long M, int ksize, int kpad, int cin, int ctail, int cout, int geglu);
+/* Does the 256 x 320 tile (bn = 320) implement the epilogue of a splitk == 1 launch with this form?  (It keeps the common
+ * forms only - bias [+ one time-embedding row per 128-pixel half] [+ residual]; split-K launches write raw partials: every
+ * form.)  1 = yes.  Both hosts ask BEFORE they fix bn, so that the tile a launch is planned, recorded and reported with is the
+ * tile that runs (es_conv_gemm itself still falls back to the 128 x 160 tile for a caller that did not ask). */
+int es_conv_gemm8p_form_ok(int act, int cout, int has_temb, long long out_hw, int has_residual);
+/* 1 when this process runs under a profiler that intercepts the HSA queues (rocprofv3: ROCP_TOOL_LIBRARIES / a rocprofiler
+ * library in LD_PRELOAD / a loaded rocprofiler_configure) while the HIP runtime still block-copies pre-built graph packets
+ * (DEBUG_CLR_GRAPH_PACKET_CAPTURE unset or not 0): hipGraphLaunch of a context's graphs then faults inside the runtime
+ * (profiles/r04_rocprof_graph_fault.txt).  The context replays its plans launch by launch in that case. */
+int es_ctx_graph_hazard(void);
 /* es_plan_set_dry(1): while a plan records on this thread, calls are validated and recorded but nothing is launched (the
  * pointers need not exist yet).  Returns the previous setting. */
 int es_plan_set_dry(int on);

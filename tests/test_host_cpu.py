@@ -502,3 +502,36 @@ def test_pointer_field_tables_match_the_descriptor_structs():
     assert g[lib.GemmDesc.out.offset] == 2 and g[lib.GemmDesc.w.offset] == 1 and g[lib.GemmDesc.workspace.offset] == 3
     # small argument records (memcpy, incr, ...) and markers / unknown kinds
     assert len(table(18)[0]) == 2 and len(table(16)[0]) == 1 and table(64) == ([], 0) and table(999) == ([], 0)
+
+
+def test_graph_hazard_guard_sees_a_queue_intercepting_profiler():
+    """es_ctx_graph_hazard (csrc/plan.hip): under rocprofv3 (ROCP_TOOL_LIBRARIES / a rocprofiler library in LD_PRELOAD) without
+    DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 the HIP runtime faults below hipGraphLaunch (profiles/r04_rocprof_graph_fault.txt); the
+    context then replays its plans launch by launch.  One process per environment: the answer is latched at first use."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from edgestyle_amd import lib; "
+            "print(ctypes.CDLL(lib.LIB_PATH).es_ctx_graph_hazard())" % ROOT)
+
+    def ask(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("ROCP_TOOL_LIBRARIES", "LD_PRELOAD", "DEBUG_CLR_GRAPH_PACKET_CAPTURE")}
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-500:]
+        return int(r.stdout.strip().splitlines()[-1]), r.stderr
+    assert ask()[0] == 0
+    v, err = ask(ROCP_TOOL_LIBRARIES="/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    assert v == 1 and "launch by launch" in err
+    assert ask(ROCP_TOOL_LIBRARIES="/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so", DEBUG_CLR_GRAPH_PACKET_CAPTURE="0")[0] == 0
+
+
+def test_big_tile_epilogue_forms():
+    """es_conv_gemm8p_form_ok: the epilogue forms the 256 x 320 tile implements for splitk == 1 (both hosts ask before they fix
+    bn = 320, so the planned / recorded / reported tile is the tile that runs)."""
+    L = lib.load()
+    ok = L.es_conv_gemm8p_form_ok
+    assert ok(lib.ACT_NONE, 320, 0, 4096, 0) == 1 and ok(lib.ACT_NONE, 320, 0, 4096, 1) == 1
+    assert ok(lib.ACT_NONE, 320, 1, 4096, 0) == 1          # one time-embedding row per 128-pixel half
+    assert ok(lib.ACT_NONE, 320, 1, 4096, 1) == 0          # ... not beside a residual
+    assert ok(lib.ACT_NONE, 320, 1, 64, 0) == 0            # ... nor when a half spans samples
+    assert ok(lib.ACT_SILU, 320, 0, 4096, 0) == 0 and ok(lib.ACT_NONE, 4, 0, 4096, 0) == 0

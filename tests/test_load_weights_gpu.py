@@ -456,7 +456,11 @@ def test_the_profiling_recipe_runs_the_native_loop_under_rocprofv3(tmp_path):
     below hipGraphLaunch, or a malformed AQL packet and a hung finalisation) - at the batch-8 size of the native leg, never
     outside the profiler, and not with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (profiles/r04_rocprof_graph_fault.txt).  tools/prof_bench.sh
     and every tools/collect_*.sh set that variable; this test holds the recipe together on a small context: per-plan graphs and
-    the whole-loop graph of an es_load_weights context under `rocprofv3 --kernel-trace`."""
+    the whole-loop graph of an es_load_weights context under `rocprofv3 --kernel-trace`.
+    This context (sample_size 64, B = 2) is SMALLER than the geometry the fault was seen at: the failing size itself is covered by
+    the recorded `tools/prof_bench.sh` runs of the batch-8 bench (profiles/r04_rocprof_graph_fault.txt, section 2), not by this test.
+    Since round 5 the library also guards itself: under a queue-intercepting profiler WITHOUT the variable its contexts replay launch
+    by launch (es_ctx_graph_hazard, tests/test_host_cpu.py)."""
     import os
     import shutil
     import subprocess

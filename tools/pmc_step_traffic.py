@@ -60,8 +60,8 @@ def main(fetch_csv, write_csv, launches_json, out_json):
     rd = 2 * 1024 * (F["conv_gemm_kernel"]["KiB_per_step"] + F["linear_xs_kernel"]["KiB_per_step"])
     wr = 1024 * (W["conv_gemm_kernel"]["KiB_per_step"] + W["linear_xs_kernel"]["KiB_per_step"])
     out = {
-        "round": int(os.environ.get("ES_ROUND", "4")),
-        "workload": "the GEMM launches (conv_gemm_kernel + linear_xs_kernel) of one batch-1 denoising step of the REAL "
+        "round": int(os.environ.get("ES_ROUND", "5")),
+        "workload": "the GEMM launches (conv_gemm_kernel + linear_xs_kernel) of one " + os.environ.get("ES_TRAFFIC_WORKLOAD", "batch-1") + " denoising step of the REAL "
                     "pipeline (bench.py --no-graph: same launch list as the captured step, eager so that counters can be "
                     f"collected per dispatch), steps averaged: {nf} (FETCH pass) / {nw} (WRITE pass)",
         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; reads = 2 x FETCH_SIZE x 1024, "
