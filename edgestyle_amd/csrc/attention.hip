@@ -916,6 +916,194 @@ __global__ __launch_bounds__(512, 2) void attention40pp_kernel(const es_attn_des
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Cross-attention over the text tokens (77 keys; Skv <= 96), head_dim 40 | 80: K AND V RESIDENT IN REGISTERS.
+// The tiled kernels above treat the 77 keys as two K / V tiles: every block of 64-256 queries stages them through LDS again (pad
+// zeroing, two barriers per tile, a rescale step between the tiles) - 33 us for the 14 x 8 x 4096 launch of a batch-1 step whose
+// Q read + O write take ~12 us of HBM time (8.7 % MFMA-busy, profiles/r04_mfma_util_b1.json).  Here a wave owns ONE head: it loads
+// that head's K as the A operands of S^T = K Q^T (3 key tiles x KS fragments of mfma 32x32x16) and V^T as the A operands of
+// O^T = V^T P^T (3 key chunks x DF fragments of mfma 16x16x32, gathered with the key order the packed P^T operands have) ONCE, then
+// walks a strip of queries in blocks of 32: Q block (prefetched one block ahead) -> 9 | 15 MFMAs -> single-pass softmax in registers
+// (every key of a query is in the lane pair l, l + 32: no running maximum, no rescale) -> 18 | 30 MFMAs -> O.  No LDS, no barrier:
+// the waves of a workgroup (four heads) only share the cache lines of their query rows.
+template <typename T, int KS /* QK k-steps of 16 */, int DF /* dv fragments of 16 (d = 40: the pad column 40 is the ones column) */, bool ONES>
+__global__ __launch_bounds__(512, 2) void attention_kvres_kernel(const es_attn_desc p, const int qper) {
+  constexpr int KT = 3;                             // key tiles of 32
+  typedef typename Traits<T>::vec8 vec8;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n32 = lane & 31, hi = lane >> 5;        // 32x32 layouts: query column / key half
+  const int col = lane & 15, g = lane >> 4;         // 16x16 layouts (PV product, epilogue)
+  const int h = blockIdx.y * 8 + wave, n = blockIdx.z;
+  if (h >= p.heads) return;                         // (wave-uniform; the kernel has no barrier)
+  const int d = p.d, dch = d / 8;
+  const T* Q = (const T*)p.q + (size_t)n * p.bsq + (size_t)h * d;
+  const T* K = (const T*)p.k + (size_t)n * p.bsk + (size_t)h * d;
+  const T* V = (const T*)p.v + (size_t)n * p.bsv + (size_t)h * d;
+  T* O = (T*)p.o + (size_t)n * p.bso + (size_t)h * d;
+  const float sl2 = p.scale * 1.4426950408889634f;
+  const int q_begin = blockIdx.x * qper;
+  int q_end = q_begin + qper;
+  q_end = q_end < p.Sq ? q_end : p.Sq;
+  // keys 80..95 of the third tile (registers 8..15 of its accumulator) are padding whenever Skv <= 80 - the 77 text tokens
+  const bool short3 = p.Skv <= 80;
+
+  auto load_q = [&](int q0, u32x4 (&raw)[KS]) __attribute__((always_inline)) {
+    int qi = q0 + n32;
+    qi = qi < p.Sq ? qi : p.Sq - 1;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int ch = 2 * s + hi;
+      raw[s] = u32x4{0u, 0u, 0u, 0u};
+      if (ch < dch) raw[s] = *(const u32x4*)(Q + (size_t)qi * p.ldq + ch * 8);
+    }
+  };
+  u32x4 qA[KS], qB[KS];                             // two blocks of query rows in flight
+  load_q(q_begin, qA);
+  if (q_begin + 32 < q_end) load_q(q_begin + 32, qB);
+
+  // K fragments, pre-scaled by scale * log2(e): lane holds K[key = 32 t + n32][16 s + 8 hi .. + 7]; keys >= Skv and channels >= d are zero
+  vec8 kf[KT][KS];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int key = 32 * t + n32, ch = 2 * s + hi;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (key < p.Skv && ch < dch) v = *(const u32x4*)(K + (size_t)key * p.ldk + ch * 8);
+      auto kv = as_vec8<T>(v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) kv[e] = from_f32<T>(to_f32(kv[e]) * sl2);
+      kf[t][s] = kv;
+    }
+  // V^T fragments: element e of lane (col, g) is V[key = 32 t + 16 (g & 1) + 4 (g >> 1) + 8 (e >> 2) + (e & 3)][dv = 16 j + col] -
+  // the key order of the packed P^T operands below (attention32_kernel reads the same map with ds_read_b64_tr_b16).
+  // ONES: column d (the first pad column) holds 1.0 for every real key, so row d of O^T is the softmax denominator.
+  vec8 vf[KT][DF];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int j = 0; j < DF; ++j) {
+      vec8 v;
+      const int dv = 16 * j + col;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int key = 32 * t + 16 * (g & 1) + 4 * (g >> 1) + 8 * (e >> 2) + (e & 3);
+        T x = from_f32<T>(0.f);
+        if (key < p.Skv) {
+          if (dv < d) x = V[(size_t)key * p.ldv + dv];
+          else if (ONES && dv == d) x = from_f32<T>(1.0f);
+        }
+        v[e] = x;
+      }
+      vf[t][j] = v;
+    }
+
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto block = [&](int q0, u32x4 (&qraw)[KS]) __attribute__((always_inline)) {
+    vec8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = as_vec8<T>(qraw[s]);
+    f32x16 sc[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) sc[t] = mfma32(kf[t][s], qf[s], s == 0 ? zero16 : sc[t]);
+    if (q0 + 64 < q_end) load_q(q0 + 64, qraw);     // this register set is free again: the block after the next one
+    // keys beyond Skv (zero K rows: score 0) leave the softmax
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+      if (32 * t + 32 > p.Skv) {                      // wave-uniform
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[t][r] = (32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.Skv) ? -3.0e38f : sc[t][r];
+      }
+    float mx = sc[0][0];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2)
+        if (t < 2 || r < 8 || !short3) mx = fmaxf(fmaxf(mx, sc[t][r]), sc[t][r + 1]);
+    mx = xor32_max(mx);
+    float rs = 0.f;
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (t < 2 || r < 8 || !short3) { sc[t][r] = __builtin_amdgcn_exp2f(sc[t][r] - mx); if (!ONES) rs += sc[t][r]; }
+        else sc[t][r] = 0.f;
+      }
+    vec8 pb[2][KT];                                 // [query half][key chunk]: B operands of the PV product
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      unsigned x[4], y[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        x[i] = pack2<T>(sc[t][2 * i], sc[t][2 * i + 1]);
+        y[i] = (t == 2 && short3) ? 0u : pack2<T>(sc[t][8 + 2 * i], sc[t][9 + 2 * i]);
+      }
+      asm volatile("s_nop 1\n\t"
+                   "v_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
+                   "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 1"
+                   : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+      pb[0][t] = as_vec8<T>(u32x4{x[0], x[1], x[2], x[3]});
+      pb[1][t] = as_vec8<T>(u32x4{y[0], y[1], y[2], y[3]});
+    }
+    f32x4 o[2][DF];
+#pragma unroll
+    for (int j = 0; j < DF; ++j)
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        o[0][j] = mfma16(vf[t][j], pb[0][t], t == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : o[0][j]);
+        o[1][j] = mfma16(vf[t][j], pb[1][t], t == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : o[1][j]);
+      }
+    float l0, l1;
+    if constexpr (ONES) {
+      // row d of O^T = fragment d / 16, lane group (d % 16) / 4, register d % 4: d = 40 -> fragment 2, lanes 32..47, register 0
+      l0 = __shfl(o[0][DF - 1][0], 32 + col, 64);
+      l1 = __shfl(o[1][DF - 1][0], 32 + col, 64);
+    } else {
+      const float l = xor32_sum(rs);                // per query, 32-query layout -> the two 16-query halves of the 16x16 layout
+      l0 = l; l1 = l;
+      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(l0), "+v"(l1));
+    }
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int qi = q0 + f * 16 + col;
+      const float inv = __builtin_amdgcn_rcpf(f ? l1 : l0);
+      if (qi < p.Sq) {
+#pragma unroll
+        for (int j = 0; j < DF; ++j) {
+          const int dv = j * 16 + g * 4;
+          if (dv < d) {
+            typename Traits<T>::vec4 pk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pk[r] = from_f32<T>(o[f][j][r] * inv);
+            store8(O + (size_t)qi * p.ldo + dv, __builtin_bit_cast(u32x2, pk));
+          }
+        }
+      }
+    }
+  };
+  for (int q0 = q_begin; q0 < q_end; q0 += 64) {
+    block(q0, qA);
+    if (q0 + 32 < q_end) block(q0 + 32, qB);
+  }
+}
+
+template <typename T, int KS, int DF, bool ONES>
+int launch_attn_kvres(const es_attn_desc& d, hipStream_t st) {
+  // strips of queries: enough workgroups (eight heads each, one wave per head) for one per CU and a little more, whole 32-query blocks
+  const int per_strip = (d.heads + 7) / 8 * d.N;
+  int strips = (320 + per_strip - 1) / per_strip;
+  const int blocks32 = (d.Sq + 31) / 32;
+  strips = strips < 1 ? 1 : (strips > blocks32 ? blocks32 : strips);
+  const int qper = ((blocks32 + strips - 1) / strips) * 32;
+  strips = (d.Sq + qper - 1) / qper;
+  dim3 grid(strips, (d.heads + 7) / 8, d.N);
+  hipLaunchKernelGGL((attention_kvres_kernel<T, KS, DF, ONES>), grid, dim3(512), 0, st, d, qper);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 template <typename T, int QB>
 int launch_attn40pp(const es_attn_desc& d, hipStream_t st) {
   constexpr int lds = 2 * (64 * (16 * 3 * 2 + 16) + 64 * (16 * 3 * 2 + 16));
@@ -938,11 +1126,21 @@ int launch_attn(const es_attn_desc& d, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// OFF by default: measured a LOSS (profiles/r05_xattn_bench.txt: 0.76-0.94x of the tiled kernels on the launches of a step).  Removing
+// the K / V staging, the barriers and the rescale was not the lever: with the softmax arithmetic cut by a third (second version) the kernel
+// got no faster, with fewer waves per SIMD it got slower - these launches are bound by the REQUEST rate of their fragment-shaped Q loads
+// and 8-byte O stores (a wave instruction touches 32 rows x 32 bytes: 32 cache lines for 1 KB), which the tiled kernels share.  What
+// would pay is Q / O tiles through LDS in whole 640-byte rows; not built (the 22 launches are 1.6 % of a batch-1 step).
+int attn_kvres = [] { const char* e = getenv("ES_ATTN_KVRES"); return e ? atoi(e) : 0; }();
+
 template <typename T>
 int dispatch(const es_attn_desc& d, hipStream_t st) {
   // 32 queries per wave (128 per block) only when that still yields >= 2 blocks per CU; else 16 per wave
   static const long long big_thr = getenv("ES_ATTN_BIG") ? atoll(getenv("ES_ATTN_BIG")) : 512;
   const bool big = (long long)((d.Sq + 127) / 128) * d.heads * d.N >= big_thr;
+  // the text-token cross-attention (77 keys) of the 64 x 64 and 32 x 32 levels: K / V resident in registers (opt-in: ES_ATTN_KVRES=1)
+  if (attn_kvres && d.Skv <= 96 && d.Sq >= 64 && (d.d == 40 || d.d == 80))
+    return d.d == 40 ? launch_attn_kvres<T, 3, 3, true>(d, st) : launch_attn_kvres<T, 5, 5, false>(d, st);
   static const bool tile32 = !(getenv("ES_ATTN32") && atoi(getenv("ES_ATTN32")) == 0);   // A/B switch (tools)
   if (big && tile32) {
     // measured (tools/attn_bench.py, 14 x 8 x 4096^2): head_dim 40 476 -> 449 us; head_dim 80 is no faster (189 VGPRs,
@@ -991,6 +1189,8 @@ extern "C" int es_attn_debug_read(unsigned long long* host16) {
   return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(es_attn_dbg), 16 * sizeof(unsigned long long));
 }
 #endif
+
+extern "C" int es_attention_set_kvres(int on) { const int prev = attn_kvres; attn_kvres = on; return prev; }
 
 extern "C" int es_attention(const es_attn_desc* d, void* stream) {
   if (!d->q || !d->k || !d->v || !d->o) { es_set_error("es_attention: null pointer"); return -1; }

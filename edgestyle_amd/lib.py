@@ -146,6 +146,7 @@ SYMBOLS = {
     "es_linear_xs": (C.c_int, [C.POINTER(XsDesc), _P]),
     "es_linear_xs_set_pp": (C.c_int, [_I]),
     "es_attention": (C.c_int, [C.POINTER(AttnDesc), _P]),
+    "es_attention_set_kvres": (C.c_int, [_I]),
     "es_group_norm": (C.c_int, [C.POINTER(GnDesc), _P]),
     "es_group_norm_partials_bytes": (C.c_size_t, [_I, _I]),
     "es_group_norm_is_slab": (C.c_int, [_I, _I, _I]),

@@ -171,6 +171,10 @@ typedef struct {
   int32_t dtype;
 } es_attn_desc;
 int es_attention(const es_attn_desc* d, void* stream);
+/* tool / test knob: 1 (ES_ATTN_KVRES=1 in the environment; default 0 - it measured slower, profiles/r05_xattn_bench.txt) = launches with
+ * Skv <= 96 and head_dim 40 | 80 (the text-token cross-attention of the two shallow UNet levels) run the K/V-resident kernel.
+ * Returns the previous setting. */
+int es_attention_set_kvres(int on);
 
 /* GroupNorm (+SiLU) over NHWC with optional channel-concat of two sources.
  * Replaces torch group_norm + silu of ResnetBlock2D.norm1/norm2, conv_norm_out, Transformer2DModel.norm.

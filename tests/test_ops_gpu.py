@@ -177,6 +177,43 @@ def test_attention_bf16(N, heads, Sq, Skv, d):
     assert rel_err(y, ref) < 2e-2
 
 
+@pytest.mark.parametrize("N,heads,Sq,Skv,d,dtype", [
+    (14, 8, 4096, 77, 40, torch.float16),      # level-0 cross-attention of the lockstep encoder pass
+    (2, 8, 1000, 77, 40, torch.float16),       # ragged query count, few samples (one block per strip)
+    (3, 8, 1024, 77, 80, torch.float16),       # level 1
+    (2, 8, 256, 96, 80, torch.bfloat16),       # all three key tiles full
+    (2, 4, 200, 33, 40, torch.bfloat16),       # one key into the second tile, four heads
+    (1, 6, 64, 5, 40, torch.float16),          # heads not a multiple of four, a handful of keys
+])
+def test_cross_attention_kv_resident_kernel(N, heads, Sq, Skv, d, dtype):
+    """attention_kvres_kernel (round 5): launches with Skv <= 96 and head_dim 40 | 80 - the text-token cross-attention of the 64 x 64 and
+    32 x 32 levels (diffusers Attention under CL:205-238 / PL:500-510, 77 keys) - keep K and V in registers and run a single-pass
+    softmax.  Against the fp32 reference, against the tiled kernels it replaces (es_attention_set_kvres(0)), with a spiking key, with
+    q / k / v that are column slices of wider buffers (the k|v projection of set_context is one [N, 77, 2C] tensor)."""
+    from edgestyle_amd import ops, lib
+    g = torch.Generator().manual_seed(Sq + d + Skv)
+    C = heads * d
+    q = torch.randn(N, Sq, C + 8, generator=g)
+    kv = torch.randn(N, Skv, 2 * C, generator=g)
+    kv[:, Skv // 2, :C] *= 6.0
+    q, kv = q.to(dtype).float(), kv.to(dtype).float()
+    qh, kh, vh = (t.reshape(N, -1, heads, d).transpose(1, 2) for t in (q[:, :, :C], kv[:, :, :C], kv[:, :, C:]))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(N, Sq, C)
+    dq, dkv = q.to(DEV, dtype), kv.to(DEV, dtype)
+    L = lib.load()
+    prev = L.es_attention_set_kvres(1)
+    try:
+        y1 = ops.attention(dq[:, :, :C], dkv[:, :, :C], dkv[:, :, C:], heads)
+        L.es_attention_set_kvres(0)
+        y0 = ops.attention(dq[:, :, :C], dkv[:, :, :C], dkv[:, :, C:], heads)
+    finally:
+        L.es_attention_set_kvres(prev)
+    tol = 4e-3 if dtype == torch.float16 else 2e-2
+    assert rel_err(y1, ref) < tol and rel_err(y0, ref) < tol
+    assert rel_err(y1, y0.float().cpu()) < tol
+    assert bool(torch.isfinite(y1).all())
+
+
 def test_attention_forced_rescale_and_strided_qkv():
     """online-softmax rescale branch: a late key dominates; q/k/v are column slices of one fused [N,S,3C] buffer"""
     from edgestyle_amd import ops
