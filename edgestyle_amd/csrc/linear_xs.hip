@@ -251,11 +251,9 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
     for (int a = 0; a < WPF && a < KC; ++a) wread(a, wf[a]);
     // the bias enters as the C operand of each accumulator's first MFMA: no add in the epilogue
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-      bias[nf] = *(const f32x4*)(sb + XS_STAGE_W + (nf * 16 + fq * 4) * 4);
-      acc[nf][0] = bias[nf];
-      acc[nf][1] = bias[nf];
-    }
+    for (int nf = 0; nf < NF; ++nf) bias[nf] = *(const f32x4*)(sb + XS_STAGE_W + (nf * 16 + fq * 4) * 4);
+    // (C = the bias registers, D = the accumulator: no copy of the bias into two accumulators per fragment - 32 v_mov per stage)
+#define XS_C(kc_, a_) ((kc_) == 0 ? bias[nf] : (a_))
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
       if constexpr (PP && XS_RDMIX) {
@@ -269,8 +267,8 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
             wf[k2 % (WPF + 1)][nf] = as_vec8<T>(*(const u32x4*)(sb + st * SUB + row * 128 + (((4 * h + fq) ^ (row & 7)) << 4)));
           }
           __builtin_amdgcn_sched_barrier(0);
-          acc[nf][0] = mfma16(wf[(XS_ABLATE & 32) ? 0 : (kc % (WPF + 1))][nf], xr[0][kc], acc[nf][0]);
-          acc[nf][1] = mfma16(wf[(XS_ABLATE & 32) ? 0 : (kc % (WPF + 1))][nf], xr[1][kc], acc[nf][1]);
+          acc[nf][0] = mfma16(wf[(XS_ABLATE & 32) ? 0 : (kc % (WPF + 1))][nf], xr[0][kc], XS_C(kc, acc[nf][0]));
+          acc[nf][1] = mfma16(wf[(XS_ABLATE & 32) ? 0 : (kc % (WPF + 1))][nf], xr[1][kc], XS_C(kc, acc[nf][1]));
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
@@ -279,10 +277,11 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) {
 #if XS_ABLATE & 1
+        if (kc == 0) { acc[nf][0] = bias[nf]; acc[nf][1] = bias[nf]; }
         asm volatile("" ::"v"(wf[(XS_ABLATE & 32) ? 0 : (kc % (WPF + 1))][nf]), "v"(xr[0][kc]), "v"(xr[1][kc]));
 #else
-        acc[nf][0] = mfma16(wf[(XS_ABLATE & 32) ? 0 : (kc % (WPF + 1))][nf], xr[0][kc], acc[nf][0]);
-        acc[nf][1] = mfma16(wf[(XS_ABLATE & 32) ? 0 : (kc % (WPF + 1))][nf], xr[1][kc], acc[nf][1]);
+        acc[nf][0] = mfma16(wf[(XS_ABLATE & 32) ? 0 : (kc % (WPF + 1))][nf], xr[0][kc], XS_C(kc, acc[nf][0]));
+        acc[nf][1] = mfma16(wf[(XS_ABLATE & 32) ? 0 : (kc % (WPF + 1))][nf], xr[1][kc], XS_C(kc, acc[nf][1]));
 #endif
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -290,6 +289,7 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
     }
   };
 
+#undef XS_C
   // epilogue of stage ci: registers -> wave-private LDS tile -> (every P stages) full-line global stores
   auto epilogue = [&](int ci, const f32x4 (&acc)[NF][2], const f32x4 (&bias)[NF], const u32x4 (&rr)[4]) __attribute__((always_inline)) {
     const int sub = ci % P;                       // position of this stage inside its 128-byte output line

@@ -522,7 +522,8 @@ def test_config4_batch4_768_bf16_vs_oracle(full96):
 @pytest.mark.parametrize("steps", [12, 50])
 def test_config4_batch4_768_bf16_many_steps_vs_golden(full96, steps):
     """BASELINE configs[4] over MORE than two steps: 768x768, bf16, batch 4, CFG 7.5, graph replayed -
-    request 0 against the committed fp32 oracle fixtures (tests/golden/make_golden_768.py): 12 DDIM steps (latents after steps 1,
+    request 0 against the committed fp32 oracle fixtures (tests/golden/make_golden_768.py - the repo's OWN oracle: for the
+    diffusers-owned blocks these gates are parity-unpinned, as oracle/sd15_oracle.py says of itself): 12 DDIM steps (latents after steps 1,
     2, 4, 8, 12) and configs[4]'s OWN 50 steps (latents after 1, 5, 10, 25, 50), each with the decoded image - so the growth of the
     bf16 error along the loop is on record.  north_star's gate is PSNR >= 40 dB on the decoded image: asserted here at both step
     counts (measured 43.9 dB at 12 steps with the wide residual stream, 43.0 without; the 2-step tests above sit at 39 dB because
@@ -550,10 +551,17 @@ def test_config4_batch4_768_bf16_many_steps_vs_golden(full96, steps):
     growth = {k: H.rel_err(v, gold[f"latents_step{k}"]) for k, v in seen.items()}
     p_ = H.psnr(img[:1], gold["image"].float())
     e_ = H.rel_err(lat_eager[:1], gold["latents_out"])
+    # the other three requests of the batch (they were checked for finiteness only): each against the SAME request
+    # served alone (batch 1) by the HIP path over the same number of steps - a request's image must not depend on what it was batched
+    # with beyond the rounding of differently tiled launches
+    solo = [pipe(output_type="pt", **dict(kw, prompt_embeds=pe[b:b + 1], negative_prompt_embeds=ne[b:b + 1], latents=lat[b:b + 1])
+                 ).images.float().cpu() for b in range(1, B)]
+    pb = [H.psnr(img[b:b + 1], solo[b - 1]) for b in range(1, B)]
     record(f"config4_batch4_768_bf16_{steps}_steps", psnr_vs_golden=p_, latents_rel=e_,
-           latents_rel_by_step={str(k): round(v, 6) for k, v in growth.items()})
+           latents_rel_by_step={str(k): round(v, 6) for k, v in growth.items()}, psnr_requests_1_3_batch4_vs_batch1=[round(p, 2) for p in pb])
     assert p_ >= (CONFIG4_PSNR_FLOOR_12 if steps == 12 else 40.0), p_
-    assert e_ <= 6e-2, e_
+    assert e_ <= 2.5e-2, e_                 # (measured 1.2e-2 ... 1.8e-2)
+    assert min(pb) >= 40.0, pb
 
 
 def test_control_guidance_window_at_full_size_vs_oracle_and_its_step_time(full):
@@ -585,4 +593,5 @@ def test_control_guidance_window_at_full_size_vs_oracle_and_its_step_time(full):
     record("control_guidance_window_full_size", psnr_vs_live_oracle=p_, ms_per_image_window_open=times["open"],
            ms_per_image_window_closed_at_half=times["closed_at_half"])
     assert p_ >= 40.0, p_
-    assert times["closed_at_half"] < 0.85 * times["open"], times
+    # (the two times are RECORDED, not asserted: a wall-clock comparison inside the parity suite fails on box noise or clock state;
+    #  profiles/r0N_fullsize_parity.jsonl carries them - 470.7 vs 366.2 ms per image in round 4)

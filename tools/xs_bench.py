@@ -38,6 +38,10 @@ shapes = [  # M, K, N, geglu, ln, groups
     (2048, 640, 5120, True, True, None),
     (2048, 640, 1920, False, True, None),
     (2048, 640, 640, False, True, None),
+    (8192, 320, 320, False, False, None),
+    (3584, 640, 1920, False, True, None),
+    (3584, 640, 640, False, True, None),
+    (3584, 640, 5120, True, True, None),
 ]
 for M, K, N, geglu, ln, groups in shapes:
     x = (torch.randn(M, K, generator=g)).to(DEV, torch.float16)
