@@ -104,6 +104,10 @@ ES_DEVICE float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf
 // with the 0.5 folded into the polynomial, the 1/sqrt 2 into p, exp as exp2 of one pre-scaled product: one rcp, one
 // exp2, 5 FMA/mul for the polynomial, 5 more ops - 14 issue slots instead of 21 for 0.5 x (1 + erf(x / sqrt 2)).
 // (Measured: 505.5 vs 505.6 ms per image - the FF projections are not bound by this epilogue arithmetic.)
+// (Round 5 tried this function as single-instruction asm helpers, to keep hipcc's SLP vectoriser from pairing neighbouring evaluations
+//  into v_pk_fma_f32 / v_pk_mul_f32: WRONG RESULTS that changed from run to run - hipcc pads the MFMA -> VALU and transcendental -> VALU
+//  wait states only for instructions it emits itself, never for the operands of an asm statement, and this function reads matrix-core
+//  accumulators and v_rcp / v_exp results.  The packing is switched off per file instead where it costs: Makefile, FLAGS_linear_xs.)
 ES_DEVICE float gelu_f(float x) {
   const float ax = fabsf(x);
   const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(ax, 0.3275911f * 0.70710678118654752f, 1.0f));
@@ -116,11 +120,7 @@ ES_DEVICE float gelu_f(float x) {
   const float h = poly * t * e;                                    // 0.5 * erfc(|x| / sqrt 2)
   // x Phi(x) = x (1 - h) for x >= 0, x h for x < 0  ==  max(x, 0) - |x| h: two instructions instead of compare,
   // subtract, select and multiply (the GEGLU epilogues are bound by their vector-instruction count)
-  // (one v_max_f32 by hand: fmaxf on a value that comes out of the matrix core costs a second, canonicalising v_max_f32 x, x -
-  //  16 more vector instructions per GEGLU epilogue stage; identical results for every non-NaN input)
-  float relu;
-  asm("v_max_f32 %0, 0, %1" : "=v"(relu) : "v"(x));
-  return __builtin_fmaf(-ax, h, relu);
+  return __builtin_fmaf(-ax, h, fmaxf(x, 0.f));
 }
 
 // transposed LDS read: 16-lane group reads a 4x16 block of 16-bit elements, lane i gets column i (4 rows)
