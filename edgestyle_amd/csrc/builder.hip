@@ -303,11 +303,37 @@ struct CA {                       // keyword arguments of ops.conv_gemm
 #pragma clang fp contract(off)
 constexpr double PLAN_T160 = 1.25, PLAN_ALONE = 0.9, PLAN_TFIX = 2.0, PLAN_RED_FIX = 12.0, PLAN_SLAB_BYTES_PER_UNIT = 4.0e6;
 constexpr double PLAN_T320 = 2.3, PLAN_T320_FIX = 3.0;
+// the 256 x 256 tile of the LayerNorm-folded / GEGLU linear layers (tools/ln256_bench.py, round 5)
+constexpr double PLAN_T256 = 2.6, PLAN_T256_FIX = 6.0, PLAN_T256_GEGLU = 7.0, PLAN_LN_TK = 1.55, PLAN_T256_MARGIN = 0.93;
 constexpr int PLAN_BIG_MIN_M = 2048, PLAN_BIG_MIN_NK = 16;
 constexpr double PLAN_T64_ALONE = 0.5, PLAN_T64 = 0.16, PLAN_T64_LONG = 1.5;
 constexpr int PLAN_SMALL_MAX_M = 16384, PLAN_MIN_SLICE = 12, PLAN_NK_NOSPLIT = 10, PLAN_RESIDENT = 512;
 
 bool plan_gemm(long long M, int rows_padded, int kpad, bool geglu, const int* bns, int nb, bool allow_split, int* o_bn, int* o_sk, int* o_st) {
+  // The 256 x 256 phase-interleaved tile (round 5) is offered by the callers for the LayerNorm-folded / GEGLU linear layers whose N is a
+  // multiple of 256.  The choice among the OTHER tiles is made first, exactly as before; the 256-wide tile then replaces it where a
+  // model fitted on those layers (tools/ln256_bench.py, profiles/r05_ln256_bench.txt: a round of 512 workgroups of the 128-wide tile
+  // takes nk x 1.55 + 6 units with the fold's statistics, a round of 256 workgroups of the 256 x 256 tile nk x 2.6 + 6, + 7 with the
+  // GEGLU epilogue; WHOLE rounds - its last part-filled round costs a full tile time) says it is at least 7 % faster.
+  int others[8], no = 0;
+  bool has256 = false;
+  for (int bi = 0; bi < nb; ++bi) { if (bns[bi] == 256) has256 = true; else if (no < 8) others[no++] = bns[bi]; }
+  if (has256) {
+    const int nk = kpad / BK;
+    int obn = 0, osk = 1, ost = 2;
+    const bool have_other = no > 0 && plan_gemm(M, rows_padded, kpad, geglu, others, no, allow_split, &obn, &osk, &ost);
+    if (rows_padded % 256) { if (!have_other) return false; *o_bn = obn; *o_sk = osk; *o_st = ost; return true; }
+    const long long t256 = ((M + 255) / 256) * (rows_padded / 256);
+    const double c256 = (double)((t256 + 255) / 256) * ((double)nk * PLAN_T256 + PLAN_T256_FIX + (geglu ? PLAN_T256_GEGLU : 0.0));
+    bool take = !have_other;
+    if (have_other && M >= PLAN_BIG_MIN_M && nk >= PLAN_BIG_MIN_NK && osk == 1 && obn != 64) {
+      const long long to = ((M + BM - 1) / BM) * (rows_padded / obn);
+      const double co = (double)((to + PLAN_RESIDENT - 1) / PLAN_RESIDENT) * ((double)nk * PLAN_LN_TK * (obn == 160 ? PLAN_T160 : 1.0) + PLAN_T256_FIX);
+      take = c256 < PLAN_T256_MARGIN * co;
+    }
+    if (take) { *o_bn = 256; *o_sk = 1; *o_st = 2; } else { *o_bn = obn; *o_sk = osk; *o_st = ost; }
+    return true;
+  }
   if (geglu) { *o_bn = 128; *o_sk = 1; *o_st = 2; return true; }
   const int nk = kpad / BK;
   bool have = false;
@@ -356,6 +382,7 @@ bool xs_shape_ok(long long M, int ksize, int kpad, int cin, int ctail, int cout,
   return true;
 }
 int choose_bn(int cout) { return (cout % 160 == 0 && cout % 128 != 0) ? 160 : 128; }
+bool big_tile_256() { static const bool on = [] { const char* e = getenv("ES_BIG_TILE_256"); return !e || e[0] != '0'; }(); return on; }
 
 // ---- the builder ------------------------------------------------------------------------------------------------------------
 struct Builder {
@@ -637,8 +664,13 @@ struct Builder {
     }
     bool big_ok = C1 % BK == 0 && C2 % BK == 0 && !pw->geglu && !pw->ln_colsum;
     if (big_ok && grouped) for (int n : a.group_n) if ((n * hw) % 256) big_ok = false;
+    // the 256 x 256 phase-interleaved tile: LayerNorm-folded and GEGLU linear layers whose N is a multiple of 256 (ops.conv_gemm: the same rule)
+    bool ln256_ok = big_tile_256() && (pw->geglu || pw->ln_colsum) && k == 1 && a.stride == 1 && !a.upsample && !a.x2 && a.tails.empty() && !a.temb &&
+                    a.x_rep == 1 && C1 % BK == 0 && pw->rows_padded % 256 == 0 && pw->cout % 8 == 0 && !(pw->geglu && a.residual) && !a.wide && a.gn_groups == 0;
+    if (ln256_ok && grouped) for (int n : a.group_n) if ((n * hw) % 256) ln256_ok = false;
     const bool small_ok = C1 % BK == 0 && C2 % BK == 0 && !pw->geglu;
-    int cand[4], nc = 0;
+    int cand[5], nc = 0;
+    if (ln256_ok) cand[nc++] = 256;
     if (big_ok) cand[nc++] = 320;
     cand[nc++] = 160; cand[nc++] = 128;
     if (small_ok) cand[nc++] = 64;
@@ -673,7 +705,7 @@ struct Builder {
       d.out_lo = lo.ptr();
       out.lo = lo.p; out.lo_b = lo.b;
     }
-    if (k == 1 && M <= 65536 && C1 % BK == 0 && C2 % BK == 0 && bn != 64 && bn != 320 && !(stages == 4 && bn != 128) && stages != 3) d.waves = 8;
+    if (k == 1 && M <= 65536 && C1 % BK == 0 && C2 % BK == 0 && bn != 64 && bn != 320 && bn != 256 && !(stages == 4 && bn != 128) && stages != 3) d.waves = 8;
     if (splitk > 1) d.workspace = (float*)workspace((unsigned long long)splitk * M * pw->rows_padded * 4);
     if (pw->ln_colsum) {
       for (const PW* q : pl) if (!q->ln_colsum) fail("LayerNorm-folded weights need a plain linear launch (all groups folded)");

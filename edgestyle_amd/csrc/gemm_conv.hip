@@ -38,7 +38,7 @@
 #define ES_W_AUX 0
 #endif
 
-int es_conv_gemm8p_launch(const es_gemm_desc& d, hipStream_t st);   // gemm_conv8p.hip: the 256 x 320 phase-interleaved tile
+int es_conv_gemm8p_launch(const es_gemm_desc& d, hipStream_t st);   // gemm_conv8p.hip: the 256 x 320 | 256 x 256 phase-interleaved tile
 bool es_conv_gemm8p_takes(const es_gemm_desc& d);                    // ... and whether its epilogue has the form this launch needs
 
 namespace {
@@ -950,6 +950,7 @@ int launch(const es_gemm_desc& d0, hipStream_t st) {
   // the 256 x 320 tile keeps the common epilogue forms only (gemm_conv8p.hip); an activation, time-embedding rows that differ inside a
   // 128-pixel half or meet a residual, or a Cout that is no multiple of 8 run on the 128 x 160 tile: the same results
   if (d.bn == 320 && !es_conv_gemm8p_takes(d)) { d.bn = 160; d.stages = 2; }
+  if (d.bn == 256 && !es_conv_gemm8p_takes(d)) { d.bn = 128; d.stages = 2; }      // (rows_padded % 256 == 0: the 128-wide tile fits too)
   const int M = d.N * d.Hout * d.Wout;
   const int nk = d.Kpad / BK;
   const int Ctot = d.C1 + d.C2;
@@ -996,7 +997,8 @@ int launch(const es_gemm_desc& d0, hipStream_t st) {
     else if (stages == 3) ES_LAUNCH(128, BNV, true, 3);                                                     \
     else ES_LAUNCH(128, BNV, true, 4);                                                                      \
   } while (0)
-  if (d.ln_colsum) {
+  if (d.bn == 256) { if (es_conv_gemm8p_launch(d, st)) return -2; }
+  else if (d.ln_colsum) {
     // LayerNorm-folded linear layers: the instantiations the planner can pick for a 1x1 launch
     const bool w8 = d.waves == 8;
     if (d.bn == 64)            { if (stages == 4) ES_LAUNCH_LN(64, 64, 4, 2); else ES_LAUNCH_LN(64, 64, 2, 2); }
@@ -1048,11 +1050,13 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
     for (int g = 0; g < d->ngroups; ++g)
       if (!d->w_g[g] || d->mt_end[g] <= (g ? d->mt_end[g - 1] : 0)) { es_set_error("es_conv_gemm: bad group table"); return -1; }
     if (d->mt_end[d->ngroups - 1] != tm || (d->N * d->Hout * d->Wout) % 128) { es_set_error("es_conv_gemm: groups must tile M in whole 128-pixel tiles"); return -1; }
-    if (d->bn == 320)
+    if (d->bn == 320 || d->bn == 256)
       for (int g = 0; g < d->ngroups; ++g)
         if (d->mt_end[g] & 1) { es_set_error("es_conv_gemm: 256-pixel tiles need groups of whole 256-pixel tiles"); return -1; }
   }
-  if (d->bn != 64 && d->bn != 128 && d->bn != 160 && d->bn != 320) { es_set_error("es_conv_gemm: bn must be 64, 128, 160 or 320"); return -1; }
+  if (d->bn != 64 && d->bn != 128 && d->bn != 160 && d->bn != 320 && d->bn != 256) { es_set_error("es_conv_gemm: bn must be 64, 128, 160, 256 or 320"); return -1; }
+  if (d->bn == 256 && (d->C1 % BK || d->C2 % BK || (d->stages != 0 && d->stages != 2) || d->waves == 8 || d->korder || d->temb)) {
+    es_set_error("es_conv_gemm: bn=256 is the 256-pixel phase-interleaved tile of the LayerNorm-folded / GEGLU linear layers: 64-aligned channels, 2 stages, tap-major K, no time embedding"); return -1; }
   if (d->bn == 64 && (d->C1 % BK || d->C2 % BK || d->stages == 3 || d->waves == 8 || d->act == ES_ACT_GEGLU)) {
     es_set_error("es_conv_gemm: bn=64 is the 64x64 tile: 64-aligned channels, 2 or 4 stages, no GEGLU"); return -1; }
   if (d->bn == 320 && (d->C1 % BK || d->C2 % BK || (d->stages != 0 && d->stages != 2) || d->act == ES_ACT_GEGLU || d->waves == 8)) {
@@ -1084,7 +1088,7 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
   if (d->splitk < 1 || d->splitk > d->Kpad / BK) { es_set_error("es_conv_gemm: bad splitk"); return -1; }
   if (d->splitk > 1 && (!d->workspace || d->act == ES_ACT_GEGLU)) { es_set_error("es_conv_gemm: splitk needs workspace and no GEGLU"); return -1; }
   if (d->splitk > 1 && (long long)d->N * d->Hout * d->Wout * (d->rows_padded / 8) >= (1ll << 31)) { es_set_error("es_conv_gemm: split-K output too large for 32-bit indices"); return -1; }
-  if (d->act == ES_ACT_GEGLU && (d->bn != 128 || d->Cout % 32)) { es_set_error("es_conv_gemm: GEGLU needs bn=128, Cout%32==0"); return -1; }
+  if (d->act == ES_ACT_GEGLU && ((d->bn != 128 && d->bn != 256) || d->Cout % 32)) { es_set_error("es_conv_gemm: GEGLU needs bn=128 | 256, Cout%32==0"); return -1; }
   if (d->N < 1 || d->Hout < 1 || d->Wout < 1) { es_set_error("es_conv_gemm: empty problem"); return -1; }
   if (d->stages != 0 && (d->stages < 2 || d->stages > 4)) { es_set_error("es_conv_gemm: stages must be 0 (auto), 2, 3 or 4"); return -1; }
   if (d->waves != 0 && d->waves != 4 && d->waves != 8) { es_set_error("es_conv_gemm: waves must be 0 (auto), 4 or 8"); return -1; }

@@ -60,12 +60,12 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // Pixel rows per workgroup are a template parameter of the kernel; only BM = 256 is instantiated.  Round 4 measured the same loop on a
 // 128 x 320 tile (10 MFMAs per phase, for launches with fewer 256-pixel tiles than CUs): never ahead of the 128 x 160 tile with its two
 // workgroups per CU (profiles/r04_bm128_ablation.txt: 844 against 1025 TFLOP/s on the level-1 grouped convolution of a batch-1 step).
-constexpr int BN = 320, RB = 128;
-constexpr int WT = BN * RB;                                   // 40 KB of weights per K-tile
-constexpr int FN = 5;                                         // cout fragments per wave
-constexpr int WI = 5;                                         // weight DMA pieces per wave per K-tile
+constexpr int RB = 128;
 constexpr unsigned OOB = 0xFFFFFF00u;
-constexpr int EROW = BN * 2 + 16;                             // epilogue tile row stride (bytes): 320 couts, 128 pixel rows per pass
+// N tile: 320 couts (FN = 5 fragments of 16 per wave, the convolutions) or - round 5 - 256 couts (FN = 4), the form the LayerNorm-folded
+// linear layers and the GEGLU projections of the C = 1280 level run on: every N of those layers is a multiple of 256 (1280, 3840, 10240),
+// the [16 hidden | 16 gate] row interleave of the GEGLU weights pairs up inside a wave's 64 couts, and the 32 accumulator registers
+// less leave room for the row statistics of the fold.
 
 template <int XI>
 ES_DEVICE void row_offsets4(unsigned (&voff)[XI], const int (&iy0)[XI], const int (&ix0)[XI], const int (&nb)[XI],
@@ -83,11 +83,19 @@ ES_DEVICE void row_offsets4(unsigned (&voff)[XI], const int (&iy0)[XI], const in
   }
 }
 
-template <typename T, bool KO /* chunk-major K order, es_gemm_desc.korder == 1 */, int BM /* 256 | 128 pixel rows */>
+template <typename T, bool KO /* chunk-major K order, es_gemm_desc.korder == 1 */, int BM /* 256 | 128 pixel rows */,
+          int FN = 5 /* cout fragments per wave: N tile = 64 FN */, bool LN = false /* LayerNorm fold (es_gemm_desc.ln_colsum) */,
+          bool GEGLU = false /* ES_ACT_GEGLU epilogue */>
 __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc p, const int M, const int nk,
                                                              const void* const tail1, const void* const tail2,
                                                              const int tailC1, const int tailC2) {
-  constexpr int XT = BM * RB, BUF = XT + WT;            // 32 | 16 KB of pixels + 40 KB of weights per K-tile
+  constexpr int BN = 64 * FN;                           // 320 | 256 couts per workgroup
+  constexpr int WT = BN * RB;                           // 40 | 32 KB of weights per K-tile
+  constexpr int WI = FN;                                // weight DMA pieces per wave per K-tile
+  constexpr int EROW = BN * 2 + 16;                     // epilogue tile row stride (bytes): BN couts, 128 pixel rows per pass
+  static_assert(FN == 5 || FN == 4, "N tile 320 or 256");
+  static_assert(!(LN || GEGLU) || FN == 4, "the LayerNorm fold and the GEGLU epilogue live on the 256-wide tile");
+  constexpr int XT = BM * RB, BUF = XT + WT;            // 32 | 16 KB of pixels + 40 | 32 KB of weights per K-tile
   constexpr int GP = BM / 2;                            // pixel rows per wave group
   constexpr int FM = GP / 16, FMH = FM / 2;             // pixel fragments per wave, per phase
   constexpr int XI = BM / 64, XQ = XI / 2;              // pixel DMA pieces per wave per K-tile, per pixel quarter
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
   // slot c ^ (r & 7); every fragment row of this lane has r & 7 == frow & 7
   const int xo0 = ((0 + fq) ^ (frow & 7)) << 4, xo1 = ((4 + fq) ^ (frow & 7)) << 4;
   const int xrow = (grp8 * GP + frow) * RB;
-  const int wrow = XT + (wn * 80 + frow) * RB;
+  const int wrow = XT + (wn * (16 * FN) + frow) * RB;
 #if ES8P_STAMPS
   stamp(1);
 #endif
@@ -336,6 +344,19 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
   if (!(ES8P_ABL & 4) && grp8 == 1) __builtin_amdgcn_s_barrier();            // group 1 runs one barrier behind group 0
 
   typename Traits<T>::vec8 xa[FMH], wa[FN];
+  // LayerNorm fold: the row statistics on the matrix core, as conv_gemm_kernel computes them (mfma(X, X) = the Gram block whose
+  // diagonal is sum x^2 of each row, mfma(ones, X) = sum x) and in the same order per row, so that the two tiles stay bit-identical:
+  // the four waves of a pixel half read the same pixel fragments; wave wn takes fragment wn of each quarter (one more ds_read_b128 per
+  // phase: its own copy, no run-time index into xa) - two more MFMAs per phase of 16.
+  f32x4 ln_gram[LN ? 2 : 1], ln_sum[LN ? 2 : 1];
+  typename Traits<T>::vec8 ln_ones, xl;
+  if constexpr (LN) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { ln_gram[h] = f32x4{0.f, 0.f, 0.f, 0.f}; ln_sum[h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ln_ones[e] = from_f32<T>(1.0f);
+  }
+  const int xlrow = xrow + wn * 16 * RB;                  // + h * (GP / 2) * RB: this wave's statistics fragment of quarter h
   int boff = 0;
   for (int t = 0; t < nkt; ++t) {
     const bool nxt = t + 1 < nkt;                         // wave-uniform
@@ -352,6 +373,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
       _Pragma("unroll") for (int j = 0; j < FMH; ++j) asm volatile("" ::"v"(xa[j]));  \
       _Pragma("unroll") for (int i = 0; i < FN; ++i) asm volatile("" ::"v"(wa[i]));   \
     } else {                                                                          \
+    if constexpr (LN) {                                                               \
+      ln_gram[H] = mfma16(xl, xl, ln_gram[H]);                                        \
+      ln_sum[H] = mfma16(ln_ones, xl, ln_sum[H]);                                     \
+    }                                                                                 \
     _Pragma("unroll") for (int i = 0; i < FN; ++i)                                    \
       _Pragma("unroll") for (int j = 0; j < FMH; ++j)                                 \
         acc[i][(H) * FMH + j] = mfma16(wa[i], xa[j], acc[i][(H) * FMH + j]);          \
@@ -362,6 +387,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
     // ---- phase 0: (h 0, kk 0) ----
 #pragma unroll
     for (int j = 0; j < FMH; ++j) xa[j] = ES_RD(xrow + xo0 + (0 * (GP / 2) + j * 16) * RB);
+    if constexpr (LN) xl = ES_RD(xlrow + xo0 + 0 * (GP / 2) * RB);
 #pragma unroll
     for (int i = 0; i < FN; ++i) wa[i] = ES_RD(wrow + xo0 + i * 16 * RB);
     if (nxt) {
@@ -374,11 +400,13 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
     // ---- phase 1: (h 1, kk 0) ----
 #pragma unroll
     for (int j = 0; j < FMH; ++j) xa[j] = ES_RD(xrow + xo0 + (1 * (GP / 2) + j * 16) * RB);
+    if constexpr (LN) xl = ES_RD(xlrow + xo0 + 1 * (GP / 2) * RB);
     if (nxt) { issue_w(ksn, nboff, 2, WI); select_x(ksn); }
     ES_MFMA(1)
     // ---- phase 2: (h 0, kk 1) ----
 #pragma unroll
     for (int j = 0; j < FMH; ++j) xa[j] = ES_RD(xrow + xo1 + (0 * (GP / 2) + j * 16) * RB);
+    if constexpr (LN) xl = ES_RD(xlrow + xo1 + 0 * (GP / 2) * RB);
 #pragma unroll
     for (int i = 0; i < FN; ++i) wa[i] = ES_RD(wrow + xo1 + i * 16 * RB);
     if (nxt) issue_x(nboff, 0);
@@ -386,6 +414,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
     // ---- phase 3: (h 1, kk 1) ----
 #pragma unroll
     for (int j = 0; j < FMH; ++j) xa[j] = ES_RD(xrow + xo1 + (1 * (GP / 2) + j * 16) * RB);
+    if constexpr (LN) xl = ES_RD(xlrow + xo1 + 1 * (GP / 2) * RB);
     if (nxt) {
       issue_x(nboff, 1);
       if (KO && (ES8P_ABL & 32) != 0 && x_skip) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -403,7 +432,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
 #endif
 
   const int prow = grp8 * GP + frow;                      // + j * 16 : pixel row inside the tile
-  const int pcol = wn * 80 + fq * 4;                      // + i * 16 : cout column inside the tile
+  const int pcol = wn * (16 * FN) + fq * 4;               // + i * 16 : cout column inside the tile
   // ---------------- split-K: raw fp32 partials ----------------
   if (p.splitk > 1) {
     float* wsp = p.workspace + (size_t)z * M * p.rows_padded;
@@ -429,20 +458,41 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
   //     row fetched once per wave when all 128 pixels belong to one sample (H*W % 128 == 0);
   //   store phase (all eight waves): 16-byte chunks of whole 640-byte rows, [+ residual | + residual pair -> value pair], coalesced stores.
   // Same arithmetic in the same order as conv_gemm_kernel: bit-identical outputs.
-  const int Cstore = p.Cout;
+  const int Cstore = GEGLU ? p.Cout / 2 : p.Cout;
   float scale = p.out_scale;
   if (p.out_scale_dev) scale *= *p.out_scale_dev;
   // lane coordinates re-derived from the thread index (opaque to the compiler: nothing of the epilogue is kept in registers across the K loop)
   int tid_e = threadIdx.x;
   asm volatile("" : "+v"(tid_e));
   const int tid = tid_e, frow = tid_e & 15, fq = (tid_e >> 4) & 3;
-  const int pcol = wn * 80 + fq * 4;
+  const int pcol = wn * (16 * FN) + fq * 4;
   char* et = smem;
+  // LayerNorm fold: (mean, rstd) of the BM pixel rows, behind the epilogue tile (conv_gemm_kernel's arithmetic, value for value)
+  float* rowstat = (float*)(smem + 2 * BUF - BM * 8);
+  const float* lnsel = nullptr;
+  if constexpr (LN) {
+    lnsel = p.ngroups > 1 ? p.ln_colsum_g[grp] : p.ln_colsum;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float dq = fq == (frow >> 2) ? ln_gram[h][frow & 3] : 0.f;
+      const float q_ = xor32_sum(xor16_sum(dq));
+      if (fq == 0) {
+        const int row = grp8 * GP + h * (GP / 2) + wn * 16 + frow;
+        const float inv_c = 1.0f / (float)p.C1;
+        const float mean = ln_sum[h][0] * inv_c;
+        float var = q_ * inv_c - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        rowstat[row * 2] = mean;
+        rowstat[row * 2 + 1] = rsqrtf(var + p.ln_eps);
+      }
+    }
+    __syncthreads();
+  }
   T* outp = (T*)p.out;
   const T* resp = (const T*)p.residual;
-  constexpr int CH = 40;                                   // 16-byte chunks per tile row
+  constexpr int CH = (GEGLU ? BN / 2 : BN) / 8;            // 16-byte chunks per tile row (40 | 32; GEGLU stores half the columns: 16)
   constexpr int RPF = GP * CH / 512;                       // chunks per thread and pass
-  const int cbase = tile_n * BN;
+  const int cbase = tile_n * (GEGLU ? BN / 2 : BN);        // first STORED channel of the tile
   const bool tuni = p.temb != nullptr;                     // (es_conv_gemm8p_takes: then H*W % GP == 0 - one sample per pixel half - and no residual)
   // WMODE: 0 = bias only, 1 = bias + one time-embedding row per wave        SMODE: 0 = no residual, 1 = residual, 2 = value pair out, 3 = value pair in and out
   // (an activation, per-pixel time-embedding rows, Cout % 8 != 0: es_conv_gemm runs those on the 128 x 160 tile, es_conv_gemm8p_takes)
@@ -461,7 +511,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
 #pragma unroll
           for (int k = 0; k < PF; ++k) {
             const int idx = tid + k * 512;
-            const int row = ((idx >> 3) * 13108) >> 16, ch = idx - row * CH;   // idx / 40 for idx < 5120
+            const int row = CH == 40 ? ((idx >> 3) * 13108) >> 16 : (CH == 32 ? idx >> 5 : idx >> 4), ch = idx - row * CH;   // idx / 40 for idx < 5120 | idx / 32 | idx / 16
             const int m = m_tile + row, c = cbase + ch * 8;
             rpre[k] = u32x4{0u, 0u, 0u, 0u};
             if (!(ES8P_ABL & 64) && resp && m < M && c < Cstore) rpre[k] = *(const u32x4*)(resp + (size_t)m * Cstore + c);
@@ -470,11 +520,17 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
       };
       if (pass) __syncthreads();                           // previous pass's tile no longer read
       if (grp8 == pass) {
-        char* wbase = et + frow * EROW + (wn * 80 + fq * 4) * 2;
+        char* wbase = et + frow * EROW + (wn * (16 * FN) + fq * 4) * 2;
+        const int gbase = tile_n * BN;                       // first GEMM column (weight row) of the tile
         f32x4 bias[FN];
 #pragma unroll
         for (int i = 0; i < FN; ++i)
-          bias[i] = bsel ? *(const f32x4*)(bsel + cbase + pcol + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+          bias[i] = bsel ? *(const f32x4*)(bsel + gbase + pcol + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 lncs[LN ? FN : 1];
+        if constexpr (LN) {
+#pragma unroll
+          for (int i = 0; i < FN; ++i) lncs[i] = *(const f32x4*)(lnsel + gbase + pcol + i * 16);
+        }
         {
           f32x4 tvv[WMODE == 1 ? FN : 1];
           if constexpr (WMODE == 1) {
@@ -483,7 +539,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
             const T* trow = (const T*)p.temb + (size_t)n * p.temb_stride;
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
-              const int c = cbase + pcol + i * 16;
+              const int c = gbase + pcol + i * 16;
               tvv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
               if (c + 3 < p.Cout) {
                 const auto t4 = *(const typename Traits<T>::vec4*)(trow + c);
@@ -496,16 +552,39 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
           }
 #pragma unroll
           for (int j = 0; j < FM; ++j) {
+            float ln_mean = 0.f, ln_rstd = 1.f;
+            if constexpr (LN) { ln_mean = rowstat[(pass * GP + j * 16 + frow) * 2]; ln_rstd = rowstat[(pass * GP + j * 16 + frow) * 2 + 1]; }
+            if constexpr (GEGLU) {
+              // [16 hidden | 16 gate] rows: fragments (i, i + 1) of this lane are hidden and gate of the same 4 output channels
+#pragma unroll
+              for (int i = 0; i < FN; i += 2) {
+                typename Traits<T>::vec4 pk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  float ah = acc[i][j][r], ag = acc[i + 1][j][r];
+                  if constexpr (LN) {
+                    ah = ln_rstd * (ah - ln_mean * lncs[i][r]);
+                    ag = ln_rstd * (ag - ln_mean * lncs[i + 1][r]);
+                  }
+                  const float hv = ah + bias[i][r], gv = ag + bias[i + 1][r];
+                  pk[r] = from_f32<T>(hv * gelu_f(gv) * scale);
+                }
+                *(typename Traits<T>::vec4*)(et + (j * 16 + frow) * EROW + ((wn * (16 * FN) + i * 16) / 2 + fq * 4) * 2) = pk;
+              }
+            } else {
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
               typename Traits<T>::vec4 pk;
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                float x = acc[i][j][r] + bias[i][r];
+                float a = acc[i][j][r];
+                if constexpr (LN) a = ln_rstd * (a - ln_mean * lncs[i][r]);
+                float x = a + bias[i][r];
                 if constexpr (WMODE == 1) x += tvv[i][r]; else x += 0.f;      // (+ 0: as the general form rounds a -0)
                 pk[r] = from_f32<T>(x * scale);
               }
               *(typename Traits<T>::vec4*)(wbase + j * 16 * EROW + i * 32) = pk;
+            }
             }
           }
         }
@@ -521,7 +600,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
 #pragma unroll
         for (int k = 0; k < RPF; ++k) {
           const int idx = tid + k * 512;
-          const int row = ((idx >> 3) * 13108) >> 16, ch = idx - row * CH;
+          const int row = CH == 40 ? ((idx >> 3) * 13108) >> 16 : (CH == 32 ? idx >> 5 : idx >> 4), ch = idx - row * CH;
           const int m = m_tile + row, c = cbase + ch * 8;
           if (m < M && c < Cstore) {
             auto v = as_vec8<T>(*(const u32x4*)(et + row * EROW + ch * 16));
@@ -580,22 +659,29 @@ extern "C" int es_conv_gemm8p_form_ok(int act, int cout, int has_temb, long long
   return 1;
 }
 bool es_conv_gemm8p_takes(const es_gemm_desc& d) {
+  if (d.bn == 256) {
+    // the 256-wide form: plain, LayerNorm-folded and GEGLU epilogues (no time embedding; a residual only without GEGLU); split-K: plain only
+    if (d.temb || (d.Cout & 7) || (d.act != ES_ACT_NONE && d.act != ES_ACT_GEGLU)) return false;
+    if (d.act == ES_ACT_GEGLU && (d.residual || d.out_lo || d.gn_part || d.splitk > 1)) return false;
+    if (d.ln_colsum && (d.splitk > 1 || d.gn_part)) return false;
+    return true;
+  }
   if (d.splitk > 1) return true;
   return es_conv_gemm8p_form_ok(d.act, d.Cout, d.temb != nullptr, (long long)d.Hout * d.Wout, d.residual != nullptr) != 0;
 }
 
-// called by es_conv_gemm (gemm_conv.hip) after validation, for d.bn == 320
+// called by es_conv_gemm (gemm_conv.hip) after validation, for d.bn == 320 | 256
 int es_conv_gemm8p_launch(const es_gemm_desc& d, hipStream_t st) {
   if (!es_conv_gemm8p_takes(d)) return -2;
   const int M = d.N * d.Hout * d.Wout;
   const int nk = d.Kpad / 64;
-  const int tn = d.rows_padded / BN;
+  const int tn = d.rows_padded / d.bn;
   constexpr int bm = 256;
   dim3 grid(((M + bm - 1) / bm) * tn * d.splitk);
-#define ES8P_LAUNCH(TT, KOV, BMV)                                                                                        \
+#define ES8P_LAUNCH(TT, KOV, FNV, LNV, GGV)                                                                              \
   do {                                                                                                                    \
-    auto kfn = conv_gemm8p_kernel<TT, KOV, BMV>;                                                                          \
-    constexpr size_t lds = 2 * ((size_t)BMV * RB + WT);                                                                   \
+    auto kfn = conv_gemm8p_kernel<TT, KOV, 256, FNV, LNV, GGV>;                                                           \
+    constexpr size_t lds = 2 * ((size_t)256 * RB + (size_t)64 * FNV * RB);                                                \
     static bool attr_set = false;                                                                                         \
     if (!attr_set) {                                                                                                      \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
@@ -605,7 +691,14 @@ int es_conv_gemm8p_launch(const es_gemm_desc& d, hipStream_t st) {
   } while (0)
 #define ES8P_LAUNCH_T(TT)                                                                                                \
   do {                                                                                                                    \
-    if (d.korder) ES8P_LAUNCH(TT, true, 256); else ES8P_LAUNCH(TT, false, 256);                                           \
+    if (d.bn == 256) {                                                                                                    \
+      const bool ln = d.ln_colsum != nullptr, gg = d.act == ES_ACT_GEGLU;                                                 \
+      if (ln && gg) ES8P_LAUNCH(TT, false, 4, true, true);                                                                \
+      else if (ln) ES8P_LAUNCH(TT, false, 4, true, false);                                                                \
+      else if (gg) ES8P_LAUNCH(TT, false, 4, false, true);                                                                \
+      else ES8P_LAUNCH(TT, false, 4, false, false);                                                                       \
+    } else if (d.korder) ES8P_LAUNCH(TT, true, 5, false, false);                                                          \
+    else ES8P_LAUNCH(TT, false, 5, false, false);                                                                         \
   } while (0)
   if (d.dtype == ES_F16) ES8P_LAUNCH_T(f16); else ES8P_LAUNCH_T(bf16);
 #undef ES8P_LAUNCH_T

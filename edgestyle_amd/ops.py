@@ -268,6 +268,8 @@ def _get_workspace(nbytes: int, device) -> torch.Tensor:
 #     where it wins as a split-K launch of ~256 workgroups (the 16 x 16 decoder level at batch 8: 1.3-1.5x, tools/plan_fit_bench.py).
 PLAN_T160, PLAN_ALONE, PLAN_TFIX, PLAN_RED_FIX, PLAN_SLAB_BYTES_PER_UNIT = 1.25, 0.9, 2.0, 12.0, 4.0e6
 PLAN_T320, PLAN_BIG_MIN_M, PLAN_T320_FIX, PLAN_BIG_MIN_NK = 2.3, 2048, 3.0, 16
+# the 256 x 256 tile of the LayerNorm-folded / GEGLU layers against the 128-wide tile on the same layers (csrc/builder.hip plan_gemm)
+PLAN_T256, PLAN_T256_FIX, PLAN_T256_GEGLU, PLAN_LN_TK, PLAN_T256_MARGIN = 2.6, 6.0, 7.0, 1.55, 0.93
 #   * the 64x64 tile (tiny launches): a K-step costs 0.5 units with the CU to itself and 0.5 + 0.16 (w - 1)^2 with w
 #     workgroups per CU (measured 0.87 at w = 2.5, 2.0 at w = 3.75); x1.5 for K > 2560, where MFMA throughput starts to
 #     matter and the small tile reads LDS twice as often per FLOP;
@@ -276,6 +278,7 @@ PLAN_T64_ALONE, PLAN_T64, PLAN_T64_LONG, PLAN_SMALL_MAX_M = 0.5, 0.16, 1.5, 1638
 # the 256 x 320 phase-interleaved tile (csrc/gemm_conv8p.hip): 1.03-1.15x the 128-pixel tile on launches of >= 1 round of
 # 256 workgroups with K >= 1024 (tools/gemm8p_bench.py: 1.07-1.30 PFLOP/s on the batch-8 3x3 launches)
 BIG_TILE = _os.environ.get("ES_BIG_TILE", "1") == "1"
+BIG_TILE_256 = _os.environ.get("ES_BIG_TILE_256", "1") != "0"     # its 256-wide form for the LayerNorm-folded / GEGLU linear layers
 PLAN_SLAB_BYTES_PER_UNIT = float(_os.environ.get("ES_PLAN_SLAB", PLAN_SLAB_BYTES_PER_UNIT))
 PLAN_RED_FIX = float(_os.environ.get("ES_PLAN_REDFIX", PLAN_RED_FIX))
 PLAN_MIN_SLICE, PLAN_NK_NOSPLIT, PLAN_RESIDENT = 12, 10, 512
@@ -303,7 +306,30 @@ def plan_gemm(M: int, rows_padded: int, kpad: int, geglu: bool = False, bns=(160
 
 def plan_gemm_reference(M: int, rows_padded: int, kpad: int, geglu: bool = False, bns=(160, 128, 64), allow_split: bool = True):
     """The Python copy of the library's planner (one more round as a guard; tuning tools): (bn, splitk, stages) with the
-    lowest modelled time among the legal N tiles (ties go to the wider tile)."""
+    lowest modelled time among the legal N tiles (ties go to the wider tile).  bn = 256 (the 256 x 256 phase-interleaved tile,
+    offered for the LayerNorm-folded / GEGLU linear layers whose N is a multiple of 256) is decided AFTER the choice among the
+    other tiles, on a model fitted on those layers (csrc/builder.hip plan_gemm, tools/ln256_bench.py)."""
+    if 256 in bns:
+        others = tuple(b for b in bns if b != 256)
+        nk = kpad // BK
+        other = None
+        if others:
+            try:
+                other = plan_gemm_reference(M, rows_padded, kpad, geglu, others, allow_split)
+            except L.EdgeStyleHipError:
+                other = None
+        if rows_padded % 256:
+            if other is None:
+                raise L.EdgeStyleHipError(f"plan_gemm: rows_padded {rows_padded} fits no N tile")
+            return other
+        t256 = ((M + 255) // 256) * (rows_padded // 256)
+        c256 = float(-(-t256 // 256)) * (nk * PLAN_T256 + PLAN_T256_FIX + (PLAN_T256_GEGLU if geglu else 0.0))
+        take = other is None
+        if other is not None and M >= PLAN_BIG_MIN_M and nk >= PLAN_BIG_MIN_NK and other[1] == 1 and other[0] != 64:
+            to = ((M + BM - 1) // BM) * (rows_padded // other[0])
+            co = float(-(-to // PLAN_RESIDENT)) * (nk * PLAN_LN_TK * (PLAN_T160 if other[0] == 160 else 1.0) + PLAN_T256_FIX)
+            take = c256 < PLAN_T256_MARGIN * co
+        return (256, 1, 2) if take else other
     if geglu:
         return 128, 1, 2
     nk = kpad // BK
@@ -567,14 +593,20 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     big_ok = BIG_TILE and C1 % BK == 0 and C2 % BK == 0 and not pw.geglu and pw.ln_colsum is None and \
         (group_n is None or all((n * Hout * Wout) % 256 == 0 for n in group_n))
     small_ok = SMALL_TILE and C1 % BK == 0 and C2 % BK == 0 and not pw.geglu and FORCE_WAVES != 8
-    cand = ((320,) if big_ok else ()) + (160, 128) + ((64,) if small_ok else ())
+    # the 256 x 256 phase-interleaved tile (round 5): LayerNorm-folded and GEGLU linear layers whose N is a multiple of 256
+    ln256_ok = BIG_TILE_256 and (pw.geglu or pw.ln_colsum is not None) and k == 1 and stride == 1 and not upsample and x2 is None \
+        and not tails and temb is None and x_rep == 1 and C1 % BK == 0 and pw.rows_padded % 256 == 0 and pw.cout % 8 == 0 \
+        and not (pw.geglu and residual is not None) and not wide and gn_groups == 0 and FORCE_WAVES != 8 \
+        and (group_n is None or all((n * Hout * Wout) % 256 == 0 for n in group_n))
+    cand = ((256,) if ln256_ok else ()) + ((320,) if big_ok else ()) + (160, 128) + ((64,) if small_ok else ())
     bn, auto_splitk, auto_stages = plan_gemm(M, pw.rows_padded, pw.kpad, pw.geglu,
                                              bns=cand if FORCE_BN == 0 else (FORCE_BN,), allow_split=pw.ln_colsum is None)
     if bn == 320 and FORCE_BN == 0 and (auto_splitk if splitk is None else splitk) == 1 and not L.load().es_conv_gemm8p_form_ok(
             int(act_i), int(pw.cout), int(temb is not None), int(Hout * Wout), int(residual is not None)):
         # the 256 x 320 tile does not implement this epilogue form (an activation, time-embedding rows that differ inside a 128-pixel
         # half or meet a residual): plan again without it, so that the tile planned, recorded and reported is the tile that runs
-        bn, auto_splitk, auto_stages = plan_gemm(M, pw.rows_padded, pw.kpad, pw.geglu, bns=cand[1:], allow_split=pw.ln_colsum is None)
+        bn, auto_splitk, auto_stages = plan_gemm(M, pw.rows_padded, pw.kpad, pw.geglu, bns=tuple(b for b in cand if b != 320),
+                                                 allow_split=pw.ln_colsum is None)
     if splitk is None:
         splitk = auto_splitk
         stages = stages or auto_stages
@@ -622,7 +654,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
     d.x_nmod = nsrc if x_rep > 1 else 0
     if FORCE_WAVES:
         d.waves = FORCE_WAVES
-    elif EIGHT_WAVES and k == 1 and M <= 65536 and C1 % BK == 0 and C2 % BK == 0 and bn not in (64, 320) \
+    elif EIGHT_WAVES and k == 1 and M <= 65536 and C1 % BK == 0 and C2 % BK == 0 and bn not in (64, 320, 256) \
             and not (int(d.stages) == 4 and bn != 128) and int(d.stages) != 3:
         # 1x1 convs / linears are short-K, latency-bound launches: two waves per SIMD on the same 128-pixel tile overlap
         # DMA issue, fragment reads and MFMAs (tools/gemm_tune.py: 3-15 % on every 1x1 shape of a batch-1 step, none on 3x3 or on the
@@ -643,7 +675,7 @@ def conv_gemm(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad: Option
             d.t2, d.Ct2 = tails[1].data_ptr(), tails[1].shape[3]
     if pws is not None:
         hw = Hout * Wout
-        gran = 256 if bn == 320 else BM
+        gran = 256 if bn in (320, 256) else BM
         if len(pws) > 4 or len(group_n) != len(pws) or sum(group_n) != N or any((n * hw) % gran for n in group_n):
             raise L.EdgeStyleHipError(f"grouped conv_gemm: groups must cover N in whole {gran}-pixel tiles (<= 4 groups)")
         d.ngroups = len(pws)

@@ -43,6 +43,14 @@ def test_launch_planner_of_the_library_equals_the_python_hosts():
         assert got == want, (M, r, k, cand, split, got, want)
         n += 1
     assert n > 10000
+    # the 256 x 256 tile of the LayerNorm-folded / GEGLU linear layers (round 5): offered first, with and without GEGLU, never split
+    for M, r, k, geglu in itertools.product(Ms, [1280, 3840, 10240, 2560, 5120], [320, 640, 1280], (False, True)):
+        for cand in ((256, 160, 128), (256, 160, 128, 64), (256,)):
+            want = ops.plan_gemm_reference(M, r, k, geglu, bns=cand, allow_split=False)
+            assert ops.plan_gemm(M, r, k, geglu, bns=cand, allow_split=False) == want, (M, r, k, geglu, cand)
+            assert want[1] == 1 and (not geglu or want[0] in (128, 256))
+            if want[0] == 256:
+                assert want[2] == 2 and (len(cand) == 1 or (M >= ops.PLAN_BIG_MIN_M and k // 64 >= ops.PLAN_BIG_MIN_NK))
     arr = (C.c_int * 2)(160, 128)
     assert lib.es_plan_gemm_choice(4096, 2560, 320, 1, arr, 2, 1, C.byref(bn), C.byref(sk), C.byref(st)) == 0
     assert (bn.value, sk.value, st.value) == ops.plan_gemm(4096, 2560, 320, True) == ops.plan_gemm_reference(4096, 2560, 320, True)

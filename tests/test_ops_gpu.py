@@ -706,6 +706,70 @@ def test_grouped_launches_equal_separate_launches():
         ops.conv_gemm(x, pws, group_n=[3, 5, 4, 2])      # 3 samples x 64 px is not a whole number of 128-px tiles
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_ln_geglu_big_tile_equals_small_tile(dtype):
+    """bn = 256 (round 5): the 256 x 256 form of the phase-interleaved tile that the LayerNorm-folded and GEGLU linear layers of the
+    C = 1280 level run on (diffusers BasicTransformerBlock norm1 -> attn1.to_q|k|v, norm2 -> attn2.to_q, norm3 -> ff.net.0 under
+    CL:205-238) must reproduce the 128-wide tile bit for bit - same MFMA order per accumulator, the row statistics of the fold summed
+    on the matrix core in the same order, the GEGLU product in the same fp32 expression - and match the fp32 reference: LayerNorm +
+    GEGLU, LayerNorm alone, GEGLU alone, a plain layer with a residual, a grouped launch, ragged M."""
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(77)
+    K = 1280
+
+    def both(fn):
+        ops.FORCE_BN = 256
+        try:
+            big = fn()
+        finally:
+            ops.FORCE_BN = 0
+        prev = ops.BIG_TILE_256
+        ops.BIG_TILE_256 = False
+        try:
+            small = fn()
+        finally:
+            ops.BIG_TILE_256 = prev
+        return big, small
+    tol = 4e-3 if dtype == torch.float16 else 2.5e-2
+    for M, N, geglu, ln in [(2304, 2560, True, True), (2304, 768, False, True), (1000, 512, True, False), (4096, 1280, False, True)]:
+        x = torch.randn(M, K, generator=g).to(dtype).float()
+        w = (torch.randn(N, K, generator=g) / math.sqrt(K))
+        b = torch.randn(N, generator=g) * 0.1
+        gam, bet = 1 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+        pw = ops.pack_weight_ln(w, b, gam, bet, 1e-5, dtype, DEV, geglu=geglu) if ln else ops.pack_weight(w, b, dtype, DEV, geglu=geglu)
+        xd = x.to(DEV, dtype)
+        big, small = both(lambda: ops.linear(xd, pw))
+        assert torch.equal(big, small), (M, N, geglu, ln)
+        h = F.layer_norm(x, (K,), gam, bet, 1e-5) if ln else x
+        y = h @ w.t() + b
+        if geglu:
+            y = y[:, :N // 2] * F.gelu(y[:, N // 2:])
+        assert rel_err(big, y) < tol, (M, N, geglu, ln, rel_err(big, y))
+    # LayerNorm-folded layer with a residual, and a grouped LayerNorm + GEGLU launch ([2, 6, 4, 2] x 256 rows)
+    M, N = 3584, 1280
+    x = torch.randn(M, K, generator=g).to(DEV, dtype)
+    res = torch.randn(M, N, generator=g).to(DEV, dtype)
+    pw = ops.pack_weight_ln(torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g) * 0.1, 1 + 0.1 * torch.randn(K, generator=g),
+                            0.1 * torch.randn(K, generator=g), 1e-5, dtype, DEV)
+    big, small = both(lambda: ops.linear(x, pw, residual=res))
+    assert torch.equal(big, small)
+    counts = [2, 6, 4, 2]
+    pws = [ops.pack_weight_ln(torch.randn(2560, K, generator=g) / math.sqrt(K), torch.randn(2560, generator=g) * 0.1, 1 + 0.1 * torch.randn(K, generator=g),
+                              0.1 * torch.randn(K, generator=g), 1e-5, dtype, DEV, geglu=True) for _ in counts]
+    xg = torch.randn(sum(counts) * 256, K, generator=g).to(DEV, dtype)
+    big, small = both(lambda: ops.linear(xg, pws, group_n=[n * 256 for n in counts]))
+    assert torch.equal(big, small)
+    a = 0
+    for pw_, n in zip(pws, counts):
+        ops.FORCE_BN = 256
+        try:
+            sep = ops.linear(xg[a * 256:(a + n) * 256], pw_)
+        finally:
+            ops.FORCE_BN = 0
+        assert torch.equal(big.reshape(-1, 1280)[a * 256:(a + n) * 256], sep)
+        a += n
+
+
 def test_conv_gemm_big_tile_equals_small_tile():
     """bn=320 (256-pixel x 320-cout tile, 8 waves, streamed W fragments, two-pass epilogue) must reproduce the
     128-pixel tile bit for bit (same K order per accumulator) and match F.conv2d: concat + temb + residual + SiLU,
