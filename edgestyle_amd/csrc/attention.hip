@@ -874,12 +874,22 @@ __global__ __launch_bounds__(512, 2) void attention40pp_kernel(const es_attn_des
   qk(0);
   __builtin_amdgcn_s_setprio(0);
   __builtin_amdgcn_s_barrier();
+#ifdef ES_ATTN_STAMPS
+  // tool build: cycles of waves 0 (group 0) and 4 (group 1) of block (1,0,0) in [V-phase work | barrier wait | M-phase work | barrier wait]
+  unsigned long long pp_acc[4] = {0, 0, 0, 0};
+  unsigned long long pp_prev = __builtin_amdgcn_s_memtime();
+#define PP_STAMP(i) do { asm volatile("s_nop 0" ::"v"(s[0][0][0]), "v"(o[0][0][0][0])); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pp_acc[i] += now_ - pp_prev; pp_prev = now_; } while (0)
+#else
+#define PP_STAMP(i)
+#endif
   for (int t = 0; t < nt; ++t) {
     // ---- V phase: softmax of S(t) ----
     if (grp == 1) { load_k(t + 2); load_v(t + 1); }
     softmax(t == 0);
     if (grp == 0 && t > 0) { store_k(t + 1); store_v(t); }
+    PP_STAMP(0);
     __builtin_amdgcn_s_barrier();
+    PP_STAMP(1);
     // ---- M phase: O += V(t) P(t), S(t+1) = K(t+1) Q ----
     if (grp == 0) { load_k(t + 2); load_v(t + 1); }
     __builtin_amdgcn_s_setprio(1);
@@ -887,8 +897,15 @@ __global__ __launch_bounds__(512, 2) void attention40pp_kernel(const es_attn_des
     if (t + 1 < nt) qk(t + 1);
     __builtin_amdgcn_s_setprio(0);
     if (grp == 1) { store_k(t + 2); store_v(t + 1); }
+    PP_STAMP(2);
     __builtin_amdgcn_s_barrier();
+    PP_STAMP(3);
   }
+#ifdef ES_ATTN_STAMPS
+  if ((tid == 0 || tid == 256) && blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0)
+    for (int i = 0; i < 4; ++i) es_attn_dbg[8 + grp * 4 + i] = pp_acc[i];
+#endif
+#undef PP_STAMP
   if (grp == 0) __builtin_amdgcn_s_barrier();
 
   // ---- epilogue: O[query][dv] = O^T / l  (l = the ones column: row 40 of O^T) ----
@@ -928,39 +945,64 @@ __global__ __launch_bounds__(512, 2) void attention40pp_kernel(const es_attn_des
 // the waves of a workgroup (four heads) only share the cache lines of their query rows.
 template <typename T, int KS /* QK k-steps of 16 */, int DF /* dv fragments of 16 (d = 40: the pad column 40 is the ones column) */, bool ONES>
 __global__ __launch_bounds__(512, 2) void attention_kvres_kernel(const es_attn_desc p, const int qper) {
+  // Third version (round 5): the first two read Q and wrote O in fragment shape - a wave instruction touched 32 rows x 32 bytes, 32 cache
+  // lines per KB - and were bound by that request rate (0.76-0.94x of the tiled kernels, profiles/r05_xattn_bench.txt).  Now the workgroup
+  // (eight waves = eight heads, one per wave) moves 32 WHOLE query rows per block: every thread loads 16-byte chunks of consecutive
+  // addresses into an LDS tile [32][heads x d] (a block ahead, through registers), the waves read their head's fragments from it, write their
+  // O fragments into a second tile, and the workgroup stores that tile as whole rows.  Two barriers per block.
   constexpr int KT = 3;                             // key tiles of 32
   typedef typename Traits<T>::vec8 vec8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n32 = lane & 31, hi = lane >> 5;        // 32x32 layouts: query column / key half
   const int col = lane & 15, g = lane >> 4;         // 16x16 layouts (PV product, epilogue)
-  const int h = blockIdx.y * 8 + wave, n = blockIdx.z;
-  if (h >= p.heads) return;                         // (wave-uniform; the kernel has no barrier)
+  const int h0 = blockIdx.y * 8, n = blockIdx.z;
+  const int nh = p.heads - h0 < 8 ? p.heads - h0 : 8;     // heads of this workgroup
+  const int h = h0 + wave;
+  const bool live = wave < nh;                      // (a wave without a head still takes part in the copies and the barriers)
   const int d = p.d, dch = d / 8;
-  const T* Q = (const T*)p.q + (size_t)n * p.bsq + (size_t)h * d;
-  const T* K = (const T*)p.k + (size_t)n * p.bsk + (size_t)h * d;
-  const T* V = (const T*)p.v + (size_t)n * p.bsv + (size_t)h * d;
-  T* O = (T*)p.o + (size_t)n * p.bso + (size_t)h * d;
+  const int CW = nh * d;                            // channels of the workgroup's rows
+  const int CH = CW / 8;                            // 16-byte chunks per row
+  const int QROW = CW * 2 + 16;                     // LDS row stride (bytes)
+  char* qt = smem;                                  // [2][32][QROW]
+  char* ot = smem + 2 * 32 * QROW;                  // [32][QROW]
+  const T* Qg = (const T*)p.q + (size_t)n * p.bsq + (size_t)h0 * d;
+  T* Og = (T*)p.o + (size_t)n * p.bso + (size_t)h0 * d;
+  const T* K = (const T*)p.k + (size_t)n * p.bsk + (size_t)(live ? h : h0) * d;
+  const T* V = (const T*)p.v + (size_t)n * p.bsv + (size_t)(live ? h : h0) * d;
   const float sl2 = p.scale * 1.4426950408889634f;
   const int q_begin = blockIdx.x * qper;
   int q_end = q_begin + qper;
   q_end = q_end < p.Sq ? q_end : p.Sq;
-  // keys 80..95 of the third tile (registers 8..15 of its accumulator) are padding whenever Skv <= 80 - the 77 text tokens
-  const bool short3 = p.Skv <= 80;
+  const bool short3 = p.Skv <= 80;                  // keys 80..95 (registers 8..15 of the third score tile) are padding: the 77 text tokens
 
-  auto load_q = [&](int q0, u32x4 (&raw)[KS]) __attribute__((always_inline)) {
-    int qi = q0 + n32;
-    qi = qi < p.Sq ? qi : p.Sq - 1;
+  // cooperative copies: chunk idx = tid + k * 512 of a 32-row tile -> (row, chunk of the row)
+  constexpr int CPT = KS == 3 ? 3 : 5;              // ceil(32 * 8 heads * d / 8 / 512): d = 40 -> 2.5, d = 80 -> 5
+  const float inv_ch = __builtin_amdgcn_rcpf((float)CH);
+  int crow[CPT], cch[CPT];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int ch = 2 * s + hi;
-      raw[s] = u32x4{0u, 0u, 0u, 0u};
-      if (ch < dch) raw[s] = *(const u32x4*)(Q + (size_t)qi * p.ldq + ch * 8);
+  for (int k = 0; k < CPT; ++k) {
+    const int idx = tid + k * 512;
+    crow[k] = fast_div(idx, CH, inv_ch);
+    cch[k] = idx - crow[k] * CH;
+    if (crow[k] >= 32) { crow[k] = -1; cch[k] = 0; }
+  }
+  u32x4 qreg[CPT];
+  auto load_q = [&](int q0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      qreg[k] = u32x4{0u, 0u, 0u, 0u};
+      const int qi = q0 + crow[k];
+      if (crow[k] >= 0 && qi < p.Sq) qreg[k] = *(const u32x4*)(Qg + (size_t)qi * p.ldq + cch[k] * 8);
     }
   };
-  u32x4 qA[KS], qB[KS];                             // two blocks of query rows in flight
-  load_q(q_begin, qA);
-  if (q_begin + 32 < q_end) load_q(q_begin + 32, qB);
+  auto store_q = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < CPT; ++k)
+      if (crow[k] >= 0) *(u32x4*)(qt + buf * 32 * QROW + crow[k] * QROW + cch[k] * 16) = qreg[k];
+  };
+  load_q(q_begin);
 
   // K fragments, pre-scaled by scale * log2(e): lane holds K[key = 32 t + n32][16 s + 8 hi .. + 7]; keys >= Skv and channels >= d are zero
   vec8 kf[KT][KS];
@@ -998,79 +1040,90 @@ __global__ __launch_bounds__(512, 2) void attention_kvres_kernel(const es_attn_d
       }
       vf[t][j] = v;
     }
+  store_q(0);
+  if (q_begin + 32 < q_end) load_q(q_begin + 32);
+  __syncthreads();
 
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  auto block = [&](int q0, u32x4 (&qraw)[KS]) __attribute__((always_inline)) {
-    vec8 qf[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) qf[s] = as_vec8<T>(qraw[s]);
-    f32x16 sc[KT];
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-#pragma unroll
-      for (int s = 0; s < KS; ++s) sc[t] = mfma32(kf[t][s], qf[s], s == 0 ? zero16 : sc[t]);
-    if (q0 + 64 < q_end) load_q(q0 + 64, qraw);     // this register set is free again: the block after the next one
-    // keys beyond Skv (zero K rows: score 0) leave the softmax
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-      if (32 * t + 32 > p.Skv) {                      // wave-uniform
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sc[t][r] = (32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.Skv) ? -3.0e38f : sc[t][r];
-      }
-    float mx = sc[0][0];
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; r += 2)
-        if (t < 2 || r < 8 || !short3) mx = fmaxf(fmaxf(mx, sc[t][r]), sc[t][r + 1]);
-    mx = xor32_max(mx);
-    float rs = 0.f;
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (t < 2 || r < 8 || !short3) { sc[t][r] = __builtin_amdgcn_exp2f(sc[t][r] - mx); if (!ONES) rs += sc[t][r]; }
-        else sc[t][r] = 0.f;
-      }
-    vec8 pb[2][KT];                                 // [query half][key chunk]: B operands of the PV product
-#pragma unroll
-    for (int t = 0; t < KT; ++t) {
-      unsigned x[4], y[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        x[i] = pack2<T>(sc[t][2 * i], sc[t][2 * i + 1]);
-        y[i] = (t == 2 && short3) ? 0u : pack2<T>(sc[t][8 + 2 * i], sc[t][9 + 2 * i]);
-      }
-      asm volatile("s_nop 1\n\t"
-                   "v_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
-                   "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 1"
-                   : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
-      pb[0][t] = as_vec8<T>(u32x4{x[0], x[1], x[2], x[3]});
-      pb[1][t] = as_vec8<T>(u32x4{y[0], y[1], y[2], y[3]});
-    }
+  const int hb = wave * d * 2;                      // byte offset of this wave's head inside a tile row
+  int buf = 0;
+  for (int q0 = q_begin; q0 < q_end; q0 += 32, buf ^= 1) {
     f32x4 o[2][DF];
+    float l0 = 1.f, l1 = 1.f;
+    if (live) {
+      vec8 qf[KS];
 #pragma unroll
-    for (int j = 0; j < DF; ++j)
+      for (int s = 0; s < KS; ++s) {
+        const int ch = 2 * s + hi;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ch < dch) v = *(const u32x4*)(qt + buf * 32 * QROW + n32 * QROW + hb + ch * 16);
+        qf[s] = as_vec8<T>(v);
+      }
+      f32x16 sc[KT];
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) sc[t] = mfma32(kf[t][s], qf[s], s == 0 ? zero16 : sc[t]);
+      // keys beyond Skv (zero K rows: score 0) leave the softmax
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+        if (32 * t + 32 > p.Skv) {                    // wave-uniform
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[t][r] = (32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.Skv) ? -3.0e38f : sc[t][r];
+        }
+      float mx = sc[0][0];
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2)
+          if (t < 2 || r < 8 || !short3) mx = fmaxf(fmaxf(mx, sc[t][r]), sc[t][r + 1]);
+      mx = xor32_max(mx);
+      float rs = 0.f;
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (t < 2 || r < 8 || !short3) { sc[t][r] = __builtin_amdgcn_exp2f(sc[t][r] - mx); if (!ONES) rs += sc[t][r]; }
+          else sc[t][r] = 0.f;
+        }
+      vec8 pb[2][KT];                                 // [query half][key chunk]: B operands of the PV product
 #pragma unroll
       for (int t = 0; t < KT; ++t) {
-        o[0][j] = mfma16(vf[t][j], pb[0][t], t == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : o[0][j]);
-        o[1][j] = mfma16(vf[t][j], pb[1][t], t == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : o[1][j]);
-      }
-    float l0, l1;
-    if constexpr (ONES) {
-      // row d of O^T = fragment d / 16, lane group (d % 16) / 4, register d % 4: d = 40 -> fragment 2, lanes 32..47, register 0
-      l0 = __shfl(o[0][DF - 1][0], 32 + col, 64);
-      l1 = __shfl(o[1][DF - 1][0], 32 + col, 64);
-    } else {
-      const float l = xor32_sum(rs);                // per query, 32-query layout -> the two 16-query halves of the 16x16 layout
-      l0 = l; l1 = l;
-      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(l0), "+v"(l1));
-    }
+        unsigned x[4], y[4];
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      const int qi = q0 + f * 16 + col;
-      const float inv = __builtin_amdgcn_rcpf(f ? l1 : l0);
-      if (qi < p.Sq) {
+        for (int i = 0; i < 4; ++i) {
+          x[i] = pack2<T>(sc[t][2 * i], sc[t][2 * i + 1]);
+          y[i] = (t == 2 && short3) ? 0u : pack2<T>(sc[t][8 + 2 * i], sc[t][9 + 2 * i]);
+        }
+        asm volatile("s_nop 1\n\t"
+                     "v_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
+                     "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 1"
+                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+        pb[0][t] = as_vec8<T>(u32x4{x[0], x[1], x[2], x[3]});
+        pb[1][t] = as_vec8<T>(u32x4{y[0], y[1], y[2], y[3]});
+      }
+#pragma unroll
+      for (int j = 0; j < DF; ++j)
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+          o[0][j] = mfma16(vf[t][j], pb[0][t], t == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : o[0][j]);
+          o[1][j] = mfma16(vf[t][j], pb[1][t], t == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : o[1][j]);
+        }
+      if constexpr (ONES) {
+        // row d of O^T = fragment d / 16, lane group (d % 16) / 4, register d % 4: d = 40 -> fragment 2, lanes 32..47, register 0
+        l0 = __shfl(o[0][DF - 1][0], 32 + col, 64);
+        l1 = __shfl(o[1][DF - 1][0], 32 + col, 64);
+      } else {
+        const float l = xor32_sum(rs);                // per query, 32-query layout -> the two 16-query halves of the 16x16 layout
+        l0 = l; l1 = l;
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(l0), "+v"(l1));
+      }
+    }
+    __syncthreads();                                // the previous block's O tile has been stored; every wave is done with Q tile `buf ^ 1`
+    if (live) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const float inv = __builtin_amdgcn_rcpf(f ? l1 : l0);
 #pragma unroll
         for (int j = 0; j < DF; ++j) {
           const int dv = j * 16 + g * 4;
@@ -1078,29 +1131,45 @@ __global__ __launch_bounds__(512, 2) void attention_kvres_kernel(const es_attn_d
             typename Traits<T>::vec4 pk;
 #pragma unroll
             for (int r = 0; r < 4; ++r) pk[r] = from_f32<T>(o[f][j][r] * inv);
-            store8(O + (size_t)qi * p.ldo + dv, __builtin_bit_cast(u32x2, pk));
+            *(typename Traits<T>::vec4*)(ot + (f * 16 + col) * QROW + hb + dv * 2) = pk;
           }
         }
       }
     }
-  };
-  for (int q0 = q_begin; q0 < q_end; q0 += 64) {
-    block(q0, qA);
-    if (q0 + 32 < q_end) block(q0 + 32, qB);
+    if (q0 + 32 < q_end) {                          // the next block's rows (in registers since the last block) -> the other Q tile
+      store_q(buf ^ 1);
+      if (q0 + 64 < q_end) load_q(q0 + 64);
+    }
+    __syncthreads();                                // O tile complete, next Q tile visible
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      const int qi = q0 + crow[k];
+      if (crow[k] >= 0 && qi < p.Sq)
+        store16(Og + (size_t)qi * p.ldo + cch[k] * 8, *(const u32x4*)(ot + crow[k] * QROW + cch[k] * 16));
+    }
   }
 }
 
 template <typename T, int KS, int DF, bool ONES>
 int launch_attn_kvres(const es_attn_desc& d, hipStream_t st) {
-  // strips of queries: enough workgroups (eight heads each, one wave per head) for one per CU and a little more, whole 32-query blocks
+  // strips of queries, whole 32-query blocks: ONE round of workgroups (eight heads each, one wave per head; one workgroup per CU) - at
+  // most 256 of them; a part-filled second round (308 workgroups in the first grid rule) cost a third of the launch
   const int per_strip = (d.heads + 7) / 8 * d.N;
-  int strips = (320 + per_strip - 1) / per_strip;
+  int strips = 256 / per_strip;
   const int blocks32 = (d.Sq + 31) / 32;
   strips = strips < 1 ? 1 : (strips > blocks32 ? blocks32 : strips);
   const int qper = ((blocks32 + strips - 1) / strips) * 32;
   strips = (d.Sq + qper - 1) / qper;
+  const int nh = d.heads < 8 ? d.heads : 8;
+  const size_t lds = (size_t)3 * 32 * (nh * d.d * 2 + 16);
+  auto kfn = attention_kvres_kernel<T, KS, DF, ONES>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32 * (8 * 80 * 2 + 16));
+    attr_set = true;
+  }
   dim3 grid(strips, (d.heads + 7) / 8, d.N);
-  hipLaunchKernelGGL((attention_kvres_kernel<T, KS, DF, ONES>), grid, dim3(512), 0, st, d, qper);
+  hipLaunchKernelGGL(kfn, grid, dim3(512), lds, st, d, qper);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -1126,21 +1195,25 @@ int launch_attn(const es_attn_desc& d, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-// OFF by default: measured a LOSS (profiles/r05_xattn_bench.txt: 0.76-0.94x of the tiled kernels on the launches of a step).  Removing
-// the K / V staging, the barriers and the rescale was not the lever: with the softmax arithmetic cut by a third (second version) the kernel
-// got no faster, with fewer waves per SIMD it got slower - these launches are bound by the REQUEST rate of their fragment-shaped Q loads
-// and 8-byte O stores (a wave instruction touches 32 rows x 32 bytes: 32 cache lines for 1 KB), which the tiled kernels share.  What
-// would pay is Q / O tiles through LDS in whole 640-byte rows; not built (the 22 launches are 1.6 % of a batch-1 step).
-int attn_kvres = [] { const char* e = getenv("ES_ATTN_KVRES"); return e ? atoi(e) : 0; }();
+// 1 (default; ES_ATTN_KVRES=0 turns it off, 2 forces it for every eligible shape): launches of enough samples to fill one round of its
+// workgroups - where it wins (profiles/r05_xattn_bench.txt: 1.13-1.45x at head_dim 40 from 14 samples up, 1.21x at head_dim 80 with 112
+// samples; it LOSES on the two-sample decoder launches and at head_dim 80 with 14-16 samples: 0.5-0.9x, those stay on the tiled kernels).
+// Two earlier versions (Q / O in fragment-shaped accesses; a grid of 1.2 rounds) lost everywhere: what matters for this kernel is whole-row
+// Q / O tiles AND exactly one round of workgroups.  It remains bound by its eight waves moving in lockstep (2.5-3 us per 32-query block
+// against ~1.2 us of vector issue).
+int attn_kvres = [] { const char* e = getenv("ES_ATTN_KVRES"); return e ? atoi(e) : 1; }();
 
 template <typename T>
 int dispatch(const es_attn_desc& d, hipStream_t st) {
   // 32 queries per wave (128 per block) only when that still yields >= 2 blocks per CU; else 16 per wave
   static const long long big_thr = getenv("ES_ATTN_BIG") ? atoll(getenv("ES_ATTN_BIG")) : 512;
   const bool big = (long long)((d.Sq + 127) / 128) * d.heads * d.N >= big_thr;
-  // the text-token cross-attention (77 keys) of the 64 x 64 and 32 x 32 levels: K / V resident in registers (opt-in: ES_ATTN_KVRES=1)
-  if (attn_kvres && d.Skv <= 96 && d.Sq >= 64 && (d.d == 40 || d.d == 80))
-    return d.d == 40 ? launch_attn_kvres<T, 3, 3, true>(d, st) : launch_attn_kvres<T, 5, 5, false>(d, st);
+  // the text-token cross-attention (77 keys) of the 64 x 64 and 32 x 32 levels: K / V resident in registers
+  if (attn_kvres && d.Skv <= 96 && d.Sq >= 64 && (d.d == 40 || d.d == 80)) {
+    const long long groups = (long long)((d.heads + 7) / 8) * d.N;           // workgroups per strip of queries
+    if (attn_kvres == 2 || groups >= (d.d == 40 ? 12 : 64))
+      return d.d == 40 ? launch_attn_kvres<T, 3, 3, true>(d, st) : launch_attn_kvres<T, 5, 5, false>(d, st);
+  }
   static const bool tile32 = !(getenv("ES_ATTN32") && atoi(getenv("ES_ATTN32")) == 0);   // A/B switch (tools)
   if (big && tile32) {
     // measured (tools/attn_bench.py, 14 x 8 x 4096^2): head_dim 40 476 -> 449 us; head_dim 80 is no faster (189 VGPRs,

@@ -171,7 +171,12 @@ ES_DEVICE void store8(void* ptr, u32x2 v) {
 //   part[((n * 2 * (HW/64) + 2 * block + slot) * groups + g) * 2 + {0, 1}]
 // slot 0 = the tile the group starts in, slot 1 = the next one (zero where the group ends in its first tile).  ONE summation
 // order for every caller - 8 sub-blocks of 8 pixels sequentially, the 8 sub-sums sequentially, the group's channels in order - so
-// the statistics do not depend on tile shape, wave count or split-K (grouped and per-net launches stay bitwise equal).
+// the per-channel sums do not depend on tile shape, wave count or split-K, and a grouped launch equals its per-net launches bit for
+// bit (same tile, same planner inputs per layer shape).  ACROSS tile widths the table is equal only up to fp32 rounding: a group
+// that straddles an N-tile edge is handed over as slot 0 + slot 1, and where that edge falls depends on the tile width (C = 640,
+// 32 groups of 20 channels: a 128-wide tile splits groups 12 + 8, the 320-wide tile and the split-K reduce keep them whole) -
+// tests/test_ops_gpu.py::test_group_norm_hand_over_does_not_depend_on_the_tile_or_the_grouping compares the SUM of the two slots
+// with a relative tolerance of 2e-6.  (Opt-in feature: ES_GN_HANDOVER; off by default, profiles/r04_gn_handover.txt.)
 // `scratch`: LDS floats, (rows / 8 + rows / 64) * cols * 2 of them.  All NT threads call it; it ends behind a barrier-free write.
 template <typename T, int NT>
 ES_DEVICE void gn_emit_partials(const char* tile, const int erow, const int rows, const int cols, float* scratch, float* part,

@@ -171,9 +171,9 @@ typedef struct {
   int32_t dtype;
 } es_attn_desc;
 int es_attention(const es_attn_desc* d, void* stream);
-/* tool / test knob: 1 (ES_ATTN_KVRES=1 in the environment; default 0 - it measured slower, profiles/r05_xattn_bench.txt) = launches with
- * Skv <= 96 and head_dim 40 | 80 (the text-token cross-attention of the two shallow UNet levels) run the K/V-resident kernel.
- * Returns the previous setting. */
+/* tool / test knob: launches with Skv <= 96 and head_dim 40 | 80 (the text-token cross-attention of the two shallow UNet levels) on the
+ * K/V-resident kernel - 0 never, 1 (default; ES_ATTN_KVRES in the environment) where it wins (>= 12 samples at head_dim 40, >= 64 at 80:
+ * profiles/r05_xattn_bench.txt), 2 every eligible launch.  Returns the previous setting. */
 int es_attention_set_kvres(int on);
 
 /* GroupNorm (+SiLU) over NHWC with optional channel-concat of two sources.

@@ -201,7 +201,7 @@ def test_cross_attention_kv_resident_kernel(N, heads, Sq, Skv, d, dtype):
     ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(N, Sq, C)
     dq, dkv = q.to(DEV, dtype), kv.to(DEV, dtype)
     L = lib.load()
-    prev = L.es_attention_set_kvres(1)
+    prev = L.es_attention_set_kvres(2)
     try:
         y1 = ops.attention(dq[:, :, :C], dkv[:, :, :C], dkv[:, :, C:], heads)
         L.es_attention_set_kvres(0)

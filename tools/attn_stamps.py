@@ -34,5 +34,28 @@ def main():
               ", ".join(f"{n} {v:.0f}" for n, v in zip(NAMES, vals)) + f" | total {sum(vals):.0f}")
 
 
+def main_pp():
+    """attention40pp_kernel (head_dim 40 self-attention, the ping-pong kernel): cycles per K/V tile of wave 0 (group 0) and wave 4 (group 1) of
+    one workgroup in [V-phase work | wait at the barrier behind it | M-phase work | wait at the barrier behind it]."""
+    lib.load()
+    raw = ctypes.CDLL(lib.LIB_PATH)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for N, h, S, d in [(14, 8, 4096, 40), (112, 8, 4096, 40), (2, 8, 4096, 40)]:
+        C = h * d
+        qkv = torch.randn(N, S, 3 * C, generator=g, device="cuda").half()
+        for _ in range(3):
+            ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], h)
+        torch.cuda.synchronize()
+        buf = (ctypes.c_ulonglong * 16)()
+        assert raw.es_attn_debug_read(buf) == 0
+        tiles = S // 64
+        for grp in (0, 1):
+            v = [buf[8 + grp * 4 + i] / tiles for i in range(4)]
+            print(f"N={N} S={S} d={d} group {grp}: V-phase work {v[0]:.0f} | wait {v[1]:.0f} | M-phase work {v[2]:.0f} | wait {v[3]:.0f} | tile {sum(v):.0f} cycles", flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if "--pp" in sys.argv:
+        main_pp()
+    else:
+        main()

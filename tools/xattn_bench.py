@@ -37,7 +37,7 @@ for N, h, Sq, Skv, d in [(14, 8, 4096, 77, 40), (2, 8, 4096, 77, 40), (14, 8, 10
     out = torch.empty_like(q)
     gs = {}
     for on in (0, 1):
-        L.es_attention_set_kvres(on)
+        L.es_attention_set_kvres(2 * on)
         gs[on] = graph_of(lambda: ops.attention(q, kv[:, :, :C], kv[:, :, C:], h, out=out))
     L.es_attention_set_kvres(1)
     ts = {0: [], 1: []}
