@@ -171,8 +171,13 @@ class ClockSampler:
     def start(self):
         import threading
         self.samples, self._stop = [], threading.Event()
-        self._th = threading.Thread(target=self._poll, daemon=True)
         self._t0 = time.time()
+        # not under a profiler: rocprofv3 preloads its library into every child, which initialises the GPU there before `rocm-smi` (a
+        # Python script) is exec'ed - the GPU boxes refuse an exec from a process that has touched the device; the fields stay null
+        if os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+            self._th = None
+            return self
+        self._th = threading.Thread(target=self._poll, daemon=True)
         self._th.start()
         return self
 
