@@ -196,7 +196,7 @@ class ClockSampler:
                 "samples": len(sm)}
 
 
-def gemm_roofline(pipe, traffic_profile="r04_gemm_pmc_traffic_b1.json", replay_iters=20):
+def gemm_roofline(pipe, traffic_profile="r05_gemm_pmc_traffic_b1.json", replay_iters=20):
     """Price the implicit-GEMM kernel against the dense fp16 MFMA peak with ALGORITHMIC flops (2*M*Cout*k*k*Cin) over
     the es_conv_gemm launches of one captured denoising step (the unit replayed 50x per image = 96 % of the image's
     FLOPs).  Two clocks, both reported:
@@ -647,7 +647,7 @@ def main(argv=None):
                                        "unit": "images/s", "ms_per_step": round(t8 * 1e3, 1), "steps": n8, "warmup": 2}
             line["throughput_mode"]["phases_ms"] = call_phases(pipe, one8)
             if not args.no_roofline:
-                r8 = gemm_roofline(pipe, traffic_profile="r04_gemm_pmc_traffic_b8.json", replay_iters=int(min(100, max(5, 1.5 / (t8 / args.ddim_steps * 0.65)))))
+                r8 = gemm_roofline(pipe, traffic_profile="r05_gemm_pmc_traffic_b8.json", replay_iters=int(min(100, max(5, 1.5 / (t8 / args.ddim_steps * 0.65)))))
                 line["throughput_mode"]["roofline"] = {k: r8[k] for k in ROOFLINE_KEYS if k in r8}
             log(f"throughput mode (batch 8): {8 / t8:.3f} images/s")
             if not args.no_native_abi and not args.no_graph:

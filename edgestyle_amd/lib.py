@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ES_HIP_LIB") or os.path.join(_HERE, "lib", "libedgestyle_hip.so")
 
 ES_F16, ES_BF16, ES_F32 = 0, 1, 2
-ABI_VERSION = 6          # include/edgestyle_hip.h ES_ABI_VERSION
+ABI_VERSION = 7          # include/edgestyle_hip.h ES_ABI_VERSION
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
 
 

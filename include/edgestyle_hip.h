@@ -23,7 +23,9 @@ extern "C" {
 enum { ES_F16 = 0, ES_BF16 = 1, ES_F32 = 2 /* es_tensor sources only: the kernels compute in ES_F16 / ES_BF16 */ };
 enum { ES_ACT_NONE = 0, ES_ACT_SILU = 1, ES_ACT_GEGLU = 2 };
 
-#define ES_ABI_VERSION 6
+/* 7 (round 5): es_gemm_desc.bn = 256; es_conv_gemm8p_form_ok, es_ctx_graph_hazard, es_linear_xs_set_pp, es_attention_set_kvres.
+ * No struct layout changed since 6; context images carry the version and are rebuilt across it. */
+#define ES_ABI_VERSION 7
 int es_abi_version(void);
 /* sizeof the descriptor structs as compiled (0 gemm, 1 attn, 2 gn, 3 fusion, 4 ln, 5 xs): lets a binding verify its mirror */
 size_t es_sizeof_desc(int which);
@@ -60,7 +62,8 @@ typedef struct {
   int32_t act;                /* ES_ACT_* ; GEGLU halves the stored width (weights packed interleaved) */
   int32_t splitk;
   int32_t bn;                 /* N tile: 128 | 160 (128-pixel tile), 64 (64 x 64 tile, tiny launches), 320 (256 x 320 phase-interleaved
-                               * tile, csrc/gemm_conv8p.hip: large launches with 64-aligned channels); rows_padded % bn == 0 */
+                               * tile, csrc/gemm_conv8p.hip: large launches with 64-aligned channels), 256 (its 256 x 256 form: the
+                               * LayerNorm-folded / GEGLU linear layers, ln_colsum / ES_ACT_GEGLU allowed, no temb); rows_padded % bn == 0 */
   int32_t dtype;
   /* Grouped launch: ngroups (<= 4) problems of identical geometry but different weights run as ONE launch over the
    * batch-concatenated activations (the 3 batched ControlNet passes + the UNet encoder of a denoising step): M tiles

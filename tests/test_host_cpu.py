@@ -28,7 +28,7 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert getattr(h, name) is not None
     L = lib.load()
-    assert L.es_abi_version() == 6
+    assert L.es_abi_version() == 7
     # struct layouts agree with the C side (sizes are what the kernels index with)
     for i, st in enumerate((lib.GemmDesc, lib.AttnDesc, lib.GnDesc, lib.FusionDesc, lib.LnDesc, lib.XsDesc)):
         assert L.es_sizeof_desc(i) == ctypes.sizeof(st)
