@@ -2,6 +2,7 @@
 import math
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("ES_XS_MIN_M", "0")          # no size policy: this tool is what the policy is fitted on
 import torch
 from edgestyle_amd import ops
 
@@ -42,8 +43,16 @@ shapes = [  # M, K, N, geglu, ln, groups
     (3584, 640, 1920, False, True, None),
     (3584, 640, 640, False, True, None),
     (3584, 640, 5120, True, True, None),
+    # the UNet decoder's own launches at batch 1 (2 samples) and 2 (4 samples): output projections with a residual, proj_in, cross to_q
+    (8192, 320, 320, False, False, None, True),
+    (16384, 320, 320, False, False, None, True),
+    (16384, 320, 320, False, True, None),
+    (16384, 320, 960, False, True, None),
+    (32768, 320, 320, False, False, None, True),
+    (32768, 320, 320, False, True, None),
 ]
-for M, K, N, geglu, ln, groups in shapes:
+for M, K, N, geglu, ln, groups, *rest in shapes:
+    resid = bool(rest and rest[0])
     x = (torch.randn(M, K, generator=g)).to(DEV, torch.float16)
     n = len(groups) if groups else 1
     pws = []
@@ -56,11 +65,13 @@ for M, K, N, geglu, ln, groups in shapes:
             pws.append(ops.pack_weight(w, b, torch.float16, DEV, geglu=geglu))
     pw = pws if groups else pws[0]
     kw = dict(group_n=groups) if groups else {}
+    if resid:
+        kw["residual"] = torch.randn(M, N, generator=g).to(DEV, torch.float16)
     res = {}
     for name, on in (("xs", True), ("tiled", False)):
         ops.XS_ENABLED = on
         res[name] = bench(lambda: ops.linear(x, pw, **kw))
     ops.XS_ENABLED = True
     fl = 2.0 * M * K * N
-    print(f"M={M} K={K} N={N} geglu={geglu} ln={ln} grouped={bool(groups)}: xs {res['xs']:.1f} us ({fl / res['xs'] / 1e6:.0f} TF)  "
+    print(f"M={M} K={K} N={N} geglu={geglu} ln={ln} res={resid} grouped={bool(groups)}: xs {res['xs']:.1f} us ({fl / res['xs'] / 1e6:.0f} TF)  "
           f"tiled {res['tiled']:.1f} us ({fl / res['tiled'] / 1e6:.0f} TF)  ratio {res['tiled'] / res['xs']:.2f}", flush=True)
