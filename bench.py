@@ -120,6 +120,7 @@ class _FakePipeline:
     def __init__(self, ucfg, vcfg):
         self.res = ucfg.sample_size * vcfg.scale
         self.use_graph = False
+        self.collect_timing, self.timing = False, {}
 
     def __call__(self, latents=None, **kw):
         import types
@@ -341,13 +342,14 @@ def cpu_baseline_and_parity(pipe, ws, ucfg, B, steps_total, tiny):
     return base, parity
 
 
-def call_phases(pipe, one):
+def call_phases(pipe, one, sync=None):
     """HIP-event times of the phases of ONE pipeline call (pipeline.collect_timing): condition embedding / per-call preparation /
-    the denoising loop / VAE decode + post-processing.  One extra call after the timed region (events + a device sync per call)."""
+    the denoising loop / VAE decode + post-processing.  One extra call after the timed region (events + a device sync per call).
+    `one` must be rank-local: no collective."""
     pipe.collect_timing = True
     try:
         one()
-        torch.cuda.synchronize()
+        (sync or torch.cuda.synchronize)()
         t = dict(getattr(pipe, "timing", {}) or {})
     finally:
         pipe.collect_timing = False
@@ -547,10 +549,12 @@ def main(argv=None):
 
     out = {}
 
+    def run_local():
+        return pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image=imgs, latents=lat, guidance_scale=7.5,
+                    num_inference_steps=args.ddim_steps, output_type="pt", cond_noise=cn)
+
     def one():
-        r = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image=imgs, latents=lat, guidance_scale=7.5,
-                 num_inference_steps=args.ddim_steps, output_type="pt", cond_noise=cn)
-        out["img"] = gather_images(r.images, world)          # the single RCCL gather of the path
+        out["img"] = gather_images(run_local().images, world)          # the single RCCL gather of the path
 
     def sync():
         if not fake:
@@ -609,8 +613,12 @@ def main(argv=None):
                                  "expected": [round(float(make_inputs(ucfg, vcfg, 1, device, 42, j)[0].mean()), 6) for j in range(world * B)]}
         if clock is not None:
             line["clock"] = dict(clock, source="rocm-smi --showclocks --showpower polled during the timed region (medians); peak clock 2400 MHz")
+        if args.steps:
+            # `run_local`, not `one`: everything from here on runs on rank 0 ALONE - a collective here waits for ranks that are already
+            # at the closing barrier (found by the two-rank rehearsal on a GPU box; the CPU rehearsal takes this path too)
+            phases = call_phases(pipe, run_local, sync)
         if not fake and args.steps:
-            line["phases_ms"] = dict(call_phases(pipe, one), how="HIP events at the phase boundaries of ONE extra pipeline call after "
+            line["phases_ms"] = dict(phases, how="HIP events at the phase boundaries of ONE extra pipeline call after "
                                      "the timed region: condition embedding / per-call preparation / denoising loop / VAE decode + post-processing")
         if not args.no_roofline:
             # enough replays of the step's GEMM launch list for the clock sampler to see the sustained state (~1.5 s)
