@@ -118,7 +118,6 @@ class Resnet:
     def __call__(self, x, tproj, x2=None):
         h = ops.group_norm(x, self.n1[0], self.n1[1], self.groups, self.eps, True, x2=x2)
         temb = None if self.temb_off is None else tproj[:, self.temb_off:]
-        # a split-K conv1 leaves its partial slabs for norm2 to sum (one-launch GroupNorm geometries only)
         # (gn_groups: the launch's epilogue hands the GroupNorm statistics of its output over to the GroupNorm that reads it -
         #  norm2 here, the next block's norm1 / Transformer2DModel.norm for the block's output; ops.GN_HANDOVER)
         h = ops.conv_gemm(h, self.conv1, temb=temb, gn_groups=self.groups)
