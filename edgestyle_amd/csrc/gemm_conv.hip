@@ -41,6 +41,8 @@
 int es_conv_gemm8p_launch(const es_gemm_desc& d, hipStream_t st);   // gemm_conv8p.hip: the 256 x 320 | 256 x 256 phase-interleaved tile
 bool es_conv_gemm8p_takes(const es_gemm_desc& d);                    // ... and whether its epilogue has the form this launch needs
 
+unsigned long long es_operand_limit_v = 0x7FFFFFFFull;   // bytes one activation operand of a launch may span (32-bit buffer offsets)
+
 namespace {
 
 constexpr int BK = 64;
@@ -1031,9 +1033,88 @@ int launch(const es_gemm_desc& d0, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// ---- launches whose operands outgrow the kernels' 32-bit buffer offsets -------------------------------------------------------
+// The kernels address activations, tail sources and outputs through buffer resources with 32-bit byte offsets (2 GiB each).  At 512 x 512
+// that is 11 try-ons per launch (the batched VAE encode of the conditions first, then the level-0 feed-forward); an MI355X holds far more.
+// Such a launch is run as several ordinary launches over runs of whole samples - per weight group first, then as many samples as fit -
+// each with its operand pointers moved to its first sample: every tile of a sub-launch computes exactly what it would have computed in
+// the whole launch (the tiles of a launch never interact), so nothing about the results depends on where the cuts fall.
+#define ES_OPERAND_LIMIT es_operand_limit_v            /* 0x7FFFFFFF; tests lower it (es_set_operand_limit) to cut small launches */
+
+unsigned long long sample_bytes(const es_gemm_desc& d) {          // of the widest activation operand, per sample
+  const unsigned long long cs = d.act == ES_ACT_GEGLU ? d.Cout / 2 : d.Cout;
+  unsigned long long b = d.x_nmod ? 0ull : (unsigned long long)d.Hsrc * d.Wsrc * (d.C1 > d.C2 ? d.C1 : d.C2) * 2;
+  const unsigned long long o = (unsigned long long)d.Hout * d.Wout * cs * 2;
+  b = b > o ? b : o;
+  if (d.t1) { const unsigned long long t = (unsigned long long)d.Hout * d.Wout * (d.Ct1 > d.Ct2 ? d.Ct1 : d.Ct2) * 2; b = b > t ? b : t; }
+  return b;
+}
+
+bool oversize(const es_gemm_desc& d) {
+  if (sample_bytes(d) * (unsigned long long)d.N >= ES_OPERAND_LIMIT) return true;
+  if (d.x_nmod && (unsigned long long)d.x_nmod * d.Hsrc * d.Wsrc * d.C1 * 2 >= ES_OPERAND_LIMIT) return true;
+  return d.splitk > 1 && (long long)d.N * d.Hout * d.Wout * (d.rows_padded / 8) >= (1ll << 31);
+}
+
+int launch_in_chunks(const es_gemm_desc& d0, hipStream_t st, const char** why, bool dry) {      // dry: the checks alone
+  const long long hw = (long long)d0.Hout * d0.Wout;
+  const unsigned long long per = sample_bytes(d0);
+  if (d0.gn_part) { *why = "es_conv_gemm: a launch larger than 2 GiB per operand cannot hand GroupNorm statistics over (gn_part)"; return -1; }
+  if (d0.x_nmod && (unsigned long long)d0.x_nmod * d0.Hsrc * d0.Wsrc * d0.C1 * 2 >= ES_OPERAND_LIMIT) { *why = "es_conv_gemm: source larger than 2 GiB (32-bit buffer offsets)"; return -1; }
+  long long ns = (long long)((ES_OPERAND_LIMIT - 1) / (per ? per : 1));
+  if (d0.splitk > 1) { const long long cap = ((1ll << 31) - 1) / (hw * (d0.rows_padded / 8)); ns = ns < cap ? ns : cap; }
+  if (hw == 1 && ns >= 256) ns -= ns % 256;                          // linear layers: rows are the samples; cut between 256-row tiles
+  if (d0.x_nmod) ns -= ns % d0.x_nmod;
+  if (ns < 1) { *why = "es_conv_gemm: one sample's operands exceed 2 GiB (32-bit buffer offsets)"; return -1; }
+  const int ng = d0.ngroups > 1 ? d0.ngroups : 1;
+  const long long cs = d0.act == ES_ACT_GEGLU ? d0.Cout / 2 : d0.Cout;
+  long long g0 = 0;
+  for (int g = 0; g < ng; ++g) {
+    long long g1 = d0.N;
+    if (d0.ngroups > 1) {
+      const long long px = (long long)d0.mt_end[g] * 128;
+      if (px % hw) { *why = "es_conv_gemm: a grouped launch larger than 2 GiB per operand needs groups of whole samples"; return -1; }
+      g1 = px / hw;
+    }
+    if (d0.x_nmod && g0 % d0.x_nmod) { *why = "es_conv_gemm: a launch larger than 2 GiB per operand needs groups that start on a multiple of x_nmod"; return -1; }
+    for (long long n0 = g0; n0 < g1; n0 += ns) {
+      es_gemm_desc s = d0;
+      s.N = (int)((g1 - n0) < ns ? (g1 - n0) : ns);
+      if (d0.ngroups > 1) {
+        s.w = d0.w_g[g]; s.bias = d0.bias_g[g];
+        if (d0.ln_colsum) s.ln_colsum = d0.ln_colsum_g[g];
+      }
+      s.ngroups = 0;
+      for (int k = 0; k < 4; ++k) s.mt_end[k] = 0x7FFFFFFF;
+      auto adv = [](const void* p, long long bytes) -> const void* { return p ? (const void*)((const char*)p + bytes) : nullptr; };
+      const long long src_px = n0 * d0.Hsrc * d0.Wsrc, out_px = n0 * hw;
+      if (!d0.x_nmod) s.x = adv(d0.x, src_px * d0.C1 * 2);
+      s.x2 = adv(d0.x2, src_px * d0.C2 * 2);
+      s.t1 = adv(d0.t1, out_px * d0.Ct1 * 2);
+      s.t2 = adv(d0.t2, out_px * d0.Ct2 * 2);
+      s.temb = adv(d0.temb, n0 * d0.temb_stride * 2);
+      s.residual = adv(d0.residual, out_px * cs * 2);
+      s.residual_lo = adv(d0.residual_lo, out_px * cs * 2);
+      s.out = (void*)adv(d0.out, out_px * cs * 2);
+      s.out_lo = (void*)adv(d0.out_lo, out_px * cs * 2);
+      if (dry) continue;
+      const int rc = s.dtype == ES_F16 ? launch<f16>(s, st) : launch<bf16>(s, st);
+      if (rc) { *why = "es_conv_gemm: launch failed"; return rc; }
+    }
+    g0 = g1;
+  }
+  return 0;
+}
+
 }  // namespace
 
 extern "C" void es_set_error(const char* msg);
+
+extern "C" unsigned long long es_set_operand_limit(unsigned long long bytes) {
+  const unsigned long long prev = es_operand_limit_v;
+  es_operand_limit_v = bytes && bytes < 0x7FFFFFFFull ? bytes : 0x7FFFFFFFull;
+  return prev;
+}
 
 extern "C" size_t es_conv_gemm_workspace_bytes(const es_gemm_desc* d) {
   if (d->splitk <= 1) return 0;
@@ -1065,12 +1146,16 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
   if (d->Kpad % BK || d->Kpad < Ktrue) { es_set_error("es_conv_gemm: bad Kpad"); return -1; }
   if (d->C1 % 8 || d->C2 % 8 || (d->C2 && !d->x2)) { es_set_error("es_conv_gemm: channels must be multiples of 8"); return -1; }
   if (d->C2 && (d->C1 % BK || d->C2 % BK)) { es_set_error("es_conv_gemm: concatenated sources need C1, C2 multiples of 64"); return -1; }
-  if ((size_t)d->N * d->Hsrc * d->Wsrc * (d->C1 > d->C2 ? d->C1 : d->C2) * 2 >= 0x7FFFFFFFull ||
-      (size_t)d->rows_padded * d->Kpad * 2 >= 0x7FFFFFFFull) { es_set_error("es_conv_gemm: operand larger than 2 GiB (32-bit buffer offsets)"); return -1; }
+  if ((size_t)d->rows_padded * d->Kpad * 2 >= 0x7FFFFFFFull) { es_set_error("es_conv_gemm: weights larger than 2 GiB (32-bit buffer offsets)"); return -1; }
+  const bool chunked = oversize(*d);       // activations beyond the 32-bit buffer offsets: runs of whole samples, one launch each (launch_in_chunks)
+  if (chunked) {
+    const char* why = nullptr;
+    if (launch_in_chunks(*d, nullptr, &why, true)) { es_set_error(why); return -1; }
+  }
   if (d->ksize != 1 && d->ksize != 3) { es_set_error("es_conv_gemm: ksize must be 1 or 3"); return -1; }
   if (d->t1 && (d->stride != 1 || d->upsample || d->C1 % BK || d->C2 % BK || d->Ct1 % BK || d->Ct2 % BK || d->Ct1 < BK ||
                 (d->Ct2 && !d->t2) || d->ln_colsum || d->Hout != d->Hsrc || d->Wout != d->Wsrc ||
-                (size_t)d->N * d->Hout * d->Wout * (d->Ct1 > d->Ct2 ? d->Ct1 : d->Ct2) * 2 >= 0x7FFFFFFFull)) {
+                false)) {
     es_set_error("es_conv_gemm: 1x1 tail sources need stride 1, no upsample, same-size output, 64-aligned channels"); return -1; }
   if (!d->t1 && (d->t2 || d->Ct1 || d->Ct2)) { es_set_error("es_conv_gemm: tail fields set without t1"); return -1; }
   if (d->x_nmod < 0 || (d->x_nmod && (d->x2 || d->t1 || d->x_nmod > d->N))) { es_set_error("es_conv_gemm: x_nmod needs a single source and 0 < x_nmod <= N"); return -1; }
@@ -1087,7 +1172,6 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
     es_set_error("es_conv_gemm: korder 1 (chunk-major K) needs ksize 3 and 64-aligned C1, C2"); return -1; }
   if (d->splitk < 1 || d->splitk > d->Kpad / BK) { es_set_error("es_conv_gemm: bad splitk"); return -1; }
   if (d->splitk > 1 && (!d->workspace || d->act == ES_ACT_GEGLU)) { es_set_error("es_conv_gemm: splitk needs workspace and no GEGLU"); return -1; }
-  if (d->splitk > 1 && (long long)d->N * d->Hout * d->Wout * (d->rows_padded / 8) >= (1ll << 31)) { es_set_error("es_conv_gemm: split-K output too large for 32-bit indices"); return -1; }
   if (d->act == ES_ACT_GEGLU && ((d->bn != 128 && d->bn != 256) || d->Cout % 32)) { es_set_error("es_conv_gemm: GEGLU needs bn=128 | 256, Cout%32==0"); return -1; }
   if (d->N < 1 || d->Hout < 1 || d->Wout < 1) { es_set_error("es_conv_gemm: empty problem"); return -1; }
   if (d->stages != 0 && (d->stages < 2 || d->stages > 4)) { es_set_error("es_conv_gemm: stages must be 0 (auto), 2, 3 or 4"); return -1; }
@@ -1107,6 +1191,12 @@ extern "C" int es_conv_gemm(const es_gemm_desc* d, void* stream) {
   // (a caller's zero-initialised table sent every tile of a TWO-group launch to groups 1..3: null weights, GPU fault)
   es_gemm_desc dd = *d;
   for (int g = dd.ngroups > 1 ? dd.ngroups : 0; g < 4; ++g) dd.mt_end[g] = 0x7FFFFFFF;
+  if (chunked) {
+    const char* why = "es_conv_gemm: launch failed";
+    const int rc = launch_in_chunks(*d, st, &why, false);
+    if (rc) es_set_error(why);
+    return rc;
+  }
   int rc = dd.dtype == ES_F16 ? launch<f16>(dd, st) : launch<bf16>(dd, st);
   if (rc) es_set_error("es_conv_gemm: launch failed");
   return rc;

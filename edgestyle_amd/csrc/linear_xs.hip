@@ -488,6 +488,8 @@ int launch(const es_xs_desc& d, hipStream_t st) {
 
 extern "C" void es_set_error(const char* msg);
 
+extern unsigned long long es_operand_limit_v;          // gemm_conv.hip: 0x7FFFFFFF unless a test lowered it
+
 extern "C" int es_linear_xs_set_pp(int on) { const int prev = xs_pp; xs_pp = on; return prev; }
 
 extern "C" int es_linear_xs(const es_xs_desc* d, void* stream) {
@@ -503,9 +505,9 @@ extern "C" int es_linear_xs(const es_xs_desc* d, void* stream) {
     es_set_error("es_linear_xs: slices must cover Cout in whole output lines, none empty"); return -1; }
   const int cstore = d->geglu ? d->Cout / 2 : d->Cout;
   if (d->ldo < cstore || d->ldo % 8) { es_set_error("es_linear_xs: bad output pitch"); return -1; }
-  if ((size_t)d->M * d->K * 2 >= 0x7FFFFFFFull || (size_t)d->rows_padded * d->K * 2 >= 0x7FFFFFFFull ||
-      ((size_t)d->M + 256) * d->ldo * 2 >= 0xFFFFFF00ull) {
-    es_set_error("es_linear_xs: operand larger than 2 GiB (32-bit buffer offsets)"); return -1; }
+  if ((size_t)d->rows_padded * d->K * 2 >= 0x7FFFFFFFull) { es_set_error("es_linear_xs: weights larger than 2 GiB (32-bit buffer offsets)"); return -1; }
+  // activations / outputs beyond the kernel's 32-bit buffer offsets: runs of whole 256-row blocks, one launch each (below)
+  const bool chunked = (size_t)d->M * d->K * 2 >= es_operand_limit_v || ((size_t)d->M + 256) * d->ldo * 2 >= es_operand_limit_v;
   if (d->ngroups > 4) { es_set_error("es_linear_xs: at most 4 groups"); return -1; }
   if (d->residual && (d->K != 320 || d->geglu || d->ln)) { es_set_error("es_linear_xs: a residual needs K = 320, no GEGLU, no LayerNorm fold (rows of ldo elements, like out)"); return -1; }
   es_xs_desc dd = *d;
@@ -518,7 +520,33 @@ extern "C" int es_linear_xs(const es_xs_desc* d, void* stream) {
   }
   for (int g = dd.ngroups > 1 ? dd.ngroups : 0; g < 4; ++g) dd.mt_end[g] = 0x7FFFFFFF;
   ES_PLAN_RECORD(ES_OP_LINEAR_XS, d, sizeof(*d));
-  int rc = dd.dtype == ES_F16 ? launch<f16>(dd, (hipStream_t)stream) : launch<bf16>(dd, (hipStream_t)stream);
+  int rc = 0;
+  if (chunked) {
+    // (like es_conv_gemm's launch_in_chunks: the row blocks of a launch never interact, so the cuts change nothing in the results)
+    const size_t wide = (size_t)(d->K > d->ldo ? d->K : d->ldo) * 2;
+    long long rows = es_operand_limit_v > 512 * wide ? (long long)((es_operand_limit_v - 256 * wide - 1) / wide) : 256;
+    rows -= rows % 256;
+    if (rows < 256) rows = 256;
+    const int ng = d->ngroups > 1 ? d->ngroups : 1;
+    long long r0 = 0;
+    for (int g = 0; g < ng && !rc; ++g) {
+      const long long r1 = d->ngroups > 1 && g + 1 < ng ? (long long)d->mt_end[g] * 128 : d->M;
+      for (long long a = r0; a < r1 && !rc; a += rows) {
+        es_xs_desc s = *d;
+        s.M = (int)(r1 - a < rows ? r1 - a : rows);
+        if (d->ngroups > 1) { s.w = d->w_g[g]; s.bias = d->bias_g[g]; }
+        s.ngroups = 0;
+        for (int k = 0; k < 4; ++k) s.mt_end[k] = 0x7FFFFFFF;
+        s.x = (const char*)d->x + (size_t)a * d->K * 2;
+        s.out = (char*)d->out + (size_t)a * d->ldo * 2;
+        if (d->residual) s.residual = (const char*)d->residual + (size_t)a * d->ldo * 2;
+        rc = s.dtype == ES_F16 ? launch<f16>(s, (hipStream_t)stream) : launch<bf16>(s, (hipStream_t)stream);
+      }
+      r0 = r1;
+    }
+  } else {
+    rc = dd.dtype == ES_F16 ? launch<f16>(dd, (hipStream_t)stream) : launch<bf16>(dd, (hipStream_t)stream);
+  }
   if (rc) es_set_error("es_linear_xs: launch failed");
   return rc;
 }

@@ -139,6 +139,7 @@ class ModelConfig(C.Structure):     # es_model_config
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
 SYMBOLS = {
     "es_abi_version": (C.c_int, []),
+    "es_set_operand_limit": (C.c_ulonglong, [C.c_ulonglong]),
     "es_last_error": (C.c_char_p, []),
     "es_sizeof_desc": (C.c_size_t, [_I]),
     "es_conv_gemm": (C.c_int, [C.POINTER(GemmDesc), _P]),

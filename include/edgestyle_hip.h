@@ -126,6 +126,11 @@ typedef struct {
   int32_t gn_groups;
 } es_gemm_desc;
 int es_conv_gemm(const es_gemm_desc* d, void* stream);
+/* The kernels address each activation operand (sources, tail sources, output) through 32-bit buffer offsets: 2 GiB.  A launch whose
+ * operands are larger is run by es_conv_gemm / es_linear_xs as several launches over runs of whole samples (per weight group, then as
+ * many samples as fit), each with its operand pointers moved to its first sample - the tiles of a launch never interact, so the results
+ * do not depend on the cuts.  Test knob: lower the limit so that small launches are cut (0 restores 2 GiB); returns the previous value. */
+unsigned long long es_set_operand_limit(unsigned long long bytes);
 size_t es_conv_gemm_workspace_bytes(const es_gemm_desc* d);
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -1187,3 +1187,72 @@ def test_group_norm_hand_over_does_not_depend_on_the_tile_or_the_grouping():
         assert torch.allclose(a.sum(2), b.sum(2), rtol=2e-6, atol=1e-4)
     assert torch.equal(grp, torch.cat(sep)) and torch.equal(grp._gnp[0], torch.cat([s._gnp[0] for s in sep]))
     assert torch.equal(n_grp, n_sep)
+
+
+def test_oversize_launches_are_cut_into_runs_of_whole_samples():
+    """es_conv_gemm / es_linear_xs run a launch whose operands outgrow the kernels' 32-bit buffer offsets (2 GiB: 12+ try-ons per
+    call at 512 x 512) as several launches over runs of whole samples.  With the limit lowered (es_set_operand_limit) small launches
+    are cut the same way: bit-identical to the uncut launch - grouped 3x3 with temb + residual, split-K, stride 2, nearest-2x
+    upsample, 1x1 tail sources, a GEGLU linear layer with the LayerNorm fold over rows, linear_xs grouped / with a residual,
+    and a source shared modulo x_nmod."""
+    from edgestyle_amd import ops, lib
+    L = lib.load()
+    g = torch.Generator().manual_seed(2024)
+    counts, H, C, Cout = [2, 6, 4, 2], 8, 64, 128
+    N = sum(counts)
+    x = torch.randn(N, H, H, C, generator=g).to(DEV, torch.float16)
+    x2 = torch.randn(N, H, H, C, generator=g).to(DEV, torch.float16)
+    res = torch.randn(N, H, H, Cout, generator=g).to(DEV, torch.float16)
+    temb = torch.randn(N, 256, generator=g).to(DEV, torch.float16)
+    pws = [ops.pack_weight(torch.randn(Cout, C, 3, 3, generator=g) / 24, torch.randn(Cout, generator=g) * 0.1, torch.float16, DEV) for _ in counts]
+    pw2 = ops.pack_weight(torch.randn(Cout, 2 * C, 3, 3, generator=g) / 34, torch.randn(Cout, generator=g) * 0.1, torch.float16, DEV)
+    pwt = ops.pack_weight_tail(torch.randn(Cout, C, 3, 3, generator=g) / 24, torch.randn(Cout, 2 * C, 1, 1, generator=g) / 11,
+                               torch.randn(Cout, generator=g) * 0.1, torch.float16, DEV)
+    M, K = 2048, 1280
+    tok = torch.randn(M, K, generator=g).to(DEV, torch.float16)
+    pwl = ops.pack_weight_ln(torch.randn(512, K, generator=g) / 36, torch.randn(512, generator=g) * 0.1, 1 + 0.1 * torch.randn(K, generator=g),
+                             0.1 * torch.randn(K, generator=g), 1e-5, torch.float16, DEV, geglu=True)
+    ehs = torch.randn(2, 77, 768, generator=g).to(DEV, torch.float16)
+    pkv = ops.pack_weight(torch.randn(640, 768, generator=g) / 28, None, torch.float16, DEV)
+    Mx = 4096
+    xs_x = torch.randn(Mx, 320, generator=g).to(DEV, torch.float16)
+    xs_r = torch.randn(Mx, 320, generator=g).to(DEV, torch.float16)
+    xs_ln = [ops.pack_weight_ln(torch.randn(960, 320, generator=g) / 18, torch.randn(960, generator=g) * 0.1, 1 + 0.1 * torch.randn(320, generator=g),
+                                0.1 * torch.randn(320, generator=g), 1e-5, torch.float16, DEV) for _ in range(2)]
+    xs_o = ops.pack_weight(torch.randn(320, 320, generator=g) / 18, torch.randn(320, generator=g) * 0.1, torch.float16, DEV)
+
+    def run():
+        outs = [ops.conv_gemm(x, pws, temb=temb[:, 64:], residual=res, group_n=counts),
+                ops.conv_gemm(x, pw2, x2=x2, splitk=3),
+                ops.conv_gemm(x, pws[0], stride=2),
+                ops.conv_gemm(x[:, :4, :4].contiguous(), pws[1], upsample=True),
+                ops.conv_gemm(x, pwt, tail=(x, x2)),
+                ops.linear(tok, pwl)]
+        old = ops.XS_MIN_M
+        ops.XS_MIN_M = 0
+        try:
+            outs.append(ops.linear(xs_x, xs_ln, group_n=[1024, 3072]))
+            outs.append(ops.linear(xs_x, xs_o, residual=xs_r))
+        finally:
+            ops.XS_MIN_M = old
+        torch.cuda.synchronize()
+        return outs
+    whole = run()
+    prev = L.es_set_operand_limit(3 * H * H * Cout * 2 + 1)         # three samples of the 8 x 8 x 128 tensors; 96 rows of the linear layers
+    try:
+        assert prev == 0x7FFFFFFF
+        cut = run()
+    finally:
+        L.es_set_operand_limit(0)
+    for i, (a, b) in enumerate(zip(whole, cut)):
+        assert torch.equal(a, b), i
+    # a source shared modulo x_nmod (the text states of a weight-sharing group) is cut at multiples of x_nmod ...
+    whole = ops.linear(ehs, pkv, x_rep=3)
+    L.es_set_operand_limit(200 * 640 * 2)
+    try:
+        assert torch.equal(ops.linear(ehs, pkv, x_rep=3), whole)
+        L.es_set_operand_limit(100 * 640 * 2)
+        with pytest.raises(Exception, match="exceed"):        # ... and says so when not even one period fits
+            ops.linear(ehs, pkv, x_rep=3)
+    finally:
+        L.es_set_operand_limit(0)
