@@ -490,11 +490,10 @@ def main(argv=None):
                     help="skip the extra 768x768 bf16 batch-4 (BASELINE configs[4]) measurement")
     ap.add_argument("--no-throughput-mode", action="store_true",
                     help="skip the extra batch-8 (BASELINE configs[2]) measurement reported beside the headline value")
-    ap.add_argument("--throughput-sweep", default="",
-                    help="more batch sizes measured beside configs[2] (2 timed calls each, comma-separated, e.g. \"10\"; default: none).  "
-                         "One call holds about ten try-ons at most: the lockstep encoder pass has 14 samples per try-on and every operand "
-                         "of a launch must stay below the 2 GiB that 32-bit buffer offsets address (batch 12 and 16 are refused by "
-                         "es_conv_gemm's operand check; a service batches above that by splitting the call, edgestyle_amd/serve.py max_batch)")
+    ap.add_argument("--throughput-sweep", default="16",
+                    help="more batch sizes measured beside configs[2] (2 timed calls each, comma-separated; \"\": none).  Above 11 try-ons "
+                         "per call some operands outgrow the kernels' 32-bit buffer offsets (2 GiB); es_conv_gemm / es_linear_xs run those "
+                         "launches as runs of whole samples (include/edgestyle_hip.h, es_set_operand_limit)")
     ap.add_argument("--no-native-abi", action="store_true",
                     help="skip the extra leg that serves the same request through the C ABI alone (es_load_weights context)")
     ap.add_argument("--native-graphs", type=int, default=2, choices=(0, 1, 2),

@@ -184,6 +184,34 @@ def test_batch8_graph_matches_batch1_requests(full):
     assert p_gold >= 40.0, p_gold
 
 
+def test_batch16_operands_beyond_2gib_match_batch1_requests(full):
+    """16 try-ons per call at 512 x 512: the batched VAE encode of the conditions (48 samples of 128 ch @ 512 x 512 = 3.2 GB) and the
+    level-0 feed-forward input (2.35 GB) outgrow the kernels' 32-bit buffer offsets; es_conv_gemm / es_linear_xs then run such a
+    launch as runs of whole samples (tests/test_ops_gpu.py checks the cuts bit for bit at small sizes).  Here: the first and the
+    last image of the batch against the same requests served alone (RGB conditions, per-image seeds as in bench.py)."""
+    import bench
+    pipe, ucfg, vcfg = full["pipe"], full["ucfg"], full["vcfg"]
+    for net in pipe.controlnet.nets:
+        if getattr(net.config, "uses_vae", False):
+            net.set_autoencoder(pipe.vae)
+    B = 16
+    lat, pe, ne, imgs, cn = bench.make_inputs(ucfg, vcfg, B, torch.device(DEV), seed=42)
+    img16 = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, image=imgs, latents=lat, guidance_scale=7.5, num_inference_steps=2,
+                 output_type="pt", cond_noise=cn).images.float().cpu()
+    assert img16.shape == (B, 3, 512, 512) and bool(torch.isfinite(img16).all())
+    ps = []
+    for j in (0, B - 1):
+        l1, p1, n1, im1, c1 = bench.make_inputs(ucfg, vcfg, 1, torch.device(DEV), seed=42, first_index=j)
+        img1 = pipe(prompt_embeds=p1, negative_prompt_embeds=n1, image=im1, latents=l1, guidance_scale=7.5, num_inference_steps=2,
+                    output_type="pt", cond_noise=c1).images.float().cpu()
+        ps.append(H.psnr(img16[j:j + 1], img1))
+    for k in [k for k in pipe._loops if k[0] == B]:
+        del pipe._loops[k]                                   # that batch size's graphs and buffers
+    torch.cuda.empty_cache()
+    record("batch16_vs_batch1", psnr=[round(p, 2) for p in ps])
+    assert min(ps) >= 45.0, ps
+
+
 @pytest.fixture(scope="module")
 def full96(full):
     """BASELINE configs[4] geometry: SD1.5 width, 96x96 latents (768x768 images), bf16.  Weights are the `full` fixture's,
