@@ -296,6 +296,28 @@ extern "C" int es_vae_sample(const void* moments, const float* noise_nchw, void*
   ES_RET("es_vae_sample");
 }
 
+// One wave that does nothing but watch two counters for `ticks` of the 100 MHz real-time counter: shader cycles (s_memtime) over real time
+// = the clock the chip holds while whatever runs beside it (another stream) runs.  It sleeps between looks (s_sleep: no issue slots
+// taken from its CU's other waves) and every wave reaches the exit: the real-time counter only moves forward.
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out, const unsigned long long ticks) {
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+  unsigned long long r = r0;
+  while (r - r0 < ticks) {
+    __builtin_amdgcn_s_sleep(64);
+    r = __builtin_amdgcn_s_memrealtime();
+  }
+  const unsigned long long c = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) { out[0] = c - c0; out[1] = r - r0; }
+}
+
+extern "C" int es_clock_probe(unsigned long long* out2, unsigned int duration_us, void* stream) {
+  if (!out2 || duration_us < 1 || duration_us > 30000000u) { es_set_error("es_clock_probe: out2 = device u64[2], 1 us ... 30 s"); return -1; }
+  if (es_plan_recording()) { es_set_error("es_clock_probe: a measurement tool, not part of a plan"); return -1; }
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out2, (unsigned long long)duration_us * 100ull);
+  ES_RET("es_clock_probe");
+}
+
 extern "C" int es_incr(int32_t* ctr, void* stream) {
   if (!ctr) { es_set_error("es_incr: null pointer"); return -1; }
   if (es_plan_recording()) { const es_op_incr a{ctr}; es_plan_record(ES_OP_INCR, &a, sizeof(a)); ES_PLAN_DRY_RETURN(); }

@@ -119,7 +119,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm8p_kernel(const es_gemm_desc 
 #if ES8P_STAMPS
   const int sblk = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 1 : (blockIdx.x == gridDim.x / 2 ? 2 : -1));
   auto stamp = [&](int k) __attribute__((always_inline)) {
-    if (p.prof && sblk >= 0 && tid == 0) p.prof[256 + sblk * 8 + k] = __builtin_amdgcn_s_memtime();
+    if (p.prof && sblk >= 0 && tid == 0) {
+      p.prof[256 + sblk * 8 + k] = __builtin_amdgcn_s_memtime();
+      if (k == 0 || k == 7) p.prof[288 + sblk * 2 + (k ? 1 : 0)] = __builtin_amdgcn_s_memrealtime();      // 100 MHz: cycles / ticks = the clock the workgroup ran at
+    }
   };
   stamp(0);
 #else

@@ -163,6 +163,7 @@ SYMBOLS = {
     "es_add": (C.c_int, [_P, _P, _P, _L, _I, _P]),
     "es_vae_sample": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "es_incr": (C.c_int, [_P, _P]),
+    "es_clock_probe": (C.c_int, [_P, C.c_uint, _P]),
     "es_gather_row": (C.c_int, [_P, _P, _P, _I, _I, _P]),
     "es_layer_norm_grouped": (C.c_int, [C.POINTER(LnDesc), _P]),
     "es_latents_to_input": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

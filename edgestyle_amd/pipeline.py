@@ -686,8 +686,8 @@ class StableDiffusionControlNetPipeline:
         gemm_replay_iters > 0 additionally times the SAME launch list as the production kernels run it (no stamp
         atomics): only the es_conv_gemm launches (with their split-K reduces), captured as one graph and replayed that
         many times between two HIP events on the launching stream; the average per replay lands in
-        `self.last_gemm_replay_ms`.  `around_replay` = (start, stop): called right before / after that event-timed
-        region (bench.py samples the sustained clock and package power there)."""
+        `self.last_gemm_replay_ms`.  `around_replay` = (start(expected_ms), stop()): called right before / after that event-timed
+        region (bench.py samples the sustained clock and package power there; expected_ms from three warm-up replays)."""
         if not self._loops:
             raise EdgeStyleHipError("run the pipeline once before profiling")
         loop = self._last_loop or list(self._loops.values())[-1]
@@ -713,28 +713,31 @@ class StableDiffusionControlNetPipeline:
         res = prof.results()
         self.last_gemm_replay_ms = self.last_conv3_replay_ms = None
         if gemm_replay_iters > 0:
-            def timed(only):
+            def timed(only, hooks=None):
                 prof.replay_gemms(only)      # eager once (same workspace sizes as the step: nothing grows)
                 torch.cuda.synchronize()
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2):
                     prof.replay_gemms(only)
-                for _ in range(3):
-                    g2.replay()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for _ in range(gemm_replay_iters):
+                for _ in range(3):
                     g2.replay()
                 e1.record()
                 torch.cuda.synchronize()
+                if hooks is not None:
+                    hooks[0](e0.elapsed_time(e1) / 3 * gemm_replay_iters)      # the expected length of the timed region, ms
+                try:
+                    e0.record()
+                    for _ in range(gemm_replay_iters):
+                        g2.replay()
+                    e1.record()
+                    torch.cuda.synchronize()
+                finally:
+                    if hooks is not None:
+                        hooks[1]()
                 return e0.elapsed_time(e1) / gemm_replay_iters
-            if around_replay is not None:
-                around_replay[0]()
-            try:
-                self.last_gemm_replay_ms = timed(0)
-            finally:
-                if around_replay is not None:
-                    around_replay[1]()
+            self.last_gemm_replay_ms = timed(0, around_replay)
             self.last_conv3_replay_ms = timed(3)     # the 3x3 convolutions alone (with their split-K reduces)
         loop.step_idx.zero_()
         del g
