@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
-ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "frac_at_sustained_clock", "sclk_in_kernel_mhz", "sclk_mhz", "power_w", "clock_samples", "traffic",
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "frac_at_sustained_clock", "sclk_mhz", "power_w", "clock_samples", "traffic",
                  "traffic_source", "mfma_util_pmc", "launches_per_step", "avg_launch_us", "gemm_time_per_step_ms", "conv3x3_only",
                  "families_stamped", "stamped", "how")
 
@@ -197,35 +197,6 @@ class ClockSampler:
                 "samples": len(sm)}
 
 
-class KernelClockProbe:
-    """The clock the chip holds WHILE a region runs, read on the chip: one wave on a side stream (es_clock_probe) counts shader cycles
-    against the 100 MHz real-time counter for the first ~70 % of the region's expected length.  rocm-smi's sclk (ClockSampler) is a
-    host-side sample of a fast-moving value: under the MFMA-dense kernels it reads 2.3 GHz where the workgroups themselves run at
-    1.8-1.9 (tools/clock_in_kernel.py, profiles/r05_clock_in_kernel.txt)."""
-    def __init__(self, device):
-        self.out = torch.zeros(2, dtype=torch.int64, device=device)
-        self.stream = torch.cuda.Stream(device=device)
-        self.launched = False
-
-    def start(self, expected_ms):
-        from edgestyle_amd import lib as L
-        us = int(max(200.0, min(expected_ms * 0.7 * 1e3, 25e6)))
-        self.out.zero_()
-        torch.cuda.synchronize()
-        try:
-            L.check(L.load().es_clock_probe(self.out.data_ptr(), us, self.stream.cuda_stream), "es_clock_probe")
-            self.launched = True
-        except Exception:
-            self.launched = False
-
-    def stop(self):
-        if not self.launched:
-            return None
-        self.stream.synchronize()
-        cyc, ticks = [int(v) for v in self.out.cpu()]
-        return round(cyc / ticks * 100.0, 0) if ticks > 0 else None
-
-
 def gemm_roofline(pipe, traffic_profile="r05_gemm_pmc_traffic_b1.json", replay_iters=20):
     """Price the implicit-GEMM kernel against the dense fp16 MFMA peak with ALGORITHMIC flops (2*M*Cout*k*k*Cin) over
     the es_conv_gemm launches of one captured denoising step (the unit replayed 50x per image = 96 % of the image's
@@ -236,18 +207,9 @@ def gemm_roofline(pipe, traffic_profile="r05_gemm_pmc_traffic_b1.json", replay_i
       * `replay`: the same launch list run by the production kernels (no stamps), GEMM launches only, captured as one
         graph and timed by HIP events around `replay_iters` replays on the launching stream - what rocprofv3's
         per-kernel average (profiles/) must agree with."""
-    sampler, probe, seen = ClockSampler(), KernelClockProbe(pipe.device), {}
-
-    def start(expected_ms):
-        probe.start(expected_ms)
-        sampler.start()
-
-    def stop():
-        sampler.stop()
-        seen["mhz"] = probe.stop()
-    res = pipe.profile_one_step(gemm_replay_iters=replay_iters, around_replay=(start, stop))
+    sampler = ClockSampler()
+    res = pipe.profile_one_step(gemm_replay_iters=replay_iters, around_replay=(lambda expected_ms: sampler.start(), sampler.stop))
     clk = sampler.summary()
-    clk["sclk_in_kernel_mhz"] = seen.get("mhz")
     tot_f = sum(m[0] for m, _ in res)
     tot_t = sum(t for _, t in res)
     f3 = sum(m[0] for m, _ in res if m[1] == 3)
@@ -323,14 +285,11 @@ def gemm_roofline(pipe, traffic_profile="r05_gemm_pmc_traffic_b1.json", replay_i
     # the ceiling the kernels actually ran under: the clock and package power held DURING the event-timed replays (`frac` itself
     # stays against the 2.4 GHz dense peak)
     out["sclk_mhz"], out["power_w"], out["clock_samples"] = clk["sclk_mhz"], clk["power_w"], clk["samples"]
-    # ... and the clock read ON the chip over the same replays (one wave on a side stream, shader cycles / 100 MHz ticks): what the
-    # fraction at the sustained clock is priced with when it is there - rocm-smi samples read high under the dense kernels
-    out["sclk_in_kernel_mhz"] = clk.get("sclk_in_kernel_mhz")
-    held = out["sclk_in_kernel_mhz"] or clk["sclk_mhz"]
-    out["frac_at_sustained_clock"] = round(out["achieved"] / (MFMA_PEAK_TFLOPS * held / 2400.0), 4) if held and out.get("achieved") else None
-    out["clock_source"] = ("sclk_in_kernel_mhz: es_clock_probe, one wave on a side stream counting shader cycles against the 100 MHz real-time counter over "
-                           "the first 70 % of the replays (frac_at_sustained_clock uses it); sclk_mhz / power_w: rocm-smi --showclocks --showpower polled "
-                           "over the same replays (medians); peak clock 2400 MHz")
+    out["frac_at_sustained_clock"] = (round(out["achieved"] / (MFMA_PEAK_TFLOPS * clk["sclk_mhz"] / 2400.0), 4)
+                                      if clk["sclk_mhz"] and out.get("achieved") else None)
+    # (checked against the chip's own counters: one idle wave beside the replays reads the same clock as rocm-smi; the workgroups of the
+    #  256 x 320 convolution tile themselves run at 1.79-1.90 GHz, single launch or back to back - profiles/r05_clock_in_kernel.txt)
+    out["clock_source"] = "rocm-smi --showclocks --showpower polled while the GEMM launch list replays (medians); peak clock 2400 MHz"
     # per family: the 3x3 convolutions against everything else (1x1 convolutions, linear layers, linear_xs), from the stamps
     fam = {}
     for (fl, k, _shp, _g), t in res:
@@ -609,26 +568,18 @@ def main(argv=None):
 
     # (the first call captures the step graph, the second - same configuration - the whole-loop graph: at least two
     #  untimed calls, so that no capture falls into the timed region whatever W was asked for)
-    t_warm = 0.0
     for i in range(max(args.warmup, 2) if args.steps else args.warmup):
-        t_warm = time.perf_counter()
         one()
         sync()
-        t_warm = time.perf_counter() - t_warm
         log(f"warmup {i} done")
     barrier()
     sampler = ClockSampler().start() if (rank == 0 and not fake) else None
-    probe = KernelClockProbe(device) if (rank == 0 and not fake and args.steps) else None
-    if probe is not None:
-        probe.start(t_warm * 1e3 * args.steps)          # one wave on a side stream: the clock the chip holds over the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one()
     barrier()
     dt = time.perf_counter() - t0
     clock = sampler.stop() if sampler is not None else None
-    if clock is not None and probe is not None:
-        clock["sclk_in_kernel_mhz"] = probe.stop()
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)       # MAX over ranks
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -662,8 +613,7 @@ def main(argv=None):
             line["rehearsal"] = {"gathered_image_means": [round(float(v), 6) for v in img[:, 0, 0, 0]],
                                  "expected": [round(float(make_inputs(ucfg, vcfg, 1, device, 42, j)[0].mean()), 6) for j in range(world * B)]}
         if clock is not None:
-            line["clock"] = dict(clock, source="sclk_in_kernel_mhz: es_clock_probe (one wave on a side stream, shader cycles / 100 MHz ticks over the first 70 % of the "
-                                                "timed region); sclk_mhz / power_w: rocm-smi --showclocks --showpower polled during the timed region (medians); peak clock 2400 MHz")
+            line["clock"] = dict(clock, source="rocm-smi --showclocks --showpower polled during the timed region (medians); peak clock 2400 MHz")
         if args.steps:
             # `run_local`, not `one`: everything from here on runs on rank 0 ALONE - a collective here waits for ranks that are already
             # at the closing barrier (found by the two-rank rehearsal on a GPU box; the CPU rehearsal takes this path too)

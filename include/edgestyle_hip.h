@@ -282,10 +282,11 @@ int es_vae_sample(const void* moments, const float* noise_nchw, void* z, int N, 
                   float scaling, int dtype, void* stream);
 /* dst (int32 device) += 1  — advances the step counter inside a captured graph */
 int es_incr(int32_t* ctr, void* stream);
-/* Measurement tool (bench.py `roofline.sclk_in_kernel_mhz`; no reference counterpart): ONE wave on `stream` watches the shader-cycle counter
- * against the 100 MHz real-time counter for duration_us and writes {shader cycles, 100 MHz ticks} to out2 (device u64[2]) - launched on a
- * side stream it reports the clock the chip holds while the work on the other streams runs (the package power limit, not the 2.4 GHz
- * the MFMA peak is quoted at, is what the dense kernels run under).  Never part of a plan. */
+/* Measurement tool (tools/clock_in_kernel.py; no reference counterpart): ONE wave on `stream` watches the shader-cycle counter against the
+ * 100 MHz real-time counter for duration_us and writes {shader cycles, 100 MHz ticks} to out2 (device u64[2]) - launched on a side
+ * stream it reports the clock the chip holds while the work on the other streams runs.  Not free: a resident wave keeps a workgroup of
+ * the one-per-CU kernels (256 x 320 tile, linear_xs) off its CU, so a launch of exactly 256 such workgroups takes two rounds beside it -
+ * which is why bench.py samples rocm-smi instead (same reading).  Never part of a plan. */
 int es_clock_probe(unsigned long long* out2, unsigned int duration_us, void* stream);
 /* out[0..row_len) = table[clamp(*idx, 0, nrows-1)][0..row_len) — selects this step's timestep / conditioning-scale row inside a
  * captured graph (PL:435, PL:464-470) so a replay needs no host-side scalar update */
