@@ -397,6 +397,7 @@ def plan_launch(M: int, pw: "PackedWeight", bn: int):
 XS_ENABLED = _os.environ.get("ES_XS", "1") == "1"      # row-stationary short-K linear kernel (csrc/linear_xs.hip)
 XS_RESIDUAL = _os.environ.get("ES_XS_RESIDUAL", "1") == "1"   # ... also for the K = 320 output projections that add a residual
 XS_TARGET_WGS = 256
+XS_FORCE_SLICES = 0
 XS_MIN_M = int(_os.environ.get("ES_XS_MIN_M", "8192"))   # 0: no size policy (tests exercise every shape)
 _zero_bias = {}
 
@@ -446,6 +447,8 @@ def linear_xs(x: torch.Tensor, pw, M: int, out: torch.Tensor, group_rows=None, r
     lines = total // pline
     rbs = (M + 255) // 256
     want = max(1, min(lines, XS_TARGET_WGS // rbs))
+    if XS_FORCE_SLICES:                                      # tool knob (tools/xs_slices_bench.py)
+        want = max(1, min(lines, XS_FORCE_SLICES))
     lps = -(-lines // want)                                  # lines per slice
     nslices = -(-lines // lps)
     d = L.XsDesc()
