@@ -1256,3 +1256,17 @@ def test_oversize_launches_are_cut_into_runs_of_whole_samples():
             ops.linear(ehs, pkv, x_rep=3)
     finally:
         L.es_set_operand_limit(0)
+
+
+def test_clock_probe_reads_a_plausible_shader_clock():
+    """es_clock_probe (measurement tool, tools/clock_in_kernel.py): one wave counts shader cycles against the 100 MHz real-time counter."""
+    from edgestyle_amd import lib
+    L = lib.load()
+    out = torch.zeros(2, dtype=torch.int64, device=DEV)
+    lib.check(L.es_clock_probe(out.data_ptr(), 2000, None), "es_clock_probe")        # 2 ms
+    torch.cuda.synchronize()
+    cyc, ticks = [int(v) for v in out.cpu()]
+    assert 200000 <= ticks <= 400000, ticks                                           # 2 ms of 100 MHz ticks (+ the last sleep)
+    assert 100.0 <= cyc / ticks * 100.0 <= 2600.0, (cyc, ticks)                       # MHz: between deep idle and the 2.4 GHz peak
+    with pytest.raises(Exception):
+        lib.check(L.es_clock_probe(None, 2000, None), "es_clock_probe")
