@@ -373,14 +373,18 @@ bool plan_gemm(long long M, int rows_padded, int kpad, bool geglu, const int* bn
 }
 
 constexpr int XS_TARGET_WGS = 256, XS_MIN_M = 8192;
-bool xs_shape_ok(long long M, int ksize, int kpad, int cin, int ctail, int cout, bool geglu) {
+bool xs_shape_fits(int ksize, int kpad, int cin, int ctail, int cout, bool geglu) {      // what the kernel can run at all
   if (ksize != 1 || (kpad != 320 && kpad != 640) || cin != kpad || ctail) return false;
   const int ch = kpad == 320 ? 64 : 32;
   const int line = ch * (128 / (geglu ? ch : 2 * ch));
-  if (cout % line || cout < 4 * line) return false;
+  return !(cout % line || cout < 4 * line);
+}
+bool xs_shape_ok(long long M, int ksize, int kpad, int cin, int ctail, int cout, bool geglu) {       // ... and where it wins
+  if (!xs_shape_fits(ksize, kpad, cin, ctail, cout, geglu)) return false;
   if (M < XS_MIN_M || (M < 4 * XS_MIN_M && cout < (kpad == 320 ? 960 : 1920))) return false;
   return true;
 }
+bool gn_fold_on() { static const bool on = [] { const char* e = getenv("ES_GN_FOLD"); return !e || std::string(e) == "1"; }(); return on; }
 int choose_bn(int cout) { return (cout % 160 == 0 && cout % 128 != 0) ? 160 : 128; }
 bool big_tile_256() { static const bool on = [] { const char* e = getenv("ES_BIG_TILE_256"); return !e || e[0] != '0'; }(); return on; }
 
@@ -436,6 +440,7 @@ struct Builder {
     if ((mode != "1" && mode != "all") || c % 8 || hw % 64 || c % groups || c / groups > 64) return false;
     return mode == "all" || !es_group_norm_is_slab((int)hw, c, groups);
   }
+  static bool gn_handover_on() { const char* e = getenv("ES_GN_HANDOVER"); const std::string m(e ? e : "0"); return m == "1" || m == "all"; }
   // ops.wide_stream: "auto" (default) = bf16 pipelines only
   bool wide_stream() const {
     static const std::string mode = [] { const char* e = getenv("ES_WIDE_STREAM"); return std::string(e ? e : "auto"); }();
@@ -586,7 +591,9 @@ struct Builder {
   // -- ops (edgestyle_amd/ops.py): descriptors handed to the C ABI, which validates and records them --------------------------
   static void ok(int rc, const char* what) { if (rc) fail(std::string(what) + ": " + es_last_error()); }
 
-  T linear_xs(const T& x, const PWs& pl, long long M, const T& out, const std::vector<long long>& group_rows, const T& residual = T()) {
+  struct GnFront { unsigned long long part = 0; std::vector<Norm> nl; int groups = 0, nchunk = 0, hw = 0; float eps = 0.f; };
+  T linear_xs(const T& x, const PWs& pl, long long M, const T& out, const std::vector<long long>& group_rows, const T& residual = T(),
+              const GnFront* gn = nullptr) {
     const PW* pw = pl[0];
     const int K = pw->kpad, ch = K == 320 ? 64 : 32;
     const int pline = 128 / (pw->geglu ? ch : 2 * ch);
@@ -607,6 +614,13 @@ struct Builder {
     d.geglu = pw->geglu; d.ln = pw->ln_colsum != 0; d.ln_eps = pw->ln_eps;
     d.nslices = nslices; d.chunks_per_slice = lps * pline; d.dtype = dt;
     if (residual) d.residual = residual.ptr();
+    if (gn) {
+      d.gn_part = (const float*)gn->part; d.gn_groups = gn->groups; d.gn_nchunk = gn->nchunk; d.gn_hw = gn->hw; d.gn_eps = gn->eps;
+      if (pl.size() > 1) {
+        if (gn->nl.size() != pl.size()) fail("grouped linear_xs: one GroupNorm parameter set per weight group");
+        for (size_t g = 0; g < pl.size(); ++g) { d.gn_gamma_g[g] = (const float*)gn->nl[g].g; d.gn_beta_g[g] = (const float*)gn->nl[g].b; }
+      } else { d.gn_gamma = (const float*)gn->nl[0].g; d.gn_beta = (const float*)gn->nl[0].b; }
+    }
     if (pl.size() > 1) {
       d.ngroups = (int)pl.size();
       long long acc = 0;
@@ -792,6 +806,46 @@ struct Builder {
     return out;
   }
   T group_norm(const T& x, const Norm& n, int groups, float eps, bool silu, const T& x2 = T()) { return group_norm(x, std::vector<Norm>{n}, groups, eps, silu, x2); }
+
+  // Transformer2DModel.norm -> proj_in (ops.gn_proj_in: the same rule, the same two launches): a statistics pass and the projection on
+  // es_linear_xs with the GroupNorm applied to the rows it holds in registers; elsewhere es_group_norm + es_conv_gemm as before
+  bool gn_fold_ok(long long M, long long hw, int groups, const PWs& pl, const std::vector<int>& group_n) const {
+    const PW* pw = pl[0];
+    if (!gn_fold_on() || gn_handover_on() || hw % 256 || groups > 32) return false;
+    if (pw->geglu || pw->ln_colsum || pw->kpad % groups || !xs_shape_fits(pw->ksize, pw->kpad, pw->cin, pw->ctail, pw->cout, pw->geglu)) return false;
+    if (M < (pw->kpad == 320 ? 8192 : 32768)) return false;
+    if (pl.size() > 1) {
+      if (pl.size() > 4) return false;
+      for (int n : group_n) if ((n * hw) % 256) return false;
+      for (const PW* q : pl)
+        if (q->rows_padded != pw->rows_padded || q->kpad != pw->kpad || q->cout != pw->cout || q->geglu != pw->geglu || q->ln_colsum) return false;
+    }
+    return true;
+  }
+  T gn_proj_in(const T& x, const std::vector<Norm>& nl, int groups, float eps, const PWs& pl, const std::vector<int>& group_n = {}) {
+    const int N = x.n;
+    const long long hw = x.hw(), M = (long long)N * hw;
+    const bool grouped = pl.size() > 1;
+    if (!(x.contig() && gn_fold_ok(M, hw, groups, pl, group_n))) {
+      CA g; g.group_n = group_n;
+      return conv_gemm(group_norm(x, nl, groups, eps, false, T(), group_n), pl, g);
+    }
+    auto key = std::make_pair(N, groups);
+    auto it = gn_partials.find(key);
+    if (it == gn_partials.end()) it = gn_partials.emplace(key, persistent(es_group_norm_partials_bytes(N, groups))).first;
+    es_gn_desc d;
+    memset(&d, 0, sizeof(d));
+    d.x = x.ptr(); d.partials = (float*)it->second;
+    d.N = N; d.HW = (int)hw; d.C1 = x.c; d.C2 = 0; d.groups = groups; d.eps = eps; d.silu = 0; d.dtype = dt; d.stats_only = 1;
+    ok(es_group_norm(&d, nullptr), "es_group_norm");
+    T out = empty(N, x.h, x.w, pl[0]->cout);
+    GnFront gn;
+    gn.part = it->second; gn.nl = nl; gn.groups = groups; gn.nchunk = es_group_norm_chunks((int)hw); gn.hw = (int)hw; gn.eps = eps;
+    std::vector<long long> rows;
+    if (grouped) for (int n : group_n) rows.push_back(n * hw);
+    linear_xs(x.view((int)M, 1, 1, x.c), pl, M, out.view((int)M, 1, 1, pl[0]->cout), rows, T(), &gn);
+    return out;
+  }
 
   T timestep_embedding(const T& t, int n, int dim) {
     T out = empty(n, 1, 1, dim);
@@ -1157,9 +1211,7 @@ struct Model {
     for (int n : counts) rows.push_back(n * H * Wd);
     std::vector<Norm> nl; PWs pin, qkv, o1, q2, o2, ff1, ffo;
     for (auto t : ts) { nl.push_back(t->norm); pin.push_back(t->proj_in); qkv.push_back(t->qkv_ln); o1.push_back(t->o1); q2.push_back(t->q2_ln); o2.push_back(t->o2); ff1.push_back(t->ff1_ln); ffo.push_back(t->ffo); }
-    T hh = B.group_norm(x, nl, t0->groups, 1e-6f, false, T(), counts);
-    CA g; g.group_n = counts;
-    T tok = B.conv_gemm(hh, pin, g).view(Nn, H * Wd, 1, C);
+    T tok = B.gn_proj_in(x, nl, t0->groups, 1e-6f, pin, counts).view(Nn, H * Wd, 1, C);
     CA gr; gr.group_n = rows;
     T q = B.linear(tok, qkv, gr);
     T a = B.attention(q.chan(0, C), q.chan(C, C), q.chan(2 * C, C), t0->heads);
@@ -1200,8 +1252,7 @@ struct Model {
   // one transformer of the UNet decoder (engine.Transformer.__call__, folded paths)
   T transformer(const Transformer& t, const T& x, const T& kv) {
     const int Nn = x.n, H = x.h, Wd = x.w, C = x.c;
-    T hh = B.group_norm(x, t.norm, t.groups, 1e-6f, false);
-    T tok = B.conv_gemm(hh, t.proj_in).view(Nn, H * Wd, 1, C);
+    T tok = B.gn_proj_in(x, std::vector<Norm>{t.norm}, t.groups, 1e-6f, PWs{t.proj_in}).view(Nn, H * Wd, 1, C);
     T q = B.linear(tok, t.qkv_ln);
     T a = B.attention(q.chan(0, C), q.chan(C, C), q.chan(2 * C, C), t.heads);
     CA r1; r1.residual = tok; r1.wide = true;

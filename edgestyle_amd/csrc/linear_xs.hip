@@ -53,7 +53,8 @@ constexpr int XS_LDS = XS_STAGES * XS_STAGE + 8 * 32 * XS_OROW;
 
 template <int N> ES_DEVICE void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int KC /* K / 32 */, bool GEGLU, bool LN, bool RES = false, bool PP = false /* two-barrier ping-pong (below) */>
+template <typename T, int KC /* K / 32 */, bool GEGLU, bool LN, bool RES = false, bool PP = false /* two-barrier ping-pong (below) */,
+          bool GN = false /* GroupNorm in front: es_xs_desc.gn_part */>
 __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
   constexpr int K = KC * 32;
   constexpr int NF = KC == 10 ? 4 : 2;          // 16-column fragments per stage
@@ -65,6 +66,7 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
   static_assert(KC == 10 || KC == 20, "K = 320 or 640");
   static_assert(!RES || (P == 1 && !GEGLU && !LN), "residual: K = 320, a full output line per stage (the attention / proj output layers)");
   static_assert(NF * 16 * K * 2 == XS_STAGE_W, "stage geometry");
+  static_assert(!GN || (!GEGLU && !LN && !RES), "GroupNorm in front: the plain projection (Transformer2DModel.norm -> proj_in)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -130,8 +132,66 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
       const unsigned off = row < p.M ? (unsigned)(((size_t)row * K + kc * 32 + fq * 8) * 2) : 0xFFFFFF00u;
       xr[rf][kc] = as_vec8<T>(__builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)off, 0, 0)));
     }
+  if constexpr (GN) {
+    // GroupNorm in front of the projection (Transformer2DModel.norm -> proj_in, eps 1e-6, no activation): x is the RAW tensor [N, hw, K]
+    // and es_group_norm(stats_only) has left the per-(sample, pixel chunk, group) sums of x and x^2 in gn_part.  A row block lies inside ONE
+    // sample (hw % 256 == 0): 16 threads per group fold the sample's chunks in a fixed order into (rstd, -mean * rstd), kept in the output
+    // staging area (nobody stages an output before the first barrier of the main loop); then every lane normalises the values it holds:
+    //   x' = x * (rstd_g * gamma_c) + (beta_c - mean_g * rstd_g * gamma_c)        rounded once to the compute dtype, like es_group_norm's output.
+    // One read of x instead of three passes over it (statistics, apply: read + write, projection: read).
+    float* gst = (float*)(smem + XS_STAGES * XS_STAGE);
+    const int n = (int)(((long long)rb * XS_ROWS) / p.gn_hw);
+    const int G = p.gn_groups, cpg = K / G;
+    const float inv_cnt = 1.0f / ((float)cpg * (float)p.gn_hw);
+    for (int g0 = 0; g0 < G; g0 += 32) {
+      const int g = g0 + (tid >> 4), l = tid & 15;
+      float s = 0.f, ss = 0.f;
+      if (g < G)
+        for (int ch = l; ch < p.gn_nchunk; ch += 16) {
+          const float* q = p.gn_part + (((size_t)n * p.gn_nchunk + ch) * G + g) * 2;
+          s += q[0]; ss += q[1];
+        }
+      s += dpp_mov<0xB1>(s); ss += dpp_mov<0xB1>(ss);          // the 16 lanes of a group are one DPP row: quad steps, then the mirrors
+      s += dpp_mov<0x4E>(s); ss += dpp_mov<0x4E>(ss);
+      s += dpp_mov<0x141>(s); ss += dpp_mov<0x141>(ss);
+      s += dpp_mov<0x140>(s); ss += dpp_mov<0x140>(ss);
+      if (g < G && l == 0) {
+        const float mean = s * inv_cnt;
+        float var = ss * inv_cnt - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        const float rstd = rsqrtf(var + p.gn_eps);
+        gst[g * 2] = rstd;
+        gst[g * 2 + 1] = -mean * rstd;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
   if (nch > 0) issue(c0, 0);
   if (nch > 1) issue(c0 + 1, 1);
+
+  if constexpr (GN) {
+    const float* gsel = p.ngroups > 1 ? p.gn_gamma_g[grp] : p.gn_gamma;
+    const float* bsel2 = p.ngroups > 1 ? p.gn_beta_g[grp] : p.gn_beta;
+    const float* gst = (const float*)(smem + XS_STAGES * XS_STAGE);
+    const int cpg = K / p.gn_groups;
+    const unsigned inv = (65536u + (unsigned)cpg - 1u) / (unsigned)cpg;          // c / cpg == (c * inv) >> 16 for c < 2^14
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      const int cb = kc * 32 + fq * 8;
+      const f32x4 g0v = *(const f32x4*)(gsel + cb), g1v = *(const f32x4*)(gsel + cb + 4);
+      const f32x4 b0v = *(const f32x4*)(bsel2 + cb), b1v = *(const f32x4*)(bsel2 + cb + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int g = (int)(((unsigned)(cb + e) * inv) >> 16);
+        const float gam = e < 4 ? g0v[e & 3] : g1v[e & 3], bet = e < 4 ? b0v[e & 3] : b1v[e & 3];
+        const float a = gst[g * 2] * gam, b = __builtin_fmaf(gst[g * 2 + 1], gam, bet);
+#pragma unroll
+        for (int rf = 0; rf < 2; ++rf) xr[rf][kc][e] = from_f32<T>(__builtin_fmaf(to_f32(xr[rf][kc][e]), a, b));
+      }
+      asm volatile("" : "+v"(xr[0][kc]), "+v"(xr[1][kc]));
+    }
+  }
 
   if constexpr (LN) {
     // LayerNorm statistics of each row from the registers (a row's K values sit in the four lanes frow, frow+16,
@@ -450,10 +510,10 @@ __global__ __launch_bounds__(512, 2) void linear_xs_kernel(const es_xs_desc p) {
 #endif
 }
 
-template <typename T, int KC, bool GEGLU, bool LN, bool RES = false, bool PP = false>
+template <typename T, int KC, bool GEGLU, bool LN, bool RES = false, bool PP = false, bool GN = false>
 int launch_one(const es_xs_desc& d, hipStream_t st) {
   const int rbs = (d.M + XS_ROWS - 1) / XS_ROWS;
-  auto kfn = linear_xs_kernel<T, KC, GEGLU, LN, RES, PP>;
+  auto kfn = linear_xs_kernel<T, KC, GEGLU, LN, RES, PP, GN>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, XS_LDS);
@@ -470,6 +530,8 @@ int xs_pp = [] { const char* e = getenv("ES_XS_PP"); return e ? atoi(e) : 1; }()
 template <typename T>
 int launch(const es_xs_desc& d, hipStream_t st) {
   const bool g = d.geglu != 0, ln = d.ln != 0;
+  if (d.gn_part)       // GroupNorm in front (checked by es_linear_xs: plain projection); the ping-pong form whatever es_linear_xs_set_pp says
+    return d.K == 320 ? launch_one<T, 10, false, false, false, true, true>(d, st) : launch_one<T, 20, false, false, false, true, true>(d, st);
   if (xs_pp && !g) {
     if (d.residual) return launch_one<T, 10, false, false, true, true>(d, st);
     if (d.K == 320) return ln ? launch_one<T, 10, false, true, false, true>(d, st) : launch_one<T, 10, false, false, false, true>(d, st);
@@ -509,6 +571,14 @@ extern "C" int es_linear_xs(const es_xs_desc* d, void* stream) {
   // activations / outputs beyond the kernel's 32-bit buffer offsets: runs of whole 256-row blocks, one launch each (below)
   const bool chunked = (size_t)d->M * d->K * 2 >= es_operand_limit_v || ((size_t)d->M + 256) * d->ldo * 2 >= es_operand_limit_v;
   if (d->ngroups > 4) { es_set_error("es_linear_xs: at most 4 groups"); return -1; }
+  if (d->gn_part) {
+    if (d->geglu || d->ln || d->residual) { es_set_error("es_linear_xs: GroupNorm in front (gn_part) needs the plain projection: no GEGLU, no LayerNorm fold, no residual"); return -1; }
+    if (d->gn_groups < 1 || d->gn_groups > 32 || d->K % d->gn_groups || d->gn_hw < 256 || d->gn_hw % 256 || d->M % d->gn_hw || d->gn_nchunk < 1 || d->gn_nchunk > 64) {
+      es_set_error("es_linear_xs: gn_part needs 1..32 groups dividing K, samples of a whole number of 256-row blocks covering M, 1..64 chunks"); return -1; }
+    if (d->ngroups <= 1 && (!d->gn_gamma || !d->gn_beta)) { es_set_error("es_linear_xs: gn_part without gn_gamma / gn_beta"); return -1; }
+    for (int g = 0; g < d->ngroups && d->ngroups > 1; ++g)
+      if (!d->gn_gamma_g[g] || !d->gn_beta_g[g]) { es_set_error("es_linear_xs: gn_part without gn_gamma_g / gn_beta_g for every group"); return -1; }
+  }
   if (d->residual && (d->K != 320 || d->geglu || d->ln)) { es_set_error("es_linear_xs: a residual needs K = 320, no GEGLU, no LayerNorm fold (rows of ldo elements, like out)"); return -1; }
   es_xs_desc dd = *d;
   if (d->ngroups > 1) {
@@ -527,6 +597,10 @@ extern "C" int es_linear_xs(const es_xs_desc* d, void* stream) {
     long long rows = es_operand_limit_v > 512 * wide ? (long long)((es_operand_limit_v - 256 * wide - 1) / wide) : 256;
     rows -= rows % 256;
     if (rows < 256) rows = 256;
+    if (d->gn_part) {                      // whole samples per cut: the statistics are per sample
+      if (rows < d->gn_hw) { es_set_error("es_linear_xs: one sample exceeds 2 GiB (32-bit buffer offsets)"); return -1; }
+      rows -= rows % d->gn_hw;
+    }
     const int ng = d->ngroups > 1 ? d->ngroups : 1;
     long long r0 = 0;
     for (int g = 0; g < ng && !rc; ++g) {
@@ -540,6 +614,10 @@ extern "C" int es_linear_xs(const es_xs_desc* d, void* stream) {
         s.x = (const char*)d->x + (size_t)a * d->K * 2;
         s.out = (char*)d->out + (size_t)a * d->ldo * 2;
         if (d->residual) s.residual = (const char*)d->residual + (size_t)a * d->ldo * 2;
+        if (d->gn_part) {
+          s.gn_part = d->gn_part + (size_t)(a / d->gn_hw) * d->gn_nchunk * d->gn_groups * 2;
+          if (d->ngroups > 1) { s.gn_gamma = d->gn_gamma_g[g]; s.gn_beta = d->gn_beta_g[g]; }
+        }
         rc = s.dtype == ES_F16 ? launch<f16>(s, (hipStream_t)stream) : launch<bf16>(s, (hipStream_t)stream);
       }
       r0 = r1;

@@ -416,7 +416,7 @@ int launch_gn(const es_gn_desc& d, hipStream_t st) {
   const int C = d.C1 + d.C2;
   int cpt = 0;
   static const bool slab_on = !(getenv("ES_GN_SLAB") && getenv("ES_GN_SLAB")[0] == '0');   // tuning switch
-  const int gpb = (slab_on && d.ext_chunks <= 0) ? gn_slab_gpb(d, cpt) : 0;
+  const int gpb = (slab_on && d.ext_chunks <= 0 && !d.stats_only) ? gn_slab_gpb(d, cpt) : 0;
   if (gpb) {
     const int W = gpb * (C / d.groups);
     const size_t lds = (size_t)(2 * (256 / (W / 8)) * W + 2 * gpb) * sizeof(float);
@@ -435,6 +435,7 @@ int launch_gn(const es_gn_desc& d, hipStream_t st) {
   const int PS = CH8 <= 256 ? 256 / CH8 : 1;
   const size_t lds_stats = (size_t)2 * PS * C * sizeof(float);
   if (d.ext_chunks <= 0) hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(nchunk, d.N), dim3(256), lds_stats, st, d);
+  if (d.stats_only) return hipGetLastError() == hipSuccess ? 0 : -2;      // the consumer normalises (es_xs_desc.gn_part)
   const long long total = (long long)d.HW * (C / 8);
   // workgroups per sample: every workgroup first reduces the partials and builds the scale / shift tables (~2 us), so a thread
   // should stream more than one round of loads behind that prologue - 16 items where that still leaves >= 1024 workgroups for the
@@ -482,6 +483,13 @@ extern "C" size_t es_group_norm_partials_bytes(int N, int groups) {
   return (size_t)N * GN_MAX_CHUNK * groups * 2 * sizeof(float);
 }
 
+extern "C" int es_group_norm_chunks(int HW) {          // pixel chunks per sample of the statistics pass: the second extent of `partials`
+  if (HW < 1) return 0;
+  int ppb = HW / GN_MAX_CHUNK;
+  if (ppb < 16) ppb = 16;
+  return (HW + ppb - 1) / ppb;
+}
+
 extern "C" int es_group_norm_is_slab(int HW, int C, int groups) {
   if (HW < 1 || C < 8 || groups < 1 || C % groups) return 0;
   static const bool slab_on = !(getenv("ES_GN_SLAB") && getenv("ES_GN_SLAB")[0] == '0');
@@ -493,10 +501,14 @@ extern "C" int es_group_norm_is_slab(int HW, int C, int groups) {
 
 extern "C" int es_group_norm(const es_gn_desc* d, void* stream) {
   const int C = d->C1 + d->C2;
-  if (!d->x || !d->out || !d->partials || (d->ngroups <= 1 && (!d->gamma || !d->beta))) { es_set_error("es_group_norm: null pointer"); return -1; }
+  if (d->stats_only) {
+    if (!d->x || !d->partials || d->ext_chunks) { es_set_error("es_group_norm: stats_only needs x and partials (and no ext_chunks)"); return -1; }
+  } else {
+    if (!d->x || !d->out || !d->partials || (d->ngroups <= 1 && (!d->gamma || !d->beta))) { es_set_error("es_group_norm: null pointer"); return -1; }
+    for (int g = 0; g < d->ngroups && d->ngroups > 1; ++g)
+      if (!d->gamma_g[g] || !d->beta_g[g]) { es_set_error("es_group_norm: null group parameter"); return -1; }
+  }
   if (d->ngroups > 4) { es_set_error("es_group_norm: at most 4 groups"); return -1; }
-  for (int g = 0; g < d->ngroups && d->ngroups > 1; ++g)
-    if (!d->gamma_g[g] || !d->beta_g[g]) { es_set_error("es_group_norm: null group parameter"); return -1; }
   if (d->ngroups > 1 && d->n_end[d->ngroups - 1] != d->N) { es_set_error("es_group_norm: group table must cover N"); return -1; }
   if (d->C1 % 8 || d->C2 % 8 || (d->C2 && !d->x2)) { es_set_error("es_group_norm: channels must be multiples of 8"); return -1; }
   if (d->groups < 1 || d->groups > GN_MAX_GROUPS || C % d->groups) { es_set_error("es_group_norm: bad group count"); return -1; }

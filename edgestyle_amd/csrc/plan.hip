@@ -145,7 +145,8 @@ const std::vector<PtrField>& ptr_fields(int kind, int& elem) {
         F_OUT(es_gemm_desc, out_lo), F_OUT(es_gemm_desc, gn_part)}; return f; }
     case ES_OP_LINEAR_XS: { static const std::vector<PtrField> f = {
         F_IN(es_xs_desc, x), F_OUT(es_xs_desc, out), F_IN(es_xs_desc, w), F_IN(es_xs_desc, bias), F_IN4(es_xs_desc, w_g),
-        F_IN4(es_xs_desc, bias_g), F_OUT(es_xs_desc, prof), F_IN(es_xs_desc, residual)}; return f; }
+        F_IN4(es_xs_desc, bias_g), F_OUT(es_xs_desc, prof), F_IN(es_xs_desc, residual), F_IN(es_xs_desc, gn_part), F_IN(es_xs_desc, gn_gamma),
+        F_IN(es_xs_desc, gn_beta), F_IN4(es_xs_desc, gn_gamma_g), F_IN4(es_xs_desc, gn_beta_g)}; return f; }
     case ES_OP_ATTENTION: { static const std::vector<PtrField> f = {
         F_IN(es_attn_desc, q), F_IN(es_attn_desc, k), F_IN(es_attn_desc, v), F_OUT(es_attn_desc, o)}; return f; }
     case ES_OP_GROUP_NORM: { static const std::vector<PtrField> f = {

@@ -173,8 +173,7 @@ class Transformer:
 
     def __call__(self, x, kv):
         N, H, W, C = x.shape
-        h = ops.group_norm(x, self.norm[0], self.norm[1], self.groups, 1e-6, False)
-        tok = ops.conv_gemm(h, self.proj_in).reshape(N, H * W, C)
+        tok = ops.gn_proj_in(x, self.norm[0], self.norm[1], self.groups, 1e-6, self.proj_in).reshape(N, H * W, C)
         fold = self.ln_fold
         qkv = ops.linear(tok, self.qkv_ln) if fold else ops.linear(ops.layer_norm(tok, *self.ln1), self.qkv)
         a = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], self.heads)
@@ -532,8 +531,7 @@ class GroupedEncoder:
         t0 = ts[0]
         N, H, W, C = x.shape
         rows = [n * H * W for n in c]
-        h = ops.group_norm(x, [t.norm[0] for t in ts], [t.norm[1] for t in ts], t0.groups, 1e-6, False, group_n=c)
-        tok = ops.conv_gemm(h, [t.proj_in for t in ts], group_n=c).reshape(N, H * W, C)
+        tok = ops.gn_proj_in(x, [t.norm[0] for t in ts], [t.norm[1] for t in ts], t0.groups, 1e-6, [t.proj_in for t in ts], group_n=c).reshape(N, H * W, C)
         fold = all(t.ln_fold for t in ts)
 
         def ln_linear(k, plain, folded):

@@ -44,6 +44,8 @@ class XsDesc(C.Structure):
         ("ldo", C.c_int32), ("geglu", C.c_int32), ("ln", C.c_int32), ("ln_eps", C.c_float),
         ("nslices", C.c_int32), ("chunks_per_slice", C.c_int32), ("dtype", C.c_int32),
         ("residual", C.c_void_p),
+        ("gn_part", C.c_void_p), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("gn_gamma_g", C.c_void_p * 4), ("gn_beta_g", C.c_void_p * 4),
+        ("gn_groups", C.c_int32), ("gn_nchunk", C.c_int32), ("gn_hw", C.c_int32), ("gn_eps", C.c_float),
     ]
 
 
@@ -81,7 +83,7 @@ class GnDesc(C.Structure):
         ("N", C.c_int32), ("HW", C.c_int32), ("C1", C.c_int32), ("C2", C.c_int32), ("groups", C.c_int32),
         ("eps", C.c_float), ("silu", C.c_int32), ("dtype", C.c_int32),
         ("ngroups", C.c_int32), ("n_end", C.c_int32 * 4), ("gamma_g", C.c_void_p * 4), ("beta_g", C.c_void_p * 4),
-        ("ext_chunks", C.c_int32),
+        ("ext_chunks", C.c_int32), ("stats_only", C.c_int32),
     ]
 
 
@@ -151,6 +153,7 @@ SYMBOLS = {
     "es_group_norm": (C.c_int, [C.POINTER(GnDesc), _P]),
     "es_group_norm_partials_bytes": (C.c_size_t, [_I, _I]),
     "es_group_norm_is_slab": (C.c_int, [_I, _I, _I]),
+    "es_group_norm_chunks": (C.c_int, [_I]),
     "es_layer_norm": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _I, _P]),
     "es_fusion_block": (C.c_int, [C.POINTER(FusionDesc), _P]),
     "es_fusion_scratch_bytes": (C.c_size_t, [_I]),

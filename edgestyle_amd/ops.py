@@ -433,9 +433,11 @@ def xs_eligible(M: int, pw: "PackedWeight", pws, group_n, hw: int) -> bool:
     return bool(L.load().es_linear_xs_eligible(int(M), int(pw.ksize), int(pw.kpad), int(pw.cin), int(pw.ctail), int(pw.cout), int(pw.geglu)))
 
 
-def linear_xs(x: torch.Tensor, pw, M: int, out: torch.Tensor, group_rows=None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+def linear_xs(x: torch.Tensor, pw, M: int, out: torch.Tensor, group_rows=None, residual: Optional[torch.Tensor] = None,
+              gn: Optional[dict] = None) -> torch.Tensor:
     """x: [M, K] contiguous; pw (or list of pw for a grouped launch with `group_rows` rows each) -> out [M, cstore]
-    (+ residual [M, cstore] contiguous: K = 320 only)."""
+    (+ residual [M, cstore] contiguous: K = 320 only).  gn = dict(part, gamma, beta, groups, nchunk, hw, eps): GroupNorm in front
+    (es_xs_desc.gn_part; gamma / beta lists for a grouped launch)."""
     pws = None
     if isinstance(pw, (list, tuple)):
         pws = list(pw) if len(pw) > 1 else None
@@ -468,6 +470,18 @@ def linear_xs(x: torch.Tensor, pw, M: int, out: torch.Tensor, group_rows=None, r
     d.geglu, d.ln, d.ln_eps = int(pw.geglu), int(pw.ln_colsum is not None), pw.ln_eps
     d.nslices, d.chunks_per_slice, d.dtype = nslices, lps * pline, _dt(x)
     d.residual = residual.data_ptr() if residual is not None else None
+    if gn is not None:
+        d.gn_part, d.gn_groups, d.gn_nchunk, d.gn_hw, d.gn_eps = gn["part"].data_ptr(), gn["groups"], gn["nchunk"], gn["hw"], gn["eps"]
+        gam, bet = gn["gamma"], gn["beta"]
+        if pws is not None:
+            if len(gam) != len(pws) or len(bet) != len(pws):
+                raise L.EdgeStyleHipError("grouped linear_xs: one GroupNorm parameter set per weight group")
+            for g in range(len(pws)):
+                d.gn_gamma_g[g], d.gn_beta_g[g] = gam[g].data_ptr(), bet[g].data_ptr()
+        else:
+            if isinstance(gam, (list, tuple)):
+                gam, bet = gam[0], bet[0]
+            d.gn_gamma, d.gn_beta = gam.data_ptr(), bet.data_ptr()
     if pws is not None:
         d.ngroups = len(pws)
         acc = 0
@@ -798,6 +812,58 @@ def group_norm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu: bool
     d.N, d.HW, d.C1, d.C2, d.groups = N, H * W, C1, C2, groups
     d.eps, d.silu, d.dtype = eps, 1 if silu else 0, _dt(x)
     L.check(L.load().es_group_norm(C.byref(d), _stream()), "es_group_norm")
+    return out
+
+
+# Transformer2DModel.norm -> proj_in as ONE read of the tensor: a statistics pass (es_group_norm stats_only) and the projection on
+# es_linear_xs, which normalises the rows it holds in registers (es_xs_desc.gn_part) - where the projection runs on that kernel anyway
+# (the grouped launches of the two shallow levels, the UNet's own at batch 8), and at K = 320 from 8192 rows on, where the row-stationary
+# kernel loses ~2 us to the tiled one but the apply pass it replaces costs 8-10 (profiles/r05_gn_proj_in.txt).  ES_GN_FOLD=0: two launches
+# + projection as before.  The native builder applies the same rule (csrc/builder.hip gn_proj_in).
+GN_FOLD = _os.environ.get("ES_GN_FOLD", "1") == "1"
+
+
+def gn_fold_ok(M: int, hw: int, groups: int, pw: "PackedWeight", pws, group_n) -> bool:
+    if not (GN_FOLD and XS_ENABLED) or GN_HANDOVER or hw % 256 or groups > 32:
+        return False
+    if pw.ksize != 1 or pw.kpad not in (320, 640) or pw.cin != pw.kpad or pw.ctail or pw.geglu or pw.ln_colsum is not None \
+            or pw.kpad % groups or not xs_shape_reference(M, pw, 0):
+        return False
+    if M < (8192 if pw.kpad == 320 else 32768):
+        return False
+    if pws is not None and (len(pws) > 4 or any((n * hw) % 256 for n in group_n)
+                            or any((q.rows_padded, q.kpad, q.cout, q.geglu, q.ln_colsum is None) != (pw.rows_padded, pw.kpad, pw.cout, pw.geglu, True)
+                                   for q in pws)):
+        return False
+    return True
+
+
+def gn_proj_in(x: torch.Tensor, gamma, beta, groups: int, eps: float, pw, group_n: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """x [N,H,W,C] -> proj_in(GroupNorm(x)) [N,H,W,Cout] (no activation in between).  gamma / beta / pw: lists for a grouped launch
+    (group_n samples each)."""
+    N, H, W, Cc = x.shape
+    pws = list(pw) if isinstance(pw, (list, tuple)) and len(pw) > 1 else None
+    p0 = pw[0] if isinstance(pw, (list, tuple)) else pw
+    M, hw = N * H * W, H * W
+    if not (x.is_contiguous() and gn_fold_ok(M, hw, groups, p0, pws, group_n)):
+        kw = {} if group_n is None else dict(group_n=group_n)
+        return conv_gemm(group_norm(x, gamma, beta, groups, eps, False, **kw), pw, **kw)
+    key = (x.device, N, groups, LANE)
+    part = _gn_partials.get(key)
+    if part is None:
+        part = torch.empty(L.load().es_group_norm_partials_bytes(N, groups) // 4, dtype=torch.float32, device=x.device)
+        _gn_partials[key] = part
+    d = L.GnDesc()
+    d.x, d.partials = x.data_ptr(), part.data_ptr()
+    d.N, d.HW, d.C1, d.C2, d.groups = N, hw, Cc, 0, groups
+    d.eps, d.silu, d.dtype, d.stats_only = eps, 0, _dt(x), 1
+    L.check(L.load().es_group_norm(C.byref(d), _stream()), "es_group_norm")
+    out = torch.empty((N, H, W, p0.cout), dtype=x.dtype, device=x.device)
+    gl = list(gamma) if isinstance(gamma, (list, tuple)) else [gamma]
+    bl = list(beta) if isinstance(beta, (list, tuple)) else [beta]
+    linear_xs(x.reshape(M, Cc), pws if pws is not None else p0, M, out.reshape(M, p0.cout),
+              None if pws is None else [n * hw for n in group_n],
+              gn=dict(part=part, gamma=gl, beta=bl, groups=groups, nchunk=L.load().es_group_norm_chunks(hw), hw=hw, eps=eps))
     return out
 
 

@@ -161,6 +161,17 @@ typedef struct {
   /* optional: out = x W^T + bias + residual - rows of ldo elements, like out (Attention.to_out + residual, BasicTransformerBlock).
    * K = 320 only, no GEGLU, no LayerNorm fold */
   const void* residual;
+  /* optional: GroupNorm in front (Transformer2DModel.norm -> proj_in: eps 1e-6, no activation).  x is then the RAW tensor [N, gn_hw, K];
+   * gn_part holds the sums of x and x^2 per (sample, pixel chunk, GroupNorm group) - fp32 [N][gn_nchunk][gn_groups][2], as
+   * es_group_norm(stats_only = 1) writes them (gn_nchunk = es_group_norm_chunks(gn_hw)) - and gn_gamma / gn_beta (gn_gamma_g / gn_beta_g
+   * per weight group of a grouped launch) the affine parameters, fp32 [K].  The kernel normalises the rows it holds in registers:
+   * one read of x instead of three passes over it.  Needs the plain projection (no GEGLU, LayerNorm fold or residual), gn_hw % 256 == 0,
+   * M == N * gn_hw, at most 32 groups.  gn_part == NULL: off. */
+  const float* gn_part;
+  const float* gn_gamma; const float* gn_beta;
+  const float* gn_gamma_g[4]; const float* gn_beta_g[4];
+  int32_t gn_groups, gn_nchunk, gn_hw;
+  float gn_eps;
 } es_xs_desc;
 int es_linear_xs(const es_xs_desc* d, void* stream);
 /* tool / test knob: the form of the plain (no GEGLU) launches - 1 = two-barrier ping-pong between the wave groups (default; ES_XS_PP=0
@@ -201,9 +212,14 @@ typedef struct {
   /* > 0: `partials` already HOLDS the statistics of x as ext_chunks partial sums per (sample, group) - written by the producing
    * es_conv_gemm launch (es_gemm_desc.gn_part, ext_chunks = 2 * HW/64): no statistics pass, one read of x.  One source only. */
   int32_t ext_chunks;
+  /* 1: the statistics pass alone - `partials` receives the sums of x and x^2 per (sample, pixel chunk, group), fp32
+   * [N][es_group_norm_chunks(HW)][groups][2]; nothing is normalised, out / gamma / beta are not read.  The consumer applies the
+   * normalisation itself (es_xs_desc.gn_part: Transformer2DModel.norm -> proj_in as one read of x). */
+  int32_t stats_only;
 } es_gn_desc;
 int es_group_norm(const es_gn_desc* d, void* stream);
 size_t es_group_norm_partials_bytes(int N, int groups);
+int es_group_norm_chunks(int HW);                       /* pixel chunks per sample of the statistics pass */
 int es_group_norm_is_slab(int HW, int C, int groups);   /* 1: this geometry runs as ONE launch (slab form) */
 
 /* LayerNorm over the last dim of [M, C] (BasicTransformerBlock.norm1/2/3), eps 1e-5. */

@@ -1270,3 +1270,54 @@ def test_clock_probe_reads_a_plausible_shader_clock():
     assert 100.0 <= cyc / ticks * 100.0 <= 2600.0, (cyc, ticks)                       # MHz: between deep idle and the 2.4 GHz peak
     with pytest.raises(Exception):
         lib.check(L.es_clock_probe(None, 2000, None), "es_clock_probe")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("C,H,counts", [(320, 32, None), (320, 16, [2, 6, 4, 2]), (640, 32, [16, 8, 8]), (640, 16, None)])
+def test_group_norm_in_front_of_the_row_stationary_projection(dtype, C, H, counts):
+    """Transformer2DModel.norm -> proj_in as one read (ops.gn_proj_in: es_group_norm stats_only + es_linear_xs gn_part) against a plain
+    fp32 GroupNorm + 1x1 convolution, and against the two-launch path it replaces (same arithmetic up to the rounding of the normalised
+    value: the fused form computes x * (rstd gamma) + (beta - mean rstd gamma), the stand-alone one (x - mean) rstd gamma + beta)."""
+    from edgestyle_amd import ops
+    g = torch.Generator().manual_seed(C + H + (len(counts) if counts else 0))
+    N = sum(counts) if counts else 36 if C == 320 else 34
+    while N * H * H < (8192 if C == 320 else 32768):
+        N *= 2
+    if counts:
+        N = sum(counts)
+        if N * H * H < (8192 if C == 320 else 32768):
+            counts = [c * 4 for c in counts]
+            N = sum(counts)
+    x = (torch.randn(N, C, H, H, generator=g) * 1.5 + 0.3 * torch.randn(N, C, 1, 1, generator=g))
+    xq = q16(x, dtype)
+    ng = len(counts) if counts else 1
+    gam = [1 + 0.2 * torch.randn(C, generator=g) for _ in range(ng)]
+    bet = [0.2 * torch.randn(C, generator=g) for _ in range(ng)]
+    ws = [q16(torch.randn(C, C, 1, 1, generator=g) / math.sqrt(C), dtype) for _ in range(ng)]
+    bs = [torch.randn(C, generator=g) * 0.1 for _ in range(ng)]
+    pws = [ops.pack_weight(w, b, dtype, DEV) for w, b in zip(ws, bs)]
+    gd, bd = [t.to(DEV) for t in gam], [t.to(DEV) for t in bet]
+    xin = nhwc(xq, dtype)
+    assert ops.gn_fold_ok(N * H * H, H * H, 32, pws[0], pws if counts else None, counts)
+    if counts:
+        y = ops.gn_proj_in(xin, gd, bd, 32, 1e-6, pws, group_n=counts)
+    else:
+        y = ops.gn_proj_in(xin, gd[0], bd[0], 32, 1e-6, pws[0])
+    old = ops.GN_FOLD
+    ops.GN_FOLD = False
+    try:
+        y2 = ops.gn_proj_in(xin, gd, bd, 32, 1e-6, pws, group_n=counts) if counts else ops.gn_proj_in(xin, gd[0], bd[0], 32, 1e-6, pws[0])
+    finally:
+        ops.GN_FOLD = old
+    torch.cuda.synchronize()
+    a = 0
+    refs = []
+    for i, n in enumerate(counts or [N]):
+        h = F.group_norm(xq[a:a + n], 32, gam[i], bet[i], 1e-6)
+        refs.append(F.conv2d(q16(h, dtype), ws[i], bs[i]))
+        a += n
+    ref = torch.cat(refs, 0)
+    tol = 3e-3 if dtype == torch.float16 else 2e-2
+    assert rel_err(y.permute(0, 3, 1, 2), ref) < tol
+    assert rel_err(y2.permute(0, 3, 1, 2), ref) < tol
+    assert rel_err(y, y2) < tol
