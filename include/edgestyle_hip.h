@@ -23,8 +23,9 @@ extern "C" {
 enum { ES_F16 = 0, ES_BF16 = 1, ES_F32 = 2 /* es_tensor sources only: the kernels compute in ES_F16 / ES_BF16 */ };
 enum { ES_ACT_NONE = 0, ES_ACT_SILU = 1, ES_ACT_GEGLU = 2 };
 
-/* 7 (round 5): es_gemm_desc.bn = 256; es_conv_gemm8p_form_ok, es_ctx_graph_hazard, es_linear_xs_set_pp, es_attention_set_kvres.
- * No struct layout changed since 6; context images carry the version and are rebuilt across it. */
+/* 7 (round 5): es_gemm_desc.bn = 256; es_xs_desc.gn_* and es_gn_desc.stats_only (both structs grew: GroupNorm in front of a row-stationary
+ * projection); es_conv_gemm8p_form_ok, es_ctx_graph_hazard, es_linear_xs_set_pp, es_attention_set_kvres, es_set_operand_limit,
+ * es_group_norm_chunks, es_clock_probe.  Context images carry the version and are rebuilt across it. */
 #define ES_ABI_VERSION 7
 int es_abi_version(void);
 /* sizeof the descriptor structs as compiled (0 gemm, 1 attn, 2 gn, 3 fusion, 4 ln, 5 xs): lets a binding verify its mirror */
