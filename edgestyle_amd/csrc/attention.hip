@@ -1223,11 +1223,14 @@ int dispatch(const es_attn_desc& d, hipStream_t st) {
     // fragments (tool build with MFMAs, v_exp and row max removed: 265 of 448 us), and a fragment then serves two blocks
     static const int qb2 = getenv("ES_ATTN_QB") ? atoi(getenv("ES_ATTN_QB")) : 2;
     // the ping-pong kernel (8 waves, two groups one barrier out of phase): ES_ATTN_PP = 0 off, 1 = 32 queries per wave,
-    // 2 = 64 queries per wave, unset = by grid size
+    // 2 = 64 queries per wave, unset (-1) = 32 queries per wave from 256 blocks of 256 queries on.
+    // (Rounds 3-4 ran 64 queries per wave from 4096 blocks on: per tile it is the faster form in isolation (tools/attn_bench.py; stamps: 1730
+    //  cycles per 64-query tile against 2 x 1050) - inside the pipeline it is the slower one, -0.6 % per batch-8 call and -1.1 % per 768 x 768
+    //  call with 32: profiles/r05_pipeline_ab.txt.  The step runs at the package power limit there; the denser form buys clock it then loses.)
     static const int pp = getenv("ES_ATTN_PP") ? atoi(getenv("ES_ATTN_PP")) : -1;
     if (d.d == 40 && pp != 0 && d.Skv % 64 == 0 && d.Skv >= 128) {
       const long long wg256 = (long long)((d.Sq + 255) / 256) * d.heads * d.N;
-      if (pp == 2 || (pp == -1 && wg256 >= 4096)) return launch_attn40pp<T, 2>(d, st);
+      if (pp == 2) return launch_attn40pp<T, 2>(d, st);
       if (pp == 1 || (pp == -1 && wg256 >= 256)) return launch_attn40pp<T, 1>(d, st);
     }
     if (d.d == 40 && qb2 == 2 && (long long)((d.Sq + 255) / 256) * d.heads * d.N >= big_thr) {
