@@ -309,7 +309,13 @@ constexpr int PLAN_BIG_MIN_M = 2048, PLAN_BIG_MIN_NK = 16;
 constexpr double PLAN_T64_ALONE = 0.5, PLAN_T64 = 0.16, PLAN_T64_LONG = 1.5;
 constexpr int PLAN_SMALL_MAX_M = 16384, PLAN_MIN_SLICE = 12, PLAN_NK_NOSPLIT = 10, PLAN_RESIDENT = 512;
 
+// Tool knobs (tools/ab_env_bench.sh: A/Bs of the planner's constants INSIDE the pipeline - the constants were fitted on launches timed
+// in isolation, and the step runs at the package power limit where the ranking can differ): ES_PLAN_T320 (cost of a K-step of the 256 x 320
+// tile, default 2.3), ES_PLAN_BIG_MIN_NK (fewest K-steps it is offered for, 16), ES_PLAN_T256_MARGIN (0.93).  Unset: the fitted values.
+double plan_env(const char* name, double dflt) { const char* e = getenv(name); return e && *e ? atof(e) : dflt; }
 bool plan_gemm(long long M, int rows_padded, int kpad, bool geglu, const int* bns, int nb, bool allow_split, int* o_bn, int* o_sk, int* o_st) {
+  static const double PLAN_T320 = plan_env("ES_PLAN_T320", ::PLAN_T320), PLAN_T256_MARGIN = plan_env("ES_PLAN_T256_MARGIN", ::PLAN_T256_MARGIN);
+  static const int PLAN_BIG_MIN_NK = (int)plan_env("ES_PLAN_BIG_MIN_NK", ::PLAN_BIG_MIN_NK);
   // The 256 x 256 phase-interleaved tile (round 5) is offered by the callers for the LayerNorm-folded / GEGLU linear layers whose N is a
   // multiple of 256.  The choice among the OTHER tiles is made first, exactly as before; the 256-wide tile then replaces it where a
   // model fitted on those layers (tools/ln256_bench.py, profiles/r05_ln256_bench.txt: a round of 512 workgroups of the 128-wide tile
