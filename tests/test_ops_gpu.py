@@ -1246,6 +1246,16 @@ def test_oversize_launches_are_cut_into_runs_of_whole_samples():
         L.es_set_operand_limit(0)
     for i, (a, b) in enumerate(zip(whole, cut)):
         assert torch.equal(a, b), i
+    # GroupNorm in front of linear_xs (es_xs_desc.gn_part): cut between whole samples, the statistics pointer moved along
+    xg = torch.randn(8, 32, 32, 320, generator=g).to(DEV, torch.float16)
+    gam, bet = (1 + 0.2 * torch.randn(320, generator=g)).to(DEV), (0.2 * torch.randn(320, generator=g)).to(DEV)
+    assert ops.gn_fold_ok(8 * 1024, 1024, 32, xs_o, None, None)
+    whole = ops.gn_proj_in(xg, gam, bet, 32, 1e-6, xs_o)
+    L.es_set_operand_limit(2 * 1024 * 640 + 256 * 640 + 1)            # two samples of 1024 rows per cut
+    try:
+        assert torch.equal(ops.gn_proj_in(xg, gam, bet, 32, 1e-6, xs_o), whole)
+    finally:
+        L.es_set_operand_limit(0)
     # a source shared modulo x_nmod (the text states of a weight-sharing group) is cut at multiples of x_nmod ...
     whole = ops.linear(ehs, pkv, x_rep=3)
     L.es_set_operand_limit(200 * 640 * 2)
